@@ -1,0 +1,18 @@
+"""gencomm_amd -- MI355X (gfx950) implementation of GenComm's generative-communication hot path.
+
+Public surface mirrors the reference's plugin API:
+
+    GenComm(model_cfg)                 opencood/models/gencomm_modules/cond_diff.py:185
+    DiffusionUNet(config)              opencood/models/gencomm_modules/unet.py:198
+    Enhancer(C, win_size, num_heads)   opencood/models/gencomm_modules/enhancer.py:359
+    AttFusion(feature_dims)            opencood/models/fuse_modules/fusion_in_one.py:126
+    regroup, normalize_pairwise_tfm    fusion_in_one.py:48, opencood/utils/transformation_utils.py:68
+
+All compute runs in hand-written HIP kernels behind the C ABI of ``include/gencomm_hip.h``.
+"""
+from .cond_diff import GenComm
+from .enhancer import Enhancer
+from .fusion import AttFusion, normalize_pairwise_tfm, regroup
+from .unet import DiffusionUNet
+
+__all__ = ["GenComm", "DiffusionUNet", "Enhancer", "AttFusion", "regroup", "normalize_pairwise_tfm"]

@@ -1,0 +1,123 @@
+"""ctypes binding of ``libgencomm_hip.so`` (C ABI in ``include/gencomm_hip.h``).
+
+The product path has no fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+import threading
+from typing import List, Tuple
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libgencomm_hip.so")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+c_float_p = C.c_void_p  # device pointers travel as plain integers
+_i, _ll, _p = C.c_int, C.c_longlong, C.c_void_p
+
+_SIGNATURES = {
+    "gencomm_abi_version": (_i, []),
+    "gencomm_last_error": (C.c_char_p, []),
+    "gencomm_unet_num_params": (_i, [_i, _i, _i]),
+    "gencomm_unet_param_info": (_i, [_i, _i, _i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
+    "gencomm_unet_raw_floats": (_ll, [_i, _i, _i]),
+    "gencomm_unet_prepared_floats": (_ll, [_i, _i, _i, _i]),
+    "gencomm_unet_prepare": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_denoise_workspace_bytes": (_ll, [_i, _i, _i, _i, _i, _i]),
+    "gencomm_unet_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_denoise_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, C.c_ulonglong,
+                                 _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_enhancer_num_params": (_i, [_i]),
+    "gencomm_enhancer_param_info": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
+    "gencomm_enhancer_raw_floats": (_ll, [_i]),
+    "gencomm_enhancer_workspace_bytes": (_ll, [_i, _i, _i, _i]),
+    "gencomm_enhancer_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class GenCommHipError(RuntimeError):
+    pass
+
+
+def hip_sources() -> List[str]:
+    return [os.path.join(CSRC_DIR, "gencomm_abi.hip")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU)."""
+    srcs = hip_sources()
+    deps = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)] + [os.path.join(REPO_DIR, "include", "gencomm_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", *srcs, "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises GenCommHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise GenCommHipError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU fallback for the GenComm hot path.")
+            l = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(l, name)  # AttributeError here = ABI mismatch, fail loudly
+                fn.restype, fn.argtypes = res, args
+            if l.gencomm_abi_version() != ABI_VERSION:
+                raise GenCommHipError(f"ABI version mismatch: library {l.gencomm_abi_version()}, binding {ABI_VERSION}")
+            _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise GenCommHipError(f"{what} failed (status {rc}): {lib().gencomm_last_error().decode()}")
+
+
+def check_size(v: int, what: str) -> int:
+    if v < 0:
+        raise GenCommHipError(f"{what} failed: {lib().gencomm_last_error().decode()}")
+    return int(v)
+
+
+def unet_param_table(Cch: int, levels: int, res_blocks: int) -> List[Tuple[str, int, int]]:
+    l = lib()
+    n = check_size(l.gencomm_unet_num_params(Cch, levels, res_blocks), "gencomm_unet_num_params")
+    out, buf, numel, off = [], C.create_string_buffer(128), _ll(), _ll()
+    for i in range(n):
+        check(l.gencomm_unet_param_info(Cch, levels, res_blocks, i, buf, 128, C.byref(numel), C.byref(off)), "gencomm_unet_param_info")
+        out.append((buf.value.decode(), int(numel.value), int(off.value)))
+    return out
+
+
+def enhancer_param_table(Cch: int) -> List[Tuple[str, int, int]]:
+    l = lib()
+    n = check_size(l.gencomm_enhancer_num_params(Cch), "gencomm_enhancer_num_params")
+    out, buf, numel, off = [], C.create_string_buffer(128), _ll(), _ll()
+    for i in range(n):
+        check(l.gencomm_enhancer_param_info(Cch, i, buf, 128, C.byref(numel), C.byref(off)), "gencomm_enhancer_param_info")
+        out.append((buf.value.decode(), int(numel.value), int(off.value)))
+    return out

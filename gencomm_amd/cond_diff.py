@@ -1,0 +1,190 @@
+"""``GenComm`` -- host-side mirror of the reference's conditional diffusion sampler
+(``opencood/models/gencomm_modules/cond_diff.py:185-432``), running the whole T-step denoise loop as
+HIP kernels through ``gencomm_denoise_fwd``.
+
+Same constructor (``GenComm(model_cfg)``), same 12 persistent schedule buffers, same forward /
+forward_single signatures and returned dict keys, same ``state_dict`` layout as the reference.
+Extra, optional keyword ``noise=(noise0, step_noise)`` injects explicit N(0,1) tensors (parity
+tests); by default noise comes from an in-kernel Philox4x32-10 stream keyed by a seed drawn from
+torch's default generator (so ``torch.manual_seed`` makes runs reproducible).
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .runtime import f32c, ptr, record_len_list, require_gpu, stream_ptr
+from .unet import DiffusionUNet
+
+
+class Config:  # cond_diff.py:177-183
+    def __init__(self, entries: dict = {}):
+        for k, v in entries.items():
+            self.__dict__[k] = Config(v) if isinstance(v, dict) else v
+
+
+def make_beta_schedule(n_timestep: int, linear_start: float = 5e-3, linear_end: float = 5e-2) -> np.ndarray:
+    """'linear' branch of opencood/utils/MDD_utils.py:208-212, float64. The reference ignores the
+    yaml's beta_start/beta_end/beta_schedule and hard-codes these (cond_diff.py:191,196-197,209)."""
+    return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+
+
+class GenComm(nn.Module):
+    def __init__(self, model_cfg):
+        super().__init__()
+        self.parameterization = "x0"
+        config = Config(model_cfg) if isinstance(model_cfg, dict) else model_cfg
+        self.num_timesteps = config.diffusion.num_diffusion_timesteps
+        self.embed_dim = config.model.embed_dim
+        timesteps = self.num_timesteps
+        self.v_posterior = 0
+        self.loss_type = "l2"
+        self.signal_scaling_rate = 1
+        self.denoiser = DiffusionUNet(config)
+
+        # cond_diff.py:209-257, all float64 then cast
+        betas = make_beta_schedule(timesteps)
+        alphas = 1.0 - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1.0, alphas_cumprod[:-1])
+        to_torch = partial(torch.tensor, dtype=torch.float32)
+        self.register_buffer("betas", to_torch(betas))
+        self.register_buffer("alphas_cumprod", to_torch(alphas_cumprod))
+        self.register_buffer("alphas_cumprod_prev", to_torch(alphas_cumprod_prev))
+        self.register_buffer("sqrt_alphas_cumprod", to_torch(np.sqrt(alphas_cumprod)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1.0 - alphas_cumprod)))
+        self.register_buffer("log_one_minus_alphas_cumprod", to_torch(np.log(1.0 - alphas_cumprod)))
+        self.register_buffer("sqrt_recip_alphas_cumprod", to_torch(np.sqrt(1.0 / alphas_cumprod)))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod", to_torch(np.sqrt(1.0 / alphas_cumprod - 1)))
+        posterior_variance = (1 - self.v_posterior) * betas * (1.0 - alphas_cumprod_prev) / (1.0 - alphas_cumprod) \
+            + self.v_posterior * betas
+        self.register_buffer("posterior_variance", to_torch(posterior_variance))
+        self.register_buffer("posterior_log_variance_clipped", to_torch(np.log(np.maximum(posterior_variance, 1e-20))))
+        self.register_buffer("posterior_mean_coef1", to_torch(betas * np.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod)))
+        self.register_buffer("posterior_mean_coef2", to_torch((1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod)))
+
+        self.learn_logvar = False
+        self.logvar = torch.full(fill_value=0.0, size=(self.num_timesteps,))
+        self.l_simple_weight = 1.0
+        lvlb_weights = 0.5 * torch.sqrt(torch.tensor(alphas_cumprod)) / (2.0 * 1 - torch.tensor(alphas_cumprod))
+        lvlb_weights = lvlb_weights.float()
+        if len(lvlb_weights) > 1:
+            lvlb_weights[0] = lvlb_weights[1]
+        self.register_buffer("lvlb_weights", lvlb_weights, persistent=False)
+        self._sched_dev = None
+        self._sched_key = None
+
+    # ------------------------------------------------------------------ helpers
+    def _sched_table(self, device: torch.device) -> torch.Tensor:
+        """[T][5] float32 rows {sqrt_ac, sqrt_1m_ac, coef1, coef2, exp(0.5*logvar)} built from the
+        registered buffers (so a loaded checkpoint's buffers are what the kernels use)."""
+        bufs = (self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, self.posterior_mean_coef1,
+                self.posterior_mean_coef2, self.posterior_log_variance_clipped)
+        key = tuple((b.data_ptr(), b._version) for b in bufs) + (str(device),)
+        if self._sched_key != key:
+            with torch.no_grad():
+                cols = [b.detach().float().to(device) for b in bufs]
+                cols[4] = (0.5 * cols[4]).exp()  # (0.5 * model_log_variance).exp(), cond_diff.py:311
+                self._sched_dev = torch.stack(cols, dim=1).contiguous()
+            self._sched_key = key
+        return self._sched_dev
+
+    def q_sample(self, x_start, t, noise=None):
+        """cond_diff.py:262-264 (torch elementwise; only used for the eval branch's two debug
+        outputs 't1'/'t2' on a single ego map)."""
+        a = self.sqrt_alphas_cumprod.gather(-1, t).reshape(-1, 1, 1, 1)
+        b = self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(-1, 1, 1, 1)
+        return a * x_start + b * noise
+
+    @staticmethod
+    def _src_rows(n: int, lens: Optional[Sequence[int]]) -> Sequence[int]:
+        """Row of `spatial_features` that provides agent i's x_start: its scene's ego
+        (cond_diff.py:332-337). With record_len None (forward_single) every agent is its own."""
+        if lens is None:
+            return list(range(n))
+        if sum(lens) != n:
+            raise ValueError(f"record_len sums to {sum(lens)} but {n} agents were given")
+        rows, o = [], 0
+        for k in lens:
+            rows += [o] * k
+            o += k
+        return rows
+
+    def _denoise(self, feat: torch.Tensor, cond: torch.Tensor, src_rows: Sequence[int],
+                 noise: Optional[Tuple[torch.Tensor, torch.Tensor]], seed: Optional[int]) -> torch.Tensor:
+        require_gpu(feat, "GenComm.forward(spatial_features)")
+        require_gpu(cond, "GenComm.forward(conditions)")
+        if torch.is_grad_enabled() and (feat.requires_grad or cond.requires_grad or
+                                        any(p.requires_grad for p in self.denoiser.parameters()) and self.training):
+            raise NotImplementedError(
+                "gencomm_amd.GenComm: backward through the HIP denoise loop is not implemented yet; "
+                "call under torch.no_grad() (inference) -- see DESIGN.md 'out of scope this round'")
+        feat, cond = f32c(feat), f32c(cond)
+        n, C, H, W = cond.shape[0], feat.shape[1], feat.shape[2], feat.shape[3]
+        if cond.shape[1] != 2 or tuple(cond.shape[2:]) != (H, W):
+            raise ValueError(f"conditions must be [n, 2, {H}, {W}], got {tuple(cond.shape)}")
+        if C != self.denoiser.feature_channels:
+            raise ValueError(f"spatial_features has {C} channels, the denoiser was built for {self.denoiser.feature_channels}")
+        T = self.num_timesteps
+        dev = feat.device
+        den = self.denoiser
+        prepared = den.prepared_params(T, dev)
+        ws = den.denoise_workspace(n, H, W, dev)
+        sched = self._sched_table(dev)
+        rows = torch.tensor(list(src_rows), dtype=torch.int32, device=dev)
+        out = torch.empty((n, C, H, W), dtype=torch.float32, device=dev)
+        n0 = sn = None
+        if noise is not None:
+            n0, sn = f32c(noise[0]), f32c(noise[1])
+            if tuple(n0.shape) != (n, C, H, W) or tuple(sn.shape) != (T, n, C, H, W):
+                raise ValueError("noise must be (noise0 [n,C,H,W], step_noise [T,n,C,H,W])")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        _lib.check(_lib.lib().gencomm_denoise_fwd(
+            ptr(prepared), ptr(sched), ptr(feat), feat.shape[0], ptr(rows), ptr(cond), ptr(out), ptr(n0), ptr(sn),
+            seed, n, C, H, W, den.num_resolutions, den.num_res_blocks, T, ptr(ws), ws.numel(), stream_ptr(dev)),
+            "gencomm_denoise_fwd")
+        return out
+
+    def _debug_t1_t2(self, spatial_features: torch.Tensor, data_dict: dict) -> None:
+        """'t1' / 't2': the eval branch's two unused q_samples of the first ego map
+        (cond_diff.py:369-371, :378-379). Only defined when T > 2, like the reference's indexing."""
+        if self.num_timesteps > 2:
+            ego = spatial_features[0].unsqueeze(0).float()
+            for key, tt in (("t1", 1), ("t2", 2)):
+                data_dict[key] = self.q_sample(ego, torch.tensor([tt], device=ego.device), torch.randn_like(ego))
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, spatial_features, conditions, record_len=None, noise=None, seed=None):
+        """spatial_features [sumN,C,H,W], conditions [sumN,2,H,W], record_len [B] ->
+        {'pred_feature': [sumN,C,H,W] (training mode: ``.squeeze()``-d like cond_diff.py:360),
+         't1','t2' (eval only)}."""
+        lens = record_len_list(record_len)
+        n = conditions.shape[0]
+        if lens is None:
+            lens = [n]  # regroup(x, None) is not valid in the reference; treat as one scene
+        pred = self._denoise(spatial_features, conditions, self._src_rows(n, lens), noise, seed)
+        data_dict = {}
+        if self.training:
+            data_dict["pred_feature"] = pred.unsqueeze(1).squeeze()
+        else:
+            self._debug_t1_t2(spatial_features, data_dict)
+            data_dict["pred_feature"] = pred
+        return data_dict
+
+    def forward_single(self, features, conditions, record_len=None, noise=None, seed=None):
+        """cond_diff.py:385-432: as forward but every agent denoises from its OWN feature."""
+        n = conditions.shape[0]
+        pred = self._denoise(features, conditions, self._src_rows(n, None), noise, seed)
+        data_dict = {}
+        if self.training:
+            data_dict["pred_feature"] = pred.unsqueeze(1).squeeze()
+        else:
+            self._debug_t1_t2(features, data_dict)
+            data_dict["pred_feature"] = pred
+        return data_dict

@@ -1,0 +1,92 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of the GenComm hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace gc {
+
+constexpr int kWave = 64;  // CDNA wavefront width (hard-coded: warpSize folds to 64 on gfx950)
+constexpr int kMaxResBlocks = 48;  // res-blocks one UNet may have (sizes the timestep-table kernel args)
+
+// ---------------------------------------------------------------------------------------------
+// error reporting: entry points return an int status and never exit()/abort()
+// ---------------------------------------------------------------------------------------------
+enum Status : int {
+  GC_OK = 0,
+  GC_ERR_ARG = 1,        // bad shape / unsupported configuration / null pointer
+  GC_ERR_WORKSPACE = 2,  // caller-provided workspace too small
+  GC_ERR_HIP = 3,        // a HIP runtime call failed
+};
+
+char* last_error_buf();  // thread-local, defined in gencomm_abi.hip
+inline int fail(int code, const char* msg) {
+  snprintf(last_error_buf(), 512, "%s", msg);
+  return code;
+}
+#define GC_CHECK_ARG(cond, msg) \
+  do {                          \
+    if (!(cond)) return ::gc::fail(::gc::GC_ERR_ARG, msg); \
+  } while (0)
+#define GC_HIP(expr)                                                             \
+  do {                                                                           \
+    hipError_t e__ = (expr);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      snprintf(::gc::last_error_buf(), 512, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+      return ::gc::GC_ERR_HIP;                                                   \
+    }                                                                            \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// device math
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float x) {
+  // 1 / (1 + 2^(-x*log2e)); v_exp_f32 + v_rcp_f32, ~1 ulp each
+  return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  // exact (erf) GELU, nn.GELU() default
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG + Box-Muller: 4 N(0,1) floats per (counter, key)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void normal4(uint64_t elem, uint32_t stream, uint64_t seed, float z[4]) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)r[0] + 0.5f) * k, u1 = ((float)r[1]) * k;
+  const float u2 = ((float)r[2] + 0.5f) * k, u3 = ((float)r[3]) * k;
+  const float m0 = sqrtf(-2.0f * __logf(fminf(u0, 0.99999994f)));
+  const float m1 = sqrtf(-2.0f * __logf(fminf(u2, 0.99999994f)));
+  float s0, c0, s1, c1;
+  __sincosf(6.283185307179586f * u1, &s0, &c0);
+  __sincosf(6.283185307179586f * u3, &s1, &c1);
+  z[0] = m0 * c0; z[1] = m0 * s0; z[2] = m1 * c1; z[3] = m1 * s1;
+}
+
+}  // namespace gc

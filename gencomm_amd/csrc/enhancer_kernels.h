@@ -1,0 +1,381 @@
+// Device kernels of the Enhancer (gfx950, wave64, fp32).
+//
+// Reference: opencood/models/gencomm_modules/enhancer.py -- Enhancer.forward :367-383,
+// Enhancer_block.forward :346-357 (attention commented out :352), FRFN.forward :222-250,
+// SplitAttn.forward :315-333 with RadixSoftmax(radix=1) = sigmoid :287-300.
+//
+// Token-major (NHWC) intermediates: the two Linear layers are [pixels x C] GEMMs and run on the
+// f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+#pragma once
+#include "common.h"
+
+namespace gc {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---------------------------------------------------------------------------------------------
+// K1: x NCHW -> Y = x + LN1(x), Z = LN2(Y) (token-major), Zc = Z[:, :dc] (compact copy that the
+// partial 3x3 conv reads its halo from).  64 pixels x all channels per workgroup, LDS transpose.
+// ---------------------------------------------------------------------------------------------
+struct EnhLnArgs {
+  const float* x;                 // [n][C][HW]
+  const float* g1; const float* b1; const float* g2; const float* b2;  // [C]
+  float* Y; float* Z; float* Zc;  // [n][HW][C], [n][HW][C], [n][HW][dc]
+  int C, dc, HW;
+};
+
+__global__ __launch_bounds__(256) void enh_ln_kernel(const EnhLnArgs a) {
+  extern __shared__ float smem[];
+  const int C = a.C, S = 65;
+  float* tile = smem;               // [C][65]
+  float* part = smem + (size_t)C * S;  // [4][64]
+  float* mu = part + 256;           // [64]
+  float* rs = mu + 64;              // [64]
+  const int tid = threadIdx.x, q = tid >> 6, p = tid & 63;
+  const int n = blockIdx.y, p0 = blockIdx.x * 64;
+  const int np = min(64, a.HW - p0);
+  const bool pv = p < np;
+  const float* __restrict__ xp = a.x + (size_t)n * C * a.HW + p0;
+  for (int c = q; c < C; c += 4) tile[c * S + p] = pv ? xp[(size_t)c * a.HW + p] : 0.f;
+  __syncthreads();
+  const float invC = 1.0f / (float)C;
+
+  auto moments = [&](float eps) {
+    float s = 0.f;
+    for (int c = q; c < C; c += 4) s += tile[c * S + p];
+    part[q * 64 + p] = s;
+    __syncthreads();
+    const float m = (part[p] + part[64 + p] + part[128 + p] + part[192 + p]) * invC;
+    __syncthreads();
+    float v = 0.f;
+    for (int c = q; c < C; c += 4) { const float d = tile[c * S + p] - m; v = fmaf(d, d, v); }
+    part[q * 64 + p] = v;
+    __syncthreads();
+    const float var = (part[p] + part[64 + p] + part[128 + p] + part[192 + p]) * invC;
+    __syncthreads();
+    if (q == 0) { mu[p] = m; rs[p] = 1.0f / sqrtf(var + eps); }
+    __syncthreads();
+  };
+
+  moments(1e-5f);
+  {
+    const float m = mu[p], r = rs[p];
+    for (int c = q; c < C; c += 4) {
+      const float v = tile[c * S + p];
+      tile[c * S + p] = v + fmaf((v - m) * r, a.g1[c], a.b1[c]);  // x + LN1(x)
+    }
+  }
+  __syncthreads();
+  moments(1e-5f);
+
+  float* __restrict__ Yp = a.Y + ((size_t)n * a.HW + p0) * C;
+  float* __restrict__ Zp = a.Z + ((size_t)n * a.HW + p0) * C;
+  float* __restrict__ Zcp = a.Zc + ((size_t)n * a.HW + p0) * a.dc;
+  const int tot = np * C;
+  for (int i = tid; i < tot; i += 256) {
+    const int pp = i / C, c = i - pp * C;
+    const float y = tile[c * S + pp];
+    const float z = fmaf((y - mu[pp]) * rs[pp], a.g2[c], a.b2[c]);
+    Yp[i] = y;
+    Zp[i] = z;
+    if (c < a.dc) Zcp[pp * a.dc + c] = z;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: FRFN.partial_conv3 -- 3x3 conv (no bias) on the first dc = C/4 channels, the rest untouched
+// (enhancer.py:232-234).  Reads Zc with halo, overwrites Z[:, :dc] in place.
+// Weights pre-transposed to [tap][ic][oc].
+// ---------------------------------------------------------------------------------------------
+struct EnhPconvArgs {
+  const float* Zc;  // [n][H][W][dc]
+  const float* wT;  // [9][dc][dcp]  (dcp = dc rounded up to 16, zero padded)
+  float* Z;         // [n][H][W][C]
+  int C, dc, dcp, H, W;
+};
+
+template <int TW, int TH>
+__global__ __launch_bounds__(TW * TH) void enh_pconv_kernel(const EnhPconvArgs a) {
+  extern __shared__ float smem[];
+  const int dc = a.dc, PS = dc + 1;  // padded pixel stride: conflict-free ds_read_b32 across pixels
+  constexpr int LW = TW + 2, LH = TH + 2;
+  const int tid = threadIdx.x, n = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const float* __restrict__ zp = a.Zc + (size_t)n * a.H * a.W * dc;
+  for (int i = tid; i < LH * LW * dc; i += TW * TH) {
+    const int pix = i / dc, c = i - pix * dc;
+    const int r = pix / LW, col = pix - r * LW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    float v = 0.f;
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = zp[((size_t)gy * a.W + gx) * dc + c];
+    smem[pix * PS + c] = v;
+  }
+  __syncthreads();
+  const int tx = tid % TW, ty = tid / TW;
+  const int gy = y0 + ty, gx = x0 + tx;
+  const bool ok = gy < a.H && gx < a.W;
+  float* __restrict__ op = a.Z + ((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * a.C;
+  for (int ob = 0; ob < dc; ob += 16) {
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const float* sp = smem + ((ty + dy) * LW + tx + dx) * PS;
+      const float* __restrict__ wp = a.wT + (size_t)tap * dc * a.dcp + ob;
+#pragma unroll 4
+      for (int ic = 0; ic < dc; ++ic) {
+        const float v = sp[ic];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = fmaf(wp[(size_t)ic * a.dcp + o], v, acc[o]);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int o = 0; o < 16; ++o) if (ob + o < dc) op[ob + o] = acc[o];
+    }
+  }
+}
+
+// [OC][IC][3][3] -> [9][IC][OCP] zero padded
+__global__ void enh_prep_pconv_kernel(const float* __restrict__ w, float* __restrict__ wT, int dc, int dcp) {
+  const int total = 9 * dc * dcp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int tap = i / (dc * dcp), rem = i - tap * dc * dcp, ic = rem / dcp, oc = rem - ic * dcp;
+    wT[i] = oc < dc ? w[((size_t)oc * dc + ic) * 9 + tap] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM on the matrix cores:  out[m][j] = epi( sum_k A[m][k] * Bw[j][k] + bias[j] )
+// A [M][K] row-major (tokens), Bw [N][K] row-major (nn.Linear weight layout), per agent (grid.z).
+// Workgroup 256 threads = 4 waves; tile 128 (M) x 64 (N); each wave 32 x 64 = two 32x32
+// accumulators; K streamed through LDS in chunks of 32.
+//   EPI 0: GELU(erf)                                   (FRFN.linear1, enhancer.py:240)
+//   EPI 1: + res[m][j], and accumulate column sums     (FRFN.linear2 + residual :355, GAP :325)
+// MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane&31][k = lane>>5],
+// B[k = lane>>5][j = lane&31]; D col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// The k order inside a chunk is permuted (lane-half h takes k = 4j+2h, 4j+2h+1) identically for
+// A and B so that each lane fetches its two k values with one ds_read_b64.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A; const float* Bw; const float* bias; const float* res;
+  float* out; float* colsum;  // colsum [agents][N] (EPI 1)
+  int M, N, K;                // per agent
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs a) {
+  constexpr int BM = 128, BN = 64, KC = 32, S = KC + 2;
+  __shared__ __align__(16) float As[BM * S];
+  __shared__ __align__(16) float Bs[BN * S];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int ag = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const float* __restrict__ Ap = a.A + (size_t)ag * a.M * a.K;
+  const bool kvec = (a.K & 3) == 0;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    __syncthreads();
+    {
+      const int kq = tid & 7, gk = k0 + 4 * kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i, gm = m0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < a.M) {
+          const float* src = Ap + (size_t)gm * a.K + gk;
+          if (kvec && gk + 3 < a.K) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gk + 0 < a.K) v.x = src[0];
+            if (gk + 1 < a.K) v.y = src[1];
+            if (gk + 2 < a.K) v.z = src[2];
+            if (gk + 3 < a.K) v.w = src[3];
+          }
+        }
+        float* d = &As[row * S + 4 * kq];
+        *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i, gn = n0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gn < a.N) {
+          const float* src = a.Bw + (size_t)gn * a.K + gk;
+          if (kvec && gk + 3 < a.K) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gk + 0 < a.K) v.x = src[0];
+            if (gk + 1 < a.K) v.y = src[1];
+            if (gk + 2 < a.K) v.z = src[2];
+            if (gk + 3 < a.K) v.w = src[3];
+          }
+        }
+        float* d = &Bs[row * S + 4 * kq];
+        *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KC / 4; ++j) {
+      const float2 af = *reinterpret_cast<const float2*>(&As[(32 * w + r) * S + 4 * j + 2 * h]);
+      const float2 b0 = *reinterpret_cast<const float2*>(&Bs[r * S + 4 * j + 2 * h]);
+      const float2 b1 = *reinterpret_cast<const float2*>(&Bs[(32 + r) * S + 4 * j + 2 * h]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b1.y, acc1, 0, 0, 0);
+    }
+  }
+
+  float* __restrict__ op = a.out + (size_t)ag * a.M * a.N;
+  const float* __restrict__ rp = EPI == 1 ? a.res + (size_t)ag * a.M * a.N : nullptr;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = n0 + 32 * t + r;
+    const bool cok = col < a.N;
+    const float b = cok ? a.bias[col] : 0.f;
+    float cs = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      float v = (t == 0 ? acc0[reg] : acc1[reg]) + b;
+      if (cok && m < a.M) {
+        if (EPI == 0) v = gelu_erf_f(v);
+        else { v += rp[(size_t)m * a.N + col]; cs += v; }
+        op[(size_t)m * a.N + col] = v;
+      }
+    }
+    if (EPI == 1) {
+      cs += __shfl_xor(cs, 32, 64);
+      if (h == 0 && cok) atomicAdd(&a.colsum[(size_t)ag * a.N + col], cs);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: depthwise 3x3 (+bias) + GELU on the first 2C hidden channels, times the other 2C
+// (enhancer.py:241-246).  Lanes run over channels (contiguous in NHWC); each thread slides a
+// 3x3 register window along a strip of SL pixels.
+// ---------------------------------------------------------------------------------------------
+struct EnhDwArgs {
+  const float* Hd;  // [n][H][W][2*hid]
+  const float* w;   // [hid][9]
+  const float* b;   // [hid]
+  float* G;         // [n][H][W][hid]
+  int hid, H, W;
+};
+
+template <int SL>
+__global__ __launch_bounds__(256) void enh_dwgate_kernel(const EnhDwArgs a) {
+  const int n = blockIdx.y;
+  const int nstrip_x = (a.W + SL - 1) / SL;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)a.H * nstrip_x * a.hid;
+  if (idx >= total) return;
+  const int j = (int)(idx % a.hid);
+  const int s = (int)(idx / a.hid);
+  const int y = s / nstrip_x, xs = (s - y * nstrip_x) * SL;
+  const int ld = 2 * a.hid;
+  const float* __restrict__ hp = a.Hd + (size_t)n * a.H * a.W * ld;
+  float wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = a.w[j * 9 + t];
+  const float bias = a.b[j];
+  auto ld3 = [&](int x, float (&col)[3]) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y - 1 + dy;
+      col[dy] = (yy >= 0 && yy < a.H && x >= 0 && x < a.W) ? hp[((size_t)yy * a.W + x) * ld + j] : 0.f;
+    }
+  };
+  float c0[3], c1[3], c2[3];
+  ld3(xs - 1, c0);
+  ld3(xs, c1);
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const int x = xs + i;
+    if (x >= a.W) break;
+    ld3(x + 1, c2);
+    float d = bias;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) d = fmaf(wv[dy * 3 + 0], c0[dy], fmaf(wv[dy * 3 + 1], c1[dy], fmaf(wv[dy * 3 + 2], c2[dy], d)));
+    const float gate = hp[((size_t)y * a.W + x) * ld + a.hid + j];
+    a.G[((size_t)n * a.H * a.W + (size_t)y * a.W + x) * a.hid + j] = gelu_erf_f(d) * gate;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) { c0[dy] = c1[dy]; c1[dy] = c2[dy]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: SplitAttn gate per agent: mean over H,W -> fc1 -> LayerNorm -> ReLU -> fc2 -> sigmoid.
+// ---------------------------------------------------------------------------------------------
+struct EnhGateArgs {
+  const float* colsum;  // [n][C] sums over pixels
+  const float* fc1; const float* lnw; const float* lnb; const float* fc2;  // [C][C],[C],[C],[C][C]
+  float* gate;          // [n][C]
+  int C; float inv_hw;
+};
+
+__global__ __launch_bounds__(256) void enh_gate_kernel(const EnhGateArgs a) {
+  extern __shared__ float smem[];
+  const int C = a.C, tid = threadIdx.x, n = blockIdx.x;
+  float* g = smem;       // [C]
+  float* t1 = smem + C;  // [C]
+  float* red = smem + 2 * C;  // [8]
+  for (int c = tid; c < C; c += 256) g[c] = a.colsum[(size_t)n * C + c] * a.inv_hw;
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s = fmaf(a.fc1[(size_t)c * C + k], g[k], s);
+    t1[c] = s;
+  }
+  __syncthreads();
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+  };
+  float s = 0.f;
+  for (int c = tid; c < C; c += 256) s += t1[c];
+  const float mean = block_sum(s) / (float)C;
+  float v = 0.f;
+  for (int c = tid; c < C; c += 256) { const float d = t1[c] - mean; v = fmaf(d, d, v); }
+  const float rstd = 1.0f / sqrtf(block_sum(v) / (float)C + 1e-5f);
+  for (int c = tid; c < C; c += 256) g[c] = fmaxf(fmaf((t1[c] - mean) * rstd, a.lnw[c], a.lnb[c]), 0.f);
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s2 = 0.f;
+    for (int k = 0; k < C; ++k) s2 = fmaf(a.fc2[(size_t)c * C + k], g[k], s2);
+    a.gate[(size_t)n * C + c] = 1.0f / (1.0f + expf(-s2));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: out[n][c][p] = O[n][p][c] * gate[n][c]   (channel gate + NHWC -> NCHW, enhancer.py:332, :380)
+// ---------------------------------------------------------------------------------------------
+struct EnhOutArgs {
+  const float* O; const float* gate; float* out; int C, HW;
+};
+__global__ __launch_bounds__(256) void enh_scale_transpose_kernel(const EnhOutArgs a) {
+  extern __shared__ float smem[];  // [32][C+1]
+  const int C = a.C, S = C + 1, tid = threadIdx.x, n = blockIdx.y, p0 = blockIdx.x * 32;
+  const int np = min(32, a.HW - p0);
+  const float* __restrict__ ip = a.O + ((size_t)n * a.HW + p0) * C;
+  for (int i = tid; i < np * C; i += 256) { const int pp = i / C, c = i - pp * C; smem[pp * S + c] = ip[i]; }
+  __syncthreads();
+  const int p = tid & 31;
+  for (int c = tid >> 5; c < C; c += 8)
+    if (p < np) a.out[((size_t)n * C + c) * a.HW + p0 + p] = smem[p * S + c] * a.gate[(size_t)n * C + c];
+}
+
+}  // namespace gc

@@ -1,0 +1,179 @@
+// C ABI of libgencomm_hip.so (declared in include/gencomm_hip.h).
+#include "../../include/gencomm_hip.h"
+
+#include "common.h"
+#include "enhancer_host.h"
+#include "fusion_kernels.h"
+#include "unet_host.h"
+
+namespace gc {
+char* last_error_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+}  // namespace gc
+
+using namespace gc;
+
+extern "C" {
+
+int gencomm_abi_version(void) { return GENCOMM_ABI_VERSION; }
+const char* gencomm_last_error(void) { return last_error_buf(); }
+
+// ------------------------------------------------------------------------------------ UNet
+int gencomm_unet_num_params(int C, int levels, int res_blocks) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, 1)) { fail(GC_ERR_ARG, e); return -1; }
+  return (int)p.params.size();
+}
+
+int gencomm_unet_param_info(int C, int levels, int res_blocks, int index, char* name, int name_cap,
+                            long long* numel, long long* offset) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, 1)) return fail(GC_ERR_ARG, e);
+  GC_CHECK_ARG(index >= 0 && index < (int)p.params.size(), "param index out of range");
+  GC_CHECK_ARG(name && name_cap > 0 && numel && offset, "null output pointer");
+  snprintf(name, (size_t)name_cap, "%s", p.params[index].name.c_str());
+  *numel = p.params[index].numel;
+  *offset = p.params[index].off;
+  return GC_OK;
+}
+
+long long gencomm_unet_raw_floats(int C, int levels, int res_blocks) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, 1)) { fail(GC_ERR_ARG, e); return -1; }
+  return p.raw_floats;
+}
+
+long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int T) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, T)) { fail(GC_ERR_ARG, e); return -1; }
+  return p.prepared_floats;
+}
+
+int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int T, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, T)) return fail(GC_ERR_ARG, e);
+  GC_CHECK_ARG(raw && prepared, "null pointer");
+  return unet_prepare_enqueue(p, raw, prepared, (hipStream_t)stream);
+}
+
+long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, 1)) { fail(GC_ERR_ARG, e); return -1; }
+  if (n < 1 || H < 1 || W < 1) { fail(GC_ERR_ARG, "n, H, W must be positive"); return -1; }
+  UNetWorkspace w;
+  if (const char* e = w.build(p, n, H, W)) { fail(GC_ERR_ARG, e); return -1; }
+  return (long long)w.total;
+}
+
+static int check_dims(int n, int C, int H, int W) {
+  GC_CHECK_ARG(n >= 1 && n <= 65535, "n (agents) must be in 1..65535");
+  GC_CHECK_ARG(H >= 1 && W >= 1 && (long long)H * W * C < (1LL << 40), "bad H/W");
+  GC_CHECK_ARG((long long)n * (C / 16) <= 65535, "n * C/16 exceeds the grid z limit");
+  return GC_OK;
+}
+
+int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,
+                     int n, int C, int H, int W, int levels, int res_blocks, int T,
+                     void* workspace, long long workspace_bytes, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, T)) return fail(GC_ERR_ARG, e);
+  if (int rc = check_dims(n, C, H, W)) return rc;
+  GC_CHECK_ARG(prepared && x_t && cond && x0_out && workspace, "null pointer");
+  GC_CHECK_ARG(t >= 0 && t < T, "timestep out of range");
+  UNetWorkspace w;
+  if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
+  if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_denoise_workspace_bytes)");
+  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream};
+  ConvOutArgs co{};
+  co.out = x0_out;
+  return unet_enqueue(c, x_t, cond, t, 0, co);
+}
+
+int gencomm_denoise_fwd(const float* prepared, const float* sched,
+                        const float* feat, int n_feat_rows, const int* src_row, const float* cond,
+                        float* out, const float* noise0, const float* step_noise, unsigned long long seed,
+                        int n, int C, int H, int W, int levels, int res_blocks, int T,
+                        void* workspace, long long workspace_bytes, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, T)) return fail(GC_ERR_ARG, e);
+  if (int rc = check_dims(n, C, H, W)) return rc;
+  GC_CHECK_ARG(prepared && sched && feat && src_row && cond && out && workspace, "null pointer");
+  GC_CHECK_ARG(n_feat_rows >= 1, "n_feat_rows must be positive");
+  GC_CHECK_ARG((noise0 == nullptr) == (step_noise == nullptr), "noise0 and step_noise must both be given or both be null");
+  UNetWorkspace w;
+  if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
+  if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_denoise_workspace_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  const bool philox = noise0 == nullptr;
+  const long long per_agent = (long long)C * H * W;
+
+  QSampleArgs q{feat, src_row, noise0, sched + (size_t)(T - 1) * 5, out, seed, (unsigned)T, per_agent};
+  const dim3 qgrid((unsigned)std::min<long long>((per_agent / 4 + 255) / 256, 2048), n);
+  if (philox) q_sample_kernel<true><<<qgrid, 256, 0, st>>>(q);
+  else q_sample_kernel<false><<<qgrid, 256, 0, st>>>(q);
+
+  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st};
+  for (int i = 0; i < T; ++i) {
+    const int t = T - 1 - i;
+    ConvOutArgs co{};
+    co.out = out;
+    co.xt = out;
+    co.sched = sched + (size_t)t * 5;
+    co.noise = philox ? nullptr : step_noise + (size_t)i * n * per_agent;
+    co.seed = seed;
+    co.stream_id = (unsigned)t;
+    const int post = t == 0 ? 0 : (philox ? 2 : 1);
+    if (int rc = unet_enqueue(c, out, cond, t, post, co)) return rc;
+  }
+  return GC_OK;
+}
+
+// ------------------------------------------------------------------------------------ Enhancer
+int gencomm_enhancer_num_params(int C) {
+  EnhancerPlan p;
+  if (const char* e = p.build(C)) { fail(GC_ERR_ARG, e); return -1; }
+  return (int)p.params.size();
+}
+int gencomm_enhancer_param_info(int C, int index, char* name, int name_cap, long long* numel, long long* offset) {
+  EnhancerPlan p;
+  if (const char* e = p.build(C)) return fail(GC_ERR_ARG, e);
+  GC_CHECK_ARG(index >= 0 && index < (int)p.params.size(), "param index out of range");
+  GC_CHECK_ARG(name && name_cap > 0 && numel && offset, "null output pointer");
+  snprintf(name, (size_t)name_cap, "%s", p.params[index].name.c_str());
+  *numel = p.params[index].numel;
+  *offset = p.params[index].off;
+  return GC_OK;
+}
+long long gencomm_enhancer_raw_floats(int C) {
+  EnhancerPlan p;
+  if (const char* e = p.build(C)) { fail(GC_ERR_ARG, e); return -1; }
+  return p.raw_floats;
+}
+long long gencomm_enhancer_workspace_bytes(int n, int C, int H, int W) {
+  EnhancerPlan p;
+  if (const char* e = p.build(C)) { fail(GC_ERR_ARG, e); return -1; }
+  if (n < 1 || H < 1 || W < 1) { fail(GC_ERR_ARG, "n, H, W must be positive"); return -1; }
+  return (long long)enhancer_workspace_bytes(p, n, H, W);
+}
+int gencomm_enhancer_fwd(const float* raw, const float* x, float* out, int n, int C, int H, int W,
+                         void* workspace, long long workspace_bytes, void* stream) {
+  EnhancerPlan p;
+  if (const char* e = p.build(C)) return fail(GC_ERR_ARG, e);
+  GC_CHECK_ARG(raw && x && out && workspace, "null pointer");
+  GC_CHECK_ARG(n >= 1 && n <= 65535 && H >= 1 && W >= 1, "bad n/H/W");
+  if ((long long)enhancer_workspace_bytes(p, n, H, W) > workspace_bytes)
+    return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_enhancer_workspace_bytes)");
+  return enhancer_enqueue(p, raw, x, out, n, H, W, (char*)workspace, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ fusion
+int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
+                             int B, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(x && theta && scene_off && out, "null pointer");
+  GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && C >= 1 && H >= 1 && W >= 1, "bad B/n/C/H/W");
+  return warp_attfuse_enqueue(x, theta, scene_off, out, B, n, C, H, W, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// Host launch logic of the UNet / sampler (stream-ordered, allocation-free, capture-safe).
+#pragma once
+#include "unet_kernels.h"
+#include "unet_plan.h"
+
+namespace gc {
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Tile choice: the largest tile that still gives every CU (256 of them) at least ~2 workgroups.
+enum TileCfg { TILE_64x16 = 0, TILE_32x16 = 1, TILE_32x8 = 2 };
+inline TileCfg pick_tile(int n, int H, int W, int zmul = 1) {
+  const long long want = 512;
+  if ((long long)cdiv(W, 64) * cdiv(H, 16) * n * zmul >= want) return TILE_64x16;
+  if ((long long)cdiv(W, 32) * cdiv(H, 16) * n * zmul >= want) return TILE_32x16;
+  return TILE_32x8;
+}
+inline void tile_dims(TileCfg t, int* tw, int* th) {
+  *tw = t == TILE_64x16 ? 64 : 32;
+  *th = t == TILE_32x8 ? 8 : 16;
+}
+
+template <int NSRC, bool GN, bool UP, int RES>
+inline void launch_conv8(TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
+  int tw, th;
+  tile_dims(t, &tw, &th);
+  const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
+  switch (t) {
+    case TILE_64x16: conv8_kernel<64, 16, NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a); break;
+    case TILE_32x16: conv8_kernel<32, 16, NSRC, GN, UP, RES><<<grid, 128, 0, st>>>(a); break;
+    default: conv8_kernel<32, 8, NSRC, GN, UP, RES><<<grid, 64, 0, st>>>(a); break;
+  }
+}
+
+struct UNetCall {
+  const UNetPlan* plan;
+  const UNetWorkspace* ws;
+  const float* prepared;
+  char* wsp;  // workspace base
+  int n, H, W;
+  hipStream_t st;
+
+  float* tensor_ptr(int id) const {
+    const TensorPlan& t = plan->tensors[id];
+    return reinterpret_cast<float*>(wsp + ws->level_base[t.level] + ws->slot_bytes[t.level] * t.slot);
+  }
+  double* stat_ptr(int id) const { return reinterpret_cast<double*>(wsp) + (size_t)id * n * 16; }
+};
+
+// Enqueue one UNet evaluation for integer timestep t.  The last op (conv_out) is launched with
+// `post` (0 plain x0, 1 explicit noise, 2 Philox) and the pointers in `co` (xt/noise/sched/out/seed).
+inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, int t, int post,
+                        ConvOutArgs co) {
+  const UNetPlan& p = *c.plan;
+  const float* P = c.prepared;
+  GC_HIP(hipMemsetAsync(c.wsp, 0, c.ws->stats_bytes, c.st));
+  for (const Op& o : p.ops) {
+    const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level];
+    switch (o.kind) {
+      case OP_CONV_IN: {
+        ConvInArgs a{cond, x_t, P + p.conv_in.p_w, P + p.conv_in.b, c.tensor_ptr(o.dst), c.stat_ptr(o.dst), p.C, Hl, Wl};
+        const TileCfg tc = pick_tile(c.n, Hl, Wl);
+        int tw, th;
+        tile_dims(tc, &tw, &th);
+        const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n);
+        if (tc == TILE_64x16) conv_in_kernel<64, 16><<<grid, 256, 0, c.st>>>(a);
+        else if (tc == TILE_32x16) conv_in_kernel<32, 16><<<grid, 128, 0, c.st>>>(a);
+        else conv_in_kernel<32, 8><<<grid, 64, 0, c.st>>>(a);
+        break;
+      }
+      case OP_RES_CONV1: {
+        const ResBlockPlan& b = p.blocks[o.blk];
+        Conv8Args a{};
+        a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
+        if (o.src[1] >= 0) { a.src[1] = c.tensor_ptr(o.src[1]); a.sstat[1] = c.stat_ptr(o.src[1]); }
+        a.gamma = P + b.n1w; a.beta = P + b.n1b;
+        a.w = P + b.p_c1w; a.bias = P + b.p_bias1 + (size_t)t * 8;
+        a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
+        a.H = a.Hin = Hl; a.W = a.Win = Wl;
+        const TileCfg tc = pick_tile(c.n, Hl, Wl);
+        if (b.cin == 8) launch_conv8<1, true, false, 0>(tc, a, c.n, c.st);
+        else launch_conv8<2, true, false, 0>(tc, a, c.n, c.st);
+        break;
+      }
+      case OP_RES_CONV2: {
+        const ResBlockPlan& b = p.blocks[o.blk];
+        Conv8Args a{};
+        a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
+        a.gamma = P + b.n2w; a.beta = P + b.n2b;
+        a.w = P + b.p_c2w; a.bias = P + b.p_bias2;
+        a.res[0] = c.tensor_ptr(o.res[0]);
+        if (o.res[1] >= 0) { a.res[1] = c.tensor_ptr(o.res[1]); a.ninw = P + b.p_ninw; }
+        a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
+        a.H = a.Hin = Hl; a.W = a.Win = Wl;
+        const TileCfg tc = pick_tile(c.n, Hl, Wl);
+        if (b.cin == 8) launch_conv8<1, true, false, 1>(tc, a, c.n, c.st);
+        else launch_conv8<1, true, false, 2>(tc, a, c.n, c.st);
+        break;
+      }
+      case OP_DOWN: {
+        const int lin = o.level - 1;
+        DownArgs a{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst),
+                   c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin]};
+        down8_kernel<<<dim3(cdiv(Hl * Wl, 256), 1, c.n), 256, 0, c.st>>>(a);
+        break;
+      }
+      case OP_UP: {
+        const int lin = o.level + 1;
+        Conv8Args a{};
+        a.src[0] = c.tensor_ptr(o.src[0]);
+        a.w = P + p.up[lin].p_w; a.bias = P + p.up[lin].b;
+        a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
+        a.H = Hl; a.W = Wl; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin];
+        launch_conv8<1, false, true, 0>(pick_tile(c.n, Hl, Wl), a, c.n, c.st);
+        break;
+      }
+      case OP_CONV_OUT: {
+        co.src = c.tensor_ptr(o.src[0]); co.sstat = c.stat_ptr(o.src[0]);
+        co.gamma = P + p.nout_w; co.beta = P + p.nout_b;
+        co.w = P + p.conv_out.p_w; co.bias = P + p.conv_out.b;
+        co.C = p.C; co.H = Hl; co.W = Wl;
+        const int nocb = p.C / 16;
+        const TileCfg tc = pick_tile(c.n, Hl, Wl, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
+        int tw, th;
+        tile_dims(tc, &tw, &th);
+        const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n * nocb);
+#define GC_LAUNCH_CO(POST)                                                             \
+  do {                                                                                 \
+    if (tc == TILE_64x16) conv_out_kernel<64, 16, POST><<<grid, 256, 0, c.st>>>(co);   \
+    else conv_out_kernel<32, 8, POST><<<grid, 64, 0, c.st>>>(co);                      \
+  } while (0)
+        if (post == 0) GC_LAUNCH_CO(0);
+        else if (post == 1) GC_LAUNCH_CO(1);
+        else GC_LAUNCH_CO(2);
+#undef GC_LAUNCH_CO
+        break;
+      }
+    }
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prepared, hipStream_t st) {
+  GC_HIP(hipMemcpyAsync(prepared, raw, (size_t)p.raw_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+  auto conv_w = [&](long long src, long long dst, int OC, int IC, int OCB) {
+    const int total = OC * IC * 9;
+    prep_conv_w_kernel<<<cdiv(total, 256), 256, 0, st>>>(raw + src, prepared + dst, OC, IC, OCB);
+  };
+  conv_w(p.conv_in.w, p.conv_in.p_w, 8, p.C + 2, 8);
+  conv_w(p.conv_out.w, p.conv_out.p_w, p.C, 8, 16);
+  for (int l = 0; l < p.L; ++l) {
+    if (p.down[l].w >= 0) conv_w(p.down[l].w, p.down[l].p_w, 8, 8, 8);
+    if (p.up[l].w >= 0) conv_w(p.up[l].w, p.up[l].p_w, 8, 8, 8);
+  }
+  TembArgs ta{};
+  ta.raw = raw; ta.prepared = prepared;
+  ta.d0w = p.d0w; ta.d0b = p.d0b; ta.d1w = p.d1w; ta.d1b = p.d1b;
+  ta.nblocks = (int)p.blocks.size(); ta.T = p.T;
+  for (size_t i = 0; i < p.blocks.size(); ++i) {
+    const ResBlockPlan& b = p.blocks[i];
+    conv_w(b.c1w, b.p_c1w, 8, b.cin, 8);
+    conv_w(b.c2w, b.p_c2w, 8, 8, 8);
+    if (b.cin != 8) prep_nin_w_kernel<<<1, 256, 0, st>>>(raw + b.ninw, prepared + b.p_ninw, 8, b.cin);
+    prep_add_kernel<<<1, 64, 0, st>>>(raw + b.c2b, b.cin != 8 ? raw + b.ninb : nullptr, prepared + b.p_bias2, 8);
+    ta.tpw[i] = b.tpw; ta.tpb[i] = b.tpb; ta.c1b[i] = b.c1b; ta.dst[i] = b.p_bias1;
+  }
+  prep_temb_kernel<<<p.T, 64, 0, st>>>(ta);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+}  // namespace gc

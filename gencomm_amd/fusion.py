@@ -1,0 +1,75 @@
+"""``AttFusion`` / ``regroup`` / ``normalize_pairwise_tfm`` -- host-side mirrors of
+``opencood/models/fuse_modules/fusion_in_one.py:126-151, :48-51`` and
+``opencood/utils/transformation_utils.py:68-92``; the warp + per-pixel attention runs as one HIP
+gather kernel (``gencomm_warp_attfuse_fwd``)."""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .runtime import f32c, ptr, record_len_list, require_gpu, stream_ptr
+
+MAX_AGENTS_PER_SCENE = 8
+
+
+def regroup(x: torch.Tensor, record_len) -> tuple:
+    """Split the sumN axis by scene (fusion_in_one.py:48-51)."""
+    lens = record_len_list(record_len)
+    return torch.split(x, lens, dim=0)
+
+
+def normalize_pairwise_tfm(pairwise_t_matrix: torch.Tensor, H, W, discrete_ratio, downsample_rate=1) -> torch.Tensor:
+    """[B,L,L,4,4] -> [B,L,L,2,3] normalised affine for ``affine_grid`` (transformation_utils.py:68-92).
+    A few dozen float64 scalars per batch: done with torch indexing on whatever device the poses
+    are on. Unlike the reference this does not modify a view of its argument."""
+    a = pairwise_t_matrix[:, :, :, [0, 1], :][:, :, :, :, [0, 1, 3]].clone()
+    a[..., 0, 1] = a[..., 0, 1] * H / W
+    a[..., 1, 0] = a[..., 1, 0] * W / H
+    a[..., 0, 2] = a[..., 0, 2] / (downsample_rate * discrete_ratio * W) * 2
+    a[..., 1, 2] = a[..., 1, 2] / (downsample_rate * discrete_ratio * H) * 2
+    return a
+
+
+def gather_ego_thetas(affine_matrix: torch.Tensor, lens: List[int]) -> torch.Tensor:
+    """[sumN, 2, 3] float64: for scene b the rows affine_matrix[b, 0, :N_b] (= ``t_matrix[0, :, :, :]``
+    in AttFusion.forward, fusion_in_one.py:140-144)."""
+    rows = [affine_matrix[b, 0, :n] for b, n in enumerate(lens)]
+    return torch.cat(rows, dim=0).to(torch.float64).contiguous()
+
+
+class ScaledDotProductAttention(nn.Module):  # fusion_in_one.py:14-45 (no parameters)
+    def __init__(self, dim):
+        super().__init__()
+        self.sqrt_dim = float(dim) ** 0.5
+
+
+class AttFusion(nn.Module):
+    def __init__(self, feature_dims):
+        super().__init__()
+        self.att = ScaledDotProductAttention(feature_dims)
+
+    def forward(self, xx, record_len, affine_matrix):
+        """xx [sumN,C,H,W], record_len [B], affine_matrix [B,L,L,2,3] -> [B,C,H,W]."""
+        require_gpu(xx, "AttFusion.forward")
+        if torch.is_grad_enabled() and xx.requires_grad:
+            raise NotImplementedError("gencomm_amd.AttFusion: backward is not implemented yet; call under torch.no_grad()")
+        lens = record_len_list(record_len)
+        n, C, H, W = xx.shape
+        B = affine_matrix.shape[0]
+        if len(lens) != B or sum(lens) != n:
+            raise ValueError(f"record_len {lens} inconsistent with {n} agents / {B} scenes")
+        if min(lens) < 1 or max(lens) > MAX_AGENTS_PER_SCENE:
+            raise ValueError(f"each scene needs 1..{MAX_AGENTS_PER_SCENE} agents, got {lens}")
+        xx = f32c(xx)
+        theta = gather_ego_thetas(affine_matrix, lens).to(xx.device)
+        off = [0]
+        for k in lens:
+            off.append(off[-1] + k)
+        scene_off = torch.tensor(off, dtype=torch.int32, device=xx.device)
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=xx.device)
+        _lib.check(_lib.lib().gencomm_warp_attfuse_fwd(ptr(xx), ptr(theta), ptr(scene_off), ptr(out), B, n, C, H, W,
+                                                       stream_ptr(xx.device)), "gencomm_warp_attfuse_fwd")
+        return out

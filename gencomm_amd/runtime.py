@@ -1,0 +1,97 @@
+"""Device-memory plumbing between torch tensors and the C ABI: pointers, the current HIP stream,
+a growable per-device scratch workspace, and parameter-blob packing with change detection."""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _lib.GenCommHipError(
+            f"{what}: tensor is on {t.device}; the GenComm hot path runs only as HIP kernels on a "
+            "ROCm device (gfx950) and has no CPU fallback")
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """float32 + contiguous view/copy (AMP callers hand in fp16/bf16; arithmetic here is fp32)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _Workspaces:
+    """One growable byte buffer per (device, tag). Kernels are stream-ordered on the caller's
+    current stream, so reuse across calls on that stream is safe."""
+
+    def __init__(self):
+        self._bufs: Dict[Tuple[int, str], torch.Tensor] = {}
+
+    def get(self, device: torch.device, nbytes: int, tag: str = "main") -> torch.Tensor:
+        key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            self._bufs.pop(key, None)
+            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+    def clear(self) -> None:
+        self._bufs.clear()
+
+
+workspaces = _Workspaces()
+
+
+class PackedParams:
+    """Flat float32 copy of selected parameters in the order the C side enumerates them, rebuilt
+    only when a parameter changed (``_version`` / storage pointer / device)."""
+
+    def __init__(self, table: Sequence[Tuple[str, int, int]], total_floats: int):
+        self.table = list(table)
+        self.total = total_floats
+        self._key = None
+        self.flat: torch.Tensor = None
+        self.generation = 0
+
+    def update(self, named: Dict[str, torch.Tensor]) -> bool:
+        """Returns True when the blob was (re)built."""
+        tensors = []
+        for name, numel, _ in self.table:
+            if name not in named:
+                raise KeyError(f"parameter '{name}' expected by the HIP library is missing from the module")
+            t = named[name]
+            if t.numel() != numel:
+                raise ValueError(f"parameter '{name}' has {t.numel()} elements, the HIP library expects {numel}")
+            tensors.append(t)
+        key = tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in tensors)
+        if key == self._key and self.flat is not None:
+            return False
+        with torch.no_grad():
+            self.flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+        assert self.flat.numel() == self.total, (self.flat.numel(), self.total)
+        self._key = key
+        self.generation += 1
+        return True
+
+
+def record_len_list(record_len) -> List[int]:
+    """Scene lengths as Python ints (one D2H sync when given a device tensor; the reference's
+    ``regroup`` does the same ``.cpu()`` on every call, fusion_in_one.py:48-51)."""
+    if record_len is None:
+        return None
+    if isinstance(record_len, torch.Tensor):
+        return [int(v) for v in record_len.detach().cpu().tolist()]
+    return [int(v) for v in record_len]

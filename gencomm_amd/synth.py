@@ -1,0 +1,158 @@
+"""Deterministic synthetic weights / inputs for the GenComm hot path.
+
+Everything here is generated with ``numpy.random.RandomState`` (MT19937, bit-reproducible across
+machines and numpy versions), never with torch's RNG, so that
+
+* the golden-vector generator (``oracle/make_golden.py``, runs where the reference is mounted),
+* the parity tests (``tests/``, run on the GPU box where the reference is absent) and
+* ``bench.py``
+
+all see byte-identical weights, inputs and diffusion noise from nothing but a seed and a shape.
+
+Workload definition follows SURVEY.md section 8(d): ``feat = relu(N(0,1))`` (post-ReLU backbone
+statistics, reference ``opencood/models/sub_modules/downsample_conv.py:23``), ``cond = N(0,1)``,
+ego pose identity, collaborators random SE(2) with yaw ~ U(-pi, pi), translation ~ U(-40, 40) m.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+__all__ = [
+    "default_gencomm_cfg",
+    "fill_params_",
+    "make_inputs",
+    "make_pairwise_t_matrix",
+    "noise_stream",
+    "make_eval_noise",
+    "make_train_noise",
+]
+
+
+def default_gencomm_cfg(C: int, T: int) -> dict:
+    """The ``model.args.gencomm`` block of every shipped yaml (e.g. reference
+    ``opencood/hypes_yaml/opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml:150-165``) with the
+    feature width and step count substituted."""
+    return {
+        "model": {
+            "embed_dim": C + 2,
+            "in_channels": C,
+            "out_ch": C,
+            "ch": 8,
+            "ch_mult": [1, 1],
+            "num_res_blocks": 2,
+            "attn_resolutions": [16],
+            "dropout": 0.0,
+            "resamp_with_conv": True,
+        },
+        "diffusion": {
+            "beta_schedule": "linear",
+            "beta_start": 0.0005,
+            "beta_end": 0.02,
+            "num_diffusion_timesteps": T,
+        },
+    }
+
+
+def _param_values(name: str, shape: Tuple[int, ...], rng: np.random.RandomState) -> np.ndarray:
+    """One tensor of synthetic weights. Norm scales are drawn around 1 and all biases are
+    non-zero so that a kernel which drops an affine term cannot pass parity."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    leaf = name.rsplit(".", 1)[-1]
+    if len(shape) <= 1:
+        if leaf == "weight":  # GroupNorm / LayerNorm scale
+            v = 1.0 + 0.2 * rng.standard_normal(n)
+        else:  # any bias
+            v = 0.1 * rng.standard_normal(n)
+    else:
+        fan_in = int(np.prod(shape[1:]))
+        bound = 1.0 / math.sqrt(max(fan_in, 1))
+        v = rng.uniform(-bound, bound, size=n)
+    return v.astype(np.float32).reshape(shape)
+
+
+def fill_params_(module, seed: int) -> None:
+    """Overwrite every parameter of ``module`` (a ``torch.nn.Module``) in sorted-name order
+    from one RandomState(seed) stream. Buffers (the diffusion schedule) are left alone."""
+    import torch
+
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in sorted(module.named_parameters(), key=lambda kv: kv[0]):
+            v = _param_values(name, tuple(p.shape), rng)
+            p.copy_(torch.from_numpy(v).to(p.device, p.dtype))
+
+
+def make_pairwise_t_matrix(record_len: Sequence[int], max_cav: int, seed: int,
+                           max_shift: float = 40.0) -> np.ndarray:
+    """[B, L, L, 4, 4] float64; entry [b, i, j] maps agent i's frame into agent j's frame
+    (reference ``opencood/utils/transformation_utils.py:20-64``: T_ji = T_jw . T_wi).
+    Agent 0 (ego) sits at the world origin."""
+    rng = np.random.RandomState(seed)
+    B = len(record_len)
+    out = np.tile(np.eye(4), (B, max_cav, max_cav, 1, 1))
+    for b, n in enumerate(record_len):
+        world = []
+        for a in range(n):
+            T = np.eye(4)
+            if a > 0:
+                yaw = rng.uniform(-math.pi, math.pi)
+                tx, ty = rng.uniform(-max_shift, max_shift, size=2)
+                c, s = math.cos(yaw), math.sin(yaw)
+                T[0, 0], T[0, 1], T[1, 0], T[1, 1] = c, -s, s, c
+                T[0, 3], T[1, 3] = tx, ty
+            world.append(T)
+        for i in range(n):
+            for j in range(n):
+                if i != j:
+                    out[b, i, j] = np.linalg.solve(world[j], world[i])
+    return out
+
+
+def make_inputs(record_len: Sequence[int], C: int, H: int, W: int, seed: int,
+                max_cav: int = 5, max_shift: float = 40.0) -> Dict[str, np.ndarray]:
+    """Synthetic batch for the path: ``feat`` [sumN,C,H,W] f32, ``cond`` [sumN,2,H,W] f32,
+    ``record_len`` [B] int64, ``pairwise_t_matrix`` [B,L,L,4,4] f64."""
+    n = int(sum(record_len))
+    rng = np.random.RandomState(seed)
+    feat = np.maximum(rng.standard_normal((n, C, H, W)), 0.0).astype(np.float32)
+    cond = rng.standard_normal((n, 2, H, W)).astype(np.float32)
+    return {
+        "feat": feat,
+        "cond": cond,
+        "record_len": np.asarray(record_len, dtype=np.int64),
+        "pairwise_t_matrix": make_pairwise_t_matrix(record_len, max_cav, seed + 7, max_shift),
+    }
+
+
+def noise_stream(seed: int, k: int, shape: Tuple[int, ...]) -> np.ndarray:
+    """The k-th N(0,1) draw of a run, as float32. Each draw has its own RandomState so that
+    a consumer may skip draws it does not need (the reference draws and discards several)."""
+    return np.random.RandomState((seed * 1000003 + k) % (2 ** 31 - 1)).standard_normal(shape).astype(np.float32)
+
+
+def make_eval_noise(seed: int, n: int, C: int, H: int, W: int, T: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Noise in the order the reference's eval branch consumes it
+    (``opencood/models/gencomm_modules/cond_diff.py:367-375``, ``:307``):
+    draw 0 = x_start noise [n,C,H,W]; draws 1,2 = dead q_samples on the ego [1,C,H,W];
+    draws 3 .. 3+T-1 = one per denoise step, in loop order t = T-1 .. 0 (the last is drawn but
+    discarded). Returns (noise0 [n,C,H,W], step_noise [T,n,C,H,W]) where step_noise[i] is the draw
+    of loop iteration i (timestep T-1-i)."""
+    shape = (n, C, H, W)
+    noise0 = noise_stream(seed, 0, shape)
+    steps = np.stack([noise_stream(seed, 3 + i, shape) for i in range(T)], axis=0)
+    return noise0, steps
+
+
+def make_train_noise(seed: int, n: int, C: int, H: int, W: int, T: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Noise in the order of the training branch (``cond_diff.py:342-360``): per agent a:
+    one x_start draw [1,C,H,W], then T step draws [1,C,H,W] (t = T-1 .. 0; the t=0 one is discarded).
+    Draw index = a*(T+1) + {0, 1+i}. Returns the same layout as :func:`make_eval_noise`."""
+    shape1 = (1, C, H, W)
+    noise0 = np.concatenate([noise_stream(seed, a * (T + 1), shape1) for a in range(n)], axis=0)
+    steps = np.stack([
+        np.concatenate([noise_stream(seed, a * (T + 1) + 1 + i, shape1) for a in range(n)], axis=0)
+        for i in range(T)], axis=0)
+    return noise0, steps

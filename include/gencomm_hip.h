@@ -1,0 +1,108 @@
+/*
+ * gencomm_hip.h -- C ABI of libgencomm_hip.so: the MI355X (gfx950) implementation of GenComm's
+ * generative-communication hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every tensor pointer is DEVICE memory, float32, contiguous, NCHW unless stated;
+ *   - the caller owns every buffer, including the scratch workspace (query *_workspace_bytes);
+ *     the library allocates nothing, keeps no global state and is re-entrant per stream;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); all work is
+ *     enqueued on it and nothing synchronises the host, so calls may be captured in a hipGraph;
+ *   - every entry point returns 0 on success, non-zero on error (1 bad argument / unsupported
+ *     configuration, 2 workspace too small, 3 HIP runtime error) and never exits the process
+ *     (contrast the reference's CHECK_* macros, opencood/pcdet_utils/iou3d_nms/src/iou3d_nms.cpp:14-25);
+ *     gencomm_last_error() returns a thread-local description of the last failure.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference checkout):
+ *   gencomm_unet_prepare      DiffusionUNet parameter reads + get_timestep_embedding + temb MLP
+ *                             (opencood/models/gencomm_modules/unet.py:10-28, :222-228, :309-312)
+ *                             and every ResnetBlock.temb_proj (unet.py:124), for all T steps at once
+ *   gencomm_unet_fwd          DiffusionUNet.forward (unet.py:307-344) = GenComm.gen_pred
+ *                             (opencood/models/gencomm_modules/cond_diff.py:317-319)
+ *   gencomm_denoise_fwd       GenComm.forward eval+train maths: ego repeat (cond_diff.py:332-337),
+ *                             q_sample (:262-264, :372), p_sample_loop / p_sample / p_mean_variance /
+ *                             q_posterior (:321-329, :302-315, :281-299, :272-279)
+ *   gencomm_enhancer_fwd      Enhancer.forward -> Enhancer_block -> FRFN -> SplitAttn
+ *                             (opencood/models/gencomm_modules/enhancer.py:367-383, :346-357, :222-250, :315-333)
+ *   gencomm_warp_attfuse_fwd  AttFusion.forward + warp_affine_simple + ScaledDotProductAttention
+ *                             (opencood/models/fuse_modules/fusion_in_one.py:131-151, :41-45;
+ *                              opencood/models/sub_modules/torch_transformation_utils.py:323-332)
+ *
+ * Supported UNet family: ch = 8, ch_mult = all ones (any number of levels), num_res_blocks >= 1,
+ * resamp_with_conv = true, dropout = 0, no AttnBlock instantiated -- i.e. every shipped GenComm
+ * yaml (60/60 use ch 8, ch_mult [1,1], 2 res-blocks, attn_resolutions [16]).  C % 16 == 0.
+ */
+#ifndef GENCOMM_HIP_H
+#define GENCOMM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENCOMM_ABI_VERSION 1
+
+int gencomm_abi_version(void);
+const char* gencomm_last_error(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * UNet parameters.  The "raw" blob is the concatenation of the module's parameters in EXECUTION
+ * order; enumerate it with gencomm_unet_param_info (name = the reference's state_dict key under
+ * `denoiser.`, e.g. "down.0.block.1.conv2.weight"; tensors keep the reference layout: conv OIHW,
+ * linear [out,in]).  gencomm_unet_prepare turns it into the kernels' layout ([ic][tap][oc] conv
+ * weights) and evaluates the timestep path for t = 0..T-1 into a bias table; call it once per
+ * weight update.
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_unet_num_params(int C, int levels, int res_blocks);
+int gencomm_unet_param_info(int C, int levels, int res_blocks, int index,
+                            char* name, int name_cap, long long* numel, long long* offset);
+long long gencomm_unet_raw_floats(int C, int levels, int res_blocks);
+long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int T);
+int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int T,
+                         void* stream);
+
+/* Scratch for one UNet call / the denoise loop on n agents of [C, H, W]. */
+long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks);
+
+/* x0_hat[n,C,H,W] = UNet(cat[cond[n,2,H,W], x_t[n,C,H,W]], t) for one integer timestep t. */
+int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,
+                     int n, int C, int H, int W, int levels, int res_blocks, int T,
+                     void* workspace, long long workspace_bytes, void* stream);
+
+/* The whole sampler.  sched = device float[T][5] rows {sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod,
+ * posterior_mean_coef1, posterior_mean_coef2, exp(0.5*posterior_log_variance_clipped)}.
+ * x_start of agent i = feat[src_row[i]] (src_row: device int32[n]; the ego row of i's scene).
+ * noise0 [n,C,H,W] and step_noise [T,n,C,H,W] (loop order t = T-1..0; entry T-1 unused) are either
+ * both given (explicit noise: parity tests) or both NULL (in-kernel Philox4x32-10 keyed by `seed`).
+ * out [n,C,H,W] receives pred_feature; it is also the in-place x_t buffer of the loop. */
+int gencomm_denoise_fwd(const float* prepared, const float* sched,
+                        const float* feat, int n_feat_rows, const int* src_row, const float* cond,
+                        float* out, const float* noise0, const float* step_noise, unsigned long long seed,
+                        int n, int C, int H, int W, int levels, int res_blocks, int T,
+                        void* workspace, long long workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Enhancer (live parameters only: block_1.{norm1,norm2,mlp.*}, split_attn.*), raw blob enumerated
+ * like the UNet's; names are the reference's state_dict keys under `enhancer.`.
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_enhancer_num_params(int C);
+int gencomm_enhancer_param_info(int C, int index, char* name, int name_cap, long long* numel, long long* offset);
+long long gencomm_enhancer_raw_floats(int C);
+long long gencomm_enhancer_workspace_bytes(int n, int C, int H, int W);
+/* out[n,C,H,W] = split_attn(block_1(x[n,C,H,W])) per agent (agents are independent). */
+int gencomm_enhancer_fwd(const float* raw, const float* x, float* out, int n, int C, int H, int W,
+                         void* workspace, long long workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Warp every agent into its scene's ego frame and fuse with per-pixel attention over agents,
+ * keeping the ego row.  theta: device double[n][2][3], theta[i] = normalised affine that maps ego
+ * grid coordinates to agent i's (= affine_matrix[b, 0, j] of normalize_pairwise_tfm,
+ * opencood/utils/transformation_utils.py:68-92).  scene_off: device int32[B+1], agents of scene b
+ * are rows scene_off[b] .. scene_off[b+1]-1 of x.  out [B,C,H,W].  At most 8 agents per scene.
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
+                             int B, int n, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENCOMM_HIP_H */

@@ -1,0 +1,308 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+CPU restatement, in plain functional PyTorch (float32, the reference's own arithmetic type and
+the same ATen kernels the reference runs on a CPU), of GenComm's generative-communication path:
+
+    diffusion schedule -> q_sample -> T x (DiffusionUNet -> x0-parameterised ancestral step)
+    -> Enhancer (block_1 + SplitAttn) -> warp to ego + per-pixel cross-agent attention.
+
+Every function cites the reference lines it follows (paths relative to ``/root/reference``).
+It works on a flat ``state_dict`` (name -> tensor) using the reference's key names, and takes
+diffusion noise as explicit tensors so that results are reproducible.
+
+Pinned: ``tests/test_oracle_golden.py`` checks this file against golden vectors produced by
+running the reference's own modules (``oracle/make_golden.py``; fixtures in ``tests/golden``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module. It is also what ``bench.py`` times as ``cpu_baseline`` (kind "port").
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# schedule  (opencood/models/gencomm_modules/cond_diff.py:193-257, opencood/utils/MDD_utils.py:208-212)
+# --------------------------------------------------------------------------------------
+def make_schedule(T: int, linear_start: float = 5e-3, linear_end: float = 5e-2) -> Dict[str, Tensor]:
+    """The 12 persistent schedule buffers. The yaml's beta keys are ignored by the reference:
+    start/end are hard-coded (cond_diff.py:196-197). All maths in float64, cast to float32 last."""
+    betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, T, dtype=np.float64) ** 2
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)  # v_posterior = 0
+    out = {
+        "betas": betas,
+        "alphas_cumprod": ac,
+        "alphas_cumprod_prev": ac_prev,
+        "sqrt_alphas_cumprod": np.sqrt(ac),
+        "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": np.log(1.0 - ac),
+        "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / ac - 1),
+        "posterior_variance": post_var,
+        "posterior_log_variance_clipped": np.log(np.maximum(post_var, 1e-20)),
+        "posterior_mean_coef1": betas * np.sqrt(ac_prev) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+    }
+    return {k: torch.tensor(v, dtype=torch.float32) for k, v in out.items()}
+
+
+# --------------------------------------------------------------------------------------
+# UNet  (opencood/models/gencomm_modules/unet.py)
+# --------------------------------------------------------------------------------------
+def timestep_embedding(t: Tensor, dim: int) -> Tensor:
+    """unet.py:10-28."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float32) * -e)
+    e = t.float()[:, None] * e[None, :]
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+    if dim % 2 == 1:
+        e = F.pad(e, (0, 1, 0, 0))
+    return e
+
+
+def _silu(x: Tensor) -> Tensor:  # unet.py:31-33
+    return x * torch.sigmoid(x)
+
+
+def _gn(sd: SD, p: str, x: Tensor) -> Tensor:  # unet.py:36-37
+    return F.group_norm(x, 4, sd[p + ".weight"], sd[p + ".bias"], eps=1e-6)
+
+
+def _conv(sd: SD, p: str, x: Tensor, stride: int = 1, padding: int = 1) -> Tensor:
+    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], stride=stride, padding=padding)
+
+
+def _resblock(sd: SD, p: str, x: Tensor, temb: Tensor) -> Tensor:
+    """unet.py:119-138 (dropout p=0 in every shipped config, eval anyway)."""
+    h = _conv(sd, p + ".conv1", _silu(_gn(sd, p + ".norm1", x)))
+    h = h + F.linear(_silu(temb), sd[p + ".temb_proj.weight"], sd[p + ".temb_proj.bias"])[:, :, None, None]
+    h = _conv(sd, p + ".conv2", _silu(_gn(sd, p + ".norm2", h)))
+    if (p + ".nin_shortcut.weight") in sd:
+        x = _conv(sd, p + ".nin_shortcut", x, padding=0)
+    return x + h
+
+
+def _attnblock(sd: SD, p: str, x: Tensor) -> Tensor:
+    """unet.py:167-193 -- only instantiated when the nominal resolution is in attn_resolutions."""
+    h = _gn(sd, p + ".norm", x)
+    q = _conv(sd, p + ".q", h, padding=0)
+    k = _conv(sd, p + ".k", h, padding=0)
+    v = _conv(sd, p + ".v", h, padding=0)
+    b, c, hh, ww = q.shape
+    q = q.reshape(b, c, hh * ww).permute(0, 2, 1)
+    k = k.reshape(b, c, hh * ww)
+    w_ = torch.bmm(q, k) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2)
+    v = v.reshape(b, c, hh * ww)
+    h = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + _conv(sd, p + ".proj_out", h, padding=0)
+
+
+def unet_forward(sd: SD, p: str, x: Tensor, t: Tensor, mcfg: dict) -> Tensor:
+    """DiffusionUNet.forward, unet.py:307-344. ``p`` is the key prefix (e.g. "denoiser")."""
+    ch = mcfg["ch"]
+    nres = len(mcfg["ch_mult"])
+    nblk = mcfg["num_res_blocks"]
+    temb = timestep_embedding(t, ch)
+    temb = F.linear(temb, sd[p + ".temb.dense.0.weight"], sd[p + ".temb.dense.0.bias"])
+    temb = F.linear(_silu(temb), sd[p + ".temb.dense.1.weight"], sd[p + ".temb.dense.1.bias"])
+    hs = [_conv(sd, p + ".conv_in", x)]
+    for lvl in range(nres):
+        for b in range(nblk):
+            h = _resblock(sd, f"{p}.down.{lvl}.block.{b}", hs[-1], temb)
+            if f"{p}.down.{lvl}.attn.{b}.norm.weight" in sd:
+                h = _attnblock(sd, f"{p}.down.{lvl}.attn.{b}", h)
+            hs.append(h)
+        if lvl != nres - 1:
+            # Downsample, unet.py:71-75: zero-pad right/bottom by one, then 3x3 stride 2 pad 0
+            hs.append(_conv(sd, f"{p}.down.{lvl}.downsample.conv", F.pad(hs[-1], (0, 1, 0, 1)), stride=2, padding=0))
+    h = hs[-1]
+    h = _resblock(sd, p + ".mid.block_1", h, temb)
+    h = _resblock(sd, p + ".mid.block_2", h, temb)
+    for lvl in reversed(range(nres)):
+        for b in range(nblk + 1):
+            h = _resblock(sd, f"{p}.up.{lvl}.block.{b}", torch.cat([h, hs.pop()], dim=1), temb)
+            if f"{p}.up.{lvl}.attn.{b}.norm.weight" in sd:
+                h = _attnblock(sd, f"{p}.up.{lvl}.attn.{b}", h)
+        if lvl != 0:
+            # Upsample, unet.py:51-56: nearest x2 then 3x3
+            h = _conv(sd, f"{p}.up.{lvl}.upsample.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+    return _conv(sd, p + ".conv_out", _silu(_gn(sd, p + ".norm_out", h)))
+
+
+# --------------------------------------------------------------------------------------
+# sampler  (cond_diff.py:262-383)
+# --------------------------------------------------------------------------------------
+def regroup_lens(record_len) -> List[int]:
+    """fusion_in_one.py:48-51 reduces to: split the sumN axis by these lengths."""
+    return [int(v) for v in (record_len.tolist() if hasattr(record_len, "tolist") else record_len)]
+
+
+def ego_repeat(feat: Tensor, record_len) -> Tensor:
+    """cond_diff.py:332-337: every agent's x_start is its scene's EGO feature."""
+    out, o = [], 0
+    for n in regroup_lens(record_len):
+        out.append(feat[o:o + 1].repeat(n, 1, 1, 1))
+        o += n
+    return torch.cat(out, dim=0)
+
+
+def q_sample(sched: Dict[str, Tensor], x0: Tensor, t: int, noise: Tensor) -> Tensor:
+    """cond_diff.py:262-264."""
+    return sched["sqrt_alphas_cumprod"][t] * x0 + sched["sqrt_one_minus_alphas_cumprod"][t] * noise
+
+
+def p_sample(sd: SD, sched, mcfg, cond: Tensor, x_t: Tensor, t: int, noise: Optional[Tensor]) -> Tensor:
+    """cond_diff.py:281-319: x0-parameterised ancestral step; channel order is cond FIRST (:318).
+    t == 0 returns the UNet output itself (``upsam`` branch); no clamping (clip_denoised=False)."""
+    tt = torch.full((x_t.shape[0],), t, dtype=torch.long)
+    x0 = unet_forward(sd, "denoiser", torch.cat([cond, x_t], dim=1), tt.float(), mcfg)
+    if t == 0:
+        return x0
+    mean = sched["posterior_mean_coef1"][t] * x0 + sched["posterior_mean_coef2"][t] * x_t
+    return mean + (0.5 * sched["posterior_log_variance_clipped"][t]).exp() * noise
+
+
+def gencomm_forward(sd: SD, cfg: dict, feat: Tensor, cond: Tensor, record_len,
+                    noise0: Tensor, step_noise: Tensor, per_agent: bool = False) -> Tensor:
+    """GenComm.forward, eval (cond_diff.py:361-381) and train (:342-360) branches compute the same
+    per-agent maths; they differ only in RNG draw order, which the caller encodes in
+    (noise0, step_noise) -- see gencomm_amd.synth.make_eval_noise / make_train_noise.
+    Returns pred_feature [sumN, C, H, W] (un-squeezed)."""
+    T = cfg["diffusion"]["num_diffusion_timesteps"]
+    sched = make_schedule(T)
+    x_start = ego_repeat(feat, record_len)
+    if per_agent:
+        # the training branch's literal structure: one batch-1 chain per agent (cond_diff.py:344-359)
+        outs = []
+        for a in range(x_start.shape[0]):
+            x = q_sample(sched, x_start[a:a + 1], T - 1, noise0[a:a + 1])
+            for i, t in enumerate(reversed(range(T))):
+                x = p_sample(sd, sched, cfg["model"], cond[a:a + 1], x, t, step_noise[i, a:a + 1] if t > 0 else None)
+            outs.append(x)
+        return torch.cat(outs, dim=0)
+    x = q_sample(sched, x_start, T - 1, noise0)
+    for i, t in enumerate(reversed(range(T))):
+        # F.interpolate(bilinear, same size) at cond_diff.py:326 is an exact identity
+        x = p_sample(sd, sched, cfg["model"], cond, x, t, step_noise[i] if t > 0 else None)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Enhancer  (opencood/models/gencomm_modules/enhancer.py:207-250, 302-383)
+# --------------------------------------------------------------------------------------
+def frfn(sd: SD, p: str, x: Tensor, H: int, W: int) -> Tensor:
+    """FRFN.forward, enhancer.py:222-250. x: [B, HW, C]."""
+    B, HW, C = x.shape
+    dc = C // 4
+    xi = x.transpose(1, 2).reshape(B, C, H, W)
+    x1 = F.conv2d(xi[:, :dc], sd[p + ".partial_conv3.weight"], None, padding=1)
+    xi = torch.cat([x1, xi[:, dc:]], dim=1)
+    x = xi.reshape(B, C, HW).transpose(1, 2)
+    x = F.gelu(F.linear(x, sd[p + ".linear1.0.weight"], sd[p + ".linear1.0.bias"]))
+    x_1, x_2 = x.chunk(2, dim=-1)
+    hid = x_1.shape[-1]
+    x_1 = x_1.transpose(1, 2).reshape(B, hid, H, W)
+    x_1 = F.gelu(F.conv2d(x_1, sd[p + ".dwconv.0.weight"], sd[p + ".dwconv.0.bias"], padding=1, groups=hid))
+    x_1 = x_1.reshape(B, hid, HW).transpose(1, 2)
+    return F.linear(x_1 * x_2, sd[p + ".linear2.0.weight"], sd[p + ".linear2.0.bias"])
+
+
+def enhancer_block(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Enhancer_block.forward, enhancer.py:346-357 (attention line :352 is commented out in the
+    reference; drop_path is Identity :344). Returns [B, H, W, C]."""
+    B, C, H, W = x.shape
+    x = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    x = x + F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps=1e-5)
+    x = x + frfn(sd, p + ".mlp", F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps=1e-5), H, W)
+    return x.view(B, H, W, C)
+
+
+def split_attn(sd: SD, p: str, sw: Tensor) -> Tensor:
+    """SplitAttn.forward with RadixSoftmax(radix=1) = sigmoid, enhancer.py:315-333, :287-300."""
+    C = sw.shape[-1]
+    g = sw.mean((1, 2), keepdim=True)
+    g = F.linear(g, sd[p + ".fc1.weight"])
+    g = F.relu(F.layer_norm(g, (C,), sd[p + ".bn1.weight"], sd[p + ".bn1.bias"], eps=1e-5))
+    a = torch.sigmoid(F.linear(g, sd[p + ".fc2.weight"]))
+    return sw * a[:, :, :, 0:C]
+
+
+def enhancer_forward(sd: SD, x: Tensor, record_len, p: str = "") -> Tensor:
+    """Enhancer.forward, enhancer.py:367-383: per scene, block_1 then split_attn([s]); the
+    affine matrix is sliced but unused by live code. Output NCHW."""
+    out, o = [], 0
+    for n in regroup_lens(record_len):
+        s = enhancer_block(sd, p + "block_1", x[o:o + n])
+        out.append(split_attn(sd, p + "split_attn", s).permute(0, 3, 1, 2).contiguous())
+        o += n
+    return torch.cat(out, 0)
+
+
+# --------------------------------------------------------------------------------------
+# warp + AttFusion  (transformation_utils.py:68-92, torch_transformation_utils.py:323-332,
+#                    fusion_in_one.py:131-151, :41-45)
+# --------------------------------------------------------------------------------------
+def normalize_pairwise_tfm(pairwise_t_matrix: Tensor, H: float, W: float, discrete_ratio: float,
+                           downsample_rate: float = 1) -> Tensor:
+    """transformation_utils.py:68-92. H, W here are the BEV extent in metres when called from the
+    model shell (heter_model_baseline_w_gencomm_stage1.py:96-98, :177)."""
+    a = pairwise_t_matrix[:, :, :, [0, 1], :][:, :, :, :, [0, 1, 3]].clone()
+    a[..., 0, 1] = a[..., 0, 1] * H / W
+    a[..., 1, 0] = a[..., 1, 0] * W / H
+    a[..., 0, 2] = a[..., 0, 2] / (downsample_rate * discrete_ratio * W) * 2
+    a[..., 1, 2] = a[..., 1, 2] / (downsample_rate * discrete_ratio * H) * 2
+    return a
+
+
+def warp_affine_simple(src: Tensor, M: Tensor, dsize) -> Tensor:
+    """torch_transformation_utils.py:323-332: grid built in M's dtype (float64), cast to src's."""
+    B, C, H, W = src.shape
+    grid = F.affine_grid(M, [B, C, dsize[0], dsize[1]], align_corners=False).to(src)
+    return F.grid_sample(src, grid, align_corners=False)
+
+
+def att_fusion(xx: Tensor, record_len, affine_matrix: Tensor) -> Tensor:
+    """AttFusion.forward, fusion_in_one.py:131-151: full N x N per-pixel attention, keep row 0."""
+    _, C, H, W = xx.shape
+    out, o = [], 0
+    for b, n in enumerate(regroup_lens(record_len)):
+        x = warp_affine_simple(xx[o:o + n], affine_matrix[b][0, :n], (H, W))
+        x = x.view(n, C, -1).permute(2, 0, 1)
+        score = torch.bmm(x, x.transpose(1, 2)) / np.sqrt(C)
+        h = torch.bmm(F.softmax(score, -1), x)
+        out.append(h.permute(1, 2, 0).view(n, C, H, W)[0])
+        o += n
+    return torch.stack(out)
+
+
+# --------------------------------------------------------------------------------------
+# whole path
+# --------------------------------------------------------------------------------------
+def split_state_dict(sd: SD, prefix: str) -> SD:
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def path_forward(gen_sd: SD, enh_sd: Optional[SD], cfg: dict, feat: Tensor, cond: Tensor, record_len,
+                 pairwise_t_matrix: Tensor, bev_h_m: float, bev_w_m: float,
+                 noise0: Tensor, step_noise: Tensor) -> Dict[str, Tensor]:
+    """GenComm -> Enhancer -> AttFusion as chained by the model shell
+    (heter_model_baseline_w_gencomm_stage1.py:177, :258, :279-282)."""
+    with torch.no_grad():
+        affine = normalize_pairwise_tfm(pairwise_t_matrix, bev_h_m, bev_w_m, 1.0)
+        pred = gencomm_forward(gen_sd, cfg, feat, cond, record_len, noise0, step_noise)
+        enh = enhancer_forward(enh_sd, pred, record_len) if enh_sd is not None else pred
+        fused = att_fusion(enh, record_len, affine)
+    return {"pred_feature": pred, "enhanced": enh, "fused": fused, "affine": affine}

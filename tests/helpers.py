@@ -1,0 +1,67 @@
+"""Shared helpers for the parity tests: rebuild a golden case's weights / inputs / noise from the
+seeds stored in the fixture (gencomm_amd.synth is numpy-deterministic)."""
+import os
+
+import numpy as np
+import torch
+
+from gencomm_amd import synth
+from gencomm_amd.cond_diff import GenComm
+from gencomm_amd.enhancer import Enhancer
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def build_modules(g, device="cpu", attn_resolutions=None):
+    C, T = int(g["C"]), int(g["T"])
+    cfg = synth.default_gencomm_cfg(C, T)
+    if attn_resolutions is not None:
+        cfg["model"]["attn_resolutions"] = list(attn_resolutions)
+    gen = GenComm(cfg).eval()
+    enh = Enhancer(C, [8, 8], 4).eval()
+    synth.fill_params_(gen, int(g["weight_seed"]))
+    synth.fill_params_(enh, int(g["weight_seed"]) + 1)
+    return cfg, gen.to(device), enh.to(device)
+
+
+def build_inputs(g, device="cpu"):
+    C, H, W = int(g["C"]), int(g["H"]), int(g["W"])
+    rl = [int(v) for v in g["record_len"]]
+    inp = synth.make_inputs(rl, C, H, W, int(g["data_seed"]), max_shift=float(g["max_shift"]) if "max_shift" in g else 40.0)
+    return {k: torch.from_numpy(v).to(device) for k, v in inp.items()}
+
+
+def eval_noise(g, device="cpu"):
+    C, H, W, T = int(g["C"]), int(g["H"]), int(g["W"]), int(g["T"])
+    n = int(sum(g["record_len"]))
+    n0, sn = synth.make_eval_noise(int(g["noise_seed"]), n, C, H, W, T)
+    return torch.from_numpy(n0).to(device), torch.from_numpy(sn).to(device)
+
+
+def train_noise(g, device="cpu"):
+    C, H, W, T = int(g["C"]), int(g["H"]), int(g["W"]), int(g["T"])
+    n = int(sum(g["record_len"]))
+    n0, sn = synth.make_train_noise(int(g["noise_seed"]), n, C, H, W, T)
+    return torch.from_numpy(n0).to(device), torch.from_numpy(sn).to(device)
+
+
+def sub(t, stride):
+    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return a.reshape(-1)[::stride]
+
+
+def assert_close(actual, expected, rtol, atol, what):
+    actual = np.asarray(actual, dtype=np.float64)
+    expected = np.asarray(expected, dtype=np.float64)
+    assert actual.shape == expected.shape, (what, actual.shape, expected.shape)
+    err = np.abs(actual - expected)
+    tol = atol + rtol * np.abs(expected)
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.size} elements out of tolerance "
+                           f"(rtol {rtol}, atol {atol}); max abs err {err.max():.3e}, "
+                           f"max |expected| {np.abs(expected).max():.3e}")
