@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the GenComm generative-communication hot path on MI355X.
+
+One "step" = one scene through GenComm (q_sample + T x0-parameterised ancestral denoise steps of
+the diffusion UNet) -> Enhancer -> warp + AttFusion, on synthetic tensors already resident in HBM.
+Workload = BASELINE.json's metric configuration: 4 agents, C=64, 200x704 BEV, T=20.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Scenes are independent, so N GPUs = N replicas each running its own scenes (no data-path
+collective; weak scaling). Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: (agents, C, H, W, T)
+    "metric": (4, 64, 200, 704, 20),   # BASELINE.json metric: 4 agents, 64x200x704 BEV, 20 steps
+    "cfg2": (2, 64, 200, 704, 10),     # BASELINE.json configs[1]
+    "shipped": (2, 128, 64, 128, 3),   # shape of every shipped yaml (control)
+}
+PX_M = 0.4           # metres per BEV pixel at 200x704 (OPV2V range +-140.8 x +-40 m)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
+
+# dominant kernel (profiles/round1_*): family id in the library's timer, MACs per output pixel
+DOMINANT = {"family": 5, "name": "conv_out_kernel"}
+
+
+def algorithmic_work(N, C, HW, T):
+    """FLOPs and bytes (fp32) per scene."""
+    flops = 2.0 * HW * (N * T * (144 * C + 11280) + N * (6.5625 * C * C + 18 * C) + 2 * N * C)
+    byts = 4.0 * HW * (N * T * (2 * C + 2) + 2 * N * C + 2 * N * C + (N + 1) * C)
+    return flops, byts
+
+
+def make_scene(N, C, H, W, seed, device):
+    """Synthetic inputs, generated on the device (seeded torch generator; the parity tests use the
+    numpy generator of gencomm_amd.synth -- here only shape/statistics matter)."""
+    from gencomm_amd import synth
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    feat = torch.randn(N, C, H, W, generator=g, device=device).clamp_(min=0)
+    cond = torch.randn(N, 2, H, W, generator=g, device=device)
+    ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N], 5, seed + 7, 40.0))
+    return feat, cond, ptm
+
+
+def build_modules(C, T, device):
+    from gencomm_amd import Enhancer, GenComm, synth
+    torch.manual_seed(0)  # "default PyTorch init, seed 0" 
+    gen = GenComm(synth.default_gencomm_cfg(C, T)).eval()
+    enh = Enhancer(C, [8, 8], 4).eval()
+    return gen.to(device), enh.to(device)
+
+
+def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, sample_steps=2):
+    """The CPU oracle (plain PyTorch restatement of the reference, oracle/torch_port.py) on this
+    host's cores, on a bounded sample: q_sample + `sample_steps` of the T denoise steps + Enhancer +
+    fusion at full tensor size; the per-step time is extrapolated to T steps (every step has
+    identical cost)."""
+    from gencomm_amd import synth
+    from oracle import torch_port as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = synth.default_gencomm_cfg(C, T)
+    sd_g = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
+    sd_e = {k: v.detach().cpu() for k, v in enh.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(N, C, H, W, generator=g).clamp_(min=0)
+    cond = torch.randn(N, 2, H, W, generator=g)
+    noise = torch.randn(N, C, H, W, generator=g)
+    sched = O.make_schedule(T)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        x = O.q_sample(sched, O.ego_repeat(feat, [N]), T - 1, noise)
+        t1 = time.perf_counter()
+        for i in range(sample_steps):
+            x = O.p_sample(sd_g, sched, cfg["model"], cond, x, T - 1 - i, noise)
+        t2 = time.perf_counter()
+        e = O.enhancer_forward(sd_e, x, [N])
+        t3 = time.perf_counter()
+        affine = O.normalize_pairwise_tfm(ptm, H * PX_M, W * PX_M, 1.0)
+        O.att_fusion(e, [N], affine)
+        t4 = time.perf_counter()
+    per_step = (t2 - t1) / sample_steps
+    scene_s = (t1 - t0) + per_step * T + (t3 - t2) + (t4 - t3)
+    return {"value": 1.0 / scene_s, "unit": "scenes/sec", "cores": cores, "kind": "port",
+            "sample": f"workload '{name}': q_sample + {sample_steps} of {T} denoise steps ({per_step:.2f} s each, extrapolated x{T}) "
+                      f"+ enhancer {t3 - t2:.2f} s + fusion {t4 - t3:.2f} s, torch {torch.__version__} CPU, {cores} threads",
+            "scene_seconds": scene_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-enhancer", action="store_true")
+    ap.add_argument("--timer-family", type=int, default=DOMINANT["family"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    from gencomm_amd import _lib, normalize_pairwise_tfm
+    from gencomm_amd.pipeline import ScenePipeline
+    lib = _lib.lib()
+
+    N, C, H, W, T = WORKLOADS[args.workload]
+    gen, enh = build_modules(C, T, device)
+    feat, cond, ptm = make_scene(N, C, H, W, 1 + rank, device)
+    pipe = ScenePipeline(gen, None if args.no_enhancer else enh, [N], C, H, W, device)
+    pipe.set_affine(normalize_pairwise_tfm(ptm, H * PX_M, W * PX_M, 1))
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            pipe.run(feat, cond, seed=1000 + i)
+        barrier()
+        # arm the kernel timer for the dominant kernel on rank 0 (HIP events on the launch stream)
+        timed = rank == 0 and args.timer_family >= 0
+        if timed:
+            _lib.check(lib.gencomm_timer_start(args.timer_family, args.steps * (T + 4) * 16), "gencomm_timer_start")
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            pipe.run(feat, cond, seed=2000 + i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    k_ms, k_n = ctypes.c_double(0.0), ctypes.c_int(0)
+    if timed:
+        _lib.check(lib.gencomm_timer_stop(ctypes.byref(k_ms), ctypes.byref(k_n)), "gencomm_timer_stop")
+    assert torch.isfinite(pipe.fused).all(), "non-finite output"
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        HW = H * W
+        flops, byts = algorithmic_work(N, C, HW, T)
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
+                                   f"T={T} x0-param ancestral steps, 1 scene/step/GPU",
+                       "agents": N, "C": C, "H": H, "W": W, "T": T, "enhancer": not args.no_enhancer,
+                       "noise": "in-kernel Philox4x32-10", "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+            "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
+                                  "achieved_tflops": flops * args.steps / elapsed / 1e12 * 1.0,
+                                  "achieved_gbs": byts * args.steps / elapsed / 1e9},
+        }
+        # roofline of the dominant kernel: algorithmic FLOPs per launch / measured launch time
+        roof = None
+        if timed and k_n.value > 0:
+            fam = args.timer_family
+            name = lib.gencomm_timer_kernel_name(fam).decode()
+            per_launch_ms = k_ms.value / k_n.value
+            macs_px = {0: 72.0 * (C + 2), 5: 72.0 * C}.get(fam)
+            traffic = None
+            pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            if macs_px is not None:
+                fl = 2.0 * macs_px * HW * N
+                roof = {"kernel": name, "bound": "mfma", "achieved": fl / (per_launch_ms * 1e-3) / 1e12,
+                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (per_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "traffic": traffic, "launches": k_n.value, "avg_launch_ms": per_launch_ms,
+                        "flops_per_launch": fl, "note": "fp32 vector FMA kernel priced against the 157.3 TFLOP/s fp32 (vector = f32-MFMA) peak"}
+            else:
+                roof = {"kernel": name, "launches": k_n.value, "avg_launch_ms": per_launch_ms}
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, N, C, H, W, T, gen, enh, ptm)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

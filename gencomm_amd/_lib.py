@@ -26,6 +26,10 @@ _i, _ll, _p = C.c_int, C.c_longlong, C.c_void_p
 _SIGNATURES = {
     "gencomm_abi_version": (_i, []),
     "gencomm_last_error": (C.c_char_p, []),
+    "gencomm_timer_num_kernels": (_i, []),
+    "gencomm_timer_kernel_name": (C.c_char_p, [_i]),
+    "gencomm_timer_start": (_i, [_i, _i]),
+    "gencomm_timer_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "gencomm_unet_num_params": (_i, [_i, _i, _i]),
     "gencomm_unet_param_info": (_i, [_i, _i, _i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
     "gencomm_unet_raw_floats": (_ll, [_i, _i, _i]),
@@ -35,6 +39,7 @@ _SIGNATURES = {
     "gencomm_unet_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_denoise_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, C.c_ulonglong,
                                  _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_q_sample_fwd": (_i, [_p, _p, _i, _p, _p, C.c_ulonglong, C.c_uint, _p, _i, _i, _i, _i, _p]),
     "gencomm_enhancer_num_params": (_i, [_i]),
     "gencomm_enhancer_param_info": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
     "gencomm_enhancer_raw_floats": (_ll, [_i]),

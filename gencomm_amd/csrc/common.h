@@ -41,6 +41,47 @@ inline int fail(int code, const char* msg) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------
+// Diagnostic kernel timer (gencomm_timer_start / gencomm_timer_stop): while armed for one kernel
+// family, every launch of that family is bracketed by a pair of HIP events recorded on the launch
+// stream. Off by default; the only process-global state in the library.
+// ---------------------------------------------------------------------------------------------
+enum KernelFamily : int {
+  KF_CONV_IN = 0, KF_CONV8 = 1, KF_CONV16 = 2, KF_DOWN = 3, KF_UP = 4, KF_CONV_OUT = 5, KF_Q_SAMPLE = 6,
+  KF_ENH_LN = 7, KF_ENH_PCONV = 8, KF_ENH_GEMM1 = 9, KF_ENH_DWGATE = 10, KF_ENH_GEMM2 = 11,
+  KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_COUNT = 15
+};
+inline const char* kernel_family_name(int id) {
+  static const char* names[KF_COUNT] = {"conv_in_kernel", "conv8_kernel<NSRC=1>", "conv8_kernel<NSRC=2>", "down8_kernel",
+                                        "conv8_kernel<UP>", "conv_out_kernel", "q_sample_kernel", "enh_ln_kernel",
+                                        "enh_pconv_kernel", "gemm_f32_mfma_kernel<0>", "enh_dwgate_kernel",
+                                        "gemm_f32_mfma_kernel<1>", "enh_gate_kernel", "enh_scale_transpose_kernel",
+                                        "warp_attfuse_kernel"};
+  return (id >= 0 && id < KF_COUNT) ? names[id] : "?";
+}
+struct KernelTimer {
+  int family = -1;
+  int cap = 0, count = 0;
+  hipEvent_t* ev = nullptr;  // 2 * cap
+};
+KernelTimer& kernel_timer();  // defined in gencomm_abi.hip
+struct TimedLaunch {
+  bool armed;
+  hipStream_t st;
+  TimedLaunch(int family, hipStream_t s) : st(s) {
+    KernelTimer& t = kernel_timer();
+    armed = t.family == family && t.count < t.cap;
+    if (armed) (void)hipEventRecord(t.ev[2 * t.count], st);
+  }
+  ~TimedLaunch() {
+    if (armed) {
+      KernelTimer& t = kernel_timer();
+      (void)hipEventRecord(t.ev[2 * t.count + 1], st);
+      ++t.count;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // device math
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_f(float x) {

@@ -78,10 +78,12 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     EnhLnArgs a{x, raw + p.n1w, raw + p.n1b, raw + p.n2w, raw + p.n2b, F(w.Y), F(w.Z), F(w.Zc), C, p.dc, HW};
     const size_t sh = ((size_t)C * 65 + 256 + 128) * sizeof(float);
     if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)enh_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    TimedLaunch tl(KF_ENH_LN, st);
     enh_ln_kernel<<<dim3((HW + 63) / 64, n), 256, sh, st>>>(a);
   }
   {  // K2
     enh_prep_pconv_kernel<<<(9 * p.dc * p.dcp + 255) / 256, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, p.dcp);
+    TimedLaunch tl(KF_ENH_PCONV, st);
     EnhPconvArgs a{F(w.Zc), F(w.wT), F(w.Z), C, p.dc, p.dcp, H, W};
     if (p.dc <= 32) {
       const size_t sh = (size_t)18 * 18 * (p.dc + 1) * sizeof(float);
@@ -94,25 +96,30 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   }
   {  // K3: linear1 + GELU
     GemmArgs a{F(w.Z), raw + p.l1w, raw + p.l1b, nullptr, F(w.Hd), nullptr, HW, 2 * p.hid, C};
+    TimedLaunch tl(KF_ENH_GEMM1, st);
     gemm_f32_mfma_kernel<0><<<dim3((HW + 127) / 128, (2 * p.hid + 63) / 64, n), 256, 0, st>>>(a);
   }
   {  // K4: dwconv + GELU, gate
     constexpr int SL = 8;
     EnhDwArgs a{F(w.Hd), raw + p.dww, raw + p.dwb, F(w.G), p.hid, H, W};
     const long long total = (long long)H * ((W + SL - 1) / SL) * p.hid;
+    TimedLaunch tl(KF_ENH_DWGATE, st);
     enh_dwgate_kernel<SL><<<dim3((unsigned)((total + 255) / 256), n), 256, 0, st>>>(a);
   }
   {  // K5: linear2 + residual, column sums for the global average pool
     GemmArgs a{F(w.G), raw + p.l2w, raw + p.l2b, F(w.Y), F(w.O), F(w.colsum), HW, C, p.hid};
+    TimedLaunch tl(KF_ENH_GEMM2, st);
     gemm_f32_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
   }
   {  // K6
     EnhGateArgs a{F(w.colsum), raw + p.fc1, raw + p.bnw, raw + p.bnb, raw + p.fc2, F(w.gate), C, 1.0f / (float)HW};
+    TimedLaunch tl(KF_ENH_GATE, st);
     enh_gate_kernel<<<n, 256, (2 * C + 8) * sizeof(float), st>>>(a);
   }
   {  // K7
     EnhOutArgs a{F(w.O), F(w.gate), out, C, HW};
     const size_t sh = (size_t)32 * (C + 1) * sizeof(float);
+    TimedLaunch tl(KF_ENH_OUT, st);
     enh_scale_transpose_kernel<<<dim3((HW + 31) / 32, n), 256, sh, st>>>(a);
   }
   GC_HIP(hipGetLastError());

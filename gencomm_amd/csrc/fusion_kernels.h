@@ -111,6 +111,7 @@ inline int warp_attfuse_enqueue(const float* x, const double* theta, const int* 
                                 int B, int n, int C, int H, int W, hipStream_t st) {
   (void)n;
   FuseArgs a{x, theta, scene_off, out, C, H, W};
+  TimedLaunch tl(KF_WARP_ATTFUSE, st);
   warp_attfuse_kernel<<<dim3((H * W + 255) / 256, B), 256, 0, st>>>(a);
   GC_HIP(hipGetLastError());
   return GC_OK;

@@ -6,10 +6,16 @@
 #include "fusion_kernels.h"
 #include "unet_host.h"
 
+#include <algorithm>
+
 namespace gc {
 char* last_error_buf() {
   static thread_local char buf[512] = {0};
   return buf;
+}
+KernelTimer& kernel_timer() {
+  static KernelTimer t;
+  return t;
 }
 }  // namespace gc
 
@@ -19,6 +25,46 @@ extern "C" {
 
 int gencomm_abi_version(void) { return GENCOMM_ABI_VERSION; }
 const char* gencomm_last_error(void) { return last_error_buf(); }
+
+// ------------------------------------------------------------------------------------ timer
+int gencomm_timer_num_kernels(void) { return KF_COUNT; }
+const char* gencomm_timer_kernel_name(int family) { return kernel_family_name(family); }
+
+int gencomm_timer_start(int family, int capacity) {
+  KernelTimer& t = kernel_timer();
+  GC_CHECK_ARG(t.ev == nullptr, "timer already armed");
+  GC_CHECK_ARG(family >= 0 && family < KF_COUNT && capacity >= 1 && capacity <= (1 << 20), "bad family/capacity");
+  t.ev = new hipEvent_t[2 * (size_t)capacity];
+  for (int i = 0; i < 2 * capacity; ++i) {
+    if (hipEventCreate(&t.ev[i]) != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(t.ev[j]);
+      delete[] t.ev;
+      t.ev = nullptr;
+      return fail(GC_ERR_HIP, "hipEventCreate failed");
+    }
+  }
+  t.family = family; t.cap = capacity; t.count = 0;
+  return GC_OK;
+}
+
+int gencomm_timer_stop(double* total_ms, int* launches) {
+  KernelTimer& t = kernel_timer();
+  GC_CHECK_ARG(t.ev != nullptr, "timer not armed");
+  double sum = 0.0;
+  int rc = GC_OK;
+  for (int i = 0; i < t.count; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]) != hipSuccess)
+      rc = fail(GC_ERR_HIP, "event timing failed");
+    sum += ms;
+  }
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = t.count;
+  for (int i = 0; i < 2 * t.cap; ++i) (void)hipEventDestroy(t.ev[i]);
+  delete[] t.ev;
+  t = KernelTimer{};
+  return rc;
+}
 
 // ------------------------------------------------------------------------------------ UNet
 int gencomm_unet_num_params(int C, int levels, int res_blocks) {
@@ -70,7 +116,7 @@ long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels
 static int check_dims(int n, int C, int H, int W) {
   GC_CHECK_ARG(n >= 1 && n <= 65535, "n (agents) must be in 1..65535");
   GC_CHECK_ARG(H >= 1 && W >= 1 && (long long)H * W * C < (1LL << 40), "bad H/W");
-  GC_CHECK_ARG((long long)n * (C / 16) <= 65535, "n * C/16 exceeds the grid z limit");
+  GC_CHECK_ARG((long long)n * ((C + 15) / 16) <= 65535, "n * ceil(C/16) exceeds the grid z limit");
   return GC_OK;
 }
 
@@ -89,6 +135,24 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
   ConvOutArgs co{};
   co.out = x0_out;
   return unet_enqueue(c, x_t, cond, t, 0, co);
+}
+
+static void launch_q_sample(const QSampleArgs& q, int n, bool philox, hipStream_t st) {
+  TimedLaunch tl(KF_Q_SAMPLE, st);
+  const dim3 qgrid((unsigned)std::min<long long>((q.per_agent / 4 + 255) / 256 + 1, 2048), n);
+  if (philox) q_sample_kernel<true><<<qgrid, 256, 0, st>>>(q);
+  else q_sample_kernel<false><<<qgrid, 256, 0, st>>>(q);
+}
+
+int gencomm_q_sample_fwd(const float* sched_row, const float* feat, int n_feat_rows, const int* src_row,
+                         const float* noise, unsigned long long seed, unsigned int stream_id,
+                         float* out, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(sched_row && feat && src_row && out, "null pointer");
+  GC_CHECK_ARG(n >= 1 && n <= 65535 && n_feat_rows >= 1 && C >= 1 && H >= 1 && W >= 1, "bad n/C/H/W");
+  QSampleArgs q{feat, src_row, noise, sched_row, out, seed, stream_id, (long long)C * H * W};
+  launch_q_sample(q, n, noise == nullptr, (hipStream_t)stream);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
 }
 
 int gencomm_denoise_fwd(const float* prepared, const float* sched,
@@ -110,9 +174,7 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
   const long long per_agent = (long long)C * H * W;
 
   QSampleArgs q{feat, src_row, noise0, sched + (size_t)(T - 1) * 5, out, seed, (unsigned)T, per_agent};
-  const dim3 qgrid((unsigned)std::min<long long>((per_agent / 4 + 255) / 256, 2048), n);
-  if (philox) q_sample_kernel<true><<<qgrid, 256, 0, st>>>(q);
-  else q_sample_kernel<false><<<qgrid, 256, 0, st>>>(q);
+  launch_q_sample(q, n, philox, st);
 
   UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st};
   for (int i = 0; i < T; ++i) {

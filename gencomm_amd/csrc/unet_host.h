@@ -22,6 +22,7 @@ inline void tile_dims(TileCfg t, int* tw, int* th) {
 
 template <int NSRC, bool GN, bool UP, int RES>
 inline void launch_conv8(TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
+  TimedLaunch tl(UP ? KF_UP : (NSRC == 2 ? KF_CONV16 : KF_CONV8), st);
   int tw, th;
   tile_dims(t, &tw, &th);
   const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
@@ -63,6 +64,7 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         int tw, th;
         tile_dims(tc, &tw, &th);
         const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n);
+        TimedLaunch tl(KF_CONV_IN, c.st);
         if (tc == TILE_64x16) conv_in_kernel<64, 16><<<grid, 256, 0, c.st>>>(a);
         else if (tc == TILE_32x16) conv_in_kernel<32, 16><<<grid, 128, 0, c.st>>>(a);
         else conv_in_kernel<32, 8><<<grid, 64, 0, c.st>>>(a);
@@ -101,6 +103,7 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         const int lin = o.level - 1;
         DownArgs a{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst),
                    c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin]};
+        TimedLaunch tl(KF_DOWN, c.st);
         down8_kernel<<<dim3(cdiv(Hl * Wl, 256), 1, c.n), 256, 0, c.st>>>(a);
         break;
       }
@@ -119,7 +122,7 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         co.gamma = P + p.nout_w; co.beta = P + p.nout_b;
         co.w = P + p.conv_out.p_w; co.bias = P + p.conv_out.b;
         co.C = p.C; co.H = Hl; co.W = Wl;
-        const int nocb = p.C / 16;
+        const int nocb = (p.C + 15) / 16;
         const TileCfg tc = pick_tile(c.n, Hl, Wl, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
         int tw, th;
         tile_dims(tc, &tw, &th);
@@ -129,6 +132,7 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
     if (tc == TILE_64x16) conv_out_kernel<64, 16, POST><<<grid, 256, 0, c.st>>>(co);   \
     else conv_out_kernel<32, 8, POST><<<grid, 64, 0, c.st>>>(co);                      \
   } while (0)
+        TimedLaunch tl(KF_CONV_OUT, c.st);
         if (post == 0) GC_LAUNCH_CO(0);
         else if (post == 1) GC_LAUNCH_CO(1);
         else GC_LAUNCH_CO(2);
@@ -148,6 +152,7 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
     prep_conv_w_kernel<<<cdiv(total, 256), 256, 0, st>>>(raw + src, prepared + dst, OC, IC, OCB);
   };
   conv_w(p.conv_in.w, p.conv_in.p_w, 8, p.C + 2, 8);
+  GC_HIP(hipMemsetAsync(prepared + p.conv_out.p_w, 0, (size_t)((p.C + 15) / 16 * 16) * 72 * sizeof(float), st));
   conv_w(p.conv_out.w, p.conv_out.p_w, p.C, 8, 16);
   for (int l = 0; l < p.L; ++l) {
     if (p.down[l].w >= 0) conv_w(p.down[l].w, p.down[l].p_w, 8, 8, 8);

@@ -390,7 +390,7 @@ struct ConvOutArgs {
   const double* sstat;  // [n][8][2]
   const float* gamma;   // [8]
   const float* beta;
-  const float* w;       // prepared [C/16][8][9][16]
+  const float* w;       // prepared [ceil(C/16)][8][9][16], zero padded
   const float* bias;    // [C]
   const float* xt;      // [n][C][H][W] (POST != 0)
   const float* noise;   // [n][C][H][W] (POST == 1)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
   __shared__ __align__(16) float tile[8][LH][LS];
   __shared__ float s_ab[8][2];
   const int tid = threadIdx.x;
-  const int nocb = a.C / OCB;
+  const int nocb = (a.C + OCB - 1) / OCB;
   const int n = blockIdx.z / nocb, ocb = blockIdx.z - n * nocb;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tx = tid % (TW / 4), ty = tid / (TW / 4);
@@ -475,6 +475,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
 #pragma unroll
   for (int o = 0; o < OCB; ++o) {
     const int oc = ocb * OCB + o;
+    if (oc >= a.C) continue;  // last chunk of a C that is not a multiple of 16 (weights zero-padded)
     const float b = a.bias[oc];
     const size_t e = ((size_t)n * a.C + oc) * plane + pix;
     float v[4];
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
   const float sa = a.sched[0], sb = a.sched[1];
   const float* __restrict__ fp = a.feat + (size_t)a.src_row[n] * a.per_agent;
   float* __restrict__ op = a.out + (size_t)n * a.per_agent;
-  const long long nvec = a.per_agent >> 2;
+  const long long nvec = (a.per_agent & 3) ? 0 : (a.per_agent >> 2);  // rows stay 16-B aligned only then
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
     const float4 f = reinterpret_cast<const float4*>(fp)[i];
     float z[4];

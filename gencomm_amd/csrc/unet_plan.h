@@ -112,7 +112,7 @@ struct UNetPlan {
   // Returns nullptr on success, else an error string.
   const char* build(int C_, int L_, int R_, int T_) {
     C = C_; L = L_; R = R_; T = T_;
-    if (C < 16 || C % 16 != 0) return "C must be a positive multiple of 16";
+    if (C < 8 || C % 8 != 0) return "C must be a positive multiple of 8";
     if (L < 1 || L > 4) return "levels must be in 1..4";
     if (R < 1 || R > 4) return "res_blocks must be in 1..4";
     if (T < 1) return "T must be >= 1";
@@ -155,7 +155,7 @@ struct UNetPlan {
     // ---- prepared blob: verbatim copy of raw, then re-laid-out tensors and tables ----
     prepared_floats = (raw_floats + 63) / 64 * 64;
     conv_in.p_w = padd(8LL * (C + 2) * 9);
-    conv_out.p_w = padd((long long)C * 8 * 9);
+    conv_out.p_w = padd((long long)((C + 15) / 16 * 16) * 8 * 9);
     for (int l = 0; l < L; ++l) {
       if (down[l].w >= 0) down[l].p_w = padd(8 * 8 * 9);
       if (up[l].w >= 0) up[l].p_w = padd(8 * 8 * 9);

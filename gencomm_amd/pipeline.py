@@ -1,0 +1,87 @@
+"""``ScenePipeline`` -- the whole hot path for a fixed batch geometry with every buffer preallocated:
+
+    GenComm (q_sample + T denoise steps)  ->  Enhancer (optional)  ->  warp + AttFusion
+
+i.e. lines :258, :279-282 of the reference shell
+(``opencood/models/heter_model_baseline_w_gencomm_stage1.py``) as three C-ABI calls on the current
+stream with no per-step host allocation, H2D copy or synchronisation. Used by ``bench.py`` and by
+callers that run many scenes of one shape (inference servers); the module classes
+(``GenComm``/``Enhancer``/``AttFusion``) are the drop-in API, this is the fast lane under them.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .cond_diff import GenComm
+from .enhancer import Enhancer
+from .fusion import MAX_AGENTS_PER_SCENE, gather_ego_thetas
+from .runtime import f32c, ptr, stream_ptr
+
+
+class ScenePipeline:
+    def __init__(self, gencomm: GenComm, enhancer: Optional[Enhancer], record_len: Sequence[int],
+                 C: int, H: int, W: int, device: torch.device):
+        self.gen, self.enh = gencomm, enhancer
+        self.lens = [int(v) for v in record_len]
+        if min(self.lens) < 1 or max(self.lens) > MAX_AGENTS_PER_SCENE:
+            raise ValueError(f"each scene needs 1..{MAX_AGENTS_PER_SCENE} agents, got {self.lens}")
+        self.B, self.n = len(self.lens), sum(self.lens)
+        self.C, self.H, self.W = C, H, W
+        self.device = torch.device(device)
+        self.T = gencomm.num_timesteps
+        den = gencomm.denoiser
+        self.L, self.R = den.num_resolutions, den.num_res_blocks
+        l = _lib.lib()
+        dev = self.device
+        rows, off, o = [], [0], 0
+        for k in self.lens:
+            rows += [o] * k
+            o += k
+            off.append(o)
+        self.src_rows = torch.tensor(rows, dtype=torch.int32, device=dev)
+        self.scene_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        self.theta = torch.zeros(self.n, 2, 3, dtype=torch.float64, device=dev)
+        self.pred = torch.empty(self.n, C, H, W, dtype=torch.float32, device=dev)
+        self.enhanced = torch.empty_like(self.pred) if enhancer is not None else self.pred
+        self.fused = torch.empty(self.B, C, H, W, dtype=torch.float32, device=dev)
+        ws_d = _lib.check_size(l.gencomm_denoise_workspace_bytes(self.n, C, H, W, self.L, self.R), "gencomm_denoise_workspace_bytes")
+        ws_e = _lib.check_size(l.gencomm_enhancer_workspace_bytes(self.n, C, H, W), "gencomm_enhancer_workspace_bytes") if enhancer is not None else 0
+        # one arena: the two stages never overlap in time on a stream
+        self.ws = torch.empty(max(ws_d, ws_e, 256), dtype=torch.uint8, device=dev)
+        self.refresh_params()
+
+    def refresh_params(self) -> None:
+        """Re-pack parameters after a weight update (cheap no-op when nothing changed)."""
+        self.prepared = self.gen.denoiser.prepared_params(self.T, self.device)
+        self.sched = self.gen._sched_table(self.device)
+        self.enh_raw = self.enh._raw_params(self.device) if self.enh is not None else None
+
+    def set_affine(self, affine_matrix: torch.Tensor) -> None:
+        """affine_matrix [B,L,L,2,3] (output of normalize_pairwise_tfm)."""
+        self.theta.copy_(gather_ego_thetas(affine_matrix, self.lens))
+
+    def run(self, feat: torch.Tensor, cond: torch.Tensor, seed: int = 0,
+            noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        """feat [sumN,C,H,W] f32, cond [sumN,2,H,W] f32 (device, contiguous) -> fused [B,C,H,W].
+        ``self.pred`` / ``self.enhanced`` hold the intermediate stage outputs afterwards."""
+        l = _lib.lib()
+        st = stream_ptr(self.device)
+        n, C, H, W = self.n, self.C, self.H, self.W
+        assert feat.is_cuda and cond.is_cuda and feat.dtype == torch.float32 and cond.dtype == torch.float32
+        assert feat.is_contiguous() and cond.is_contiguous()
+        assert tuple(feat.shape) == (n, C, H, W) and tuple(cond.shape) == (n, 2, H, W)
+        n0 = sn = None
+        if noise is not None:
+            n0, sn = f32c(noise[0]), f32c(noise[1])
+        _lib.check(l.gencomm_denoise_fwd(ptr(self.prepared), ptr(self.sched), ptr(feat), n, ptr(self.src_rows), ptr(cond),
+                                         ptr(self.pred), ptr(n0), ptr(sn), seed, n, C, H, W, self.L, self.R, self.T,
+                                         ptr(self.ws), self.ws.numel(), st), "gencomm_denoise_fwd")
+        if self.enh is not None:
+            _lib.check(l.gencomm_enhancer_fwd(ptr(self.enh_raw), ptr(self.pred), ptr(self.enhanced), n, C, H, W,
+                                              ptr(self.ws), self.ws.numel(), st), "gencomm_enhancer_fwd")
+        _lib.check(l.gencomm_warp_attfuse_fwd(ptr(self.enhanced), ptr(self.theta), ptr(self.scene_off), ptr(self.fused),
+                                              self.B, n, C, H, W, st), "gencomm_warp_attfuse_fwd")
+        return self.fused

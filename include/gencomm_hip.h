@@ -19,6 +19,7 @@
  *                             and every ResnetBlock.temb_proj (unet.py:124), for all T steps at once
  *   gencomm_unet_fwd          DiffusionUNet.forward (unet.py:307-344) = GenComm.gen_pred
  *                             (opencood/models/gencomm_modules/cond_diff.py:317-319)
+ *   gencomm_q_sample_fwd      GenComm.q_sample (cond_diff.py:262-264)
  *   gencomm_denoise_fwd       GenComm.forward eval+train maths: ego repeat (cond_diff.py:332-337),
  *                             q_sample (:262-264, :372), p_sample_loop / p_sample / p_mean_variance /
  *                             q_posterior (:321-329, :302-315, :281-299, :272-279)
@@ -30,7 +31,7 @@
  *
  * Supported UNet family: ch = 8, ch_mult = all ones (any number of levels), num_res_blocks >= 1,
  * resamp_with_conv = true, dropout = 0, no AttnBlock instantiated -- i.e. every shipped GenComm
- * yaml (60/60 use ch 8, ch_mult [1,1], 2 res-blocks, attn_resolutions [16]).  C % 16 == 0.
+ * yaml (60/60 use ch 8, ch_mult [1,1], 2 res-blocks, attn_resolutions [16]).  C % 8 == 0.
  */
 #ifndef GENCOMM_HIP_H
 #define GENCOMM_HIP_H
@@ -43,6 +44,17 @@ extern "C" {
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
+
+/* Diagnostic kernel timer: gencomm_timer_start(family, capacity) arms it for ONE kernel family
+ * (0 <= family < gencomm_timer_num_kernels(), name via gencomm_timer_kernel_name); until
+ * gencomm_timer_stop every launch of that family (up to `capacity`) is bracketed by a pair of HIP
+ * events on the stream it is launched on. stop() synchronises those events and returns the summed
+ * device time and the number of launches. This is the only process-global state in the library;
+ * do not arm it while capturing a graph. */
+int gencomm_timer_num_kernels(void);
+const char* gencomm_timer_kernel_name(int family);
+int gencomm_timer_start(int family, int capacity);
+int gencomm_timer_stop(double* total_ms, int* launches);
 
 /* ----------------------------------------------------------------------------------------------
  * UNet parameters.  The "raw" blob is the concatenation of the module's parameters in EXECUTION
@@ -79,6 +91,14 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
                         float* out, const float* noise0, const float* step_noise, unsigned long long seed,
                         int n, int C, int H, int W, int levels, int res_blocks, int T,
                         void* workspace, long long workspace_bytes, void* stream);
+
+/* q_sample alone (cond_diff.py:262-264 with the ego repeat of :332-337 folded in):
+ *   out[i] = sched_row[0] * feat[src_row[i]] + sched_row[1] * eps[i]
+ * sched_row: device float[5] (one row of the table above).  noise NULL = Philox stream `stream_id`
+ * of `seed` (gencomm_denoise_fwd uses stream_id = T for this draw and t for the step draws). */
+int gencomm_q_sample_fwd(const float* sched_row, const float* feat, int n_feat_rows, const int* src_row,
+                         const float* noise, unsigned long long seed, unsigned int stream_id,
+                         float* out, int n, int C, int H, int W, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Enhancer (live parameters only: block_1.{norm1,norm2,mlp.*}, split_attn.*), raw blob enumerated
