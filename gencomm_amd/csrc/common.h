@@ -82,11 +82,20 @@ struct TimedLaunch {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Wave-uniform read-only tables (conv weights, biases, schedule rows) are read through the
+// constant address space so that they always come in via the scalar cache (s_load_dwordxN into
+// SGPRs) whatever the compiler can or cannot prove about aliasing; they are written only by
+// EARLIER kernels, never by the kernel that reads them.
+// ---------------------------------------------------------------------------------------------
+typedef const float __attribute__((address_space(4)))* cfloat_p;
+__device__ __forceinline__ cfloat_p as_const(const float* p) { return (cfloat_p)(p); }
+
+// ---------------------------------------------------------------------------------------------
 // device math
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_f(float x) {
-  // 1 / (1 + 2^(-x*log2e)); v_exp_f32 + v_rcp_f32, ~1 ulp each
-  return __frcp_rn(1.0f + __expf(-x));
+  // 1 / (1 + 2^(-x*log2e)): one v_exp_f32 + one v_rcp_f32 (~1 ulp each), no IEEE divide sequence
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float gelu_erf_f(float x) {

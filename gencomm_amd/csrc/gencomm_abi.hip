@@ -115,7 +115,7 @@ long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels
 
 static int check_dims(int n, int C, int H, int W) {
   GC_CHECK_ARG(n >= 1 && n <= 65535, "n (agents) must be in 1..65535");
-  GC_CHECK_ARG(H >= 1 && W >= 1 && (long long)H * W * C < (1LL << 40), "bad H/W");
+  GC_CHECK_ARG(H >= 1 && W >= 1 && (long long)H * W * (C + 8) < (1LL << 31), "C*H*W per agent must stay below 2^31 elements");
   GC_CHECK_ARG((long long)n * ((C + 15) / 16) <= 65535, "n * ceil(C/16) exceeds the grid z limit");
   return GC_OK;
 }

@@ -66,6 +66,116 @@ __device__ __forceinline__ void block_stats_commit(float (&part)[16], float (*s_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage NCH channel planes of a (TH+2) x (TW+2) tile (1-pixel halo, zeros outside the image) into
+// LDS, optionally applying GroupNorm+SiLU (scale/shift per channel in `ab`) and optionally reading
+// through a nearest-neighbour x2 upsampling (UP). The interior is fetched as float4 (float2 for UP)
+// with ALL of a thread's loads issued before the first use, so one HBM/L2 latency is paid per
+// tile, not per element; the two halo columns follow the same pattern with scalar loads.
+// Tile column index = gx - (x0 - 1), row index = gy - (y0 - 1).
+// ---------------------------------------------------------------------------------------------
+template <int TW, int TH, int NT, int NCH, bool GN, bool UP, int LS>
+__device__ __forceinline__ void stage_tile_vec(float (*tile)[TH + 2][LS], const float* __restrict__ sp,
+                                               unsigned plane_in, int Win, int H, int W, int x0, int y0,
+                                               const float (*ab)[2], int tid) {
+  // Fast path: W % 4 == 0 (UP: Win % 2 == 0), so a quad that starts inside the image lies inside
+  // it entirely and is 16-B (UP: 8-B) aligned. 32-bit element offsets from the uniform base `sp`.
+  constexpr int LH = TH + 2, QPR = TW / 4;
+  constexpr int NQ = NCH * LH * QPR, QIT = (NQ + NT - 1) / NT;
+  constexpr int NHALO = NCH * LH * 2, HIT = (NHALO + NT - 1) / NT;
+  float4 v[QIT];
+  float hv[HIT];
+#pragma unroll
+  for (int k = 0; k < QIT; ++k) {
+    const int q = tid + k * NT;
+    const int row = q / QPR, qx = q - row * QPR;
+    const int c = row / LH, r = row - c * LH;
+    const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
+    const bool ok = (NQ % NT == 0 || q < NQ) && gy >= 0 && gy < H && gx < W;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      if (!UP) {
+        v[k] = *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx));
+      } else {
+        const float2 t = *reinterpret_cast<const float2*>(sp + ((unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)));
+        v[k] = make_float4(t.x, t.x, t.y, t.y);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < HIT; ++k) {
+    const int hq = tid + k * NT;
+    const int row = hq >> 1, side = hq & 1;
+    const int c = row / LH, r = row - c * LH;
+    const int gy = y0 - 1 + r, gx = side ? x0 + TW : x0 - 1;
+    const bool ok = (NHALO % NT == 0 || hq < NHALO) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    hv[k] = 0.f;
+    if (ok) hv[k] = UP ? sp[(unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)]
+                       : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
+  }
+#pragma unroll
+  for (int k = 0; k < QIT; ++k) {
+    const int q = tid + k * NT;
+    if (NQ % NT == 0 || q < NQ) {
+      const int row = q / QPR, qx = q - row * QPR;
+      const int c = row / LH, r = row - c * LH;
+      float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      if (GN) {
+        const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
+        const bool ok = gy >= 0 && gy < H && gx < W;
+        const float A = ab[c][0], B = ab[c][1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = ok ? silu_f(fmaf(A, e[j], B)) : 0.f;
+      }
+      float* d = &tile[c][r][1 + 4 * qx];
+      d[0] = e[0]; d[1] = e[1]; d[2] = e[2]; d[3] = e[3];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < HIT; ++k) {
+    const int hq = tid + k * NT;
+    if (NHALO % NT == 0 || hq < NHALO) {
+      const int row = hq >> 1, side = hq & 1;
+      const int c = row / LH, r = row - c * LH;
+      float e = hv[k];
+      if (GN) {
+        const int gy = y0 - 1 + r, gx = side ? x0 + TW : x0 - 1;
+        e = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? silu_f(fmaf(ab[c][0], e, ab[c][1])) : 0.f;
+      }
+      tile[c][r][side ? TW + 1 : 0] = e;
+    }
+  }
+}
+
+// Slow path for widths that are not a multiple of 4: one element at a time (rare; tests only).
+template <int TW, int TH, int NT, int NCH, bool GN, bool UP, int LS>
+__device__ __noinline__ void stage_tile_scalar(float (*tile)[TH + 2][LS], const float* __restrict__ sp,
+                                               unsigned plane_in, int Win, int H, int W, int x0, int y0,
+                                               const float (*ab)[2], int tid) {
+  constexpr int LH = TH + 2, LW = TW + 2;
+  for (int i = tid; i < NCH * LH * LW; i += NT) {
+    const int c = i / (LH * LW), rem = i - c * (LH * LW);
+    const int r = rem / LW, col = rem - r * LW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    float e = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      e = UP ? sp[(unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)]
+             : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
+      if (GN) e = silu_f(fmaf(ab[c][0], e, ab[c][1]));
+    }
+    tile[c][r][col] = e;
+  }
+}
+
+template <int TW, int TH, int NT, int NCH, bool GN, bool UP, int LS>
+__device__ __forceinline__ void stage_tile(float (*tile)[TH + 2][LS], const float* __restrict__ sp,
+                                           size_t plane_in, int Win, int H, int W, int x0, int y0,
+                                           const float (*ab)[2], int tid) {
+  const bool wvec = UP ? ((Win & 1) == 0) : ((W & 3) == 0);
+  if (wvec) stage_tile_vec<TW, TH, NT, NCH, GN, UP, LS>(tile, sp, (unsigned)plane_in, Win, H, W, x0, y0, ab, tid);
+  else stage_tile_scalar<TW, TH, NT, NCH, GN, UP, LS>(tile, sp, (unsigned)plane_in, Win, H, W, x0, y0, ab, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 convolution, 8 (or 8+8) input channels -> 8 output channels, stride 1, zero padding 1.
 // ---------------------------------------------------------------------------------------------
 struct Conv8Args {
@@ -121,23 +231,8 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   for (int s = 0; s < NSRC; ++s) {
     if (s > 0) __syncthreads();
     // ---- stage one 8-channel tile (+halo) into LDS, applying GroupNorm+SiLU on the way ----
-    const float* __restrict__ sp = a.src[s] + (size_t)n * 8 * plane_in;
-#pragma unroll 1
-    for (int c = 0; c < 8; ++c) {
-      float A = 1.f, B = 0.f;
-      if (GN) { A = s_ab[s * 8 + c][0]; B = s_ab[s * 8 + c][1]; }
-      const float* __restrict__ cp = sp + (size_t)c * plane_in;
-      for (int i = tid; i < LH * LW; i += NT) {
-        const int r = i / LW, col = i - r * LW;
-        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
-        float v = 0.f;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-          v = UP ? cp[(size_t)(gy >> 1) * a.Win + (gx >> 1)] : cp[(size_t)gy * a.Win + gx];
-          if (GN) v = silu_f(fmaf(A, v, B));
-        }
-        tile[c][r][col] = v;
-      }
-    }
+    stage_tile<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[s] + (size_t)n * 8 * plane_in, plane_in, a.Win, a.H, a.W,
+                                           x0, y0, &s_ab[s * 8], tid);
     __syncthreads();
     // ---- 8 input channels x 9 taps x 8 output channels x 4 pixels ----
 #pragma unroll 2
@@ -149,7 +244,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
         const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
         in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
       }
-      const float* __restrict__ wp = a.w + (size_t)((s * 8 + ic) * 72);
+      const cfloat_p wp = as_const(a.w) + (size_t)((s * 8 + ic) * 72);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -181,7 +276,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
       for (int p = 0; p < 4; ++p) r[p] = ok[p] ? rp[p] : 0.f;
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
-        const float wv = a.ninw[c * 8 + o];
+        const float wv = as_const(a.ninw)[c * 8 + o];
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[o][p] = fmaf(wv, r[p], acc[o][p]);
       }
@@ -191,7 +286,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   float part[16];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    const float b = a.bias[o];
+    const float b = as_const(a.bias)[o];
     float v[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) v[p] = acc[o][p] + b;
@@ -244,7 +339,7 @@ __global__ __launch_bounds__(256) void down8_kernel(const DownArgs a) {
   const size_t plane_in = (size_t)a.Hin * a.Win;
   float acc[8];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) acc[o] = a.bias[o];
+  for (int o = 0; o < 8; ++o) acc[o] = as_const(a.bias)[o];
   const float* __restrict__ sp = a.src + (size_t)n * 8 * plane_in;
 #pragma unroll 2
   for (int ic = 0; ic < 8; ++ic) {
@@ -256,7 +351,7 @@ __global__ __launch_bounds__(256) void down8_kernel(const DownArgs a) {
         const int iy = 2 * oy + dy, ix = 2 * ox + dx;
         in[dy * 3 + dx] = (ok && iy < a.Hin && ix < a.Win) ? sp[(size_t)ic * plane_in + (size_t)iy * a.Win + ix] : 0.f;
       }
-    const float* __restrict__ wp = a.w + ic * 72;
+    const cfloat_p wp = as_const(a.w) + ic * 72;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -313,17 +408,8 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
                                            : a.x + ((size_t)n * a.C + (size_t)(ch - 1) * 8) * plane;
     const int wbase = ch == 0 ? 0 : 2 + (ch - 1) * 8;
     if (ch > 0) __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < nc; ++c) {
-      const float* __restrict__ cp = sp + (size_t)c * plane;
-      for (int i = tid; i < LH * LW; i += NT) {
-        const int r = i / LW, col = i - r * LW;
-        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
-        float v = 0.f;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = cp[(size_t)gy * a.W + gx];
-        tile[c][r][col] = v;
-      }
-    }
+    if (ch == 0) stage_tile<TW, TH, NT, 2, false, false, LS>(tile, sp, plane, a.W, a.H, a.W, x0, y0, nullptr, tid);
+    else stage_tile<TW, TH, NT, 8, false, false, LS>(tile, sp, plane, a.W, a.H, a.W, x0, y0, nullptr, tid);
     __syncthreads();
 #pragma unroll 1
     for (int ic = 0; ic < nc; ++ic) {
@@ -334,7 +420,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
         const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
         in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
       }
-      const float* __restrict__ wp = a.w + (size_t)(wbase + ic) * 72;
+      const cfloat_p wp = as_const(a.w) + (size_t)(wbase + ic) * 72;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -355,7 +441,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
   float part[16];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    const float b = a.bias[o];
+    const float b = as_const(a.bias)[o];
     float v[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) v[p] = acc[o][p] + b;
@@ -423,19 +509,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
     s_ab[tid][1] = B;
   }
   __syncthreads();
-  const float* __restrict__ sp = a.src + (size_t)n * 8 * plane;
-#pragma unroll 1
-  for (int c = 0; c < 8; ++c) {
-    const float A = s_ab[c][0], B = s_ab[c][1];
-    const float* __restrict__ cp = sp + (size_t)c * plane;
-    for (int i = tid; i < LH * LW; i += NT) {
-      const int r = i / LW, col = i - r * LW;
-      const int gy = y0 - 1 + r, gx = x0 - 1 + col;
-      float v = 0.f;
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = silu_f(fmaf(A, cp[(size_t)gy * a.W + gx], B));
-      tile[c][r][col] = v;
-    }
-  }
+  stage_tile<TW, TH, NT, 8, true, false, LS>(tile, a.src + (size_t)n * 8 * plane, plane, a.W, a.H, a.W, x0, y0, s_ab, tid);
   __syncthreads();
 
   float acc[OCB][4];
@@ -453,7 +527,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
       const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
       in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
     }
-    const float* __restrict__ wp = a.w + ((size_t)ocb * 8 + ic) * (9 * OCB);
+    const cfloat_p wp = as_const(a.w) + ((size_t)ocb * 8 + ic) * (9 * OCB);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -471,12 +545,12 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
   const bool vec_ok = row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
   const size_t pix = (size_t)gy * a.W + gx;
   float c1 = 0.f, c2 = 0.f, sg = 0.f;
-  if (POST != 0) { c1 = a.sched[2]; c2 = a.sched[3]; sg = a.sched[4]; }
+  if (POST != 0) { c1 = as_const(a.sched)[2]; c2 = as_const(a.sched)[3]; sg = as_const(a.sched)[4]; }
 #pragma unroll
   for (int o = 0; o < OCB; ++o) {
     const int oc = ocb * OCB + o;
     if (oc >= a.C) continue;  // last chunk of a C that is not a multiple of 16 (weights zero-padded)
-    const float b = a.bias[oc];
+    const float b = as_const(a.bias)[oc];
     const size_t e = ((size_t)n * a.C + oc) * plane + pix;
     float v[4];
 #pragma unroll
@@ -532,7 +606,7 @@ struct QSampleArgs {
 template <bool PHILOX>
 __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
   const int n = blockIdx.y;
-  const float sa = a.sched[0], sb = a.sched[1];
+  const float sa = as_const(a.sched)[0], sb = as_const(a.sched)[1];
   const float* __restrict__ fp = a.feat + (size_t)a.src_row[n] * a.per_agent;
   float* __restrict__ op = a.out + (size_t)n * a.per_agent;
   const long long nvec = (a.per_agent & 3) ? 0 : (a.per_agent >> 2);  // rows stay 16-B aligned only then
