@@ -9,13 +9,16 @@
 //     per workgroup), and the CONSUMING kernel folds mean/rstd/gamma/beta into one scale+shift per
 //     channel and applies GroupNorm + SiLU while it stages its input tile into LDS;
 //   * 3x3 taps are served from an LDS tile with a 1-pixel halo; each lane owns a 1x4 pixel strip x
-//     8 (or 16) output channels in registers; weights are wave-uniform and come in through the
-//     scalar cache (s_load) in [ic][tap][oc] order, so the inner loop is v_fma_f32 with an SGPR
-//     operand and 6 ds_read per 288 FMAs;
+//     8 (or 16) output channels in registers; the multiply-accumulates run on the matrix cores as
+//     v_mfma_f32_4x4x1_16b_f32 with CBSZ/ABID weight broadcast (see mfma_wbcast): all weights of
+//     8 input channels sit in 9 VGPRs, loaded with 9 coalesced 256-B loads, and each instruction
+//     does 64 pixels x 4 output channels x 1 (ic, tap) = 256 exact fp32 FMAs;
 //   * the timestep path, residual adds, the 1x1 nin_shortcut, nearest-x2 upsampling, the skip
 //     concat (two source pointers), bias, and the ancestral-sampling update with in-kernel Philox
 //     noise are all fused into those convolution kernels.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace gc {
@@ -73,52 +76,90 @@ __device__ __forceinline__ void block_stats_commit(float (&part)[16], float (*s_
 // tile, not per element; the two halo columns follow the same pattern with scalar loads.
 // Tile column index = gx - (x0 - 1), row index = gy - (y0 - 1).
 // ---------------------------------------------------------------------------------------------
-template <int TW, int TH, int NT, int NCH, bool GN, bool UP, int LS>
-__device__ __forceinline__ void stage_tile_vec(float (*tile)[TH + 2][LS], const float* __restrict__ sp,
-                                               unsigned plane_in, int Win, int H, int W, int x0, int y0,
-                                               const float (*ab)[2], int tid) {
-  // Fast path: W % 4 == 0 (UP: Win % 2 == 0), so a quad that starts inside the image lies inside
-  // it entirely and is 16-B (UP: 8-B) aligned. 32-bit element offsets from the uniform base `sp`.
-  constexpr int LH = TH + 2, QPR = TW / 4;
-  constexpr int NQ = NCH * LH * QPR, QIT = (NQ + NT - 1) / NT;
-  constexpr int NHALO = NCH * LH * 2, HIT = (NHALO + NT - 1) / NT;
+// compile-time loop (MFMA broadcast selectors must be immediates)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(static_cast<F&&>(f));
+  }
+}
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// v_mfma_f32_4x4x1_16b_f32 as a 64-pixel x 4-channel outer-product unit.
+// 16 blocks of 4x4, K = 1: D_b[i][j] += A_b[i] * B_b[j]; lane l = 4*b + idx holds A_b[idx], B_b[idx]
+// and D_b[reg][idx]. With CBSZ = 4 every block takes its A from block ABID, so:
+//   A = a register of WEIGHTS whose lanes 4*q .. 4*q+3 hold w[q][oc0 .. oc0+3] for 16 different q,
+//   B = one PIXEL value per lane,
+//   D: lane l, reg i += w[ABID][oc0 + i] * pixel_l.
+// 256 MACs per instruction at the full fp32 rate, exact fmaf semantics, one VGPR per operand, and
+// 16 (k, oc-group) weight vectors live in ONE register. Layout verified on gfx950 by
+// tools/probes/mfma4x4_probe.hip.
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma_wbcast(float w, float x, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(w, x, c, 4, ABID, 0);
+}
+
+// Registers holding one staged tile in flight: interior quads + halo scalars of this thread.
+template <int TW, int TH, int NT, int NCH>
+struct TileRegs {
+  static constexpr int LH = TH + 2, QPR = TW / 4;
+  static constexpr int NQ = NCH * LH * QPR, QIT = (NQ + NT - 1) / NT;
+  static constexpr int NHALO = NCH * LH * 2, HIT = (NHALO + NT - 1) / NT;
   float4 v[QIT];
   float hv[HIT];
+};
+
+// Issue every global load of this thread's share of the tile (fast path: W % 4 == 0, or for UP
+// Win % 2 == 0, so a quad that starts inside the image lies inside it entirely and is aligned).
+template <int TW, int TH, int NT, int NCH, bool UP>
+__device__ __forceinline__ void stage_load(TileRegs<TW, TH, NT, NCH>& R, const float* __restrict__ sp,
+                                           unsigned plane_in, int Win, int H, int W, int x0, int y0, int tid) {
+  using TR = TileRegs<TW, TH, NT, NCH>;
 #pragma unroll
-  for (int k = 0; k < QIT; ++k) {
+  for (int k = 0; k < TR::QIT; ++k) {
     const int q = tid + k * NT;
-    const int row = q / QPR, qx = q - row * QPR;
-    const int c = row / LH, r = row - c * LH;
+    const int row = q / TR::QPR, qx = q - row * TR::QPR;
+    const int c = row / TR::LH, r = row - c * TR::LH;
     const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
-    const bool ok = (NQ % NT == 0 || q < NQ) && gy >= 0 && gy < H && gx < W;
-    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = (TR::NQ % NT == 0 || q < TR::NQ) && gy >= 0 && gy < H && gx < W;
+    R.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
       if (!UP) {
-        v[k] = *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx));
+        R.v[k] = *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx));
       } else {
         const float2 t = *reinterpret_cast<const float2*>(sp + ((unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)));
-        v[k] = make_float4(t.x, t.x, t.y, t.y);
+        R.v[k] = make_float4(t.x, t.x, t.y, t.y);
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < HIT; ++k) {
+  for (int k = 0; k < TR::HIT; ++k) {
     const int hq = tid + k * NT;
     const int row = hq >> 1, side = hq & 1;
-    const int c = row / LH, r = row - c * LH;
+    const int c = row / TR::LH, r = row - c * TR::LH;
     const int gy = y0 - 1 + r, gx = side ? x0 + TW : x0 - 1;
-    const bool ok = (NHALO % NT == 0 || hq < NHALO) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    hv[k] = 0.f;
-    if (ok) hv[k] = UP ? sp[(unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)]
-                       : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
+    const bool ok = (TR::NHALO % NT == 0 || hq < TR::NHALO) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    R.hv[k] = 0.f;
+    if (ok) R.hv[k] = UP ? sp[(unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)]
+                         : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
   }
+}
+
+// Apply GroupNorm+SiLU (scale/shift per channel in `ab`) and write the tile to LDS.
+// Tile column index = gx - (x0 - 1), row index = gy - (y0 - 1); zeros outside the image.
+template <int TW, int TH, int NT, int NCH, bool GN, int LS>
+__device__ __forceinline__ void stage_store(float (*tile)[TH + 2][LS], const TileRegs<TW, TH, NT, NCH>& R,
+                                            int H, int W, int x0, int y0, const float (*ab)[2], int tid) {
+  using TR = TileRegs<TW, TH, NT, NCH>;
 #pragma unroll
-  for (int k = 0; k < QIT; ++k) {
+  for (int k = 0; k < TR::QIT; ++k) {
     const int q = tid + k * NT;
-    if (NQ % NT == 0 || q < NQ) {
-      const int row = q / QPR, qx = q - row * QPR;
-      const int c = row / LH, r = row - c * LH;
-      float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    if (TR::NQ % NT == 0 || q < TR::NQ) {
+      const int row = q / TR::QPR, qx = q - row * TR::QPR;
+      const int c = row / TR::LH, r = row - c * TR::LH;
+      float e[4] = {R.v[k].x, R.v[k].y, R.v[k].z, R.v[k].w};
       if (GN) {
         const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
         const bool ok = gy >= 0 && gy < H && gx < W;
@@ -131,12 +172,12 @@ __device__ __forceinline__ void stage_tile_vec(float (*tile)[TH + 2][LS], const 
     }
   }
 #pragma unroll
-  for (int k = 0; k < HIT; ++k) {
+  for (int k = 0; k < TR::HIT; ++k) {
     const int hq = tid + k * NT;
-    if (NHALO % NT == 0 || hq < NHALO) {
+    if (TR::NHALO % NT == 0 || hq < TR::NHALO) {
       const int row = hq >> 1, side = hq & 1;
-      const int c = row / LH, r = row - c * LH;
-      float e = hv[k];
+      const int c = row / TR::LH, r = row - c * TR::LH;
+      float e = R.hv[k];
       if (GN) {
         const int gy = y0 - 1 + r, gx = side ? x0 + TW : x0 - 1;
         e = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? silu_f(fmaf(ab[c][0], e, ab[c][1])) : 0.f;
@@ -146,7 +187,7 @@ __device__ __forceinline__ void stage_tile_vec(float (*tile)[TH + 2][LS], const 
   }
 }
 
-// Slow path for widths that are not a multiple of 4: one element at a time (rare; tests only).
+// Slow path for widths that are not a multiple of 4: one element at a time (tests only).
 template <int TW, int TH, int NT, int NCH, bool GN, bool UP, int LS>
 __device__ __noinline__ void stage_tile_scalar(float (*tile)[TH + 2][LS], const float* __restrict__ sp,
                                                unsigned plane_in, int Win, int H, int W, int x0, int y0,
@@ -166,13 +207,38 @@ __device__ __noinline__ void stage_tile_scalar(float (*tile)[TH + 2][LS], const 
   }
 }
 
-template <int TW, int TH, int NT, int NCH, bool GN, bool UP, int LS>
-__device__ __forceinline__ void stage_tile(float (*tile)[TH + 2][LS], const float* __restrict__ sp,
-                                           size_t plane_in, int Win, int H, int W, int x0, int y0,
-                                           const float (*ab)[2], int tid) {
-  const bool wvec = UP ? ((Win & 1) == 0) : ((W & 3) == 0);
-  if (wvec) stage_tile_vec<TW, TH, NT, NCH, GN, UP, LS>(tile, sp, (unsigned)plane_in, Win, H, W, x0, y0, ab, tid);
-  else stage_tile_scalar<TW, TH, NT, NCH, GN, UP, LS>(tile, sp, (unsigned)plane_in, Win, H, W, x0, y0, ab, tid);
+// Weight registers: reg g, lane l <- wp[g*64 + l] for a [k][4*NOG] table of NK rows (coalesced).
+template <int NREG>
+__device__ __forceinline__ void load_wregs(float (&wr)[NREG], const float* __restrict__ wp, int nfloats, int lane) {
+#pragma unroll
+  for (int g = 0; g < NREG; ++g) wr[g] = (g * 64 + lane < nfloats) ? wp[g * 64 + lane] : 0.f;
+}
+
+// NIC input channels x 9 taps x (4*NOG) output channels x 4 pixels on the matrix cores.
+// acc[og][p][i] accumulates out[pixel p of this lane's strip][oc = 4*og + i].
+template <int NIC, int NOG, int LH, int LS, int NREG>
+__device__ __forceinline__ void conv_tile_mfma(const float (*tile)[LH][LS], const float (&wr)[NREG],
+                                               f32x4 (&acc)[NOG][4], int tx, int ty) {
+  static_assert(NREG * 16 >= NIC * 9 * NOG, "weight registers do not cover the tile");
+  static_for<0, NIC>([&](auto IC) {
+    constexpr int ic = decltype(IC)::value;
+    float in[3][6];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const float4 v = *reinterpret_cast<const float4*>(&tile[ic][ty + dy][tx * 4]);
+      const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
+      in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
+    }
+    static_for<0, 9>([&](auto TAP) {
+      constexpr int tap = decltype(TAP)::value, dy = tap / 3, dx = tap % 3;
+      static_for<0, NOG>([&](auto OG) {
+        constexpr int og = decltype(OG)::value;
+        constexpr int f = (ic * 9 + tap) * NOG + og;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[og][p] = mfma_wbcast<f % 16>(wr[f / 16], in[dy][p + dx], acc[og][p]);
+      });
+    });
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,12 +268,23 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   __shared__ float s_ab[16][2];
   __shared__ float s_red[NT / 64][16];
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tx = tid % (TW / 4), ty = tid / (TW / 4);
   const size_t plane_in = (size_t)a.Hin * a.Win;
   const size_t plane = (size_t)a.H * a.W;
+  const bool wvec = UP ? ((a.Win & 1) == 0) : ((a.W & 3) == 0);
+
+  // everything that does not depend on the statistics is requested first: weights, bias, tile 0
+  float wr[NSRC][9];
+#pragma unroll
+  for (int s = 0; s < NSRC; ++s) load_wregs<9>(wr[s], a.w + s * 576, 576, lane);
+  float bias[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) bias[o] = as_const(a.bias)[o];
+  TileRegs<TW, TH, NT, 8> R;
+  if (wvec) stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
 
   if (GN) {
     if (tid < NSRC * 8) {
@@ -221,41 +298,24 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
     __syncthreads();
   }
 
-  float acc[8][4];
+  f32x4 acc[2][4];
 #pragma unroll
-  for (int o = 0; o < 8; ++o)
+  for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[o][p] = 0.f;
+    for (int p = 0; p < 4; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-  for (int s = 0; s < NSRC; ++s) {
-    if (s > 0) __syncthreads();
-    // ---- stage one 8-channel tile (+halo) into LDS, applying GroupNorm+SiLU on the way ----
-    stage_tile<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[s] + (size_t)n * 8 * plane_in, plane_in, a.Win, a.H, a.W,
-                                           x0, y0, &s_ab[s * 8], tid);
+  if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[0], tid);
+  else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
+  if (NSRC == 2 && wvec)  // prefetch the skip tensor's tile while the first half is computed
+    stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  __syncthreads();
+  conv_tile_mfma<8, 2, LH, LS, 9>(tile, wr[0], acc, tx, ty);
+  if (NSRC == 2) {
     __syncthreads();
-    // ---- 8 input channels x 9 taps x 8 output channels x 4 pixels ----
-#pragma unroll 2
-    for (int ic = 0; ic < 8; ++ic) {
-      float in[3][6];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const float4 v = *reinterpret_cast<const float4*>(&tile[ic][ty + dy][tx * 4]);
-        const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
-        in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
-      }
-      const cfloat_p wp = as_const(a.w) + (size_t)((s * 8 + ic) * 72);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-          for (int o = 0; o < 8; ++o) {
-            const float wv = wp[(dy * 3 + dx) * 8 + o];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[o][p] = fmaf(wv, in[dy][p + dx], acc[o][p]);
-          }
-    }
+    if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid);
+    else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
+    __syncthreads();
+    conv_tile_mfma<8, 2, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
   }
 
   // ---- epilogue: bias, residual, store, statistics of the output ----
@@ -267,18 +327,42 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   for (int p = 0; p < 4; ++p) ok[p] = row_ok && (gx + p < a.W);
   const size_t pix = (size_t)gy * a.W + gx;
 
-  if (RES == 2) {
+  float out[8][4];
+#pragma unroll
+  for (int o = 0; o < 8; ++o)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) out[o][p] = acc[o >> 2][p][o & 3] + bias[o];
+
+  if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
 #pragma unroll 4
     for (int c = 0; c < 16; ++c) {
       const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + pix;
-      float r[4];
+      float r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec_ok) {
+        const float4 t = *reinterpret_cast<const float4*>(rp);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+      } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) r[p] = ok[p] ? rp[p] : 0.f;
+        for (int p = 0; p < 4; ++p) if (ok[p]) r[p] = rp[p];
+      }
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
         const float wv = as_const(a.ninw)[c * 8 + o];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[o][p] = fmaf(wv, r[p], acc[o][p]);
+        for (int p = 0; p < 4; ++p) out[o][p] = fmaf(wv, r[p], out[o][p]);
+      }
+    }
+  }
+  if (RES == 1) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + o) * plane + pix;
+      if (vec_ok) {
+        const float4 r = *reinterpret_cast<const float4*>(rp);
+        out[o][0] += r.x; out[o][1] += r.y; out[o][2] += r.z; out[o][3] += r.w;
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) if (ok[p]) out[o][p] += rp[p];
       }
     }
   }
@@ -286,30 +370,16 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   float part[16];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    const float b = as_const(a.bias)[o];
-    float v[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) v[p] = acc[o][p] + b;
     float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
-    if (RES == 1) {
-      const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + o) * plane + pix;
-      if (vec_ok) {
-        const float4 r = *reinterpret_cast<const float4*>(rp);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      } else {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) if (ok[p]) v[p] += rp[p];
-      }
-    }
     if (vec_ok) {
-      *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(dp) = make_float4(out[o][0], out[o][1], out[o][2], out[o][3]);
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) if (ok[p]) dp[p] = v[p];
+      for (int p = 0; p < 4; ++p) if (ok[p]) dp[p] = out[o][p];
     }
     float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) if (ok[p]) { s += v[p]; q = fmaf(v[p], v[p], q); }
+    for (int p = 0; p < 4; ++p) if (ok[p]) { s += out[o][p]; q = fmaf(out[o][p], out[o][p], q); }
     part[o] = s;
     part[8 + o] = q;
   }
@@ -388,50 +458,60 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
   constexpr int LS = (LW + 3) / 4 * 4;
   __shared__ __align__(16) float tile[8][LH][LS];
   __shared__ float s_red[NT / 64][16];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tx = tid % (TW / 4), ty = tid / (TW / 4);
   const size_t plane = (size_t)a.H * a.W;
+  const bool wvec = (a.W & 3) == 0;
+  const int nchunk = a.C / 8;  // 8-channel chunks of x_t (after the 2-channel message chunk)
 
-  float acc[8][4];
+  float bias[8];
 #pragma unroll
-  for (int o = 0; o < 8; ++o)
+  for (int o = 0; o < 8; ++o) bias[o] = as_const(a.bias)[o];
+  f32x4 acc[2][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[o][p] = 0.f;
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = 1 + a.C / 8;
+  // ---- chunk 0: the two message channels (channel order: cond first, cond_diff.py:318) ----
+  {
+    const float* __restrict__ sp = a.cond + (size_t)n * 2 * plane;
+    float wc[3];
+    load_wregs<3>(wc, a.w, 144, lane);
+    if (wvec) {
+      TileRegs<TW, TH, NT, 2> Rc;
+      stage_load<TW, TH, NT, 2, false>(Rc, sp, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
+      stage_store<TW, TH, NT, 2, false, LS>(tile, Rc, a.H, a.W, x0, y0, nullptr, tid);
+    } else {
+      stage_tile_scalar<TW, TH, NT, 2, false, false, LS>(tile, sp, (unsigned)plane, a.W, a.H, a.W, x0, y0, nullptr, tid);
+    }
+    __syncthreads();
+    conv_tile_mfma<2, 2, LH, LS, 3>(tile, wc, acc, tx, ty);
+  }
+
+  // ---- x_t in chunks of 8 channels; chunk k+1's tile and weights are in flight while chunk k
+  //      is on the matrix cores ----
+  const float* __restrict__ xp = a.x + (size_t)n * a.C * plane;
+  TileRegs<TW, TH, NT, 8> R;
+  float wn[9];
+  if (wvec) stage_load<TW, TH, NT, 8, false>(R, xp, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
+  load_wregs<9>(wn, a.w + 144, 576, lane);
 #pragma unroll 1
   for (int ch = 0; ch < nchunk; ++ch) {
-    const int nc = ch == 0 ? 2 : 8;
-    const float* __restrict__ sp = ch == 0 ? a.cond + (size_t)n * 2 * plane
-                                           : a.x + ((size_t)n * a.C + (size_t)(ch - 1) * 8) * plane;
-    const int wbase = ch == 0 ? 0 : 2 + (ch - 1) * 8;
-    if (ch > 0) __syncthreads();
-    if (ch == 0) stage_tile<TW, TH, NT, 2, false, false, LS>(tile, sp, plane, a.W, a.H, a.W, x0, y0, nullptr, tid);
-    else stage_tile<TW, TH, NT, 8, false, false, LS>(tile, sp, plane, a.W, a.H, a.W, x0, y0, nullptr, tid);
-    __syncthreads();
-#pragma unroll 1
-    for (int ic = 0; ic < nc; ++ic) {
-      float in[3][6];
+    __syncthreads();  // previous chunk's LDS reads are done
+    if (wvec) stage_store<TW, TH, NT, 8, false, LS>(tile, R, a.H, a.W, x0, y0, nullptr, tid);
+    else stage_tile_scalar<TW, TH, NT, 8, false, false, LS>(tile, xp + (size_t)ch * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, nullptr, tid);
+    float wcur[9];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const float4 v = *reinterpret_cast<const float4*>(&tile[ic][ty + dy][tx * 4]);
-        const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
-        in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
-      }
-      const cfloat_p wp = as_const(a.w) + (size_t)(wbase + ic) * 72;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-          for (int o = 0; o < 8; ++o) {
-            const float wv = wp[(dy * 3 + dx) * 8 + o];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[o][p] = fmaf(wv, in[dy][p + dx], acc[o][p]);
-          }
+    for (int g = 0; g < 9; ++g) wcur[g] = wn[g];
+    if (ch + 1 < nchunk) {
+      if (wvec) stage_load<TW, TH, NT, 8, false>(R, xp + (size_t)(ch + 1) * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
+      load_wregs<9>(wn, a.w + 144 + (size_t)(ch + 1) * 576, 576, lane);
     }
+    __syncthreads();
+    conv_tile_mfma<8, 2, LH, LS, 9>(tile, wcur, acc, tx, ty);
   }
 
   const int gy = y0 + ty, gx = x0 + tx * 4;
@@ -441,10 +521,9 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
   float part[16];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    const float b = as_const(a.bias)[o];
     float v[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) v[p] = acc[o][p] + b;
+    for (int p = 0; p < 4; ++p) v[p] = acc[o >> 2][p][o & 3] + bias[o];
     float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
     float s = 0.f, q = 0.f;
     if (vec_ok) {
@@ -495,13 +574,18 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
   constexpr int OCB = 16;
   __shared__ __align__(16) float tile[8][LH][LS];
   __shared__ float s_ab[8][2];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int nocb = (a.C + OCB - 1) / OCB;
   const int n = blockIdx.z / nocb, ocb = blockIdx.z - n * nocb;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tx = tid % (TW / 4), ty = tid / (TW / 4);
   const size_t plane = (size_t)a.H * a.W;
+  const bool wvec = (a.W & 3) == 0;
 
+  float wr[18];  // [8 ic][9 taps][16 oc] of this channel block
+  load_wregs<18>(wr, a.w + (size_t)ocb * 1152, 1152, lane);
+  TileRegs<TW, TH, NT, 8> R;
+  if (wvec) stage_load<TW, TH, NT, 8, false>(R, a.src + (size_t)n * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
   if (tid < 8) {
     float A, B;
     gn_coeff(a.sstat + (size_t)n * 16, tid, 2, 2.0 * (double)plane, a.gamma[tid], a.beta[tid], &A, &B);
@@ -509,36 +593,16 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
     s_ab[tid][1] = B;
   }
   __syncthreads();
-  stage_tile<TW, TH, NT, 8, true, false, LS>(tile, a.src + (size_t)n * 8 * plane, plane, a.W, a.H, a.W, x0, y0, s_ab, tid);
+  if (wvec) stage_store<TW, TH, NT, 8, true, LS>(tile, R, a.H, a.W, x0, y0, s_ab, tid);
+  else stage_tile_scalar<TW, TH, NT, 8, true, false, LS>(tile, a.src + (size_t)n * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, s_ab, tid);
   __syncthreads();
 
-  float acc[OCB][4];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int o = 0; o < OCB; ++o)
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[o][p] = 0.f;
-
-#pragma unroll 1
-  for (int ic = 0; ic < 8; ++ic) {
-    float in[3][6];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const float4 v = *reinterpret_cast<const float4*>(&tile[ic][ty + dy][tx * 4]);
-      const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
-      in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
-    }
-    const cfloat_p wp = as_const(a.w) + ((size_t)ocb * 8 + ic) * (9 * OCB);
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int o = 0; o < OCB; ++o) {
-          const float wv = wp[(dy * 3 + dx) * OCB + o];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) acc[o][p] = fmaf(wv, in[dy][p + dx], acc[o][p]);
-        }
-  }
+    for (int p = 0; p < 4; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  conv_tile_mfma<8, 4, LH, LS, 18>(tile, wr, acc, tx, ty);
 
   const int gy = y0 + ty, gx = x0 + tx * 4;
   const bool row_ok = gy < a.H;
@@ -554,7 +618,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
     const size_t e = ((size_t)n * a.C + oc) * plane + pix;
     float v[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) v[p] = acc[o][p] + b;
+    for (int p = 0; p < 4; ++p) v[p] = acc[o >> 2][p][o & 3] + b;
     if (POST != 0) {
       float z[4] = {0.f, 0.f, 0.f, 0.f};
       float xt[4] = {0.f, 0.f, 0.f, 0.f};
