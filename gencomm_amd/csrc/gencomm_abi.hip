@@ -66,6 +66,15 @@ int gencomm_timer_stop(double* total_ms, int* launches) {
   return rc;
 }
 
+#ifdef GC_STAMPS
+// diagnostic build only: copy the stamp buffer to the host (synchronises the device)
+int gencomm_diag_read_stamps(unsigned long long* host, int nblocks) {
+  GC_HIP(hipDeviceSynchronize());
+  GC_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(gc::g_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)));
+  return GC_OK;
+}
+#endif
+
 // ------------------------------------------------------------------------------------ UNet
 int gencomm_unet_num_params(int C, int levels, int res_blocks) {
   UNetPlan p;

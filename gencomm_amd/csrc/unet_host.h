@@ -7,7 +7,10 @@ namespace gc {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Tile choice: the largest tile that still gives every CU (256 of them) at least ~2 workgroups.
+// Tile choice. 64x16 px / 256 threads / 4 px per lane (least LDS traffic per FMA) when that
+// still gives every one of the 256 CUs ~2 workgroups; else 32x16 / 128 threads; maps that are
+// smaller still run 32x8 px / 256 threads / ONE pixel per lane, which has 4x the waves and a
+// quarter of the serial work per wave (these layers are latency-bound, not throughput-bound).
 enum TileCfg { TILE_64x16 = 0, TILE_32x16 = 1, TILE_32x8 = 2 };
 inline TileCfg pick_tile(int n, int H, int W, int zmul = 1) {
   const long long want = 512;
@@ -27,9 +30,9 @@ inline void launch_conv8(TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
   tile_dims(t, &tw, &th);
   const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
   switch (t) {
-    case TILE_64x16: conv8_kernel<64, 16, NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a); break;
-    case TILE_32x16: conv8_kernel<32, 16, NSRC, GN, UP, RES><<<grid, 128, 0, st>>>(a); break;
-    default: conv8_kernel<32, 8, NSRC, GN, UP, RES><<<grid, 64, 0, st>>>(a); break;
+    case TILE_64x16: conv8_kernel<64, 16, 4, NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a); break;
+    case TILE_32x16: conv8_kernel<32, 16, 4, NSRC, GN, UP, RES><<<grid, 128, 0, st>>>(a); break;
+    default: conv8_kernel<32, 8, 1, NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a); break;
   }
 }
 
@@ -65,9 +68,9 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         tile_dims(tc, &tw, &th);
         const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n);
         TimedLaunch tl(KF_CONV_IN, c.st);
-        if (tc == TILE_64x16) conv_in_kernel<64, 16><<<grid, 256, 0, c.st>>>(a);
-        else if (tc == TILE_32x16) conv_in_kernel<32, 16><<<grid, 128, 0, c.st>>>(a);
-        else conv_in_kernel<32, 8><<<grid, 64, 0, c.st>>>(a);
+        if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
+        else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
+        else conv_in_kernel<32, 8, 1><<<grid, 256, 0, c.st>>>(a);
         break;
       }
       case OP_RES_CONV1: {
@@ -79,6 +82,7 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         a.w = P + b.p_c1w; a.bias = P + b.p_bias1 + (size_t)t * 8;
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = a.Hin = Hl; a.W = a.Win = Wl;
+        a.inv_cnt = 1.0 / ((b.cin == 8 ? 2.0 : 4.0) * Hl * Wl);
         const TileCfg tc = pick_tile(c.n, Hl, Wl);
         if (b.cin == 8) launch_conv8<1, true, false, 0>(tc, a, c.n, c.st);
         else launch_conv8<2, true, false, 0>(tc, a, c.n, c.st);
@@ -94,6 +98,7 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         if (o.res[1] >= 0) { a.res[1] = c.tensor_ptr(o.res[1]); a.ninw = P + b.p_ninw; }
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = a.Hin = Hl; a.W = a.Win = Wl;
+        a.inv_cnt = 1.0 / (2.0 * Hl * Wl);
         const TileCfg tc = pick_tile(c.n, Hl, Wl);
         if (b.cin == 8) launch_conv8<1, true, false, 1>(tc, a, c.n, c.st);
         else launch_conv8<1, true, false, 2>(tc, a, c.n, c.st);
@@ -122,6 +127,7 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         co.gamma = P + p.nout_w; co.beta = P + p.nout_b;
         co.w = P + p.conv_out.p_w; co.bias = P + p.conv_out.b;
         co.C = p.C; co.H = Hl; co.W = Wl;
+        co.inv_cnt = 1.0 / (2.0 * Hl * Wl);
         const int nocb = (p.C + 15) / 16;
         const TileCfg tc = pick_tile(c.n, Hl, Wl, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
         int tw, th;
@@ -129,8 +135,8 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n * nocb);
 #define GC_LAUNCH_CO(POST)                                                             \
   do {                                                                                 \
-    if (tc == TILE_64x16) conv_out_kernel<64, 16, POST><<<grid, 256, 0, c.st>>>(co);   \
-    else conv_out_kernel<32, 8, POST><<<grid, 64, 0, c.st>>>(co);                      \
+    if (tc == TILE_64x16) conv_out_kernel<64, 16, 4, POST><<<grid, 256, 0, c.st>>>(co); \
+    else conv_out_kernel<32, 8, 1, POST><<<grid, 256, 0, c.st>>>(co);                  \
   } while (0)
         TimedLaunch tl(KF_CONV_OUT, c.st);
         if (post == 0) GC_LAUNCH_CO(0);

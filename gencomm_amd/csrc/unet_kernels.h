@@ -29,18 +29,19 @@ namespace gc {
 // `gs` = channels per group inside one 8-channel source (2 for an 8-ch map, 4 for a 16-ch concat).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gn_coeff(const double* __restrict__ stat /*[8][2] of this sample*/,
-                                         int c, int gs, double cnt, float gamma, float beta,
+                                         int c, int gs, double inv_cnt, float gamma, float beta,
                                          float* A, float* B) {
+  // The sums are accumulated in f64 (so E[x^2] - mean^2 does not cancel); everything after the
+  // subtraction is float: one v_rsq_f32 instead of f64 sqrt + divide on the consumer's critical path.
   const int g0 = c & ~(gs - 1);
   double s = 0.0, q = 0.0;
   for (int j = 0; j < gs; ++j) {
     s += stat[(g0 + j) * 2 + 0];
     q += stat[(g0 + j) * 2 + 1];
   }
-  const double mean = s / cnt;
-  double var = q / cnt - mean * mean;
-  var = var < 0.0 ? 0.0 : var;
-  const float rstd = (float)(1.0 / sqrt(var + 1e-6));
+  const double mean = s * inv_cnt;
+  const float var = fmaxf((float)(q * inv_cnt - mean * mean), 0.f);
+  const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
   const float a = gamma * rstd;
   *A = a;
   *B = beta - (float)mean * a;
@@ -53,7 +54,15 @@ __device__ __forceinline__ void block_stats_commit(float (&part)[16], float (*s_
                                                    double* __restrict__ dstat /*[8][2]*/) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) part[i] = wave_sum(part[i]);
+  for (int i = 0; i < 16; ++i) part[i] = wave_total(part[i]);  // wave-uniform totals
+  if (NT == 64) {
+    // single wave: lane i < 16 commits total i
+    float v = part[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) v = (tid == i) ? part[i] : v;
+    if (tid < 16) atomicAdd(&dstat[(tid & 7) * 2 + (tid >> 3)], (double)v);
+    return;
+  }
   if ((tid & 63) == 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_red[tid >> 6][i] = part[i];
@@ -68,14 +77,21 @@ __device__ __forceinline__ void block_stats_commit(float (&part)[16], float (*s_
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Stage NCH channel planes of a (TH+2) x (TW+2) tile (1-pixel halo, zeros outside the image) into
-// LDS, optionally applying GroupNorm+SiLU (scale/shift per channel in `ab`) and optionally reading
-// through a nearest-neighbour x2 upsampling (UP). The interior is fetched as float4 (float2 for UP)
-// with ALL of a thread's loads issued before the first use, so one HBM/L2 latency is paid per
-// tile, not per element; the two halo columns follow the same pattern with scalar loads.
-// Tile column index = gx - (x0 - 1), row index = gy - (y0 - 1).
-// ---------------------------------------------------------------------------------------------
+// Diagnostic build only (-DGC_STAMPS, tools/stamps.py): wave 0 of every workgroup records the
+// 100 MHz real-time counter at phase boundaries into a buffer nothing else reads.
+#ifdef GC_STAMPS
+__device__ unsigned long long g_stamps[1 << 16][8];
+#define GC_STAMP(slot)                                                                         \
+  do {                                                                                         \
+    if (threadIdx.x == 0) {                                                                    \
+      const unsigned b__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);     \
+      if (b__ < (1u << 16)) g_stamps[b__][slot] = __builtin_amdgcn_s_memrealtime();           \
+    }                                                                                          \
+  } while (0)
+#else
+#define GC_STAMP(slot) do {} while (0)
+#endif
+
 // compile-time loop (MFMA broadcast selectors must be immediates)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -148,7 +164,8 @@ __device__ __forceinline__ void stage_load(TileRegs<TW, TH, NT, NCH>& R, const f
 }
 
 // Apply GroupNorm+SiLU (scale/shift per channel in `ab`) and write the tile to LDS.
-// Tile column index = gx - (x0 - 1), row index = gy - (y0 - 1); zeros outside the image.
+// Tile column index = gx - x0 + 4 (interior quads 16-B aligned: one ds_write_b128 each, halo in
+// columns 3 and TW+4), row index = gy - (y0 - 1); zeros outside the image.
 template <int TW, int TH, int NT, int NCH, bool GN, int LS>
 __device__ __forceinline__ void stage_store(float (*tile)[TH + 2][LS], const TileRegs<TW, TH, NT, NCH>& R,
                                             int H, int W, int x0, int y0, const float (*ab)[2], int tid) {
@@ -167,8 +184,7 @@ __device__ __forceinline__ void stage_store(float (*tile)[TH + 2][LS], const Til
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = ok ? silu_f(fmaf(A, e[j], B)) : 0.f;
       }
-      float* d = &tile[c][r][1 + 4 * qx];
-      d[0] = e[0]; d[1] = e[1]; d[2] = e[2]; d[3] = e[3];
+      *reinterpret_cast<float4*>(&tile[c][r][4 + 4 * qx]) = make_float4(e[0], e[1], e[2], e[3]);
     }
   }
 #pragma unroll
@@ -182,7 +198,7 @@ __device__ __forceinline__ void stage_store(float (*tile)[TH + 2][LS], const Til
         const int gy = y0 - 1 + r, gx = side ? x0 + TW : x0 - 1;
         e = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? silu_f(fmaf(ab[c][0], e, ab[c][1])) : 0.f;
       }
-      tile[c][r][side ? TW + 1 : 0] = e;
+      tile[c][r][side ? TW + 4 : 3] = e;
     }
   }
 }
@@ -203,7 +219,7 @@ __device__ __noinline__ void stage_tile_scalar(float (*tile)[TH + 2][LS], const 
              : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
       if (GN) e = silu_f(fmaf(ab[c][0], e, ab[c][1]));
     }
-    tile[c][r][col] = e;
+    tile[c][r][col + 3] = e;
   }
 }
 
@@ -214,20 +230,31 @@ __device__ __forceinline__ void load_wregs(float (&wr)[NREG], const float* __res
   for (int g = 0; g < NREG; ++g) wr[g] = (g * 64 + lane < nfloats) ? wp[g * 64 + lane] : 0.f;
 }
 
-// NIC input channels x 9 taps x (4*NOG) output channels x 4 pixels on the matrix cores.
+// NIC input channels x 9 taps x (4*NOG) output channels x PPL pixels per lane on the matrix cores.
 // acc[og][p][i] accumulates out[pixel p of this lane's strip][oc = 4*og + i].
-template <int NIC, int NOG, int LH, int LS, int NREG>
+// PPL = 4: a lane owns a 1x4 strip (wide LDS reads, least LDS traffic per FMA);
+// PPL = 1: a lane owns one pixel -- 4x the waves and a quarter of the serial work per wave, for
+//          maps too small to fill the chip otherwise.
+template <int NIC, int NOG, int PPL, int LH, int LS, int NREG>
 __device__ __forceinline__ void conv_tile_mfma(const float (*tile)[LH][LS], const float (&wr)[NREG],
-                                               f32x4 (&acc)[NOG][4], int tx, int ty) {
+                                               f32x4 (&acc)[NOG][PPL], int tx, int ty) {
   static_assert(NREG * 16 >= NIC * 9 * NOG, "weight registers do not cover the tile");
+  static_assert(PPL == 4 || PPL == 1, "pixels per lane");
   static_for<0, NIC>([&](auto IC) {
     constexpr int ic = decltype(IC)::value;
-    float in[3][6];
+    float in[3][PPL + 2];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-      const float4 v = *reinterpret_cast<const float4*>(&tile[ic][ty + dy][tx * 4]);
-      const float2 u = *reinterpret_cast<const float2*>(&tile[ic][ty + dy][tx * 4 + 4]);
-      in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = u.x; in[dy][5] = u.y;
+      if constexpr (PPL == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(&tile[ic][ty + dy][tx * 4 + 4]);
+        in[dy][0] = tile[ic][ty + dy][tx * 4 + 3];
+        in[dy][1] = v.x; in[dy][2] = v.y; in[dy][3] = v.z; in[dy][4] = v.w;
+        in[dy][5] = tile[ic][ty + dy][tx * 4 + 8];
+      } else {
+        in[dy][0] = tile[ic][ty + dy][tx + 3];
+        in[dy][1] = tile[ic][ty + dy][tx + 4];
+        in[dy][2] = tile[ic][ty + dy][tx + 5];
+      }
     }
     static_for<0, 9>([&](auto TAP) {
       constexpr int tap = decltype(TAP)::value, dy = tap / 3, dx = tap % 3;
@@ -235,7 +262,7 @@ __device__ __forceinline__ void conv_tile_mfma(const float (*tile)[LH][LS], cons
         constexpr int og = decltype(OG)::value;
         constexpr int f = (ic * 9 + tap) * NOG + og;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[og][p] = mfma_wbcast<f % 16>(wr[f / 16], in[dy][p + dx], acc[og][p]);
+        for (int p = 0; p < PPL; ++p) acc[og][p] = mfma_wbcast<f % 16>(wr[f / 16], in[dy][p + dx], acc[og][p]);
       });
     });
   });
@@ -255,14 +282,14 @@ struct Conv8Args {
   const float* ninw;      // prepared nin_shortcut [16][8] = (ic, oc)
   float* dst;             // [n][8][H][W]
   double* dstat;          // [n][8][2] accumulators for dst (may be null)
+  double inv_cnt;         // 1 / (channels per group * Hin * Win)
   int H, W, Hin, Win;
 };
 
-template <int TW, int TH, int NSRC, bool GN, bool UP, int RES>
-__global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a) {
-  constexpr int NT = (TW / 4) * TH;
-  constexpr int LW = TW + 2, LH = TH + 2;
-  constexpr int LS = (LW + 3) / 4 * 4;  // row stride (floats), keeps float4 reads 16-B aligned
+template <int TW, int TH, int PPL, int NSRC, bool GN, bool UP, int RES>
+__global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args a) {
+  constexpr int NT = (TW / PPL) * TH;
+  constexpr int LH = TH + 2, LS = TW + 8;
   static_assert(NT % 64 == 0, "workgroup must be whole waves");
   __shared__ __align__(16) float tile[8][LH][LS];
   __shared__ float s_ab[16][2];
@@ -271,12 +298,21 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int tx = tid % (TW / 4), ty = tid / (TW / 4);
+  const int tx = tid % (TW / PPL), ty = tid / (TW / PPL);
   const size_t plane_in = (size_t)a.Hin * a.Win;
   const size_t plane = (size_t)a.H * a.W;
   const bool wvec = UP ? ((a.Win & 1) == 0) : ((a.W & 3) == 0);
+  const int gy = y0 + ty, gx = x0 + tx * PPL;
+  const bool row_ok = gy < a.H;
+  const bool vec_ok = PPL == 4 && row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
+  bool ok[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) ok[p] = row_ok && (gx + p < a.W);
+  const size_t pix = (size_t)gy * a.W + gx;
 
-  // everything that does not depend on the statistics is requested first: weights, bias, tile 0
+  GC_STAMP(0);
+  // everything that does not depend on the statistics is requested first: weights, bias, tile 0,
+  // the identity residual
   float wr[NSRC][9];
 #pragma unroll
   for (int s = 0; s < NSRC; ++s) load_wregs<9>(wr[s], a.w + s * 576, 576, lane);
@@ -285,84 +321,80 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   for (int o = 0; o < 8; ++o) bias[o] = as_const(a.bias)[o];
   TileRegs<TW, TH, NT, 8> R;
   if (wvec) stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
-
-  if (GN) {
-    if (tid < NSRC * 8) {
-      const int s = tid >> 3, c = tid & 7;
-      float A, B;
-      gn_coeff(a.sstat[s] + (size_t)n * 16, c, 2 * NSRC, (double)(2 * NSRC) * (double)plane_in,
-               a.gamma[tid], a.beta[tid], &A, &B);
-      s_ab[tid][0] = A;
-      s_ab[tid][1] = B;
-    }
-    __syncthreads();
-  }
-
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[0], tid);
-  else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
-  if (NSRC == 2 && wvec)  // prefetch the skip tensor's tile while the first half is computed
-    stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
-  __syncthreads();
-  conv_tile_mfma<8, 2, LH, LS, 9>(tile, wr[0], acc, tx, ty);
-  if (NSRC == 2) {
-    __syncthreads();
-    if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid);
-    else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
-    __syncthreads();
-    conv_tile_mfma<8, 2, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
-  }
-
-  // ---- epilogue: bias, residual, store, statistics of the output ----
-  const int gy = y0 + ty, gx = x0 + tx * 4;
-  const bool row_ok = gy < a.H;
-  const bool vec_ok = row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
-  bool ok[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) ok[p] = row_ok && (gx + p < a.W);
-  const size_t pix = (size_t)gy * a.W + gx;
-
-  float out[8][4];
-#pragma unroll
-  for (int o = 0; o < 8; ++o)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) out[o][p] = acc[o >> 2][p][o & 3] + bias[o];
-
-  if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
-#pragma unroll 4
-    for (int c = 0; c < 16; ++c) {
-      const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + pix;
-      float r[4] = {0.f, 0.f, 0.f, 0.f};
-      if (vec_ok) {
-        const float4 t = *reinterpret_cast<const float4*>(rp);
-        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-      } else {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) if (ok[p]) r[p] = rp[p];
-      }
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const float wv = as_const(a.ninw)[c * 8 + o];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) out[o][p] = fmaf(wv, r[p], out[o][p]);
-      }
-    }
-  }
+  float resv[RES == 1 ? 8 : 1][PPL];
   if (RES == 1) {
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + o) * plane + pix;
       if (vec_ok) {
         const float4 r = *reinterpret_cast<const float4*>(rp);
-        out[o][0] += r.x; out[o][1] += r.y; out[o][2] += r.z; out[o][3] += r.w;
+        resv[o][0] = r.x; resv[o][1 % PPL] = r.y; resv[o][2 % PPL] = r.z; resv[o][3 % PPL] = r.w;
       } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) if (ok[p]) out[o][p] += rp[p];
+        for (int p = 0; p < PPL; ++p) resv[o][p] = ok[p] ? rp[p] : 0.f;
+      }
+    }
+  }
+
+  if (GN) {
+    if (tid < NSRC * 8) {
+      const int s = tid >> 3, c = tid & 7;
+      float A, B;
+      gn_coeff(a.sstat[s] + (size_t)n * 16, c, 2 * NSRC, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
+      s_ab[tid][0] = A;
+      s_ab[tid][1] = B;
+    }
+    __syncthreads();
+  }
+
+  GC_STAMP(1);
+  f32x4 acc[2][PPL];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[0], tid);
+  else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
+  if (NSRC == 2 && wvec)  // prefetch the skip tensor's tile while the first half is computed
+    stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  __syncthreads();
+  GC_STAMP(2);
+  conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[0], acc, tx, ty);
+  GC_STAMP(3);
+  if (NSRC == 2) {
+    __syncthreads();
+    if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid);
+    else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
+    __syncthreads();
+    conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
+  }
+
+  GC_STAMP(4);
+  // ---- epilogue: bias, residual, store, statistics of the output ----
+  float out[8][PPL];
+#pragma unroll
+  for (int o = 0; o < 8; ++o)
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) out[o][p] = acc[o >> 2][p][o & 3] + bias[o] + (RES == 1 ? resv[o][p] : 0.f);
+
+  if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+      const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + pix;
+      float r[PPL];
+      if (vec_ok) {
+        const float4 t = *reinterpret_cast<const float4*>(rp);
+        r[0] = t.x; r[1 % PPL] = t.y; r[2 % PPL] = t.z; r[3 % PPL] = t.w;
+      } else {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) r[p] = ok[p] ? rp[p] : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const float wv = as_const(a.ninw)[c * 8 + o];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) out[o][p] = fmaf(wv, r[p], out[o][p]);
       }
     }
   }
@@ -372,18 +404,20 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv8_kernel(const Conv8Args a)
   for (int o = 0; o < 8; ++o) {
     float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
     if (vec_ok) {
-      *reinterpret_cast<float4*>(dp) = make_float4(out[o][0], out[o][1], out[o][2], out[o][3]);
+      *reinterpret_cast<float4*>(dp) = make_float4(out[o][0], out[o][1 % PPL], out[o][2 % PPL], out[o][3 % PPL]);
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) if (ok[p]) dp[p] = out[o][p];
+      for (int p = 0; p < PPL; ++p) if (ok[p]) dp[p] = out[o][p];
     }
     float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) if (ok[p]) { s += out[o][p]; q = fmaf(out[o][p], out[o][p], q); }
+    for (int p = 0; p < PPL; ++p) if (ok[p]) { s += out[o][p]; q = fmaf(out[o][p], out[o][p], q); }
     part[o] = s;
     part[8 + o] = q;
   }
+  GC_STAMP(5);
   if (a.dstat != nullptr) block_stats_commit<NT>(part, s_red, a.dstat + (size_t)n * 16);
+  GC_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -451,17 +485,16 @@ struct ConvInArgs {
   int C, H, W;
 };
 
-template <int TW, int TH>
-__global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs a) {
-  constexpr int NT = (TW / 4) * TH;
-  constexpr int LW = TW + 2, LH = TH + 2;
-  constexpr int LS = (LW + 3) / 4 * 4;
+template <int TW, int TH, int PPL>
+__global__ __launch_bounds__((TW / PPL) * TH) void conv_in_kernel(const ConvInArgs a) {
+  constexpr int NT = (TW / PPL) * TH;
+  constexpr int LH = TH + 2, LS = TW + 8;
   __shared__ __align__(16) float tile[8][LH][LS];
   __shared__ float s_red[NT / 64][16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int tx = tid % (TW / 4), ty = tid / (TW / 4);
+  const int tx = tid % (TW / PPL), ty = tid / (TW / PPL);
   const size_t plane = (size_t)a.H * a.W;
   const bool wvec = (a.W & 3) == 0;
   const int nchunk = a.C / 8;  // 8-channel chunks of x_t (after the 2-channel message chunk)
@@ -469,11 +502,11 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
   float bias[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) bias[o] = as_const(a.bias)[o];
-  f32x4 acc[2][4];
+  f32x4 acc[2][PPL];
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < PPL; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- chunk 0: the two message channels (channel order: cond first, cond_diff.py:318) ----
   {
@@ -488,7 +521,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
       stage_tile_scalar<TW, TH, NT, 2, false, false, LS>(tile, sp, (unsigned)plane, a.W, a.H, a.W, x0, y0, nullptr, tid);
     }
     __syncthreads();
-    conv_tile_mfma<2, 2, LH, LS, 3>(tile, wc, acc, tx, ty);
+    conv_tile_mfma<2, 2, PPL, LH, LS, 3>(tile, wc, acc, tx, ty);
   }
 
   // ---- x_t in chunks of 8 channels; chunk k+1's tile and weights are in flight while chunk k
@@ -511,28 +544,28 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_in_kernel(const ConvInArgs
       load_wregs<9>(wn, a.w + 144 + (size_t)(ch + 1) * 576, 576, lane);
     }
     __syncthreads();
-    conv_tile_mfma<8, 2, LH, LS, 9>(tile, wcur, acc, tx, ty);
+    conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wcur, acc, tx, ty);
   }
 
-  const int gy = y0 + ty, gx = x0 + tx * 4;
+  const int gy = y0 + ty, gx = x0 + tx * PPL;
   const bool row_ok = gy < a.H;
-  const bool vec_ok = row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
+  const bool vec_ok = PPL == 4 && row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
   const size_t pix = (size_t)gy * a.W + gx;
   float part[16];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    float v[4];
+    float v[PPL];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) v[p] = acc[o >> 2][p][o & 3] + bias[o];
+    for (int p = 0; p < PPL; ++p) v[p] = acc[o >> 2][p][o & 3] + bias[o];
     float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
     float s = 0.f, q = 0.f;
     if (vec_ok) {
-      *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1 % PPL], v[2 % PPL], v[3 % PPL]);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) { s += v[p]; q = fmaf(v[p], v[p], q); }
+      for (int p = 0; p < PPL; ++p) { s += v[p]; q = fmaf(v[p], v[p], q); }
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < PPL; ++p)
         if (row_ok && gx + p < a.W) { dp[p] = v[p]; s += v[p]; q = fmaf(v[p], v[p], q); }
     }
     part[o] = s;
@@ -560,17 +593,17 @@ struct ConvOutArgs {
   const float* xt;      // [n][C][H][W] (POST != 0)
   const float* noise;   // [n][C][H][W] (POST == 1)
   const float* sched;   // device [5] row of this timestep (POST != 0)
+  double inv_cnt;       // 1 / (2 * H * W)
   float* out;           // [n][C][H][W]
   unsigned long long seed;
   unsigned int stream_id;
   int C, H, W;
 };
 
-template <int TW, int TH, int POST>
-__global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutArgs a) {
-  constexpr int NT = (TW / 4) * TH;
-  constexpr int LW = TW + 2, LH = TH + 2;
-  constexpr int LS = (LW + 3) / 4 * 4;
+template <int TW, int TH, int PPL, int POST>
+__global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOutArgs a) {
+  constexpr int NT = (TW / PPL) * TH;
+  constexpr int LH = TH + 2, LS = TW + 8;
   constexpr int OCB = 16;
   __shared__ __align__(16) float tile[8][LH][LS];
   __shared__ float s_ab[8][2];
@@ -578,7 +611,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
   const int nocb = (a.C + OCB - 1) / OCB;
   const int n = blockIdx.z / nocb, ocb = blockIdx.z - n * nocb;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int tx = tid % (TW / 4), ty = tid / (TW / 4);
+  const int tx = tid % (TW / PPL), ty = tid / (TW / PPL);
   const size_t plane = (size_t)a.H * a.W;
   const bool wvec = (a.W & 3) == 0;
 
@@ -588,7 +621,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
   if (wvec) stage_load<TW, TH, NT, 8, false>(R, a.src + (size_t)n * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
   if (tid < 8) {
     float A, B;
-    gn_coeff(a.sstat + (size_t)n * 16, tid, 2, 2.0 * (double)plane, a.gamma[tid], a.beta[tid], &A, &B);
+    gn_coeff(a.sstat + (size_t)n * 16, tid, 2, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
     s_ab[tid][0] = A;
     s_ab[tid][1] = B;
   }
@@ -597,16 +630,16 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
   else stage_tile_scalar<TW, TH, NT, 8, true, false, LS>(tile, a.src + (size_t)n * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, s_ab, tid);
   __syncthreads();
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][PPL];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  conv_tile_mfma<8, 4, LH, LS, 18>(tile, wr, acc, tx, ty);
+    for (int p = 0; p < PPL; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  conv_tile_mfma<8, 4, PPL, LH, LS, 18>(tile, wr, acc, tx, ty);
 
-  const int gy = y0 + ty, gx = x0 + tx * 4;
+  const int gy = y0 + ty, gx = x0 + tx * PPL;
   const bool row_ok = gy < a.H;
-  const bool vec_ok = row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
+  const bool vec_ok = PPL == 4 && row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
   const size_t pix = (size_t)gy * a.W + gx;
   float c1 = 0.f, c2 = 0.f, sg = 0.f;
   if (POST != 0) { c1 = as_const(a.sched)[2]; c2 = as_const(a.sched)[3]; sg = as_const(a.sched)[4]; }
@@ -616,18 +649,18 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
     if (oc >= a.C) continue;  // last chunk of a C that is not a multiple of 16 (weights zero-padded)
     const float b = as_const(a.bias)[oc];
     const size_t e = ((size_t)n * a.C + oc) * plane + pix;
-    float v[4];
+    float v[PPL];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) v[p] = acc[o >> 2][p][o & 3] + b;
+    for (int p = 0; p < PPL; ++p) v[p] = acc[o >> 2][p][o & 3] + b;
     if (POST != 0) {
       float z[4] = {0.f, 0.f, 0.f, 0.f};
-      float xt[4] = {0.f, 0.f, 0.f, 0.f};
+      float xt[PPL];
       if (vec_ok) {
         const float4 t4 = *reinterpret_cast<const float4*>(a.xt + e);
-        xt[0] = t4.x; xt[1] = t4.y; xt[2] = t4.z; xt[3] = t4.w;
+        xt[0] = t4.x; xt[1 % PPL] = t4.y; xt[2 % PPL] = t4.z; xt[3 % PPL] = t4.w;
       } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) if (row_ok && gx + p < a.W) xt[p] = a.xt[e + p];
+        for (int p = 0; p < PPL; ++p) xt[p] = (row_ok && gx + p < a.W) ? a.xt[e + p] : 0.f;
       }
       if (POST == 1) {
         if (vec_ok) {
@@ -635,19 +668,20 @@ __global__ __launch_bounds__((TW / 4) * TH) void conv_out_kernel(const ConvOutAr
           z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
         } else {
 #pragma unroll
-          for (int p = 0; p < 4; ++p) if (row_ok && gx + p < a.W) z[p] = a.noise[e + p];
+          for (int p = 0; p < PPL; ++p) if (row_ok && gx + p < a.W) z[p] = a.noise[e + p];
         }
       } else {
+        // counter = element index of the first pixel of this lane's strip: unique per (lane, oc)
         normal4((uint64_t)e, a.stream_id, a.seed, z);
       }
 #pragma unroll
-      for (int p = 0; p < 4; ++p) v[p] = fmaf(sg, z[p], fmaf(c1, v[p], c2 * xt[p]));
+      for (int p = 0; p < PPL; ++p) v[p] = fmaf(sg, z[p], fmaf(c1, v[p], c2 * xt[p]));
     }
     if (vec_ok) {
-      *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1 % PPL], v[2 % PPL], v[3 % PPL]);
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) if (row_ok && gx + p < a.W) a.out[e + p] = v[p];
+      for (int p = 0; p < PPL; ++p) if (row_ok && gx + p < a.W) a.out[e + p] = v[p];
     }
   }
 }
