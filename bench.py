@@ -119,9 +119,8 @@ def main():
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from gencomm_amd import dist as gdist
+    rank, world, local_rank = gdist.env_rank_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -129,11 +128,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+    dist = gdist.init_process_group("nccl", device)  # RCCL; only the timing barrier/reduction use it
 
     from gencomm_amd import _lib, normalize_pairwise_tfm
     from gencomm_amd.pipeline import ScenePipeline
@@ -185,18 +180,15 @@ def main():
     for pipe in pipes:
         assert torch.isfinite(pipe.fused).all(), "non-finite output"
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # every rank ran `steps` scenes of its own; whole-job rate = all scenes / slowest rank
+    value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps, elapsed, dist, device)
 
     if rank == 0:
         HW = H * W
         flops, byts = algorithmic_work(N, C, HW, T)
-        value = world * args.steps / elapsed
         out = {
             "metric": "scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "total_scenes": total_scenes,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
