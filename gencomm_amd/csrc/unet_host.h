@@ -1,5 +1,7 @@
 // Host launch logic of the UNet / sampler (stream-ordered, allocation-free, capture-safe).
 #pragma once
+#include <stdlib.h>
+
 #include "unet_kernels.h"
 #include "unet_plan.h"
 
@@ -12,8 +14,16 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // smaller still run 32x8 px / 256 threads / ONE pixel per lane, which has 4x the waves and a
 // quarter of the serial work per wave (these layers are latency-bound, not throughput-bound).
 enum TileCfg { TILE_64x16 = 0, TILE_32x16 = 1, TILE_32x8 = 2 };
+inline long long tile_want() {
+  // tuning hook (GENCOMM_TILE_WANT): minimum number of workgroups before a larger tile is chosen
+  static const long long v = [] {
+    const char* e = getenv("GENCOMM_TILE_WANT");
+    return e ? atoll(e) : 512LL;
+  }();
+  return v;
+}
 inline TileCfg pick_tile(int n, int H, int W, int zmul = 1) {
-  const long long want = 512;
+  const long long want = tile_want();
   if ((long long)cdiv(W, 64) * cdiv(H, 16) * n * zmul >= want) return TILE_64x16;
   if ((long long)cdiv(W, 32) * cdiv(H, 16) * n * zmul >= want) return TILE_32x16;
   return TILE_32x8;
