@@ -49,15 +49,15 @@ def algorithmic_work(N, C, HW, T):
     return flops, byts
 
 
-def make_scene(N, C, H, W, seed, device):
-    """Synthetic inputs, generated on the device (seeded torch generator; the parity tests use the
-    numpy generator of gencomm_amd.synth -- here only shape/statistics matter)."""
+def make_scene(N, C, H, W, seed, device, B=1):
+    """Synthetic inputs for B scenes of N agents, generated on the device (seeded torch generator;
+    the parity tests use the numpy generator of gencomm_amd.synth -- here only shape/statistics matter)."""
     from gencomm_amd import synth
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    feat = torch.randn(N, C, H, W, generator=g, device=device).clamp_(min=0)
-    cond = torch.randn(N, 2, H, W, generator=g, device=device)
-    ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N], 5, seed + 7, 40.0))
+    feat = torch.randn(B * N, C, H, W, generator=g, device=device).clamp_(min=0)
+    cond = torch.randn(B * N, 2, H, W, generator=g, device=device)
+    ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N] * B, 5, seed + 7, 40.0))
     return feat, cond, ptm
 
 
@@ -115,7 +115,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-enhancer", action="store_true")
     ap.add_argument("--timer-family", type=int, default=DOMINANT["family"])
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--batch", type=int, default=4, help="scenes per step (batched in one launch sequence, record_len=[N]*B)")
+    ap.add_argument("--streams", type=int, default=2,
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
     args = ap.parse_args()
 
@@ -139,12 +140,12 @@ def main():
     # S scenes in flight: the path is a chain of ~600 short dependent launches per scene, so two
     # independent scenes on two streams fill each other's latency gaps (memory phases of one overlap
     # compute phases of the other). Every stream has its own inputs, workspace and outputs.
-    S = max(1, args.streams)
+    S, B = max(1, args.streams), max(1, args.batch)
     streams = [torch.cuda.Stream(device=device) for _ in range(S)]
     scenes, pipes = [], []
     for si in range(S):
-        feat, cond, ptm = make_scene(N, C, H, W, 1 + rank * S + si, device)
-        pipe = ScenePipeline(gen, None if args.no_enhancer else enh, [N], C, H, W, device)
+        feat, cond, ptm = make_scene(N, C, H, W, 1 + rank * S + si, device, B)
+        pipe = ScenePipeline(gen, None if args.no_enhancer else enh, [N] * B, C, H, W, device)
         pipe.set_affine(normalize_pairwise_tfm(ptm, H * PX_M, W * PX_M, 1))
         scenes.append((feat, cond))
         pipes.append(pipe)
@@ -175,13 +176,22 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     k_ms, k_n = ctypes.c_double(0.0), ctypes.c_int(0)
+    iso_ms, iso_n = ctypes.c_double(0.0), ctypes.c_int(0)
     if timed:
         _lib.check(lib.gencomm_timer_stop(ctypes.byref(k_ms), ctypes.byref(k_n)), "gencomm_timer_stop")
+        # the same kernel with nothing else in flight (one stream, outside the timed region): what
+        # the kernel itself achieves when it does not share the chip with another scene
+        with torch.no_grad():
+            _lib.check(lib.gencomm_timer_start(args.timer_family, 4 * (T + 4) * 16), "gencomm_timer_start")
+            for i in range(2):
+                pipes[0].run(scenes[0][0], scenes[0][1], seed=3000 + i)
+            torch.cuda.synchronize(device)
+            _lib.check(lib.gencomm_timer_stop(ctypes.byref(iso_ms), ctypes.byref(iso_n)), "gencomm_timer_stop")
     for pipe in pipes:
         assert torch.isfinite(pipe.fused).all(), "non-finite output"
 
     # every rank ran `steps` scenes of its own; whole-job rate = all scenes / slowest rank
-    value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps, elapsed, dist, device)
+    value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed, dist, device)
 
     if rank == 0:
         HW = H * W
@@ -192,12 +202,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
-                                   f"T={T} x0-param ancestral steps, 1 scene/step/GPU",
+                                   f"T={T} x0-param ancestral steps, {B} scene(s)/step/GPU",
                        "agents": N, "C": C, "H": H, "W": W, "T": T, "enhancer": not args.no_enhancer,
-                       "noise": "in-kernel Philox4x32-10", "streams_per_gpu": S, "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+                       "noise": "in-kernel Philox4x32-10", "streams_per_gpu": S, "scenes_per_step": B, "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
             "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
-                                  "achieved_tflops": flops * args.steps / elapsed / 1e12 * 1.0,
-                                  "achieved_gbs": byts * args.steps / elapsed / 1e9},
+                                  "achieved_tflops": flops * args.steps * B / elapsed / 1e12,
+                                  "achieved_gbs": byts * args.steps * B / elapsed / 1e9},
         }
         # roofline of the dominant kernel: algorithmic FLOPs per launch / measured launch time
         roof = None
@@ -214,11 +224,18 @@ def main():
                 except Exception:
                     traffic = None
             if macs_px is not None:
-                fl = 2.0 * macs_px * HW * N
+                fl = 2.0 * macs_px * HW * N * B
                 roof = {"kernel": name, "bound": "mfma", "achieved": fl / (per_launch_ms * 1e-3) / 1e12,
                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (per_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                         "traffic": traffic, "launches": k_n.value, "avg_launch_ms": per_launch_ms,
-                        "flops_per_launch": fl, "note": "fp32 vector FMA kernel priced against the 157.3 TFLOP/s fp32 (vector = f32-MFMA) peak"}
+                        "flops_per_launch": fl,
+                        "isolated": ({"avg_launch_ms": iso_ms.value / iso_n.value,
+                                      "achieved": fl / (iso_ms.value / iso_n.value * 1e-3) / 1e12,
+                                      "frac": fl / (iso_ms.value / iso_n.value * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+                                     if iso_n.value else None),
+                        "note": "v_mfma_f32_4x4x1 (exact fp32) priced against the 157.3 TFLOP/s fp32 matrix/vector peak; "
+                                "'achieved' is event-timed inside the timed region (other scenes share the chip when "
+                                "streams > 1), 'isolated' is the same kernel with one scene in flight"}
             else:
                 roof = {"kernel": name, "launches": k_n.value, "avg_launch_ms": per_launch_ms}
         out["roofline"] = roof
