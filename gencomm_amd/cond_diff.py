@@ -119,11 +119,6 @@ class GenComm(nn.Module):
                  noise: Optional[Tuple[torch.Tensor, torch.Tensor]], seed: Optional[int]) -> torch.Tensor:
         require_gpu(feat, "GenComm.forward(spatial_features)")
         require_gpu(cond, "GenComm.forward(conditions)")
-        if torch.is_grad_enabled() and (feat.requires_grad or cond.requires_grad or
-                                        any(p.requires_grad for p in self.denoiser.parameters()) and self.training):
-            raise NotImplementedError(
-                "gencomm_amd.GenComm: backward through the HIP denoise loop is not implemented yet; "
-                "call under torch.no_grad() (inference) -- see DESIGN.md 'out of scope this round'")
         feat, cond = f32c(feat), f32c(cond)
         n, C, H, W = cond.shape[0], feat.shape[1], feat.shape[2], feat.shape[3]
         if cond.shape[1] != 2 or tuple(cond.shape[2:]) != (H, W):
@@ -151,6 +146,28 @@ class GenComm(nn.Module):
             "gencomm_denoise_fwd")
         return out
 
+    def _needs_grad(self, *tensors) -> bool:
+        return torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
+                                            any(p.requires_grad for p in self.denoiser.parameters()))
+
+    def _run(self, feat, cond, src_rows, noise, seed) -> torch.Tensor:
+        """HIP forward; when gradients are required, wrap it in the recompute-based autograd
+        Function (explicit noise so that the recomputation sees the same draws)."""
+        if not self._needs_grad(feat, cond):
+            return self._denoise(feat, cond, src_rows, noise, seed)
+        from .autograd import DenoiseFunction
+        require_gpu(feat, "GenComm.forward(spatial_features)")
+        n, (C, H, W), T = cond.shape[0], feat.shape[1:], self.num_timesteps
+        if noise is None:
+            g = None
+            if seed is not None:
+                g = torch.Generator(device=feat.device)
+                g.manual_seed(int(seed))
+            noise = (torch.randn(n, C, H, W, device=feat.device, generator=g),
+                     torch.randn(T, n, C, H, W, device=feat.device, generator=g))
+        params = list(self.denoiser.parameters())
+        return DenoiseFunction.apply(self, list(src_rows), f32c(feat), f32c(cond), f32c(noise[0]), f32c(noise[1]), *params)
+
     def _debug_t1_t2(self, spatial_features: torch.Tensor, data_dict: dict) -> None:
         """'t1' / 't2': the eval branch's two unused q_samples of the first ego map
         (cond_diff.py:369-371, :378-379). Only defined when T > 2, like the reference's indexing."""
@@ -168,7 +185,7 @@ class GenComm(nn.Module):
         n = conditions.shape[0]
         if lens is None:
             lens = [n]  # regroup(x, None) is not valid in the reference; treat as one scene
-        pred = self._denoise(spatial_features, conditions, self._src_rows(n, lens), noise, seed)
+        pred = self._run(spatial_features, conditions, self._src_rows(n, lens), noise, seed)
         data_dict = {}
         if self.training:
             data_dict["pred_feature"] = pred.unsqueeze(1).squeeze()
@@ -180,7 +197,7 @@ class GenComm(nn.Module):
     def forward_single(self, features, conditions, record_len=None, noise=None, seed=None):
         """cond_diff.py:385-432: as forward but every agent denoises from its OWN feature."""
         n = conditions.shape[0]
-        pred = self._denoise(features, conditions, self._src_rows(n, None), noise, seed)
+        pred = self._run(features, conditions, self._src_rows(n, None), noise, seed)
         data_dict = {}
         if self.training:
             data_dict["pred_feature"] = pred.unsqueeze(1).squeeze()

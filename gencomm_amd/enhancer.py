@@ -97,8 +97,6 @@ class Enhancer(nn.Module):
         the reference's live code (enhancer.py:375 slices it, nothing reads the slice); agents are
         processed independently so ``record_len`` only serves as a consistency check."""
         require_gpu(x, "Enhancer.forward")
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("gencomm_amd.Enhancer: backward is not implemented yet; call under torch.no_grad()")
         lens = record_len_list(record_len)
         n, C, H, W = x.shape
         if C != self.C:
@@ -106,6 +104,13 @@ class Enhancer(nn.Module):
         if lens is not None and sum(lens) != n:
             raise ValueError(f"record_len sums to {sum(lens)} but x has {n} agents")
         x = f32c(x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import EnhancerFunction  # HIP forward, recompute-based backward
+            return EnhancerFunction.apply(self, x, *list(self.parameters()))
+        return self._forward_hip(x)
+
+    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
+        n, C, H, W = x.shape
         l = _lib.lib()
         raw = self._raw_params(x.device)
         ws = workspaces.get(x.device, _lib.check_size(l.gencomm_enhancer_workspace_bytes(n, C, H, W), "gencomm_enhancer_workspace_bytes"), "enhancer")

@@ -54,8 +54,6 @@ class AttFusion(nn.Module):
     def forward(self, xx, record_len, affine_matrix):
         """xx [sumN,C,H,W], record_len [B], affine_matrix [B,L,L,2,3] -> [B,C,H,W]."""
         require_gpu(xx, "AttFusion.forward")
-        if torch.is_grad_enabled() and xx.requires_grad:
-            raise NotImplementedError("gencomm_amd.AttFusion: backward is not implemented yet; call under torch.no_grad()")
         lens = record_len_list(record_len)
         n, C, H, W = xx.shape
         B = affine_matrix.shape[0]
@@ -64,6 +62,14 @@ class AttFusion(nn.Module):
         if min(lens) < 1 or max(lens) > MAX_AGENTS_PER_SCENE:
             raise ValueError(f"each scene needs 1..{MAX_AGENTS_PER_SCENE} agents, got {lens}")
         xx = f32c(xx)
+        if torch.is_grad_enabled() and xx.requires_grad:
+            from .autograd import AttFusionFunction  # HIP forward, recompute-based backward
+            return AttFusionFunction.apply(self, lens, affine_matrix, xx)
+        return self._forward_hip(xx, lens, affine_matrix)
+
+    def _forward_hip(self, xx, lens, affine_matrix):
+        n, C, H, W = xx.shape
+        B = affine_matrix.shape[0]
         theta = gather_ego_thetas(affine_matrix, lens).to(xx.device)
         off = [0]
         for k in lens:
