@@ -76,8 +76,7 @@ def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, sample_steps=2):
     identical cost)."""
     from gencomm_amd import synth
     from oracle import torch_port as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cfg = synth.default_gencomm_cfg(C, T)
     sd_g = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
     sd_e = {k: v.detach().cpu() for k, v in enh.state_dict().items()}
@@ -86,6 +85,22 @@ def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, sample_steps=2):
     cond = torch.randn(N, 2, H, W, generator=g)
     noise = torch.randn(N, C, H, W, generator=g)
     sched = O.make_schedule(T)
+    # thread count: ATen's CPU convolutions on these 8-channel maps stop scaling (and then slow down
+    # badly) well below the core count of a 2-socket host, so calibrate on one denoise step and
+    # keep the fastest of a few candidates; `cores` reports the threads actually used
+    best = None
+    with torch.no_grad():
+        for th in [c for c in (8, 16, 32, 64) if c <= avail] or [avail]:
+            torch.set_num_threads(th)
+            tc = time.perf_counter()
+            O.p_sample(sd_g, sched, cfg["model"], cond, feat, T - 1, noise)
+            tc = time.perf_counter() - tc
+            if best is None or tc < best[1]:
+                best = (th, tc)
+            if tc > 20.0:
+                break
+    cores = best[0]
+    torch.set_num_threads(cores)
     with torch.no_grad():
         t0 = time.perf_counter()
         x = O.q_sample(sched, O.ego_repeat(feat, [N]), T - 1, noise)
@@ -102,7 +117,8 @@ def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, sample_steps=2):
     scene_s = (t1 - t0) + per_step * T + (t3 - t2) + (t4 - t3)
     return {"value": 1.0 / scene_s, "unit": "scenes/sec", "cores": cores, "kind": "port",
             "sample": f"workload '{name}': q_sample + {sample_steps} of {T} denoise steps ({per_step:.2f} s each, extrapolated x{T}) "
-                      f"+ enhancer {t3 - t2:.2f} s + fusion {t4 - t3:.2f} s, torch {torch.__version__} CPU, {cores} threads",
+                      f"+ enhancer {t3 - t2:.2f} s + fusion {t4 - t3:.2f} s, torch {torch.__version__} CPU, {cores} threads "
+                      f"(fastest of 8/16/32/64 on one step; host exposes {avail} logical CPUs)",
             "scene_seconds": scene_s}
 
 
@@ -220,7 +236,8 @@ def main():
             pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")  # measured at 1 scene/launch
+                    traffic = traffic * B if traffic is not None else None
                 except Exception:
                     traffic = None
             if macs_px is not None:
