@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -30,15 +30,15 @@ _SIGNATURES = {
     "gencomm_timer_kernel_name": (C.c_char_p, [_i]),
     "gencomm_timer_start": (_i, [_i, _i]),
     "gencomm_timer_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
-    "gencomm_unet_num_params": (_i, [_i, _i, _i]),
-    "gencomm_unet_param_info": (_i, [_i, _i, _i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
-    "gencomm_unet_raw_floats": (_ll, [_i, _i, _i]),
-    "gencomm_unet_prepared_floats": (_ll, [_i, _i, _i, _i]),
-    "gencomm_unet_prepare": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "gencomm_denoise_workspace_bytes": (_ll, [_i, _i, _i, _i, _i, _i]),
-    "gencomm_unet_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_unet_num_params": (_i, [_i, _i, _i, _i]),
+    "gencomm_unet_param_info": (_i, [_i, _i, _i, _i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
+    "gencomm_unet_raw_floats": (_ll, [_i, _i, _i, _i]),
+    "gencomm_unet_prepared_floats": (_ll, [_i, _i, _i, _i, _i]),
+    "gencomm_unet_prepare": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_denoise_workspace_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
+    "gencomm_unet_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_denoise_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, C.c_ulonglong,
-                                 _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+                                 _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_q_sample_fwd": (_i, [_p, _p, _i, _p, _p, C.c_ulonglong, C.c_uint, _p, _i, _i, _i, _i, _p]),
     "gencomm_enhancer_num_params": (_i, [_i]),
     "gencomm_enhancer_param_info": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
@@ -108,12 +108,12 @@ def check_size(v: int, what: str) -> int:
     return int(v)
 
 
-def unet_param_table(Cch: int, levels: int, res_blocks: int) -> List[Tuple[str, int, int]]:
+def unet_param_table(Cch: int, levels: int, res_blocks: int, attn_mask: int = 0) -> List[Tuple[str, int, int]]:
     l = lib()
-    n = check_size(l.gencomm_unet_num_params(Cch, levels, res_blocks), "gencomm_unet_num_params")
+    n = check_size(l.gencomm_unet_num_params(Cch, levels, res_blocks, attn_mask), "gencomm_unet_num_params")
     out, buf, numel, off = [], C.create_string_buffer(128), _ll(), _ll()
     for i in range(n):
-        check(l.gencomm_unet_param_info(Cch, levels, res_blocks, i, buf, 128, C.byref(numel), C.byref(off)), "gencomm_unet_param_info")
+        check(l.gencomm_unet_param_info(Cch, levels, res_blocks, attn_mask, i, buf, 128, C.byref(numel), C.byref(off)), "gencomm_unet_param_info")
         out.append((buf.value.decode(), int(numel.value), int(off.value)))
     return out
 

@@ -37,6 +37,16 @@ def _resblock(blk, x, temb):
     return x + h
 
 
+def _attnblock(ab, x):
+    h = F.group_norm(x, 4, ab.norm.weight, ab.norm.bias, 1e-6)
+    q, k, v = (F.conv2d(h, m.weight, m.bias) for m in (ab.q, ab.k, ab.v))
+    b, c, hh, ww = q.shape
+    w_ = torch.bmm(q.reshape(b, c, hh * ww).permute(0, 2, 1), k.reshape(b, c, hh * ww)) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2)
+    o = torch.bmm(v.reshape(b, c, hh * ww), w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + F.conv2d(o, ab.proj_out.weight, ab.proj_out.bias)
+
+
 def unet_forward(unet, x, t_int: int):
     half = unet.ch // 2
     freq = torch.exp(torch.arange(half, dtype=torch.float32, device=x.device) * -(math.log(10000) / (half - 1)))
@@ -47,15 +57,20 @@ def unet_forward(unet, x, t_int: int):
     hs = [F.conv2d(x, unet.conv_in.weight, unet.conv_in.bias, padding=1)]
     L = unet.num_resolutions
     for lvl in range(L):
-        for blk in unet.down[lvl].block:
-            hs.append(_resblock(blk, hs[-1], temb))
+        for i, blk in enumerate(unet.down[lvl].block):
+            h = _resblock(blk, hs[-1], temb)
+            if len(unet.down[lvl].attn) > 0:
+                h = _attnblock(unet.down[lvl].attn[i], h)
+            hs.append(h)
         if lvl != L - 1:
             c = unet.down[lvl].downsample.conv
             hs.append(F.conv2d(F.pad(hs[-1], (0, 1, 0, 1)), c.weight, c.bias, stride=2))
     h = _resblock(unet.mid.block_2, _resblock(unet.mid.block_1, hs[-1], temb), temb)
     for lvl in reversed(range(L)):
-        for blk in unet.up[lvl].block:
+        for i, blk in enumerate(unet.up[lvl].block):
             h = _resblock(blk, torch.cat([h, hs.pop()], dim=1), temb)
+            if len(unet.up[lvl].attn) > 0:
+                h = _attnblock(unet.up[lvl].attn[i], h)
         if lvl != 0:
             c = unet.up[lvl].upsample.conv
             h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), c.weight, c.bias, padding=1)

@@ -142,7 +142,7 @@ class GenComm(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         _lib.check(_lib.lib().gencomm_denoise_fwd(
             ptr(prepared), ptr(sched), ptr(feat), feat.shape[0], ptr(rows), ptr(cond), ptr(out), ptr(n0), ptr(sn),
-            seed, n, C, H, W, den.num_resolutions, den.num_res_blocks, T, ptr(ws), ws.numel(), stream_ptr(dev)),
+            seed, n, C, H, W, den.num_resolutions, den.num_res_blocks, den.attn_mask, T, ptr(ws), ws.numel(), stream_ptr(dev)),
             "gencomm_denoise_fwd")
         return out
 

@@ -76,16 +76,16 @@ int gencomm_diag_read_stamps(unsigned long long* host, int nblocks) {
 #endif
 
 // ------------------------------------------------------------------------------------ UNet
-int gencomm_unet_num_params(int C, int levels, int res_blocks) {
+int gencomm_unet_num_params(int C, int levels, int res_blocks, int attn_mask) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, 1)) { fail(GC_ERR_ARG, e); return -1; }
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, 1)) { fail(GC_ERR_ARG, e); return -1; }
   return (int)p.params.size();
 }
 
-int gencomm_unet_param_info(int C, int levels, int res_blocks, int index, char* name, int name_cap,
+int gencomm_unet_param_info(int C, int levels, int res_blocks, int attn_mask, int index, char* name, int name_cap,
                             long long* numel, long long* offset) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, 1)) return fail(GC_ERR_ARG, e);
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, 1)) return fail(GC_ERR_ARG, e);
   GC_CHECK_ARG(index >= 0 && index < (int)p.params.size(), "param index out of range");
   GC_CHECK_ARG(name && name_cap > 0 && numel && offset, "null output pointer");
   snprintf(name, (size_t)name_cap, "%s", p.params[index].name.c_str());
@@ -94,28 +94,28 @@ int gencomm_unet_param_info(int C, int levels, int res_blocks, int index, char* 
   return GC_OK;
 }
 
-long long gencomm_unet_raw_floats(int C, int levels, int res_blocks) {
+long long gencomm_unet_raw_floats(int C, int levels, int res_blocks, int attn_mask) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, 1)) { fail(GC_ERR_ARG, e); return -1; }
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, 1)) { fail(GC_ERR_ARG, e); return -1; }
   return p.raw_floats;
 }
 
-long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int T) {
+long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int attn_mask, int T) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, T)) { fail(GC_ERR_ARG, e); return -1; }
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, T)) { fail(GC_ERR_ARG, e); return -1; }
   return p.prepared_floats;
 }
 
-int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int T, void* stream) {
+int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int attn_mask, int T, void* stream) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, T)) return fail(GC_ERR_ARG, e);
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, T)) return fail(GC_ERR_ARG, e);
   GC_CHECK_ARG(raw && prepared, "null pointer");
   return unet_prepare_enqueue(p, raw, prepared, (hipStream_t)stream);
 }
 
-long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks) {
+long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, 1)) { fail(GC_ERR_ARG, e); return -1; }
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, 1)) { fail(GC_ERR_ARG, e); return -1; }
   if (n < 1 || H < 1 || W < 1) { fail(GC_ERR_ARG, "n, H, W must be positive"); return -1; }
   UNetWorkspace w;
   if (const char* e = w.build(p, n, H, W)) { fail(GC_ERR_ARG, e); return -1; }
@@ -130,10 +130,10 @@ static int check_dims(int n, int C, int H, int W) {
 }
 
 int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,
-                     int n, int C, int H, int W, int levels, int res_blocks, int T,
+                     int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
                      void* workspace, long long workspace_bytes, void* stream) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, T)) return fail(GC_ERR_ARG, e);
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, T)) return fail(GC_ERR_ARG, e);
   if (int rc = check_dims(n, C, H, W)) return rc;
   GC_CHECK_ARG(prepared && x_t && cond && x0_out && workspace, "null pointer");
   GC_CHECK_ARG(t >= 0 && t < T, "timestep out of range");
@@ -167,10 +167,10 @@ int gencomm_q_sample_fwd(const float* sched_row, const float* feat, int n_feat_r
 int gencomm_denoise_fwd(const float* prepared, const float* sched,
                         const float* feat, int n_feat_rows, const int* src_row, const float* cond,
                         float* out, const float* noise0, const float* step_noise, unsigned long long seed,
-                        int n, int C, int H, int W, int levels, int res_blocks, int T,
+                        int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
                         void* workspace, long long workspace_bytes, void* stream) {
   UNetPlan p;
-  if (const char* e = p.build(C, levels, res_blocks, T)) return fail(GC_ERR_ARG, e);
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, T)) return fail(GC_ERR_ARG, e);
   if (int rc = check_dims(n, C, H, W)) return rc;
   GC_CHECK_ARG(prepared && sched && feat && src_row && cond && out && workspace, "null pointer");
   GC_CHECK_ARG(n_feat_rows >= 1, "n_feat_rows must be positive");

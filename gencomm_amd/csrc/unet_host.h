@@ -2,6 +2,7 @@
 #pragma once
 #include <stdlib.h>
 
+#include "attn_kernels.h"
 #include "unet_kernels.h"
 #include "unet_plan.h"
 
@@ -130,6 +131,17 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = Hl; a.W = Wl; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin];
         launch_conv8<1, false, true, 0>(pick_tile(c.n, Hl, Wl), a, c.n, c.st);
+        break;
+      }
+      case OP_ATTN: {
+        const AttnPlan& at = p.attns[o.blk];
+        const int HW = Hl * Wl;
+        float* Q = c.tensor_ptr(o.src[1]); float* K = c.tensor_ptr(o.res[0]); float* V = c.tensor_ptr(o.res[1]);
+        AttnQkvArgs qa{c.tensor_ptr(o.src[0]), c.stat_ptr(o.src[0]), P + at.nw, P + at.nb, P + at.qw, P + at.qb,
+                       P + at.kw, P + at.kb, P + at.vw, P + at.vb, Q, K, V, 1.0 / (2.0 * HW), HW};
+        attn_qkv_kernel<<<dim3(cdiv(HW, 256), c.n), 256, 0, c.st>>>(qa);
+        AttnFlashArgs fa{Q, K, V, c.tensor_ptr(o.src[0]), P + at.pw, P + at.pb, c.tensor_ptr(o.dst), c.stat_ptr(o.dst), HW};
+        attn_flash_kernel<<<dim3(cdiv(HW, 256), c.n), 256, 0, c.st>>>(fa);
         break;
       }
       case OP_CONV_OUT: {

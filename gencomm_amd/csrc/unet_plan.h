@@ -26,12 +26,16 @@ struct ResBlockPlan {
   long long p_c1w, p_c2w, p_ninw, p_bias1 /*[T][8]*/, p_bias2 /*[8]*/;
 };
 
+struct AttnPlan {  // AttnBlock parameters (raw offsets; 1x1 conv weights are used as stored, [oc][ic])
+  long long nw, nb, qw, qb, kw, kb, vw, vb, pw, pb;
+};
+
 struct ConvPlan {  // plain 3x3 conv (conv_in, downsample, upsample, conv_out)
   long long w, b;  // raw
   long long p_w;   // prepared
 };
 
-enum OpKind { OP_CONV_IN, OP_RES_CONV1, OP_RES_CONV2, OP_DOWN, OP_UP, OP_CONV_OUT };
+enum OpKind { OP_CONV_IN, OP_RES_CONV1, OP_RES_CONV2, OP_DOWN, OP_UP, OP_CONV_OUT, OP_ATTN };
 
 struct Op {
   OpKind kind;
@@ -49,7 +53,8 @@ struct TensorPlan {
 };
 
 struct UNetPlan {
-  int C, L, R, T;
+  int C, L, R, T, attn_mask;
+  std::vector<AttnPlan> attns;
   std::vector<ParamEntry> params;
   long long raw_floats = 0;
   long long prepared_floats = 0;
@@ -96,6 +101,23 @@ struct UNetPlan {
     return (int)blocks.size() - 1;
   }
 
+  int add_attn(const std::string& p) {
+    AttnPlan a{};
+    a.nw = add(p + ".norm.weight", 8); a.nb = add(p + ".norm.bias", 8);
+    a.qw = add(p + ".q.weight", 64); a.qb = add(p + ".q.bias", 8);
+    a.kw = add(p + ".k.weight", 64); a.kb = add(p + ".k.bias", 8);
+    a.vw = add(p + ".v.weight", 64); a.vb = add(p + ".v.bias", 8);
+    a.pw = add(p + ".proj_out.weight", 64); a.pb = add(p + ".proj_out.bias", 8);
+    attns.push_back(a);
+    return (int)attns.size() - 1;
+  }
+  // AttnBlock = one op (two launches); Q, K, V are temporaries with the footprint of an 8-ch map
+  int emit_attn(int attn, int in, int level) {
+    const int q = new_tensor(level), k = new_tensor(level), v = new_tensor(level), out = new_tensor(level);
+    ops.push_back({OP_ATTN, attn, {in, q}, {k, v}, out, level});
+    return out;
+  }
+
   int new_tensor(int level) {
     tensors.push_back({level, -1, -1});
     return (int)tensors.size() - 1;
@@ -110,13 +132,14 @@ struct UNetPlan {
   }
 
   // Returns nullptr on success, else an error string.
-  const char* build(int C_, int L_, int R_, int T_) {
-    C = C_; L = L_; R = R_; T = T_;
+  const char* build(int C_, int L_, int R_, int attn_mask_, int T_) {
+    C = C_; L = L_; R = R_; T = T_; attn_mask = attn_mask_;
+    if (attn_mask < 0 || attn_mask >= (1 << L_)) return "attn_mask has bits beyond the number of levels";
     if (C < 8 || C % 8 != 0) return "C must be a positive multiple of 8";
     if (L < 1 || L > 4) return "levels must be in 1..4";
     if (R < 1 || R > 4) return "res_blocks must be in 1..4";
     if (T < 1) return "T must be >= 1";
-    params.clear(); blocks.clear(); ops.clear(); tensors.clear();
+    params.clear(); blocks.clear(); ops.clear(); tensors.clear(); attns.clear();
     raw_floats = prepared_floats = 0;
     down.assign(L, ConvPlan{-1, -1, -1});
     up.assign(L, ConvPlan{-1, -1, -1});
@@ -128,10 +151,12 @@ struct UNetPlan {
     d1b = add("temb.dense.1.bias", 32);
     conv_in.w = add("conv_in.weight", 8LL * (C + 2) * 9);
     conv_in.b = add("conv_in.bias", 8);
-    std::vector<std::vector<int>> down_blk(L), up_blk(L);
+    std::vector<std::vector<int>> down_blk(L), up_blk(L), down_att(L), up_att(L);
     for (int l = 0; l < L; ++l) {
-      for (int b = 0; b < R; ++b)
+      for (int b = 0; b < R; ++b) {
         down_blk[l].push_back(add_resblock("down." + std::to_string(l) + ".block." + std::to_string(b), 8));
+        if (attn_mask >> l & 1) down_att[l].push_back(add_attn("down." + std::to_string(l) + ".attn." + std::to_string(b)));
+      }
       if (l != L - 1) {
         down[l].w = add("down." + std::to_string(l) + ".downsample.conv.weight", 8 * 8 * 9);
         down[l].b = add("down." + std::to_string(l) + ".downsample.conv.bias", 8);
@@ -139,8 +164,10 @@ struct UNetPlan {
     }
     const int mid1 = add_resblock("mid.block_1", 8), mid2 = add_resblock("mid.block_2", 8);
     for (int l = L - 1; l >= 0; --l) {
-      for (int b = 0; b <= R; ++b)
+      for (int b = 0; b <= R; ++b) {
         up_blk[l].push_back(add_resblock("up." + std::to_string(l) + ".block." + std::to_string(b), 16));
+        if (attn_mask >> l & 1) up_att[l].push_back(add_attn("up." + std::to_string(l) + ".attn." + std::to_string(b)));
+      }
       if (l != 0) {
         up[l].w = add("up." + std::to_string(l) + ".upsample.conv.weight", 8 * 8 * 9);
         up[l].b = add("up." + std::to_string(l) + ".upsample.conv.bias", 8);
@@ -174,7 +201,11 @@ struct UNetPlan {
     ops.push_back({OP_CONV_IN, 0, {-1, -1}, {-1, -1}, h, 0});
     hs.push_back(h);
     for (int l = 0; l < L; ++l) {
-      for (int b = 0; b < R; ++b) hs.push_back(emit_resblock(down_blk[l][b], hs.back(), -1, l));
+      for (int b = 0; b < R; ++b) {
+        int t = emit_resblock(down_blk[l][b], hs.back(), -1, l);
+        if (attn_mask >> l & 1) t = emit_attn(down_att[l][b], t, l);
+        hs.push_back(t);
+      }
       if (l != L - 1) {
         const int d = new_tensor(l + 1);
         ops.push_back({OP_DOWN, l, {hs.back(), -1}, {-1, -1}, d, l + 1});
@@ -189,6 +220,7 @@ struct UNetPlan {
         const int skip = hs.back();
         hs.pop_back();
         h = emit_resblock(up_blk[l][b], h, skip, l);
+        if (attn_mask >> l & 1) h = emit_attn(up_att[l][b], h, l);
       }
       if (l != 0) {
         const int u = new_tensor(l - 1);
@@ -208,17 +240,19 @@ struct UNetPlan {
     }
     slots_per_level.assign(L, 0);
     std::vector<std::vector<int>> free_slots(L);
+    auto take_slot = [&](int id) {
+      TensorPlan& t = tensors[id];
+      if (!free_slots[t.level].empty()) {
+        t.slot = free_slots[t.level].back();
+        free_slots[t.level].pop_back();
+      } else {
+        t.slot = slots_per_level[t.level]++;
+      }
+    };
     for (int i = 0; i < (int)ops.size(); ++i) {
       const Op& o = ops[i];
-      if (o.dst >= 0) {
-        TensorPlan& t = tensors[o.dst];
-        if (!free_slots[t.level].empty()) {
-          t.slot = free_slots[t.level].back();
-          free_slots[t.level].pop_back();
-        } else {
-          t.slot = slots_per_level[t.level]++;
-        }
-      }
+      if (o.kind == OP_ATTN) { take_slot(o.src[1]); take_slot(o.res[0]); take_slot(o.res[1]); }
+      if (o.dst >= 0) take_slot(o.dst);
       for (int k = 0; k < 4; ++k) {
         const int id = k < 2 ? o.src[k] : o.res[k - 2];
         if (id >= 0 && tensors[id].last_use == i && tensors[id].slot >= 0) {

@@ -33,7 +33,7 @@ class ScenePipeline:
         self.device = torch.device(device)
         self.T = gencomm.num_timesteps
         den = gencomm.denoiser
-        self.L, self.R = den.num_resolutions, den.num_res_blocks
+        self.L, self.R, self.A = den.num_resolutions, den.num_res_blocks, den.attn_mask
         l = _lib.lib()
         dev = self.device
         rows, off, o = [], [0], 0
@@ -47,7 +47,7 @@ class ScenePipeline:
         self.pred = torch.empty(self.n, C, H, W, dtype=torch.float32, device=dev)
         self.enhanced = torch.empty_like(self.pred) if enhancer is not None else self.pred
         self.fused = torch.empty(self.B, C, H, W, dtype=torch.float32, device=dev)
-        ws_d = _lib.check_size(l.gencomm_denoise_workspace_bytes(self.n, C, H, W, self.L, self.R), "gencomm_denoise_workspace_bytes")
+        ws_d = _lib.check_size(l.gencomm_denoise_workspace_bytes(self.n, C, H, W, self.L, self.R, self.A), "gencomm_denoise_workspace_bytes")
         ws_e = _lib.check_size(l.gencomm_enhancer_workspace_bytes(self.n, C, H, W), "gencomm_enhancer_workspace_bytes") if enhancer is not None else 0
         # one arena: the two stages never overlap in time on a stream
         self.ws = torch.empty(max(ws_d, ws_e, 256), dtype=torch.uint8, device=dev)
@@ -77,7 +77,7 @@ class ScenePipeline:
         if noise is not None:
             n0, sn = f32c(noise[0]), f32c(noise[1])
         _lib.check(l.gencomm_denoise_fwd(ptr(self.prepared), ptr(self.sched), ptr(feat), n, ptr(self.src_rows), ptr(cond),
-                                         ptr(self.pred), ptr(n0), ptr(sn), seed, n, C, H, W, self.L, self.R, self.T,
+                                         ptr(self.pred), ptr(n0), ptr(sn), seed, n, C, H, W, self.L, self.R, self.A, self.T,
                                          ptr(self.ws), self.ws.numel(), st), "gencomm_denoise_fwd")
         if self.enh is not None:
             _lib.check(l.gencomm_enhancer_fwd(ptr(self.enh_raw), ptr(self.pred), ptr(self.enhanced), n, C, H, W,

@@ -60,7 +60,7 @@ class ResnetBlock(nn.Module):  # unet.py:81-138
                 self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
 
-class AttnBlock(nn.Module):  # unet.py:141-193 (parameters only; no shipped config instantiates it)
+class AttnBlock(nn.Module):  # unet.py:141-193 (no shipped config instantiates it; runs as flash-style HIP attention)
     def __init__(self, in_channels):
         super().__init__()
         self.in_channels = in_channels
@@ -155,8 +155,6 @@ class DiffusionUNet(nn.Module):
         why = None
         if self.ch != 8 or any(m != 1 for m in self.ch_mult):
             why = f"ch={self.ch}, ch_mult={self.ch_mult}: the HIP kernels cover ch=8 with ch_mult all ones"
-        elif any(len(d.attn) for d in self.down) or any(len(u.attn) for u in self.up):
-            why = "AttnBlock instantiated (nominal resolution in attn_resolutions): no HIP kernel for BEV self-attention yet"
         elif not self.resamp_with_conv:
             why = "resamp_with_conv=False is not supported"
         elif self.training and self.dropout_p != 0.0:
@@ -170,14 +168,19 @@ class DiffusionUNet(nn.Module):
     def feature_channels(self) -> int:
         return self.in_channels - 2
 
+    @property
+    def attn_mask(self) -> int:
+        """bit l = level l carries AttnBlocks (down and up paths agree by construction, unet.py:252,:286)."""
+        return sum(1 << l for l in range(self.num_resolutions) if len(self.down[l].attn) > 0)
+
     def prepared_params(self, T: int, device: torch.device) -> torch.Tensor:
         """Device blob in kernel layout + the [block][t][8] timestep-bias tables for t < T."""
         self._check_supported()
         l = _lib.lib()
-        C, L, R = self.feature_channels, self.num_resolutions, self.num_res_blocks
+        C, L, R, A = self.feature_channels, self.num_resolutions, self.num_res_blocks, self.attn_mask
         if self._packed is None:
-            table = _lib.unet_param_table(C, L, R)
-            self._packed = PackedParams(table, _lib.check_size(l.gencomm_unet_raw_floats(C, L, R), "gencomm_unet_raw_floats"))
+            table = _lib.unet_param_table(C, L, R, A)
+            self._packed = PackedParams(table, _lib.check_size(l.gencomm_unet_raw_floats(C, L, R, A), "gencomm_unet_raw_floats"))
         named = dict(self.named_parameters())
         for p in named.values():
             require_gpu(p, "DiffusionUNet parameters")
@@ -185,16 +188,16 @@ class DiffusionUNet(nn.Module):
         changed = self._packed.update(named)
         key = (self._packed.generation, T, str(device))
         if changed or self._prepared is None or self._prepared_key != key:
-            nflt = _lib.check_size(l.gencomm_unet_prepared_floats(C, L, R, T), "gencomm_unet_prepared_floats")
+            nflt = _lib.check_size(l.gencomm_unet_prepared_floats(C, L, R, A, T), "gencomm_unet_prepared_floats")
             prepared = torch.zeros(nflt, dtype=torch.float32, device=device)
-            _lib.check(l.gencomm_unet_prepare(ptr(self._packed.flat), ptr(prepared), C, L, R, T, stream_ptr(device)),
+            _lib.check(l.gencomm_unet_prepare(ptr(self._packed.flat), ptr(prepared), C, L, R, A, T, stream_ptr(device)),
                        "gencomm_unet_prepare")
             self._prepared, self._prepared_key = prepared, key
         return self._prepared
 
     def denoise_workspace(self, n: int, H: int, W: int, device: torch.device) -> torch.Tensor:
         nbytes = _lib.check_size(_lib.lib().gencomm_denoise_workspace_bytes(
-            n, self.feature_channels, H, W, self.num_resolutions, self.num_res_blocks), "gencomm_denoise_workspace_bytes")
+            n, self.feature_channels, H, W, self.num_resolutions, self.num_res_blocks, self.attn_mask), "gencomm_denoise_workspace_bytes")
         return workspaces.get(device, nbytes, "unet")
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, T: int = None) -> torch.Tensor:
@@ -216,6 +219,6 @@ class DiffusionUNet(nn.Module):
         ws = self.denoise_workspace(n, H, W, x.device)
         out = torch.empty((n, C, H, W), dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().gencomm_unet_fwd(ptr(prepared), ptr(x_t), ptr(cond), ptr(out), t_int, n, C, H, W,
-                                               self.num_resolutions, self.num_res_blocks, T,
+                                               self.num_resolutions, self.num_res_blocks, self.attn_mask, T,
                                                ptr(ws), ws.numel(), stream_ptr(x.device)), "gencomm_unet_fwd")
         return out

@@ -29,9 +29,11 @@
  *                             (opencood/models/fuse_modules/fusion_in_one.py:131-151, :41-45;
  *                              opencood/models/sub_modules/torch_transformation_utils.py:323-332)
  *
- * Supported UNet family: ch = 8, ch_mult = all ones (any number of levels), num_res_blocks >= 1,
- * resamp_with_conv = true, dropout = 0, no AttnBlock instantiated -- i.e. every shipped GenComm
- * yaml (60/60 use ch 8, ch_mult [1,1], 2 res-blocks, attn_resolutions [16]).  C % 8 == 0.
+ * Supported UNet family: ch = 8, ch_mult = all ones (levels <= 4), 1 <= num_res_blocks <= 4,
+ * resamp_with_conv = true, dropout = 0, C % 8 == 0 -- a superset of every shipped GenComm yaml
+ * (60/60 use ch 8, ch_mult [1,1], 2 res-blocks, attn_resolutions [16] = no AttnBlock).
+ * `attn_mask`: bit l set = the AttnBlocks of level l exist (nominal resolution 128 >> l is in
+ * attn_resolutions, unet.py:237,:252-253,:286-287); they run as flash-style streaming attention.
  */
 #ifndef GENCOMM_HIP_H
 #define GENCOMM_HIP_H
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 1
+#define GENCOMM_ABI_VERSION 2
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -64,20 +66,20 @@ int gencomm_timer_stop(double* total_ms, int* launches);
  * weights) and evaluates the timestep path for t = 0..T-1 into a bias table; call it once per
  * weight update.
  * -------------------------------------------------------------------------------------------- */
-int gencomm_unet_num_params(int C, int levels, int res_blocks);
-int gencomm_unet_param_info(int C, int levels, int res_blocks, int index,
+int gencomm_unet_num_params(int C, int levels, int res_blocks, int attn_mask);
+int gencomm_unet_param_info(int C, int levels, int res_blocks, int attn_mask, int index,
                             char* name, int name_cap, long long* numel, long long* offset);
-long long gencomm_unet_raw_floats(int C, int levels, int res_blocks);
-long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int T);
-int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int T,
+long long gencomm_unet_raw_floats(int C, int levels, int res_blocks, int attn_mask);
+long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int attn_mask, int T);
+int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int attn_mask, int T,
                          void* stream);
 
 /* Scratch for one UNet call / the denoise loop on n agents of [C, H, W]. */
-long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks);
+long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask);
 
 /* x0_hat[n,C,H,W] = UNet(cat[cond[n,2,H,W], x_t[n,C,H,W]], t) for one integer timestep t. */
 int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,
-                     int n, int C, int H, int W, int levels, int res_blocks, int T,
+                     int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
                      void* workspace, long long workspace_bytes, void* stream);
 
 /* The whole sampler.  sched = device float[T][5] rows {sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod,
@@ -89,7 +91,7 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
 int gencomm_denoise_fwd(const float* prepared, const float* sched,
                         const float* feat, int n_feat_rows, const int* src_row, const float* cond,
                         float* out, const float* noise0, const float* step_noise, unsigned long long seed,
-                        int n, int C, int H, int W, int levels, int res_blocks, int T,
+                        int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
                         void* workspace, long long workspace_bytes, void* stream);
 
 /* q_sample alone (cond_diff.py:262-264 with the ego repeat of :332-337 folded in):

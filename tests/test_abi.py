@@ -39,14 +39,14 @@ def test_unet_param_table_matches_module(lib):
     for C in (8, 16, 64, 128):
         gen = GenComm(synth.default_gencomm_cfg(C, 3))
         named = dict(gen.denoiser.named_parameters())
-        table = _lib.unet_param_table(C, 2, 2)
+        table = _lib.unet_param_table(C, 2, 2, 0)
         assert sorted(n for n, _, _ in table) == sorted(named)  # every UNet parameter is consumed
         off = 0
         for name, numel, o in table:
             assert named[name].numel() == numel and o == off
             off += numel
-        assert off == lib.gencomm_unet_raw_floats(C, 2, 2)
-        assert lib.gencomm_unet_prepared_floats(C, 2, 2, 3) > off
+        assert off == lib.gencomm_unet_raw_floats(C, 2, 2, 0)
+        assert lib.gencomm_unet_prepared_floats(C, 2, 2, 0, 3) > off
 
 
 def test_enhancer_param_table_matches_module(lib):
@@ -61,13 +61,13 @@ def test_enhancer_param_table_matches_module(lib):
 
 
 def test_argument_errors_are_status_codes_not_exits(lib):
-    assert lib.gencomm_unet_raw_floats(7, 2, 2) == -1
+    assert lib.gencomm_unet_raw_floats(7, 2, 2, 0) == -1
     assert b"multiple of 8" in lib.gencomm_last_error()
-    assert lib.gencomm_denoise_workspace_bytes(4, 64, 201, 704, 2, 2) == -1  # odd H with a downsample
+    assert lib.gencomm_denoise_workspace_bytes(4, 64, 201, 704, 2, 2, 0) == -1  # odd H with a downsample
     assert b"even" in lib.gencomm_last_error()
-    assert lib.gencomm_denoise_workspace_bytes(4, 64, 200, 704, 2, 2) > 0
+    assert lib.gencomm_denoise_workspace_bytes(4, 64, 200, 704, 2, 2, 0) > 0
     # null pointers are rejected before anything is launched
-    assert lib.gencomm_unet_fwd(None, None, None, None, 0, 1, 64, 16, 16, 2, 2, 3, None, 0, None) == 1
+    assert lib.gencomm_unet_fwd(None, None, None, None, 0, 1, 64, 16, 16, 2, 2, 0, 3, None, 0, None) == 1
     assert lib.gencomm_warp_attfuse_fwd(None, None, None, None, 1, 1, 8, 4, 4, None) == 1
 
 
@@ -84,3 +84,15 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(_lib.GenCommHipError):
         with torch.no_grad():
             AttFusion(16)(torch.zeros(2, 16, 8, 8), torch.tensor([2]), torch.zeros(1, 5, 5, 2, 3))
+
+
+def test_attnblock_params_are_enumerated_when_present(lib):
+    from gencomm_amd import GenComm, synth
+    cfg = synth.default_gencomm_cfg(8, 3)
+    cfg["model"]["attn_resolutions"] = [64]  # nominal 128 -> 64 at level 1
+    gen = GenComm(cfg)
+    assert gen.denoiser.attn_mask == 0b10
+    named = dict(gen.denoiser.named_parameters())
+    table = _lib.unet_param_table(8, 2, 2, 0b10)
+    assert sorted(n for n, _, _ in table) == sorted(named)
+    assert lib.gencomm_unet_raw_floats(8, 2, 2, 0b100) == -1  # bit beyond the number of levels

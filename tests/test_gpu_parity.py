@@ -189,3 +189,18 @@ def test_enhancer_and_fusion_gradients_flow():
     y2.square().mean().backward()
     assert torch.allclose(gx, x2.grad, rtol=1e-3, atol=1e-6)
     assert enh.block_1.mlp.linear2[0].weight.grad is not None
+
+
+def test_attnblock_unet_vs_reference_golden():
+    """UNet with AttnBlocks (attn_resolutions [64] -> 5 blocks at half resolution): flash-style HIP
+    attention against the reference's dense N x N softmax (golden 'attn')."""
+    g = load_case("attn")
+    _, gen, _ = build_modules(g, DEV, attn_resolutions=g["attn_resolutions"])
+    assert gen.denoiser.attn_mask == 0b10
+    inp = build_inputs(g, DEV)
+    n = inp["feat"].shape[0]
+    with torch.no_grad():
+        for t in range(int(g["T"])):
+            tt = torch.full((n,), t, dtype=torch.long, device=DEV)
+            y = gen.denoiser(torch.cat([inp["cond"], inp["feat"]], 1), tt.float(), T=int(g["T"]))
+            assert_close(y.cpu().numpy(), g[f"unet_out_t{t}"], RTOL, ATOL, f"unet(attn) t={t}")
