@@ -7,12 +7,14 @@ Public surface mirrors the reference's plugin API:
     Enhancer(C, win_size, num_heads)   opencood/models/gencomm_modules/enhancer.py:359
     AttFusion(feature_dims)            opencood/models/fuse_modules/fusion_in_one.py:126
     regroup, normalize_pairwise_tfm    fusion_in_one.py:48, opencood/utils/transformation_utils.py:68
+    MessageExtractorv2(in_ch, out_ch)  opencood/models/gencomm_modules/message_extractor_v2.py:109
 
 All compute runs in hand-written HIP kernels behind the C ABI of ``include/gencomm_hip.h``.
 """
 from .cond_diff import GenComm
 from .enhancer import Enhancer
 from .fusion import AttFusion, normalize_pairwise_tfm, regroup
+from .message_extractor import MessageExtractorv2
 from .unet import DiffusionUNet
 
-__all__ = ["GenComm", "DiffusionUNet", "Enhancer", "AttFusion", "regroup", "normalize_pairwise_tfm"]
+__all__ = ["GenComm", "DiffusionUNet", "Enhancer", "AttFusion", "MessageExtractorv2", "regroup", "normalize_pairwise_tfm"]

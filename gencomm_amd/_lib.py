@@ -45,6 +45,11 @@ _SIGNATURES = {
     "gencomm_enhancer_raw_floats": (_ll, [_i]),
     "gencomm_enhancer_workspace_bytes": (_ll, [_i, _i, _i, _i]),
     "gencomm_enhancer_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_msgext_num_params": (_i, [_i]),
+    "gencomm_msgext_param_info": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
+    "gencomm_msgext_raw_floats": (_ll, [_i]),
+    "gencomm_msgext_workspace_bytes": (_ll, [_i, _i, _i, _i]),
+    "gencomm_msgext_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -124,5 +129,15 @@ def enhancer_param_table(Cch: int) -> List[Tuple[str, int, int]]:
     out, buf, numel, off = [], C.create_string_buffer(128), _ll(), _ll()
     for i in range(n):
         check(l.gencomm_enhancer_param_info(Cch, i, buf, 128, C.byref(numel), C.byref(off)), "gencomm_enhancer_param_info")
+        out.append((buf.value.decode(), int(numel.value), int(off.value)))
+    return out
+
+
+def msgext_param_table(Cch: int) -> List[Tuple[str, int, int]]:
+    l = lib()
+    n = check_size(l.gencomm_msgext_num_params(Cch), "gencomm_msgext_num_params")
+    out, buf, numel, off = [], C.create_string_buffer(128), _ll(), _ll()
+    for i in range(n):
+        check(l.gencomm_msgext_param_info(Cch, i, buf, 128, C.byref(numel), C.byref(off)), "gencomm_msgext_param_info")
         out.append((buf.value.decode(), int(numel.value), int(off.value)))
     return out

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "enhancer_host.h"
 #include "fusion_kernels.h"
+#include "msgext_host.h"
 #include "unet_host.h"
 
 #include <algorithm>
@@ -237,6 +238,44 @@ int gencomm_enhancer_fwd(const float* raw, const float* x, float* out, int n, in
   if ((long long)enhancer_workspace_bytes(p, n, H, W) > workspace_bytes)
     return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_enhancer_workspace_bytes)");
   return enhancer_enqueue(p, raw, x, out, n, H, W, (char*)workspace, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ message extractor
+int gencomm_msgext_num_params(int C) {
+  MsgExtPlan p;
+  if (const char* e = p.build(C)) { fail(GC_ERR_ARG, e); return -1; }
+  return (int)p.params.size();
+}
+int gencomm_msgext_param_info(int C, int index, char* name, int name_cap, long long* numel, long long* offset) {
+  MsgExtPlan p;
+  if (const char* e = p.build(C)) return fail(GC_ERR_ARG, e);
+  GC_CHECK_ARG(index >= 0 && index < (int)p.params.size(), "param index out of range");
+  GC_CHECK_ARG(name && name_cap > 0 && numel && offset, "null output pointer");
+  snprintf(name, (size_t)name_cap, "%s", p.params[index].name.c_str());
+  *numel = p.params[index].numel;
+  *offset = p.params[index].off;
+  return GC_OK;
+}
+long long gencomm_msgext_raw_floats(int C) {
+  MsgExtPlan p;
+  if (const char* e = p.build(C)) { fail(GC_ERR_ARG, e); return -1; }
+  return p.raw_floats;
+}
+long long gencomm_msgext_workspace_bytes(int n, int C, int H, int W) {
+  MsgExtPlan p;
+  if (const char* e = p.build(C)) { fail(GC_ERR_ARG, e); return -1; }
+  if (n < 1 || H < 1 || W < 1) { fail(GC_ERR_ARG, "n, H, W must be positive"); return -1; }
+  return (long long)msgext_ws(p, n, H, W).total;
+}
+int gencomm_msgext_fwd(const float* raw, const float* x, float* out, int n, int C, int H, int W,
+                       void* workspace, long long workspace_bytes, void* stream) {
+  MsgExtPlan p;
+  if (const char* e = p.build(C)) return fail(GC_ERR_ARG, e);
+  GC_CHECK_ARG(raw && x && out && workspace, "null pointer");
+  GC_CHECK_ARG(n >= 1 && n <= 65535 && H >= 1 && W >= 1 && (long long)H * W * (C + 64) < (1LL << 31), "bad n/H/W");
+  if ((long long)msgext_ws(p, n, H, W).total > workspace_bytes)
+    return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_msgext_workspace_bytes)");
+  return msgext_enqueue(p, raw, x, out, n, H, W, (char*)workspace, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ fusion

@@ -25,6 +25,7 @@
  *                             q_posterior (:321-329, :302-315, :281-299, :272-279)
  *   gencomm_enhancer_fwd      Enhancer.forward -> Enhancer_block -> FRFN -> SplitAttn
  *                             (opencood/models/gencomm_modules/enhancer.py:367-383, :346-357, :222-250, :315-333)
+ *   gencomm_msgext_fwd        MessageExtractorv2.forward (message_extractor_v2.py:103-118; DeformConv2d = torchvision DCNv1)
  *   gencomm_warp_attfuse_fwd  AttFusion.forward + warp_affine_simple + ScaledDotProductAttention
  *                             (opencood/models/fuse_modules/fusion_in_one.py:131-151, :41-45;
  *                              opencood/models/sub_modules/torch_transformation_utils.py:323-332)
@@ -113,6 +114,19 @@ long long gencomm_enhancer_workspace_bytes(int n, int C, int H, int W);
 /* out[n,C,H,W] = split_attn(block_1(x[n,C,H,W])) per agent (agents are independent). */
 int gencomm_enhancer_fwd(const float* raw, const float* x, float* out, int n, int C, int H, int W,
                          void* workspace, long long workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * MessageExtractorv2 (opencood/models/gencomm_modules/message_extractor_v2.py:70-120): the producer
+ * of `conditions`. out[n,2,H,W] = fuse(dcn(x, offset_conv(x)) * se_gate). x [n,C,H,W], C % 8 == 0.
+ * Raw blob enumerated like the UNet's; names = state_dict keys under `message_extractor_m<k>.`
+ * (`bev_extractor.{offset1,dcn1,fuse.0,fuse.2,attn.1,attn.3}.{weight,bias}`).
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_msgext_num_params(int C);
+int gencomm_msgext_param_info(int C, int index, char* name, int name_cap, long long* numel, long long* offset);
+long long gencomm_msgext_raw_floats(int C);
+long long gencomm_msgext_workspace_bytes(int n, int C, int H, int W);
+int gencomm_msgext_fwd(const float* raw, const float* x, float* out, int n, int C, int H, int W,
+                       void* workspace, long long workspace_bytes, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Warp every agent into its scene's ego frame and fuse with per-pixel attention over agents,

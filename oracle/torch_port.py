@@ -306,3 +306,55 @@ def path_forward(gen_sd: SD, enh_sd: Optional[SD], cfg: dict, feat: Tensor, cond
         enh = enhancer_forward(enh_sd, pred, record_len) if enh_sd is not None else pred
         fused = att_fusion(enh, record_len, affine)
     return {"pred_feature": pred, "enhanced": enh, "fused": fused, "affine": affine}
+
+
+# --------------------------------------------------------------------------------------
+# MessageExtractorv2  (opencood/models/gencomm_modules/message_extractor_v2.py:70-120)
+#
+# PARITY UNPINNED for the deformable convolution: the reference calls torchvision.ops.DeformConv2d
+# (torchvision==0.13.1 per README.md:109; call sites message_extractor_v2.py:78,:101), which is not
+# installed in this image and is not part of /root/reference. The restatement below follows the
+# published DCNv1 algorithm exactly as torchvision implements it (deform_conv2d kernel,
+# `bilinear_interpolate`): offset channel 2k is the vertical and 2k+1 the horizontal displacement of
+# tap k (row-major 3x3), sample position = output position - pad + tap + offset, bilinear
+# interpolation with zero contribution from corners outside the map and zero for positions
+# <= -1 or >= size. It is anchored by degenerate cases in tests/test_msgext_oracle.py (zero offsets
+# == F.conv2d, integer offsets == shifted taps).
+# --------------------------------------------------------------------------------------
+def deform_conv2d_ref(x: Tensor, offset: Tensor, weight: Tensor, bias: Optional[Tensor], pad: int = 1) -> Tensor:
+    B, C, H, W = x.shape
+    O, _, kh, kw = weight.shape
+    ys = torch.arange(H, dtype=x.dtype).view(1, H, 1)
+    xs = torch.arange(W, dtype=x.dtype).view(1, 1, W)
+    cols = []
+    xf = x.reshape(B, C, H * W)
+    for k in range(kh * kw):
+        ky, kx = k // kw, k % kw
+        py = ys - pad + ky + offset[:, 2 * k]          # [B,H,W]
+        px = xs - pad + kx + offset[:, 2 * k + 1]
+        inside = (py > -1) & (py < H) & (px > -1) & (px < W)
+        y0, x0 = torch.floor(py), torch.floor(px)
+        ly, lx = py - y0, px - x0
+        hy, hx = 1 - ly, 1 - lx
+        val = torch.zeros(B, C, H, W, dtype=x.dtype)
+        for (yy, xx, wgt) in ((y0, x0, hy * hx), (y0, x0 + 1, hy * lx), (y0 + 1, x0, ly * hx), (y0 + 1, x0 + 1, ly * lx)):
+            ok = inside & (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+            idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long().view(B, 1, H * W).expand(B, C, H * W)
+            g = torch.gather(xf, 2, idx).view(B, C, H, W)
+            val = val + g * (wgt * ok).unsqueeze(1)
+        cols.append(val)
+    col = torch.stack(cols, dim=2)                      # [B, C, K, H, W]
+    out = torch.einsum("ock,bckhw->bohw", weight.reshape(O, C, kh * kw), col)
+    return out + bias.view(1, O, 1, 1) if bias is not None else out
+
+
+def message_extractor_forward(sd: SD, x: Tensor, p: str = "bev_extractor.") -> Tensor:
+    """BEVDeformableExtractor.forward, message_extractor_v2.py:103-118."""
+    off = F.conv2d(x, sd[p + "offset1.weight"], sd[p + "offset1.bias"], padding=1)
+    b1 = deform_conv2d_ref(x, off, sd[p + "dcn1.weight"], sd[p + "dcn1.bias"], pad=1)
+    g = b1.mean((2, 3), keepdim=True)                                   # AdaptiveAvgPool2d(1)
+    g = F.relu(F.conv2d(g, sd[p + "attn.1.weight"], sd[p + "attn.1.bias"]))
+    g = torch.sigmoid(F.conv2d(g, sd[p + "attn.3.weight"], sd[p + "attn.3.bias"]))
+    e = b1 * g
+    h = F.relu(F.conv2d(e, sd[p + "fuse.0.weight"], sd[p + "fuse.0.bias"]))
+    return F.conv2d(h, sd[p + "fuse.2.weight"], sd[p + "fuse.2.bias"])

@@ -204,3 +204,26 @@ def test_attnblock_unet_vs_reference_golden():
             tt = torch.full((n,), t, dtype=torch.long, device=DEV)
             y = gen.denoiser(torch.cat([inp["cond"], inp["feat"]], 1), tt.float(), T=int(g["T"]))
             assert_close(y.cpu().numpy(), g[f"unet_out_t{t}"], RTOL, ATOL, f"unet(attn) t={t}")
+
+
+@pytest.mark.parametrize("C,H,W,n", [(16, 12, 20, 2), (64, 36, 52, 3), (128, 64, 128, 2)])
+def test_message_extractor_vs_oracle(C, H, W, n):
+    """MessageExtractorv2: offset conv -> deformable conv -> SE gate -> 1x1 fuse, against
+    the CPU restatement (deformable conv parity is unpinned: torchvision absent, see oracle)."""
+    from gencomm_amd import MessageExtractorv2, synth
+    from oracle import torch_port as O
+    m = MessageExtractorv2(C, 2).eval()
+    synth.fill_params_(m, 41)
+    with torch.no_grad():
+        # make the learned offsets non-trivial (default-scale weights give sub-pixel offsets only)
+        m.bev_extractor.offset1.weight.mul_(6.0)
+        m.bev_extractor.offset1.bias.mul_(10.0)
+    x = torch.from_numpy(synth.make_inputs([n], C, H, W, 42)["feat"])
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.message_extractor_forward(sd, x)
+        off = torch.nn.functional.conv2d(x, sd["bev_extractor.offset1.weight"], sd["bev_extractor.offset1.bias"], padding=1)
+        assert off.abs().max() > 1.5 and (off.abs() > 1.0).float().mean() > 0.05  # taps really move across pixels
+        got = m.to(DEV)(x.to(DEV)).cpu()
+    assert got.shape == (n, 2, H, W)
+    assert_close(got.numpy(), ref.numpy(), RTOL, ATOL, "message")
