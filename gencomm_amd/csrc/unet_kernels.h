@@ -118,12 +118,19 @@ __device__ __forceinline__ f32x4 mfma_wbcast(float w, float x, f32x4 c) {
 }
 
 // Registers holding one staged tile in flight: interior quads + halo scalars of this thread.
+// Thread -> quad mapping is chosen so that the index arithmetic is one multiply per TILE, not per
+// quad: the "main" pass gives thread tid the quad (row tid / QPR, column quad tid % QPR) of EVERY
+// channel (channel = loop index, a uniform plane stride apart); when the workgroup's rows-per-pass
+// equals TH, the two leftover halo rows of all channels form exactly one more "remainder" pass
+// (channel tid / (2*QPR), row TH + (tid / QPR & 1)).
 template <int TW, int TH, int NT, int NCH>
 struct TileRegs {
-  static constexpr int LH = TH + 2, QPR = TW / 4;
-  static constexpr int NQ = NCH * LH * QPR, QIT = (NQ + NT - 1) / NT;
+  static constexpr int LH = TH + 2, QPR = TW / 4, RPP = NT / QPR;
+  static constexpr bool REM = RPP < LH;
+  static_assert(!REM || RPP == TH, "rows per pass must cover the tile or exactly TH rows");
   static constexpr int NHALO = NCH * LH * 2, HIT = (NHALO + NT - 1) / NT;
-  float4 v[QIT];
+  float4 v[NCH];
+  float4 vr;
   float hv[HIT];
 };
 
@@ -133,22 +140,25 @@ template <int TW, int TH, int NT, int NCH, bool UP>
 __device__ __forceinline__ void stage_load(TileRegs<TW, TH, NT, NCH>& R, const float* __restrict__ sp,
                                            unsigned plane_in, int Win, int H, int W, int x0, int y0, int tid) {
   using TR = TileRegs<TW, TH, NT, NCH>;
-#pragma unroll
-  for (int k = 0; k < TR::QIT; ++k) {
-    const int q = tid + k * NT;
-    const int row = q / TR::QPR, qx = q - row * TR::QPR;
-    const int c = row / TR::LH, r = row - c * TR::LH;
+  auto load_quad = [&](int c, int r, int qx) {
     const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
-    const bool ok = (TR::NQ % NT == 0 || q < TR::NQ) && gy >= 0 && gy < H && gx < W;
-    R.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) {
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < TR::LH && gy >= 0 && gy < H && gx < W) {
       if (!UP) {
-        R.v[k] = *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx));
+        out = *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx));
       } else {
         const float2 t = *reinterpret_cast<const float2*>(sp + ((unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)));
-        R.v[k] = make_float4(t.x, t.x, t.y, t.y);
+        out = make_float4(t.x, t.x, t.y, t.y);
       }
     }
+    return out;
+  };
+  const int r0 = tid / TR::QPR, qx = tid % TR::QPR;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) R.v[c] = load_quad(c, r0, qx);
+  if (TR::REM) {
+    const int cr = tid / (2 * TR::QPR), rr = TR::RPP + ((tid / TR::QPR) & 1);
+    R.vr = (cr < NCH) ? load_quad(cr, rr, qx) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int k = 0; k < TR::HIT; ++k) {
@@ -170,22 +180,24 @@ template <int TW, int TH, int NT, int NCH, bool GN, int LS>
 __device__ __forceinline__ void stage_store(float (*tile)[TH + 2][LS], const TileRegs<TW, TH, NT, NCH>& R,
                                             int H, int W, int x0, int y0, const float (*ab)[2], int tid) {
   using TR = TileRegs<TW, TH, NT, NCH>;
+  auto store_quad = [&](int c, int r, int qx, float4 q) {
+    if (r >= TR::LH) return;
+    float e[4] = {q.x, q.y, q.z, q.w};
+    if (GN) {
+      const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
+      const bool ok = gy >= 0 && gy < H && gx < W;
+      const float A = ab[c][0], B = ab[c][1];
 #pragma unroll
-  for (int k = 0; k < TR::QIT; ++k) {
-    const int q = tid + k * NT;
-    if (TR::NQ % NT == 0 || q < TR::NQ) {
-      const int row = q / TR::QPR, qx = q - row * TR::QPR;
-      const int c = row / TR::LH, r = row - c * TR::LH;
-      float e[4] = {R.v[k].x, R.v[k].y, R.v[k].z, R.v[k].w};
-      if (GN) {
-        const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
-        const bool ok = gy >= 0 && gy < H && gx < W;
-        const float A = ab[c][0], B = ab[c][1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = ok ? silu_f(fmaf(A, e[j], B)) : 0.f;
-      }
-      *reinterpret_cast<float4*>(&tile[c][r][4 + 4 * qx]) = make_float4(e[0], e[1], e[2], e[3]);
+      for (int j = 0; j < 4; ++j) e[j] = ok ? silu_f(fmaf(A, e[j], B)) : 0.f;
     }
+    *reinterpret_cast<float4*>(&tile[c][r][4 + 4 * qx]) = make_float4(e[0], e[1], e[2], e[3]);
+  };
+  const int r0 = tid / TR::QPR, qx = tid % TR::QPR;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) store_quad(c, r0, qx, R.v[c]);
+  if (TR::REM) {
+    const int cr = tid / (2 * TR::QPR), rr = TR::RPP + ((tid / TR::QPR) & 1);
+    if (cr < NCH) store_quad(cr, rr, qx, R.vr);
   }
 #pragma unroll
   for (int k = 0; k < TR::HIT; ++k) {
