@@ -50,6 +50,8 @@ _SIGNATURES = {
     "gencomm_msgext_raw_floats": (_ll, [_i]),
     "gencomm_msgext_workspace_bytes": (_ll, [_i, _i, _i, _i]),
     "gencomm_msgext_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_pillar_encode_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
+                                       C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

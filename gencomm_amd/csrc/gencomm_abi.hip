@@ -5,6 +5,7 @@
 #include "enhancer_host.h"
 #include "fusion_kernels.h"
 #include "msgext_host.h"
+#include "pillar_kernels.h"
 #include "unet_host.h"
 
 #include <algorithm>
@@ -276,6 +277,28 @@ int gencomm_msgext_fwd(const float* raw, const float* x, float* out, int n, int 
   if ((long long)msgext_ws(p, n, H, W).total > workspace_bytes)
     return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_msgext_workspace_bytes)");
   return msgext_enqueue(p, raw, x, out, n, H, W, (char*)workspace, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ PointPillars front half
+int gencomm_pillar_encode_fwd(const float* voxel_features, const int* voxel_num_points, const int* voxel_coords,
+                              const float* linear_w, const float* bn_weight, const float* bn_bias,
+                              const float* bn_running_mean, const float* bn_running_var,
+                              float* out, float* scratch128, int M, int P, int B, int nx, int ny,
+                              const float* voxel_size3, const float* pc_range6, void* stream) {
+  GC_CHECK_ARG(voxel_features && voxel_num_points && voxel_coords && linear_w && bn_weight && bn_bias &&
+               bn_running_mean && bn_running_var && out && scratch128 && voxel_size3 && pc_range6, "null pointer");
+  GC_CHECK_ARG(M >= 0 && P >= 1 && P <= 32 && B >= 1 && nx >= 1 && ny >= 1, "bad M/P/B/nx/ny (P <= 32 point slots)");
+  hipStream_t st = (hipStream_t)stream;
+  GC_HIP(hipMemsetAsync(out, 0, (size_t)B * 64 * nx * ny * sizeof(float), st));
+  bn_fold_kernel<<<1, 64, 0, st>>>(bn_weight, bn_bias, bn_running_mean, bn_running_var, 1e-3f, scratch128, scratch128 + 64, 64);
+  if (M > 0) {
+    PillarArgs a{voxel_features, voxel_num_points, voxel_coords, linear_w, scratch128, scratch128 + 64, out, M, P, B, nx, ny,
+                 voxel_size3[0], voxel_size3[1], voxel_size3[2],
+                 voxel_size3[0] / 2 + pc_range6[0], voxel_size3[1] / 2 + pc_range6[1], voxel_size3[2] / 2 + pc_range6[2]};
+    pillar_vfe_scatter_kernel<<<(M + 3) / 4, 256, 0, st>>>(a);
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
 }
 
 // ------------------------------------------------------------------------------------ fusion

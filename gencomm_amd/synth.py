@@ -156,3 +156,26 @@ def make_train_noise(seed: int, n: int, C: int, H: int, W: int, T: int) -> Tuple
         np.concatenate([noise_stream(seed, a * (T + 1) + 1 + i, shape1) for a in range(n)], axis=0)
         for i in range(T)], axis=0)
     return noise0, steps
+
+
+def make_pillars(M: int, B: int, nx: int, ny: int, seed: int, voxel_size=(0.4, 0.4, 4.0),
+                 pc_range=(-140.8, -40.0, -3.0, 140.8, 40.0, 1.0), max_points: int = 32) -> Dict[str, np.ndarray]:
+    """Synthetic output of the voxeliser for the PointPillars front half:
+    ``voxel_features`` [M,32,4] (x,y,z,intensity; unused slots zero), ``voxel_num_points`` [M],
+    ``voxel_coords`` [M,4] = (batch, z, y, x) with UNIQUE (batch, y, x) so that the scatter has no
+    write conflicts (a voxeliser never emits duplicates)."""
+    rng = np.random.RandomState(seed)
+    cells = rng.choice(B * ny * nx, size=M, replace=False)
+    b, rem = cells // (ny * nx), cells % (ny * nx)
+    yy, xx = rem // nx, rem % nx
+    coords = np.stack([b, np.zeros_like(b), yy, xx], axis=1).astype(np.int32)
+    npts = rng.randint(1, max_points + 1, size=M).astype(np.int32)
+    feats = np.zeros((M, max_points, 4), dtype=np.float32)
+    u = rng.uniform(0.0, 1.0, size=(M, max_points, 3))
+    feats[:, :, 0] = pc_range[0] + (xx[:, None] + u[:, :, 0]) * voxel_size[0]
+    feats[:, :, 1] = pc_range[1] + (yy[:, None] + u[:, :, 1]) * voxel_size[1]
+    feats[:, :, 2] = pc_range[2] + u[:, :, 2] * voxel_size[2]
+    feats[:, :, 3] = rng.uniform(0.0, 1.0, size=(M, max_points))
+    mask = np.arange(max_points)[None, :] < npts[:, None]
+    feats *= mask[:, :, None]
+    return {"voxel_features": feats, "voxel_num_points": npts, "voxel_coords": coords}

@@ -26,6 +26,7 @@
  *   gencomm_enhancer_fwd      Enhancer.forward -> Enhancer_block -> FRFN -> SplitAttn
  *                             (opencood/models/gencomm_modules/enhancer.py:367-383, :346-357, :222-250, :315-333)
  *   gencomm_msgext_fwd        MessageExtractorv2.forward (message_extractor_v2.py:103-118; DeformConv2d = torchvision DCNv1)
+ *   gencomm_pillar_encode_fwd PointPillar encoder front half: PillarVFE + PointPillarScatter (heter_encoders.py:22-50)
  *   gencomm_warp_attfuse_fwd  AttFusion.forward + warp_affine_simple + ScaledDotProductAttention
  *                             (opencood/models/fuse_modules/fusion_in_one.py:131-151, :41-45;
  *                              opencood/models/sub_modules/torch_transformation_utils.py:323-332)
@@ -127,6 +128,20 @@ long long gencomm_msgext_raw_floats(int C);
 long long gencomm_msgext_workspace_bytes(int n, int C, int H, int W);
 int gencomm_msgext_fwd(const float* raw, const float* x, float* out, int n, int C, int H, int W,
                        void* workspace, long long workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * PointPillars front half, eval mode (opencood/models/heter_encoders.py:22-50 = PillarVFE
+ * opencood/models/sub_modules/pillar_vfe.py:105-155 + PointPillarScatter point_pillar_scatter.py:42-76):
+ * voxel_features [M,P,4] (P <= 32), voxel_num_points int32 [M], voxel_coords int32 [M,4] = (b,z,y,x)
+ * -> out [B,64,ny,nx] (zero where no pillar). linear_w [64,10]; BatchNorm1d running statistics are
+ * folded on the device into scratch128 (device float[128]). voxel_size3 / pc_range6 are HOST arrays.
+ * The cell index is the reference's `z + y*nx + x`.
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_pillar_encode_fwd(const float* voxel_features, const int* voxel_num_points, const int* voxel_coords,
+                              const float* linear_w, const float* bn_weight, const float* bn_bias,
+                              const float* bn_running_mean, const float* bn_running_var,
+                              float* out, float* scratch128, int M, int P, int B, int nx, int ny,
+                              const float* voxel_size3, const float* pc_range6, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Warp every agent into its scene's ego frame and fuse with per-pixel attention over agents,

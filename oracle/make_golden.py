@@ -192,6 +192,39 @@ def run_attn_case() -> None:
     print(f"attn: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), state_dict keys {rec['n_keys']}")
 
 
+def run_pillar_case() -> None:
+    """PointPillars front half: the reference's own PillarVFE + PointPillarScatter
+    (torch-only modules, opencood/models/sub_modules/{pillar_vfe,point_pillar_scatter}.py) in eval mode."""
+    from opencood.models.sub_modules.pillar_vfe import PillarVFE
+    from opencood.models.sub_modules.point_pillar_scatter import PointPillarScatter
+    nx, ny, B, M = 88, 50, 2, 1500
+    vs, rng_ = [0.4, 0.4, 4.0], [-17.6, -10.0, -3.0, 17.6, 10.0, 1.0]
+    vfe = PillarVFE({"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+                    num_point_features=4, voxel_size=vs, point_cloud_range=rng_).eval()
+    synth.fill_params_(vfe, WEIGHT_SEED + 5)
+    r = np.random.RandomState(9)
+    with torch.no_grad():  # non-trivial running statistics
+        vfe.pfn_layers[0].norm.running_mean.copy_(torch.from_numpy(r.normal(0, 0.5, 64).astype(np.float32)))
+        vfe.pfn_layers[0].norm.running_var.copy_(torch.from_numpy(r.uniform(0.5, 2.0, 64).astype(np.float32)))
+    sc = PointPillarScatter({"num_features": 64, "grid_size": np.array([nx, ny, 1])})
+    pil = synth.make_pillars(M, B, nx, ny, DATA_SEED + 5, voxel_size=vs, pc_range=rng_)
+    bd = {"voxel_features": torch.from_numpy(pil["voxel_features"]), "voxel_num_points": torch.from_numpy(pil["voxel_num_points"]),
+          "voxel_coords": torch.from_numpy(pil["voxel_coords"])}
+    with torch.no_grad():
+        bd = vfe(bd)
+        pf = bd["pillar_features"].clone()
+        bd = sc(bd)
+    sp = bd["spatial_features"]
+    nz = (sp.abs().sum(1) > 0)
+    rec = dict(nx=nx, ny=ny, B=B, M=M, voxel_size=np.asarray(vs), pc_range=np.asarray(rng_), weight_seed=WEIGHT_SEED + 5,
+               data_seed=DATA_SEED + 5, bn_seed=9, pillar_features=pf.numpy(), spatial_shape=np.asarray(sp.shape),
+               occupied_index=torch.nonzero(nz.flatten()).flatten().numpy().astype(np.int64),
+               spatial_sample=sub(sp.numpy(), 13), spatial_absmean=np.float64(sp.abs().double().mean().item()))
+    path = os.path.join(OUT, "pillars.npz")
+    np.savez_compressed(path, **rec)
+    print(f"pillars: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), occupied cells {int(nz.sum())}")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -218,6 +251,7 @@ def main() -> None:
     for case in CASES:
         run_case(case)
     run_attn_case()
+    run_pillar_case()
     dump_state_dict_keys()
 
 

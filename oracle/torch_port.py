@@ -358,3 +358,40 @@ def message_extractor_forward(sd: SD, x: Tensor, p: str = "bev_extractor.") -> T
     e = b1 * g
     h = F.relu(F.conv2d(e, sd[p + "fuse.0.weight"], sd[p + "fuse.0.bias"]))
     return F.conv2d(h, sd[p + "fuse.2.weight"], sd[p + "fuse.2.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# PointPillars front half, eval mode. PINNED against the reference's own modules
+# (tests/golden/pillars.npz from opencood/models/sub_modules/{pillar_vfe,point_pillar_scatter}.py).
+# --------------------------------------------------------------------------------------
+def pillar_vfe_forward(sd: SD, voxel_features: Tensor, voxel_num_points: Tensor, coords: Tensor,
+                       voxel_size, pc_range, p: str = "pfn_layers.0.") -> Tensor:
+    """PillarVFE.forward + one last-layer PFNLayer (pillar_vfe.py:105-155, :31-54) with
+    use_norm, use_absolute_xyz, no distance (every shipped yaml, e.g. m1_att.yaml:101-105)."""
+    vx, vy, vz = voxel_size
+    xo, yo, zo = vx / 2 + pc_range[0], vy / 2 + pc_range[1], vz / 2 + pc_range[2]
+    vf = voxel_features
+    mean = vf[:, :, :3].sum(dim=1, keepdim=True) / voxel_num_points.type_as(vf).view(-1, 1, 1)
+    f_cluster = vf[:, :, :3] - mean
+    f_center = torch.zeros_like(vf[:, :, :3])
+    f_center[:, :, 0] = vf[:, :, 0] - (coords[:, 3].to(vf.dtype).unsqueeze(1) * vx + xo)
+    f_center[:, :, 1] = vf[:, :, 1] - (coords[:, 2].to(vf.dtype).unsqueeze(1) * vy + yo)
+    f_center[:, :, 2] = vf[:, :, 2] - (coords[:, 1].to(vf.dtype).unsqueeze(1) * vz + zo)
+    feats = torch.cat([vf, f_cluster, f_center], dim=-1)
+    mask = (voxel_num_points.int().unsqueeze(1) > torch.arange(vf.shape[1], dtype=torch.int).view(1, -1)).unsqueeze(-1).type_as(vf)
+    feats = feats * mask
+    x = F.linear(feats, sd[p + "linear.weight"])
+    x = F.batch_norm(x.permute(0, 2, 1), sd[p + "norm.running_mean"], sd[p + "norm.running_var"],
+                     sd[p + "norm.weight"], sd[p + "norm.bias"], False, 0.01, 1e-3).permute(0, 2, 1)
+    return torch.max(F.relu(x), dim=1)[0]
+
+
+def pillar_scatter(pillar_features: Tensor, coords: Tensor, B: int, nx: int, ny: int) -> Tensor:
+    """PointPillarScatter.forward (point_pillar_scatter.py:42-76): index = z + y*nx + x."""
+    Cc = pillar_features.shape[1]
+    out = torch.zeros(B, Cc, ny * nx, dtype=pillar_features.dtype)
+    for b in range(B):
+        m = coords[:, 0] == b
+        idx = (coords[m, 1] + coords[m, 2] * nx + coords[m, 3]).long()
+        out[b][:, idx] = pillar_features[m].t()
+    return out.view(B, Cc, ny, nx)
