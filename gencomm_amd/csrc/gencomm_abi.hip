@@ -9,6 +9,8 @@
 #include "unet_host.h"
 
 #include <algorithm>
+#include <stdlib.h>
+#include <string.h>
 
 namespace gc {
 char* last_error_buf() {
@@ -188,17 +190,38 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
   launch_q_sample(q, n, philox, st);
 
   UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st};
+  // Sampler structure: "latent" (default) carries the loop on the 8-channel map hs0 = conv_in(x_t)
+  // (latent_kernels.h); "direct" is the literal conv_in ... conv_out + update per step.
+  const char* mode_env = getenv("GENCOMM_SAMPLER");  // read per call so that tests can compare both structures
+  const bool force_direct = mode_env && strcmp(mode_env, "direct") == 0;
+  const bool latent = !force_direct && T >= 2 && (W % 4) == 0;
+  if (!latent) {
+    for (int i = 0; i < T; ++i) {
+      const int t = T - 1 - i;
+      ConvOutArgs co{};
+      co.out = out;
+      co.xt = out;
+      co.sched = sched + (size_t)t * 5;
+      co.noise = philox ? nullptr : step_noise + (size_t)i * n * per_agent;
+      co.seed = seed;
+      co.stream_id = (unsigned)t;
+      const int post = t == 0 ? 0 : (philox ? 2 : 1);
+      if (int rc = unet_enqueue(c, out, cond, t, post, co)) return rc;
+    }
+    return GC_OK;
+  }
+  const int nops = (int)p.ops.size();
+  kmap_enqueue(c, cond);
   for (int i = 0; i < T; ++i) {
     const int t = T - 1 - i;
     ConvOutArgs co{};
     co.out = out;
-    co.xt = out;
-    co.sched = sched + (size_t)t * 5;
-    co.noise = philox ? nullptr : step_noise + (size_t)i * n * per_agent;
-    co.seed = seed;
-    co.stream_id = (unsigned)t;
-    const int post = t == 0 ? 0 : (philox ? 2 : 1);
-    if (int rc = unet_enqueue(c, out, cond, t, post, co)) return rc;
+    // step 0 of the loop starts from x_{T-1} through conv_in (op 0); later steps start from hs0
+    if (int rc = unet_enqueue_range(c, out, cond, t, 0, co, i == 0 ? 0 : 1, t == 0 ? nops : nops - 1, i != 0)) return rc;
+    if (t > 0) {
+      const float* nz = philox ? nullptr : step_noise + (size_t)i * n * per_agent;
+      if (int rc = latent_step_enqueue(c, sched + (size_t)t * 5, nz, seed, (unsigned)t)) return rc;
+    }
   }
   return GC_OK;
 }

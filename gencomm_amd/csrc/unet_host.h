@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "attn_kernels.h"
+#include "latent_kernels.h"
 #include "unet_kernels.h"
 #include "unet_plan.h"
 
@@ -64,12 +65,18 @@ struct UNetCall {
 
 // Enqueue one UNet evaluation for integer timestep t.  The last op (conv_out) is launched with
 // `post` (0 plain x0, 1 explicit noise, 2 Philox) and the pointers in `co` (xt/noise/sched/out/seed).
-inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, int t, int post,
-                        ConvOutArgs co) {
+// ops [first, last) of the launch program; `keep_hs0_stats` leaves tensor 0's statistics alone
+// (they were produced by the previous latent step).
+inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* cond, int t, int post,
+                              ConvOutArgs co, int first, int last, bool keep_hs0_stats) {
   const UNetPlan& p = *c.plan;
   const float* P = c.prepared;
-  GC_HIP(hipMemsetAsync(c.wsp, 0, c.ws->stats_bytes, c.st));
-  for (const Op& o : p.ops) {
+  {
+    const size_t skip = keep_hs0_stats ? (size_t)c.n * 16 * sizeof(double) : 0;  // hs0 is tensor 0
+    GC_HIP(hipMemsetAsync(c.wsp + skip, 0, c.ws->stats_bytes - skip, c.st));
+  }
+  for (int oi = first; oi < last; ++oi) {
+    const Op& o = p.ops[oi];
     const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level];
     switch (o.kind) {
       case OP_CONV_IN: {
@@ -173,6 +180,53 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
   return GC_OK;
 }
 
+inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, int t, int post, ConvOutArgs co) {
+  return unet_enqueue_range(c, x_t, cond, t, post, co, 0, (int)c.plan->ops.size(), false);
+}
+
+// k = W_cond (*) cond + b_in : conv_in restricted to the two message channels (C = 0 mode)
+inline void kmap_enqueue(const UNetCall& c, const float* cond) {
+  const UNetPlan& p = *c.plan;
+  ConvInArgs a{cond, nullptr, c.prepared + p.conv_in.p_w, c.prepared + p.conv_in.b,
+               reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W};
+  const TileCfg tc = pick_tile(c.n, c.H, c.W);
+  int tw, th;
+  tile_dims(tc, &tw, &th);
+  const dim3 grid(cdiv(c.W, tw), cdiv(c.H, th), c.n);
+  if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
+  else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
+  else conv_in_kernel<32, 8, 1><<<grid, 256, 0, c.st>>>(a);
+}
+
+// one latent step: hs0 <- k + c2 (hs0 - k) + c1 [Wc5 (*) A + bsum + fix] + s (W_x (*) eps)
+inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const float* noise, unsigned long long seed,
+                               unsigned stream_id) {
+  const UNetPlan& p = *c.plan;
+  const float* P = c.prepared;
+  GC_HIP(hipMemsetAsync(c.stat_ptr(p.hs0_tensor), 0, (size_t)c.n * 16 * sizeof(double), c.st));
+  LatentArgs a{};
+  a.a_src = c.tensor_ptr(p.last_body_tensor); a.a_stat = c.stat_ptr(p.last_body_tensor);
+  a.gamma = P + p.nout_w; a.beta = P + p.nout_b;
+  a.kmap = reinterpret_cast<const float*>(c.wsp + c.ws->kmap_off);
+  a.hs0 = c.tensor_ptr(p.hs0_tensor); a.hs0_stat = c.stat_ptr(p.hs0_tensor);
+  a.wc5 = P + p.p_wc5; a.wc1 = P + p.p_wc1; a.bring = P + p.p_bring; a.bsum = P + p.p_bsum;
+  a.wx = P + p.conv_in.p_w + 144;
+  a.noise = noise; a.sched = sched_row; a.inv_cnt = 1.0 / (2.0 * c.H * c.W);
+  a.seed = seed; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
+  TimedLaunch tl(KF_CONV_OUT, c.st);  // takes conv_out's place in the step
+  if (pick_tile(c.n, c.H, c.W) == TILE_64x16) {
+    const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
+    if (noise) latent_step_kernel<64, 16, 1><<<grid, 256, 0, c.st>>>(a);
+    else latent_step_kernel<64, 16, 2><<<grid, 256, 0, c.st>>>(a);
+  } else {
+    const dim3 grid(cdiv(c.W, 32), cdiv(c.H, 16), c.n);
+    if (noise) latent_step_kernel<32, 16, 1><<<grid, 128, 0, c.st>>>(a);
+    else latent_step_kernel<32, 16, 2><<<grid, 128, 0, c.st>>>(a);
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prepared, hipStream_t st) {
   GC_HIP(hipMemcpyAsync(prepared, raw, (size_t)p.raw_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
   auto conv_w = [&](long long src, long long dst, int OC, int IC, int OCB) {
@@ -199,6 +253,11 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
     ta.tpw[i] = b.tpw; ta.tpb[i] = b.tpb; ta.c1b[i] = b.c1b; ta.dst[i] = b.p_bias1;
   }
   prep_temb_kernel<<<p.T, 64, 0, st>>>(ta);
+  {
+    PrepLatentArgs la{raw + p.conv_in.w, raw + p.conv_out.w, raw + p.conv_out.b, prepared + p.p_wc5, prepared + p.p_wc1,
+                      prepared + p.p_bring, prepared + p.p_bsum, p.C};
+    prep_latent_kernel<<<cdiv(1600 + 5184 + 72 + 8, 256), 256, 0, st>>>(la);
+  }
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

@@ -541,8 +541,10 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_in_kernel(const ConvInAr
   const float* __restrict__ xp = a.x + (size_t)n * a.C * plane;
   TileRegs<TW, TH, NT, 8> R;
   float wn[9];
-  if (wvec) stage_load<TW, TH, NT, 8, false>(R, xp, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
-  load_wregs<9>(wn, a.w + 144, 576, lane);
+  if (nchunk > 0) {  // C == 0: message channels only (the sampler's constant map k = W_cond (*) cond + b_in)
+    if (wvec) stage_load<TW, TH, NT, 8, false>(R, xp, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
+    load_wregs<9>(wn, a.w + 144, 576, lane);
+  }
 #pragma unroll 1
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();  // previous chunk's LDS reads are done
@@ -683,8 +685,16 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOut
           for (int p = 0; p < PPL; ++p) if (row_ok && gx + p < a.W) z[p] = a.noise[e + p];
         }
       } else {
-        // counter = element index of the first pixel of this lane's strip: unique per (lane, oc)
-        normal4((uint64_t)e, a.stream_id, a.seed, z);
+        // canonical noise field: element (n, c, y, x) = component (x & 3) of the Philox block whose
+        // counter is the element index of the aligned quad (x & ~3) -- independent of the tiling and
+        // shared with the latent sampler (latent_kernels.h)
+        if (PPL == 4) {
+          normal4((uint64_t)e, a.stream_id, a.seed, z);
+        } else {
+          float zz[4];
+          normal4((uint64_t)(e - (size_t)(gx & 3)), a.stream_id, a.seed, zz);
+          z[0] = zz[gx & 3];
+        }
       }
 #pragma unroll
       for (int p = 0; p < PPL; ++p) v[p] = fmaf(sg, z[p], fmaf(c1, v[p], c2 * xt[p]));

@@ -61,6 +61,8 @@ struct UNetPlan {
   long long d0w, d0b, d1w, d1b;
   ConvPlan conv_in, conv_out;
   long long nout_w, nout_b;
+  long long p_wc5, p_wc1, p_bring, p_bsum;  // latent sampler tables (latent_kernels.h)
+  int hs0_tensor = 0, last_body_tensor = 0;
   std::vector<ConvPlan> down, up;  // indexed by level (down[l] valid for l < L-1, up[l] for l > 0)
   std::vector<ResBlockPlan> blocks;
   std::vector<Op> ops;
@@ -187,6 +189,7 @@ struct UNetPlan {
       if (down[l].w >= 0) down[l].p_w = padd(8 * 8 * 9);
       if (up[l].w >= 0) up[l].p_w = padd(8 * 8 * 9);
     }
+    p_wc5 = padd(1600); p_wc1 = padd(5184); p_bring = padd(72); p_bsum = padd(8);
     for (auto& b : blocks) {
       b.p_c1w = padd(8LL * b.cin * 9);
       b.p_c2w = padd(8 * 8 * 9);
@@ -229,6 +232,8 @@ struct UNetPlan {
       }
     }
     ops.push_back({OP_CONV_OUT, 0, {h, -1}, {-1, -1}, -1, 0});
+    hs0_tensor = ops[0].dst;
+    last_body_tensor = h;
 
     // ---- liveness -> slots ----
     for (int i = 0; i < (int)ops.size(); ++i) {
@@ -238,6 +243,7 @@ struct UNetPlan {
         if (o.res[k] >= 0) tensors[o.res[k]].last_use = i;
       }
     }
+    tensors[hs0_tensor].last_use = (int)ops.size();  // never released: the latent step rewrites it in place
     slots_per_level.assign(L, 0);
     std::vector<std::vector<int>> free_slots(L);
     auto take_slot = [&](int id) {
@@ -271,7 +277,7 @@ struct UNetPlan {
 struct UNetWorkspace {
   std::vector<int> Hl, Wl;
   std::vector<size_t> level_base, slot_bytes;
-  size_t stats_bytes = 0, total = 0;
+  size_t stats_bytes = 0, total = 0, kmap_off = 0;
 
   const char* build(const UNetPlan& p, int n, int H, int W) {
     Hl.assign(p.L, 0); Wl.assign(p.L, 0);
@@ -290,6 +296,8 @@ struct UNetWorkspace {
       level_base[l] = off;
       off += slot_bytes[l] * p.slots_per_level[l];
     }
+    kmap_off = off;  // persistent k = W_cond (*) cond + b_in of the latent sampler
+    off += slot_bytes[0];
     total = off;
     return nullptr;
   }
