@@ -38,8 +38,8 @@ PX_M = 0.4           # metres per BEV pixel at 200x704 (OPV2V range +-140.8 x +-
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 
-# dominant kernel (profiles/round1_*): family id in the library's timer, MACs per output pixel
-DOMINANT = {"family": 5, "name": "conv_out_kernel"}
+# dominant kernel (profiles/r1_bench_default_kernel_stats.csv: 22 % of kernel time): family id in the library's timer
+DOMINANT = {"family": 15, "name": "latent_step_kernel"}
 
 
 def algorithmic_work(N, C, HW, T):
@@ -231,7 +231,9 @@ def main():
             fam = args.timer_family
             name = lib.gencomm_timer_kernel_name(fam).decode()
             per_launch_ms = k_ms.value / k_n.value
-            macs_px = {0: 72.0 * (C + 2), 5: 72.0 * C}.get(fam)
+            # MACs per agent-pixel the kernel executes: conv_in 72(C+2); conv_out 72C; latent step = 5x5 composite
+            # (8*8*25) + noise conv (72C) -- DESIGN.md section 4
+            macs_px = {0: 72.0 * (C + 2), 5: 72.0 * C, 15: 1600.0 + 72.0 * C}.get(fam)
             traffic = None
             pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
@@ -250,7 +252,8 @@ def main():
                                       "achieved": fl / (iso_ms.value / iso_n.value * 1e-3) / 1e12,
                                       "frac": fl / (iso_ms.value / iso_n.value * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
                                      if iso_n.value else None),
-                        "note": "v_mfma_f32_4x4x1 (exact fp32) priced against the 157.3 TFLOP/s fp32 matrix/vector peak; "
+                        "note": "latent_step_kernel = conv_out + sampler update + conv_in of one step fused by linearity; "
+                                "v_mfma_f32_4x4x1 (exact fp32) priced against the 157.3 TFLOP/s fp32 matrix/vector peak; "
                                 "'achieved' is event-timed inside the timed region (other scenes share the chip when "
                                 "streams > 1), 'isolated' is the same kernel with one scene in flight"}
             else:

@@ -48,14 +48,14 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum KernelFamily : int {
   KF_CONV_IN = 0, KF_CONV8 = 1, KF_CONV16 = 2, KF_DOWN = 3, KF_UP = 4, KF_CONV_OUT = 5, KF_Q_SAMPLE = 6,
   KF_ENH_LN = 7, KF_ENH_PCONV = 8, KF_ENH_GEMM1 = 9, KF_ENH_DWGATE = 10, KF_ENH_GEMM2 = 11,
-  KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_COUNT = 15
+  KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_LATENT_STEP = 15, KF_COUNT = 16
 };
 inline const char* kernel_family_name(int id) {
   static const char* names[KF_COUNT] = {"conv_in_kernel", "conv8_kernel<NSRC=1>", "conv8_kernel<NSRC=2>", "down8_kernel",
                                         "conv8_kernel<UP>", "conv_out_kernel", "q_sample_kernel", "enh_ln_kernel",
                                         "enh_pconv_kernel", "gemm_f32_mfma_kernel<0>", "enh_dwgate_kernel",
                                         "gemm_f32_mfma_kernel<1>", "enh_gate_kernel", "enh_scale_transpose_kernel",
-                                        "warp_attfuse_kernel"};
+                                        "warp_attfuse_kernel", "latent_step_kernel"};
   return (id >= 0 && id < KF_COUNT) ? names[id] : "?";
 }
 struct KernelTimer {

@@ -213,7 +213,7 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   a.wx = P + p.conv_in.p_w + 144;
   a.noise = noise; a.sched = sched_row; a.inv_cnt = 1.0 / (2.0 * c.H * c.W);
   a.seed = seed; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
-  TimedLaunch tl(KF_CONV_OUT, c.st);  // takes conv_out's place in the step
+  TimedLaunch tl(KF_LATENT_STEP, c.st);
   if (pick_tile(c.n, c.H, c.W) == TILE_64x16) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
     if (noise) latent_step_kernel<64, 16, 1><<<grid, 256, 0, c.st>>>(a);
