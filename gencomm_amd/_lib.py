@@ -53,6 +53,7 @@ _SIGNATURES = {
     "gencomm_pillar_encode_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_warp_attfuse_tok_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -116,7 +116,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     TimedLaunch tl(KF_ENH_GATE, st);
     enh_gate_kernel<<<n, 256, (2 * C + 8) * sizeof(float), st>>>(a);
   }
-  {  // K7
+  if (out != nullptr) {  // K7 (skipped when the caller consumes the token-major result + gate directly)
     EnhOutArgs a{F(w.O), F(w.gate), out, C, HW};
     const size_t sh = (size_t)32 * (C + 1) * sizeof(float);
     TimedLaunch tl(KF_ENH_OUT, st);

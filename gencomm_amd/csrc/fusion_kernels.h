@@ -117,4 +117,147 @@ inline int warp_attfuse_enqueue(const float* x, const double* theta, const int* 
   return GC_OK;
 }
 
+
+
+// ---------------------------------------------------------------------------------------------
+// Token-major fast path (ScenePipeline): reads the Enhancer's token-major result O [n][HW][C] and
+// its channel gate [n][C] straight from the Enhancer workspace (the NHWC->NCHW transpose launch is
+// skipped and the gate multiply happens here). QL lanes share one output pixel, each owning C/QL
+// consecutive channels as float4 quads, so a bilinear corner is ONE contiguous C*4-byte row fetched
+// by QL adjacent lanes (fully coalesced however the agent is rotated); every agent's warped
+// feature stays in registers (no second gather pass); the <x_0, x_j> dot products are reduced over
+// the QL lanes with DPP-free xor shuffles inside the 16-lane group; results are transposed through
+// LDS so that the NCHW output is written in 256-B runs.
+// ---------------------------------------------------------------------------------------------
+struct FuseTokArgs {
+  const float* O;        // [n][HW][C]
+  const float* gate;     // [n][C]
+  const double* theta;   // [n][2][3]
+  const int* scene_off;  // [B+1]
+  float* out;            // [B][C][H][W]
+  int C, H, W;
+};
+
+template <int N, int QPL /*float4 quads per lane*/>
+__device__ __forceinline__ void fuse_tok_body(const FuseTokArgs& a, int b, int off, float* s_out /*[64][C+1]*/) {
+  const int tid = threadIdx.x;
+  const int C = a.C, H = a.H, W = a.W, HW = H * W;
+  const int lp = tid >> 4, ql = tid & 15;       // 16 pixels per 256-thread block pass, 16 lanes per pixel
+  const int c0 = ql * 4 * QPL;                  // first channel of this lane
+  for (int pass = 0; pass < 4; ++pass) {        // 64 pixels per block
+    const int pl = pass * 16 + lp;              // local pixel 0..63
+    const int pix = blockIdx.x * 64 + pl;
+    const bool ok = pix < HW;
+    const int h = ok ? pix / W : 0, w = ok ? pix - h * W : 0;
+    const double xb = (2.0 * w + 1.0) / (double)W - 1.0, yb = (2.0 * h + 1.0) / (double)H - 1.0;
+    float4 v[N][QPL];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double* __restrict__ th = a.theta + (size_t)(off + j) * 6;
+      const float gx = (float)(th[0] * xb + th[1] * yb + th[2]);
+      const float gy = (float)(th[3] * xb + th[4] * yb + th[5]);
+      const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+      const float tx = ix - fx, ty = iy - fy;
+      const bool far = fx != (float)x0 || fy != (float)y0;
+      const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W;
+      const bool yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
+      const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+      const bool val[4] = {ok && xl && yt && !far, ok && xr && yt && !far, ok && xl && yb_ && !far, ok && xr && yb_ && !far};
+      const int idx[4] = {y0 * W + x0, y0 * W + x0 + 1, (y0 + 1) * W + x0, (y0 + 1) * W + x0 + 1};
+      const float* __restrict__ base = a.O + (size_t)(off + j) * HW * C + c0;
+#pragma unroll
+      for (int q = 0; q < QPL; ++q) v[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (val[k]) {
+#pragma unroll
+          for (int q = 0; q < QPL; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(base + (size_t)idx[k] * C + 4 * q);
+            v[j][q].x = fmaf(t.x, wgt[k], v[j][q].x); v[j][q].y = fmaf(t.y, wgt[k], v[j][q].y);
+            v[j][q].z = fmaf(t.z, wgt[k], v[j][q].z); v[j][q].w = fmaf(t.w, wgt[k], v[j][q].w);
+          }
+        }
+      }
+      // channel gate of agent j (sigmoid output of SplitAttn), constant over pixels
+#pragma unroll
+      for (int q = 0; q < QPL; ++q) {
+        const float4 g = *reinterpret_cast<const float4*>(a.gate + (size_t)(off + j) * C + c0 + 4 * q);
+        v[j][q].x *= g.x; v[j][q].y *= g.y; v[j][q].z *= g.z; v[j][q].w *= g.w;
+      }
+    }
+    float sc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float d = 0.f;
+#pragma unroll
+      for (int q = 0; q < QPL; ++q)
+        d += v[0][q].x * v[j][q].x + v[0][q].y * v[j][q].y + v[0][q].z * v[j][q].z + v[0][q].w * v[j][q].w;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 16);   // over the 16 lanes of this pixel
+      sc[j] = d;
+    }
+    const float inv = 1.0f / sqrtf((float)C);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { sc[j] *= inv; mx = fmaxf(mx, sc[j]); }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+    const float rden = 1.0f / den;
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float wj = sc[j] * rden;
+        o.x = fmaf(wj, v[j][q].x, o.x); o.y = fmaf(wj, v[j][q].y, o.y); o.z = fmaf(wj, v[j][q].z, o.z); o.w = fmaf(wj, v[j][q].w, o.w);
+      }
+      float* d = s_out + pl * (C + 1) + c0 + 4 * q;
+      d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.w;
+    }
+  }
+  __syncthreads();
+  // NCHW store: lanes over the 64 pixels of the block, waves over channels
+  const int p = tid & 63;
+  const int pix = blockIdx.x * 64 + p;
+  if (pix < HW)
+    for (int c = tid >> 6; c < C; c += 4) a.out[((size_t)b * C + c) * HW + pix] = s_out[p * (C + 1) + c];
+}
+
+template <int QPL>
+__global__ __launch_bounds__(256) void warp_attfuse_tok_kernel(const FuseTokArgs a) {
+  extern __shared__ float s_out[];
+  const int b = blockIdx.y;
+  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
+  switch (N) {
+    case 1: fuse_tok_body<1, QPL>(a, b, off, s_out); break;
+    case 2: fuse_tok_body<2, QPL>(a, b, off, s_out); break;
+    case 3: fuse_tok_body<3, QPL>(a, b, off, s_out); break;
+    case 4: fuse_tok_body<4, QPL>(a, b, off, s_out); break;
+    case 5: fuse_tok_body<5, QPL>(a, b, off, s_out); break;
+    case 6: fuse_tok_body<6, QPL>(a, b, off, s_out); break;
+    case 7: fuse_tok_body<7, QPL>(a, b, off, s_out); break;
+    case 8: fuse_tok_body<8, QPL>(a, b, off, s_out); break;
+    default: break;
+  }
+}
+
+inline int warp_attfuse_tok_enqueue(const float* O, const float* gate, const double* theta, const int* scene_off, float* out,
+                                    int B, int C, int H, int W, hipStream_t st) {
+  FuseTokArgs a{O, gate, theta, scene_off, out, C, H, W};
+  const dim3 grid((H * W + 63) / 64, B);
+  const size_t sh = (size_t)64 * (C + 1) * sizeof(float);
+  TimedLaunch tl(KF_WARP_ATTFUSE, st);
+  if (C == 64) warp_attfuse_tok_kernel<1><<<grid, 256, sh, st>>>(a);
+  else if (C == 128) warp_attfuse_tok_kernel<2><<<grid, 256, sh, st>>>(a);
+  else if (C == 256) {
+    GC_HIP(hipFuncSetAttribute((const void*)warp_attfuse_tok_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    warp_attfuse_tok_kernel<4><<<grid, 256, sh, st>>>(a);
+  } else return fail(GC_ERR_ARG, "token-major fusion supports C in {64, 128, 256}");
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 }  // namespace gc

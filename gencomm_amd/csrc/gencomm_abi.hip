@@ -257,7 +257,7 @@ int gencomm_enhancer_fwd(const float* raw, const float* x, float* out, int n, in
                          void* workspace, long long workspace_bytes, void* stream) {
   EnhancerPlan p;
   if (const char* e = p.build(C)) return fail(GC_ERR_ARG, e);
-  GC_CHECK_ARG(raw && x && out && workspace, "null pointer");
+  GC_CHECK_ARG(raw && x && workspace, "null pointer");  // out may be NULL: token-major result stays in the workspace
   GC_CHECK_ARG(n >= 1 && n <= 65535 && H >= 1 && W >= 1, "bad n/H/W");
   if ((long long)enhancer_workspace_bytes(p, n, H, W) > workspace_bytes)
     return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_enhancer_workspace_bytes)");
@@ -330,6 +330,18 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
   GC_CHECK_ARG(x && theta && scene_off && out, "null pointer");
   GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && C >= 1 && H >= 1 && W >= 1, "bad B/n/C/H/W");
   return warp_attfuse_enqueue(x, theta, scene_off, out, B, n, C, H, W, (hipStream_t)stream);
+}
+
+int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* theta, const int* scene_off, float* out,
+                                 int B, int n, int C, int H, int W, void* stream) {
+  EnhancerPlan p;
+  if (const char* e = p.build(C)) return fail(GC_ERR_ARG, e);
+  GC_CHECK_ARG(enhancer_workspace && theta && scene_off && out, "null pointer");
+  GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && H >= 1 && W >= 1, "bad B/n/H/W");
+  const EnhancerWs w = enhancer_ws(p, n, H, W);
+  const char* base = (const char*)enhancer_workspace;
+  return warp_attfuse_tok_enqueue(reinterpret_cast<const float*>(base + w.O), reinterpret_cast<const float*>(base + w.gate),
+                                  theta, scene_off, out, B, C, H, W, (hipStream_t)stream);
 }
 
 }  // extern "C"

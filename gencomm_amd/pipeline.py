@@ -23,8 +23,10 @@ from .runtime import f32c, ptr, stream_ptr
 
 class ScenePipeline:
     def __init__(self, gencomm: GenComm, enhancer: Optional[Enhancer], record_len: Sequence[int],
-                 C: int, H: int, W: int, device: torch.device):
+                 C: int, H: int, W: int, device: torch.device, token_fast_path: Optional[bool] = None):
         self.gen, self.enh = gencomm, enhancer
+        # Enhancer -> fusion without the NCHW round trip (self.enhanced is then NOT produced)
+        self.token_fast_path = (C in (64, 128, 256)) if token_fast_path is None else bool(token_fast_path)
         self.lens = [int(v) for v in record_len]
         if min(self.lens) < 1 or max(self.lens) > MAX_AGENTS_PER_SCENE:
             raise ValueError(f"each scene needs 1..{MAX_AGENTS_PER_SCENE} agents, got {self.lens}")
@@ -79,6 +81,13 @@ class ScenePipeline:
         _lib.check(l.gencomm_denoise_fwd(ptr(self.prepared), ptr(self.sched), ptr(feat), n, ptr(self.src_rows), ptr(cond),
                                          ptr(self.pred), ptr(n0), ptr(sn), seed, n, C, H, W, self.L, self.R, self.A, self.T,
                                          ptr(self.ws), self.ws.numel(), st), "gencomm_denoise_fwd")
+        if self.enh is not None and self.token_fast_path:
+            # Enhancer result stays token-major in the workspace; the fusion kernel applies the channel gate
+            _lib.check(l.gencomm_enhancer_fwd(ptr(self.enh_raw), ptr(self.pred), None, n, C, H, W,
+                                              ptr(self.ws), self.ws.numel(), st), "gencomm_enhancer_fwd")
+            _lib.check(l.gencomm_warp_attfuse_tok_fwd(ptr(self.ws), ptr(self.theta), ptr(self.scene_off), ptr(self.fused),
+                                                      self.B, n, C, H, W, st), "gencomm_warp_attfuse_tok_fwd")
+            return self.fused
         if self.enh is not None:
             _lib.check(l.gencomm_enhancer_fwd(ptr(self.enh_raw), ptr(self.pred), ptr(self.enhanced), n, C, H, W,
                                               ptr(self.ws), self.ws.numel(), st), "gencomm_enhancer_fwd")

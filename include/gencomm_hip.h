@@ -153,6 +153,13 @@ int gencomm_pillar_encode_fwd(const float* voxel_features, const int* voxel_num_
 int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
                              int B, int n, int C, int H, int W, void* stream);
 
+/* Fast lane for callers that chain Enhancer -> fusion themselves (ScenePipeline): call
+ * gencomm_enhancer_fwd with out == NULL (the token-major result and the channel gate stay in the
+ * workspace, the NHWC->NCHW transpose launch is skipped), then this entry point with the SAME
+ * workspace pointer and (n, C, H, W). Same maths as gencomm_warp_attfuse_fwd(enhancer output). C in {64,128,256}. */
+int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* theta, const int* scene_off, float* out,
+                                 int B, int n, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

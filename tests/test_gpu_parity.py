@@ -257,3 +257,48 @@ def test_latent_and_direct_samplers_agree():
             err = (a - b).abs()
             # two HIP structures, each within rtol 1e-4 / atol 1e-5 of the reference: allow twice that between them
             assert (err <= 2e-5 + 2e-4 * b.abs()).all(), (C, H, W, kind, err.max().item())
+
+
+@pytest.mark.parametrize("name", ["mid", "shipped"])
+def test_scene_pipeline_vs_reference_golden(name):
+    """The preallocated fast lane (token-major Enhancer -> fusion hand-over, no NCHW round trip)
+    against the reference's `fused` vector of the same case."""
+    from gencomm_amd import normalize_pairwise_tfm
+    from gencomm_amd.pipeline import ScenePipeline
+    g = load_case(name)
+    _, gen, enh = build_modules(g, DEV)
+    inp = build_inputs(g, DEV)
+    noise = eval_noise(g, DEV)
+    H, W, px, C = int(g["H"]), int(g["W"]), float(g["px_m"]), int(g["C"])
+    st = int(g["stride"])
+    rl = [int(v) for v in g["record_len"]]
+    with torch.no_grad():
+        affine = normalize_pairwise_tfm(inp["pairwise_t_matrix"], H * px, W * px, 1)
+        pipe = ScenePipeline(gen, enh, rl, C, H, W, torch.device(DEV))
+        assert pipe.token_fast_path
+        pipe.set_affine(affine)
+        fused = pipe.run(inp["feat"].contiguous(), inp["cond"].contiguous(), noise=noise)
+        assert_close(sub(fused, max(1, st // 2)), g["fused"], RTOL, ATOL, "fused (pipeline)")
+
+
+def test_scene_pipeline_token_path_equals_nchw_path():
+    """Ragged scenes (3, 1, 2 agents incl. one far out of range), HW not a multiple of the 64-pixel block."""
+    from gencomm_amd import Enhancer, GenComm, normalize_pairwise_tfm, synth
+    from gencomm_amd.pipeline import ScenePipeline
+    C, H, W, T, rl = 64, 22, 46, 3, [3, 1, 2]
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen, enh = GenComm(cfg).eval().to(DEV), Enhancer(C, [8, 8], 4).eval().to(DEV)
+    synth.fill_params_(gen, 5)
+    synth.fill_params_(enh, 6)
+    inp = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_inputs(rl, C, H, W, 7, max_shift=12.0).items()}
+    with torch.no_grad():
+        ptm = inp["pairwise_t_matrix"].clone()
+        ptm[2, 0, 1, 0, 3] = 500.0  # second agent of the last scene: far outside the map
+        affine = normalize_pairwise_tfm(ptm, H * 0.8, W * 0.8, 1)
+        outs = []
+        for fast in (True, False):
+            pipe = ScenePipeline(gen, enh, rl, C, H, W, torch.device(DEV), token_fast_path=fast)
+            pipe.set_affine(affine)
+            outs.append(pipe.run(inp["feat"].contiguous(), inp["cond"].contiguous(), seed=3).clone())
+    err = (outs[0] - outs[1]).abs()
+    assert (err <= 1e-5 + 1e-5 * outs[1].abs()).all(), err.max().item()
