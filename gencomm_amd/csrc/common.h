@@ -128,6 +128,36 @@ __device__ __forceinline__ float wave_total(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// 16 per-lane partials -> wave totals with a recursive-halving exchange instead of 16 full ladders:
+// lanes trade halves of the vector across lane bits 0 and 1 (quad_perm DPP), the surviving 4 values
+// are summed down each 16-lane row (row_shr 4/8) and across the 4 rows (two ds_bpermute steps).
+// On return lanes with (lane & 15) >= 12 hold, in tot[i], the WAVE total of
+// part[8 * (lane & 1) + 4 * ((lane >> 1) & 1) + i]; other lanes hold partial sums.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void wave_reduce16(const float (&part)[16], float (&tot)[4]) {
+  const int lane = threadIdx.x & 63;
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  float h[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float keep = b0 ? part[8 + i] : part[i], send = b0 ? part[i] : part[8 + i];
+    h[i] = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]: partner lane ^ 1
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float keep = b1 ? h[4 + i] : h[i], send = b1 ? h[i] : h[4 + i];
+    float g = keep + dpp_mov<0x4E>(send);  // quad_perm [2,3,0,1]: partner lane ^ 2
+    g = dpp_add<0x114, 0xf>(g);            // row_shr:4
+    g = dpp_add<0x118, 0xf>(g);            // row_shr:8 -> lanes 12..15 of a row: row total of their class
+    g += __shfl_xor(g, 16, 64);
+    g += __shfl_xor(g, 32, 64);
+    tot[i] = g;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG + Box-Muller: 4 N(0,1) floats per (counter, key)
 // ---------------------------------------------------------------------------------------------

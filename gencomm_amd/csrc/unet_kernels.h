@@ -52,27 +52,28 @@ __device__ __forceinline__ void gn_coeff(const double* __restrict__ stat /*[8][2
 template <int NT>
 __device__ __forceinline__ void block_stats_commit(float (&part)[16], float (*s_red)[16],
                                                    double* __restrict__ dstat /*[8][2]*/) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) part[i] = wave_total(part[i]);  // wave-uniform totals
+  const int tid = threadIdx.x, lane = tid & 63;
+  float tot[4];
+  wave_reduce16(part, tot);
+  // lanes 12..15 own 4 totals each: value index v = 8 * bit0 + 4 * bit1 + i;
+  // v < 8 is the sum of channel v, v >= 8 the sum of squares of channel v - 8
+  const int vbase = 8 * (lane & 1) + 4 * ((lane >> 1) & 1);
   if (NT == 64) {
-    // single wave: lane i < 16 commits total i
-    float v = part[0];
+    if (lane >= 12 && lane < 16) {
 #pragma unroll
-    for (int i = 1; i < 16; ++i) v = (tid == i) ? part[i] : v;
-    if (tid < 16) atomicAdd(&dstat[(tid & 7) * 2 + (tid >> 3)], (double)v);
+      for (int i = 0; i < 4; ++i) atomicAdd(&dstat[((vbase + i) & 7) * 2 + ((vbase + i) >> 3)], (double)tot[i]);
+    }
     return;
   }
-  if ((tid & 63) == 0) {
+  if (lane >= 12 && lane < 16) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s_red[tid >> 6][i] = part[i];
+    for (int i = 0; i < 4; ++i) s_red[tid >> 6][vbase + i] = tot[i];
   }
   __syncthreads();
   if (tid < 16) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) v += s_red[w][tid];
-    // part[i] for i < 8 is sum of channel i, i >= 8 sum of squares of channel i-8
     atomicAdd(&dstat[(tid & 7) * 2 + (tid >> 3)], (double)v);
   }
 }
@@ -90,6 +91,13 @@ __device__ unsigned long long g_stamps[1 << 16][8];
   } while (0)
 #else
 #define GC_STAMP(slot) do {} while (0)
+#endif
+
+// Diagnostic ablations (never defined in the shipped build): -DGC_EXP=<mask> removes one phase of
+// conv8_kernel so that its share of the launch time can be read off a kernel trace.
+//   1 no MFMA/LDS-read phase   2 no GN+SiLU maths   4 no global stores   8 no statistics   16 no tile loads
+#ifndef GC_EXP
+#define GC_EXP 0
 #endif
 
 // compile-time loop (MFMA broadcast selectors must be immediates)
@@ -185,10 +193,11 @@ __device__ __forceinline__ void stage_store(float (*tile)[TH + 2][LS], const Til
     float e[4] = {q.x, q.y, q.z, q.w};
     if (GN) {
       const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
+      // zero padding through the coefficients: out-of-image quads were loaded as 0 and silu(0*0+0) == 0
       const bool ok = gy >= 0 && gy < H && gx < W;
-      const float A = ab[c][0], B = ab[c][1];
+      const float A = ok ? ab[c][0] : 0.f, B = ok ? ab[c][1] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = ok ? silu_f(fmaf(A, e[j], B)) : 0.f;
+      for (int j = 0; j < 4; ++j) e[j] = silu_f(fmaf(A, e[j], B));
     }
     *reinterpret_cast<float4*>(&tile[c][r][4 + 4 * qx]) = make_float4(e[0], e[1], e[2], e[3]);
   };
@@ -332,7 +341,8 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
 #pragma unroll
   for (int o = 0; o < 8; ++o) bias[o] = as_const(a.bias)[o];
   TileRegs<TW, TH, NT, 8> R;
-  if (wvec) stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  if (GC_EXP & 16) R = TileRegs<TW, TH, NT, 8>{};
+  else if (wvec) stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   float resv[RES == 1 ? 8 : 1][PPL];
   if (RES == 1) {
 #pragma unroll
@@ -366,20 +376,20 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
 #pragma unroll
     for (int p = 0; p < PPL; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[0], tid);
+  if (wvec) stage_store<TW, TH, NT, 8, GN && !(GC_EXP & 2), LS>(tile, R, a.H, a.W, x0, y0, &s_ab[0], tid);
   else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
   if (NSRC == 2 && wvec)  // prefetch the skip tensor's tile while the first half is computed
     stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   __syncthreads();
   GC_STAMP(2);
-  conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[0], acc, tx, ty);
+  if (!(GC_EXP & 1)) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[0], acc, tx, ty);
   GC_STAMP(3);
   if (NSRC == 2) {
     __syncthreads();
-    if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid);
+    if (wvec) stage_store<TW, TH, NT, 8, GN && !(GC_EXP & 2), LS>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid);
     else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
     __syncthreads();
-    conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
+    if (!(GC_EXP & 1)) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
   }
 
   GC_STAMP(4);
@@ -415,7 +425,8 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
-    if (vec_ok) {
+    if ((GC_EXP & 4) && out[o][0] != 1.2345e30f) {
+    } else if (vec_ok) {
       *reinterpret_cast<float4*>(dp) = make_float4(out[o][0], out[o][1 % PPL], out[o][2 % PPL], out[o][3 % PPL]);
     } else {
 #pragma unroll
@@ -423,12 +434,16 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
     }
     float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int p = 0; p < PPL; ++p) if (ok[p]) { s += out[o][p]; q = fmaf(out[o][p], out[o][p], q); }
+    for (int p = 0; p < PPL; ++p) {
+      const float m = ok[p] ? out[o][p] : 0.f;
+      s += m;
+      q = fmaf(m, m, q);
+    }
     part[o] = s;
     part[8 + o] = q;
   }
   GC_STAMP(5);
-  if (a.dstat != nullptr) block_stats_commit<NT>(part, s_red, a.dstat + (size_t)n * 16);
+  if (a.dstat != nullptr && (!(GC_EXP & 8) || part[0] == 1.2345e30f)) block_stats_commit<NT>(part, s_red, a.dstat + (size_t)n * 16);
   GC_STAMP(6);
 }
 

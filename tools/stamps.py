@@ -23,6 +23,7 @@ ap.add_argument("--n", type=int, default=4)
 ap.add_argument("--C", type=int, default=64)
 ap.add_argument("--H", type=int, default=200)
 ap.add_argument("--W", type=int, default=704)
+ap.add_argument("--blocks", type=int, default=0, help="workgroups of the stamped launch (persistent grid)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 gen = GenComm(synth.default_gencomm_cfg(a.C, 20)).eval().to(dev)
@@ -33,17 +34,17 @@ with torch.no_grad():
         gen.denoiser(x, t, T=20)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-nb = -(-a.W // 64) * -(-a.H // 16) * a.n
+nb = a.blocks or -(-a.W // 64) * -(-a.H // 16) * a.n
 buf = np.zeros((nb, 8), dtype=np.uint64)
 rc = lib.gencomm_diag_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), nb)
 assert rc == 0
 st = buf[:, :7].astype(np.float64) * 0.01  # us (100 MHz)
 t0 = st[:, 0].min()
-names = ["start", "loads+gn", "store+sync", "mfma", "(src2)", "epilogue", "stats"]
+names = ["iter start", "wait tile+coeffs", "gn+store+prefetch+sync", "mfma", "(src2)", "epilogue", "stats"]
 print(f"{nb} workgroups; kernel span {st[:, 6].max() - t0:.2f} us (first start -> last end)")
 print(f"start spread: {st[:, 0].max() - t0:.2f} us; per-phase mean / p95 duration (us):")
 for i in range(1, 7):
     d = st[:, i] - st[:, i - 1]
-    print(f"  {names[i]:12s} mean {d.mean():6.2f}  p95 {np.percentile(d, 95):6.2f}  max {d.max():6.2f}")
+    print(f"  {names[i]:24s} mean {d.mean():6.2f}  p95 {np.percentile(d, 95):6.2f}  max {d.max():6.2f}")
 life = st[:, 6] - st[:, 0]
 print(f"workgroup lifetime mean {life.mean():.2f} us, max {life.max():.2f} us; last end at {st[:, 6].max() - t0:.2f}, median end {np.median(st[:, 6]) - t0:.2f}")
