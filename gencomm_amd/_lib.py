@@ -52,6 +52,9 @@ _SIGNATURES = {
     "gencomm_msgext_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_pillar_encode_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
+    "gencomm_conv2d_prepare": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_conv2d_fold": (_i, [_p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _p]),
+    "gencomm_conv2d_fwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 13 + [_p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_attfuse_tok_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }

@@ -1,0 +1,221 @@
+"""``BaseBEVBackbone`` / ``DownsampleConv`` / 1x1 heads -- host-side mirrors of the dense 2-D conv stacks
+on either side of the hot path:
+
+  BaseBEVBackbone   opencood/models/sub_modules/base_bev_backbone.py:6-156
+  DownsampleConv    opencood/models/sub_modules/downsample_conv.py:7-49
+  heads             opencood/models/heter_model_baseline_w_gencomm_stage1.py:137-142
+
+The modules own their parameters in the reference's ``nn.Sequential`` layout, so ``state_dict`` keys are
+identical (``blocks.0.1.weight``, ``blocks.0.2.running_mean``, ``deblocks.1.0.weight``,
+``layers.0.double_conv.2.bias`` ...). ``forward`` never calls the torch layers: every conv (+ folded
+eval-mode BatchNorm + ReLU) is one launch of the implicit-GEMM HIP kernel through the C ABI; deblocks write
+straight into their channel slice of the concatenated output. BatchNorm in training mode (batch statistics)
+is not implemented on this path and raises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .runtime import f32c, ptr, require_gpu, stream_ptr
+
+
+def _versions(*tensors):
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+
+
+def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
+               pad: Optional[int] = None, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+    """act(BN(conv(x))) as one HIP launch. ``conv`` is an ``nn.Conv2d`` (3x3 stride 1|2, or 1x1) or an
+    ``nn.ConvTranspose2d`` whose kernel equals its stride; ``pad`` overrides ``conv.padding`` (ZeroPad2d(1)
+    in front of a padding-0 conv). ``out``/``out_coff``: write into a channel slice of a larger tensor."""
+    require_gpu(x, "conv2d_hip")
+    x = f32c(x)
+    transposed = isinstance(conv, nn.ConvTranspose2d)
+    w = conv.weight
+    if transposed:
+        cin, cout, kh, kw = w.shape
+        s = conv.stride[0]
+        if not (kh == kw == s == conv.stride[1]) or conv.padding != (0, 0) or conv.output_padding != (0, 0):
+            raise NotImplementedError("ConvTranspose2d is supported with kernel == stride, no padding")
+        stride, p, ups, gkh, gkw = 1, 0, s, 1, 1
+    else:
+        cout, cin, kh, kw = w.shape
+        if conv.groups != 1 or conv.dilation != (1, 1) or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
+            raise NotImplementedError("grouped / dilated / anisotropic Conv2d is not supported")
+        stride, ups, gkh, gkw = conv.stride[0], 1, kh, kw
+        p = conv.padding[0] if pad is None else pad
+    if bn is not None and bn.training:
+        raise NotImplementedError("BatchNorm2d in training mode (batch statistics) is not implemented on the HIP path; call .eval()")
+    n, c, H, W = x.shape
+    if c != cin:
+        raise ValueError(f"expected {cin} input channels, got {c}")
+    l = _lib.lib()
+    st = stream_ptr(x.device)
+    bnp = (bn.weight, bn.bias, bn.running_mean, bn.running_var) if bn is not None else (None,) * 4
+    key = _versions(w, conv.bias, *bnp) + (str(x.device),)
+    cache = getattr(conv, "_gc_cache", None)
+    if cache is None or cache[0] != key:
+        wd = f32c(w.detach())
+        prepared = torch.empty(wd.numel(), dtype=torch.float32, device=x.device)
+        _lib.check(l.gencomm_conv2d_prepare(ptr(wd), ptr(prepared), cin, cout, kh, kw, int(transposed), st), "gencomm_conv2d_prepare")
+        ss = torch.empty(2, cout, dtype=torch.float32, device=x.device)
+        d = [f32c(t.detach()) if t is not None else None for t in bnp]
+        b = f32c(conv.bias.detach()) if conv.bias is not None else None
+        _lib.check(l.gencomm_conv2d_fold(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(b), float(bn.eps) if bn is not None else 0.0,
+                                         cout, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
+        cache = (key, prepared, ss)
+        conv._gc_cache = cache
+    _, prepared, ss = cache
+    Ho = ((H + 2 * p - gkh) // stride + 1) * ups
+    Wo = ((W + 2 * p - gkw) // stride + 1) * ups
+    if out is None:
+        out = torch.empty(n, cout, Ho, Wo, dtype=torch.float32, device=x.device)
+        out_coff = 0
+    if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != n or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError(f"output buffer must be contiguous f32 [n, *, {Ho}, {Wo}], got {tuple(out.shape)}")
+    _lib.check(l.gencomm_conv2d_fwd(ptr(x), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(out), n, cin, H, W, cout, gkh, gkw,
+                                    stride, p, int(relu), ups, out.shape[1], out_coff, st), "gencomm_conv2d_fwd")
+    return out
+
+
+class BaseBEVBackbone(nn.Module):
+    """Constructor mirrors base_bev_backbone.py:7-92 (same Sequential indices => same checkpoint keys)."""
+
+    def __init__(self, model_cfg, input_channels):
+        super().__init__()
+        self.model_cfg = model_cfg
+        if 'layer_nums' in model_cfg:
+            assert len(model_cfg['layer_nums']) == len(model_cfg['layer_strides']) == len(model_cfg['num_filters'])
+            layer_nums, layer_strides, num_filters = model_cfg['layer_nums'], model_cfg['layer_strides'], model_cfg['num_filters']
+        else:
+            layer_nums = layer_strides = num_filters = []
+        if 'upsample_strides' in model_cfg:
+            assert len(model_cfg['upsample_strides']) == len(model_cfg['num_upsample_filter'])
+            num_upsample_filters, upsample_strides = model_cfg['num_upsample_filter'], model_cfg['upsample_strides']
+        else:
+            upsample_strides = num_upsample_filters = []
+        num_levels = len(layer_nums)
+        self.num_levels = num_levels
+        c_in_list = [input_channels, *num_filters[:-1]]
+        self.blocks = nn.ModuleList()
+        self.deblocks = nn.ModuleList()
+        for idx in range(num_levels):
+            cur = [nn.ZeroPad2d(1),
+                   nn.Conv2d(c_in_list[idx], num_filters[idx], kernel_size=3, stride=layer_strides[idx], padding=0, bias=False),
+                   nn.BatchNorm2d(num_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()]
+            for _ in range(layer_nums[idx]):
+                cur.extend([nn.Conv2d(num_filters[idx], num_filters[idx], kernel_size=3, padding=1, bias=False),
+                            nn.BatchNorm2d(num_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()])
+            self.blocks.append(nn.Sequential(*cur))
+            if len(upsample_strides) > 0:
+                stride = upsample_strides[idx]
+                if stride >= 1:
+                    self.deblocks.append(nn.Sequential(
+                        nn.ConvTranspose2d(num_filters[idx], num_upsample_filters[idx], upsample_strides[idx],
+                                           stride=upsample_strides[idx], bias=False),
+                        nn.BatchNorm2d(num_upsample_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()))
+                else:
+                    stride = int(np.round(1 / stride))
+                    self.deblocks.append(nn.Sequential(
+                        nn.Conv2d(num_filters[idx], num_upsample_filters[idx], stride, stride=stride, bias=False),
+                        nn.BatchNorm2d(num_upsample_filters[idx], eps=1e-3, momentum=0.01), nn.ReLU()))
+        c_in = sum(num_upsample_filters)
+        if len(upsample_strides) > num_levels:
+            self.deblocks.append(nn.Sequential(
+                nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
+                nn.BatchNorm2d(c_in, eps=1e-3, momentum=0.01), nn.ReLU()))
+        self.num_bev_features = c_in
+
+    # ---- HIP path
+    @staticmethod
+    def _run_block(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+        mods = list(seq)
+        x = conv2d_hip(x, mods[1], mods[2], relu=True, pad=1)  # ZeroPad2d(1) + padding-0 conv
+        for j in range(4, len(mods), 3):
+            x = conv2d_hip(x, mods[j], mods[j + 1], relu=True)
+        return x
+
+    @staticmethod
+    def _run_deblock(seq: nn.Sequential, x: torch.Tensor, out=None, coff=0) -> torch.Tensor:
+        conv, bn = seq[0], seq[1]
+        if isinstance(conv, nn.Conv2d) and conv.kernel_size != (1, 1):
+            raise NotImplementedError("deblocks with upsample_stride < 1 (strided k x k conv) are not supported")
+        return conv2d_hip(x, conv, bn, relu=True, out=out, out_coff=coff)
+
+    def _decode(self, feats):
+        if len(self.deblocks) == 0:
+            ups = list(feats)
+            x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        else:
+            chans = [seq[1].num_features for seq in list(self.deblocks)[:len(feats)]]
+            s0 = self.deblocks[0][0].stride[0] if isinstance(self.deblocks[0][0], nn.ConvTranspose2d) else 1
+            n, _, h0, w0 = feats[0].shape
+            x = torch.empty(n, sum(chans), h0 * s0, w0 * s0, dtype=torch.float32, device=feats[0].device)
+            off = 0
+            for i, f in enumerate(feats):
+                self._run_deblock(self.deblocks[i], f, out=x, coff=off)  # writes its slice of the concat
+                off += chans[i]
+        if len(self.deblocks) > len(self.blocks):
+            x = self._run_deblock(self.deblocks[-1], x)
+        return x
+
+    def forward(self, data_dict):
+        spatial_features = data_dict['spatial_features']
+        x = spatial_features
+        feats = []
+        for i in range(len(self.blocks)):
+            x = self._run_block(self.blocks[i], x)
+            feats.append(x)  # (the reference's per-stride entries go to a local dict that is dropped, :100-108)
+        data_dict['spatial_features_2d'] = self._decode(feats)
+        return data_dict
+
+    def get_multiscale_feature(self, spatial_features):
+        feats, x = [], spatial_features
+        for i in range(len(self.blocks)):
+            x = self._run_block(self.blocks[i], x)
+            feats.append(x)
+        return feats
+
+    def decode_multiscale_feature(self, x):
+        return self._decode(list(x)[:self.num_levels])
+
+
+class DoubleConv(nn.Module):  # downsample_conv.py:7-27
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        super().__init__()
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1),
+            nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        x = conv2d_hip(x, self.double_conv[0], None, relu=True)
+        return conv2d_hip(x, self.double_conv[2], None, relu=True)
+
+
+class DownsampleConv(nn.Module):  # downsample_conv.py:30-49 ('kernal_size' is the reference's spelling)
+    def __init__(self, config):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        input_dim = config['input_dim']
+        for (ksize, dim, stride, padding) in zip(config['kernal_size'], config['dim'], config['stride'], config['padding']):
+            self.layers.append(DoubleConv(input_dim, dim, kernel_size=ksize, stride=stride, padding=padding))
+            input_dim = dim
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class HipConv2d(nn.Conv2d):
+    """``nn.Conv2d`` whose forward is the HIP kernel (detection heads: 1x1, bias, no activation)."""
+
+    def forward(self, x):
+        return conv2d_hip(x, self, None, relu=False)

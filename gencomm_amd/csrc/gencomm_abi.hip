@@ -2,6 +2,7 @@
 #include "../../include/gencomm_hip.h"
 
 #include "common.h"
+#include "conv_kernels.h"
 #include "enhancer_host.h"
 #include "fusion_kernels.h"
 #include "msgext_host.h"
@@ -322,6 +323,41 @@ int gencomm_pillar_encode_fwd(const float* voxel_features, const int* voxel_num_
   }
   GC_HIP(hipGetLastError());
   return GC_OK;
+}
+
+// ------------------------------------------------------------------------------------ general conv (backbone / heads)
+int gencomm_conv2d_prepare(const float* weight, float* prepared, int Cin, int Cout, int KH, int KW, int transposed, void* stream) {
+  GC_CHECK_ARG(weight && prepared, "null pointer");
+  GC_CHECK_ARG(Cin >= 1 && Cout >= 1 && KH >= 1 && KW >= 1, "bad Cin/Cout/KH/KW");
+  const long long total = (long long)Cin * Cout * KH * KW;
+  PrepWArgs a{weight, prepared, Cin, Cout, KH, KW, transposed};
+  conv_prep_w_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const float* bn_running_mean, const float* bn_running_var,
+                        const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream) {
+  GC_CHECK_ARG(scale && shift && C >= 1, "null pointer / bad C");
+  GC_CHECK_ARG((bn_weight == nullptr) == (bn_bias == nullptr) && (bn_weight == nullptr) == (bn_running_mean == nullptr) &&
+               (bn_weight == nullptr) == (bn_running_var == nullptr), "BatchNorm tensors must be all present or all null");
+  FoldArgs a{bn_weight, bn_bias, bn_running_mean, bn_running_var, conv_bias, scale, shift, eps, C};
+  conv_fold_kernel<<<(C + 63) / 64, 64, 0, (hipStream_t)stream>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale, const float* shift, float* y,
+                       int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
+                       int ups, int out_ctotal, int out_coff, void* stream) {
+  GC_CHECK_ARG(x && prepared && scale && shift && y, "null pointer");
+  GC_CHECK_ARG(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && stride >= 1 && pad >= 0 && ups >= 1, "bad dims");
+  GC_CHECK_ARG(ups == 1 || (KH == 1 && KW == 1 && stride == 1 && pad == 0), "ups > 1 (ConvTranspose2d, kernel == stride) runs as a 1x1 GEMM");
+  GC_CHECK_ARG(out_coff >= 0 && out_coff + Cout <= out_ctotal, "output channel slice out of range");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
+  Conv2dArgs a{x, prepared, scale, shift, y, Cin, H, W, Cout * ups * ups, Ho, Wo, stride, pad, relu, ups, out_ctotal, out_coff};
+  return conv2d_enqueue(a, N, KH, KW, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ fusion

@@ -179,3 +179,15 @@ def make_pillars(M: int, B: int, nx: int, ny: int, seed: int, voxel_size=(0.4, 0
     mask = np.arange(max_points)[None, :] < npts[:, None]
     feats *= mask[:, :, None]
     return {"voxel_features": feats, "voxel_num_points": npts, "voxel_coords": coords}
+
+
+def fill_bn_stats_(module, seed: int) -> None:
+    """Deterministic non-trivial BatchNorm running statistics (sorted buffer order): mean ~ N(0, 0.5), var ~ U(0.5, 2)."""
+    import torch
+    r = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, b in sorted(module.named_buffers(), key=lambda kv: kv[0]):
+            if name.endswith("running_mean"):
+                b.copy_(torch.from_numpy(r.normal(0.0, 0.5, tuple(b.shape)).astype(np.float32)))
+            elif name.endswith("running_var"):
+                b.copy_(torch.from_numpy(r.uniform(0.5, 2.0, tuple(b.shape)).astype(np.float32)))

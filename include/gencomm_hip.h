@@ -153,6 +153,25 @@ int gencomm_pillar_encode_fwd(const float* voxel_features, const int* voxel_num_
 int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
                              int B, int n, int C, int H, int W, void* stream);
 
+/* ---- General 2-D convolution for the layers around the hot path -------------------------------------
+ * Replaces the nn.Conv2d / nn.ConvTranspose2d (+ BatchNorm2d eval + ReLU) stacks of
+ *   BaseBEVBackbone            opencood/models/sub_modules/base_bev_backbone.py:40-92, :94-123
+ *   DownsampleConv/DoubleConv  opencood/models/sub_modules/downsample_conv.py:17-24
+ *   cls/reg/dir heads          opencood/models/heter_model_baseline_w_gencomm_stage1.py:137-142
+ * prepare: OIHW (transposed = 0) or ConvTranspose2d IOHW with kernel == stride (transposed = 1) -> k-major matrix
+ *          [Cin*KH*KW][Cout] (resp. [Cin][Cout*KH*KW]) of the same number of floats.
+ * fold:    BatchNorm2d (eval) and/or conv bias -> per-channel scale/shift; pass NULL for the four BN tensors
+ *          (and/or conv_bias) when absent.
+ * fwd:     y[:, out_coff:out_coff+Cout] = act(conv(x) * scale + shift); supported: 3x3 stride 1|2 any pad, 1x1 stride 1;
+ *          ups = s > 1 runs ConvTranspose2d(kernel = stride = s) (KH = KW = 1 on the prepared matrix, output H*s x W*s).
+ *          y has out_ctotal channels (write into a slice of a concat buffer without a copy). */
+int gencomm_conv2d_prepare(const float* weight, float* prepared, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
+int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const float* bn_running_mean, const float* bn_running_var,
+                        const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream);
+int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale, const float* shift, float* y,
+                       int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
+                       int ups, int out_ctotal, int out_coff, void* stream);
+
 /* Fast lane for callers that chain Enhancer -> fusion themselves (ScenePipeline): call
  * gencomm_enhancer_fwd with out == NULL (the token-major result and the channel gate stay in the
  * workspace, the NHWC->NCHW transpose launch is skipped), then this entry point with the SAME

@@ -225,6 +225,40 @@ def run_pillar_case() -> None:
     print(f"pillars: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), occupied cells {int(nz.sum())}")
 
 
+BACKBONE_CFG = {"layer_nums": [1, 2, 2], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+                "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]}
+SHRINK_CFG = {"kernal_size": [3], "stride": [2], "padding": [1], "dim": [128], "input_dim": 384}
+
+
+def run_backbone_case() -> None:
+    """Dense conv stacks around the hot path: the reference's own BaseBEVBackbone and DownsampleConv
+    (opencood/models/sub_modules/{base_bev_backbone,downsample_conv}.py) in eval mode + three 1x1 heads."""
+    from opencood.models.sub_modules.base_bev_backbone import BaseBEVBackbone
+    from opencood.models.sub_modules.downsample_conv import DownsampleConv
+    bb = BaseBEVBackbone(dict(BACKBONE_CFG), 64).eval()
+    sh = DownsampleConv(dict(SHRINK_CFG)).eval()
+    heads = torch.nn.ModuleList([torch.nn.Conv2d(128, 2, 1), torch.nn.Conv2d(128, 14, 1), torch.nn.Conv2d(128, 4, 1)]).eval()
+    for k, m in enumerate((bb, sh, heads)):
+        synth.fill_params_(m, WEIGHT_SEED + 20 + k)
+    synth.fill_bn_stats_(bb, WEIGHT_SEED + 30)
+    x = torch.from_numpy(np.maximum(synth.noise_stream(DATA_SEED + 20, 0, (2, 64, 48, 80)), 0.0).astype(np.float32))
+    with torch.no_grad():
+        d = bb({"spatial_features": x})
+        y = d["spatial_features_2d"]
+        assert sorted(d.keys()) == ["spatial_features", "spatial_features_2d"]  # the per-stride entries stay in a local dict
+        z = sh(y)
+        hs = [h(z) for h in heads]
+    rec = dict(weight_seed=WEIGHT_SEED + 20, bn_seed=WEIGHT_SEED + 30, data_seed=DATA_SEED + 20, in_shape=np.asarray(x.shape),
+               backbone_shape=np.asarray(y.shape), backbone=sub(y.numpy(), 7), backbone_absmean=np.float64(y.abs().double().mean().item()),
+               ms_feat=np.concatenate([sub(f.detach().numpy(), 11) for f in bb.get_multiscale_feature(x)]),
+               shrink_shape=np.asarray(z.shape), shrink=sub(z.numpy(), 3),
+               cls=hs[0].numpy(), reg=hs[1].numpy(), dir=hs[2].numpy(),
+               backbone_keys=np.asarray(sorted(bb.state_dict().keys())), shrink_keys=np.asarray(sorted(sh.state_dict().keys())))
+    path = os.path.join(OUT, "backbone.npz")
+    np.savez_compressed(path, **rec)
+    print(f"backbone: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), out {tuple(y.shape)} -> {tuple(z.shape)}")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -248,11 +282,14 @@ def main() -> None:
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])  # e.g. `python oracle/make_golden.py backbone` regenerates one fixture
     for case in CASES:
-        run_case(case)
-    run_attn_case()
-    run_pillar_case()
-    dump_state_dict_keys()
+        if not only or case["name"] in only:
+            run_case(case)
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "keys": dump_state_dict_keys}
+    for name, fn in extra.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

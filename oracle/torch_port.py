@@ -395,3 +395,37 @@ def pillar_scatter(pillar_features: Tensor, coords: Tensor, B: int, nx: int, ny:
         idx = (coords[m, 1] + coords[m, 2] * nx + coords[m, 3]).long()
         out[b][:, idx] = pillar_features[m].t()
     return out.view(B, Cc, ny, nx)
+
+
+# ---------------------------------------------------------------------------------------------
+# Dense conv stacks around the hot path: BaseBEVBackbone
+# (opencood/models/sub_modules/base_bev_backbone.py:94-123) and DownsampleConv
+# (opencood/models/sub_modules/downsample_conv.py:25-27, :45-48). Pinned by tests/golden/backbone.npz.
+# ---------------------------------------------------------------------------------------------
+def _bn_eval(x, sd, pre, eps=1e-3):
+    return F.batch_norm(x, sd[pre + ".running_mean"], sd[pre + ".running_var"], sd[pre + ".weight"], sd[pre + ".bias"], False, 0.0, eps)
+
+
+def bev_backbone_forward(sd, prefix, x, cfg):
+    """cfg: layer_nums, layer_strides, num_filters, upsample_strides (>= 1), num_upsample_filter."""
+    pre = prefix + "." if prefix else ""
+    ups = []
+    for i, (ln, ls) in enumerate(zip(cfg["layer_nums"], cfg["layer_strides"])):
+        b = f"{pre}blocks.{i}"
+        x = F.relu(_bn_eval(F.conv2d(F.pad(x, (1, 1, 1, 1)), sd[f"{b}.1.weight"], None, stride=ls), sd, f"{b}.2"))
+        for k in range(ln):
+            j = 4 + 3 * k
+            x = F.relu(_bn_eval(F.conv2d(x, sd[f"{b}.{j}.weight"], None, padding=1), sd, f"{b}.{j + 1}"))
+        s = cfg["upsample_strides"][i]
+        d = f"{pre}deblocks.{i}"
+        ups.append(F.relu(_bn_eval(F.conv_transpose2d(x, sd[f"{d}.0.weight"], None, stride=s), sd, f"{d}.1")))
+    return torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+
+
+def downsample_conv_forward(sd, prefix, x, cfg):
+    pre = prefix + "." if prefix else ""
+    for i, (st, pd) in enumerate(zip(cfg["stride"], cfg["padding"])):
+        l = f"{pre}layers.{i}.double_conv"
+        x = F.relu(F.conv2d(x, sd[f"{l}.0.weight"], sd[f"{l}.0.bias"], stride=st, padding=pd))
+        x = F.relu(F.conv2d(x, sd[f"{l}.2.weight"], sd[f"{l}.2.bias"], padding=1))
+    return x
