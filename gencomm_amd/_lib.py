@@ -56,6 +56,7 @@ _SIGNATURES = {
     "gencomm_conv2d_fold": (_i, [_p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _p]),
     "gencomm_conv2d_fwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 13 + [_p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_warp_maxfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_attfuse_tok_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -20,6 +20,7 @@ struct FuseArgs {
   const int* scene_off;  // [B+1]
   float* out;            // [B][C][H][W]
   int C, H, W;
+  int mode;              // 0 = ego-row attention (AttFusion), 1 = element-wise max over agents (MaxFusion)
 };
 
 template <int N>
@@ -61,6 +62,16 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, int b, int off, int
     return v;
   };
   const float* __restrict__ xs = a.x + (size_t)off * a.C * HW;
+  if (a.mode == 1) {  // MaxFusion (fusion_in_one.py:87-124): max over the warped agents, zeros where an agent is out of range
+    float* __restrict__ op = a.out + (size_t)b * a.C * HW + pix;
+    for (int c = 0; c < a.C; ++c) {
+      float o = sample(0, xs + (size_t)c * HW);
+#pragma unroll
+      for (int j = 1; j < N; ++j) o = fmaxf(o, sample(j, xs + ((size_t)j * a.C + c) * HW));
+      op[(size_t)c * HW] = o;
+    }
+    return;
+  }
   float score[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) score[j] = 0.f;
@@ -108,9 +119,9 @@ __global__ __launch_bounds__(256) void warp_attfuse_kernel(const FuseArgs a) {
 }
 
 inline int warp_attfuse_enqueue(const float* x, const double* theta, const int* scene_off, float* out,
-                                int B, int n, int C, int H, int W, hipStream_t st) {
+                                int B, int n, int C, int H, int W, hipStream_t st, int mode = 0) {
   (void)n;
-  FuseArgs a{x, theta, scene_off, out, C, H, W};
+  FuseArgs a{x, theta, scene_off, out, C, H, W, mode};
   TimedLaunch tl(KF_WARP_ATTFUSE, st);
   warp_attfuse_kernel<<<dim3((H * W + 255) / 256, B), 256, 0, st>>>(a);
   GC_HIP(hipGetLastError());

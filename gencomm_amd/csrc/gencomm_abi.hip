@@ -368,6 +368,13 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
   return warp_attfuse_enqueue(x, theta, scene_off, out, B, n, C, H, W, (hipStream_t)stream);
 }
 
+int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
+                             int B, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(x && theta && scene_off && out, "null pointer");
+  GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && C >= 1 && H >= 1 && W >= 1, "bad B/n/C/H/W");
+  return warp_attfuse_enqueue(x, theta, scene_off, out, B, n, C, H, W, (hipStream_t)stream, 1);
+}
+
 int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* theta, const int* scene_off, float* out,
                                  int B, int n, int C, int H, int W, void* stream) {
   EnhancerPlan p;

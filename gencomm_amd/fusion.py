@@ -67,6 +67,8 @@ class AttFusion(nn.Module):
             return AttFusionFunction.apply(self, lens, affine_matrix, xx)
         return self._forward_hip(xx, lens, affine_matrix)
 
+    _entry = "gencomm_warp_attfuse_fwd"
+
     def _forward_hip(self, xx, lens, affine_matrix):
         n, C, H, W = xx.shape
         B = affine_matrix.shape[0]
@@ -76,6 +78,24 @@ class AttFusion(nn.Module):
             off.append(off[-1] + k)
         scene_off = torch.tensor(off, dtype=torch.int32, device=xx.device)
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=xx.device)
-        _lib.check(_lib.lib().gencomm_warp_attfuse_fwd(ptr(xx), ptr(theta), ptr(scene_off), ptr(out), B, n, C, H, W,
-                                                       stream_ptr(xx.device)), "gencomm_warp_attfuse_fwd")
+        _lib.check(getattr(_lib.lib(), self._entry)(ptr(xx), ptr(theta), ptr(scene_off), ptr(out), B, n, C, H, W,
+                                                    stream_ptr(xx.device)), self._entry)
         return out
+
+
+class MaxFusion(AttFusion):
+    """fusion_in_one.py:87-124: warp every agent to the ego frame, element-wise max over the agents (inference path;
+    no autograd)."""
+    _entry = "gencomm_warp_maxfuse_fwd"
+
+    def __init__(self):
+        nn.Module.__init__(self)
+
+    def forward(self, x, record_len, affine_matrix):
+        require_gpu(x, "MaxFusion.forward")
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("MaxFusion: backward is not implemented on the HIP path")
+        lens = record_len_list(record_len)
+        if len(lens) != affine_matrix.shape[0] or sum(lens) != x.shape[0] or min(lens) < 1 or max(lens) > MAX_AGENTS_PER_SCENE:
+            raise ValueError(f"record_len {lens} inconsistent with input / 1..{MAX_AGENTS_PER_SCENE} agents per scene")
+        return self._forward_hip(f32c(x), lens, affine_matrix)

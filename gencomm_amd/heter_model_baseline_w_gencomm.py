@@ -1,0 +1,7 @@
+"""Plugin module for ``core_method: heter_model_baseline_w_gencomm`` (resolved by opencood/tools/train_utils.py:269-287: the first
+attribute whose lower-cased name equals the module name without underscores). See INTEGRATION.md for the
+two-line shim that exposes it as ``opencood.models.heter_model_baseline_w_gencomm``."""
+from .heter_model import HeterModelBaselineWGenComm
+
+
+__all__ = ["HeterModelBaselineWGenComm"]

@@ -172,6 +172,11 @@ int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale
                        int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
                        int ups, int out_ctotal, int out_coff, void* stream);
 
+/* MaxFusion.forward (opencood/models/fuse_modules/fusion_in_one.py:87-124): same warp, element-wise max over the
+ * agents of a scene instead of the attention; arguments as gencomm_warp_attfuse_fwd. */
+int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
+                             int B, int n, int C, int H, int W, void* stream);
+
 /* Fast lane for callers that chain Enhancer -> fusion themselves (ScenePipeline): call
  * gencomm_enhancer_fwd with out == NULL (the token-major result and the channel gate stay in the
  * workspace, the NHWC->NCHW transpose launch is skipped), then this entry point with the SAME

@@ -47,15 +47,76 @@ def _install_stubs() -> None:
         def forward(self, x):
             return x
 
+    _install_auto_stubs()
     stub("icecream", ic=lambda *a, **k: None)
     stub("timm")
     stub("timm.models")
     stub("timm.models.layers", DropPath=DropPath, PatchEmbed=object, Mlp=object,
          trunc_normal_=lambda *a, **k: None, lecun_normal_=lambda *a, **k: None,
          to_2tuple=lambda x: (x, x))
-    stub("shapely")
-    stub("shapely.geometry", Polygon=object)
-    stub("pyquaternion", Quaternion=object)
+
+
+def _install_auto_stubs() -> None:
+    """Import-time stand-ins for third-party packages the model SHELLS import but the hot path never calls
+    (torchvision, cv2, spconv, matplotlib ...): any attribute is a do-nothing class. The one member that is
+    executed -- torchvision.ops.DeformConv2d in MessageExtractorv2 -- is bound to the oracle's restatement of the
+    published DCNv1 formula (third-party arithmetic, PARITY UNPINNED; see oracle/torch_port.py)."""
+    import importlib.abc
+    import importlib.machinery
+
+    auto = ("torchvision", "cv2", "open3d", "spconv", "matplotlib", "efficientnet_pytorch", "numba", "tensorboardX",
+            "swanlab", "wandb", "h5py", "termcolor", "easydict", "cumm", "seaborn", "shapely", "pyquaternion")
+
+    class _Auto(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            if k[0].islower():  # sub-module or function: another callable stand-in module
+                m = _Auto(self.__name__ + "." + k)
+                m.__path__ = []
+                setattr(self, k, m)
+                return m
+            return type(k, (), {"__init__": lambda self, *a, **kw: None, "__call__": lambda self, *a, **kw: None})
+
+        def __call__(self, *a, **kw):
+            return None
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            if name.split(".")[0] in auto and name not in sys.modules:
+                try:
+                    if importlib.machinery.PathFinder.find_spec(name, path):
+                        return None
+                except Exception:
+                    pass
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+        def create_module(self, spec):
+            m = _Auto(spec.name)
+            m.__path__ = []
+            return m
+
+        def exec_module(self, m):
+            pass
+
+    sys.meta_path.append(_Finder())
+    import torch_port as O  # oracle/ is on sys.path (this script lives there)
+
+    class DeformConv2d(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size=3, padding=1):
+            super().__init__()
+            self.padding = padding
+            self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+            self.bias = nn.Parameter(torch.empty(out_channels))
+
+        def forward(self, x, offset):
+            return O.deform_conv2d_ref(x, offset, self.weight, self.bias, self.padding)
+
+    ops = types.ModuleType("torchvision.ops")
+    ops.DeformConv2d = DeformConv2d
+    import torchvision  # the auto stub
+    sys.modules["torchvision.ops"] = ops
+    torchvision.ops = ops
 
 
 class PatchedNoise:
@@ -259,6 +320,62 @@ def run_backbone_case() -> None:
     print(f"backbone: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), out {tuple(y.shape)} -> {tuple(z.shape)}")
 
 
+def shell_args(T: int = 3) -> dict:
+    """A reduced stage-1 yaml `model.args` block (structure of opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml):
+    128 x 64 pillars of 0.4 m, backbone [1,1,2] layers, feature 128 x 16 x 32 at the GenComm input."""
+    rng_ = [-25.6, -12.8, -3, 25.6, 12.8, 1]
+    return {
+        "ego_modality": "m1", "lidar_range": rng_,
+        "m1": {"core_method": "point_pillar", "sensor_type": "lidar",
+               "encoder_args": {"voxel_size": [0.4, 0.4, 4], "lidar_range": rng_,
+                                "pillar_vfe": {"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+                                "point_pillar_scatter": {"num_features": 64}},
+               "backbone_args": {"layer_nums": [1, 1, 2], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+                                 "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]},
+               "shrink_header": {"kernal_size": [3], "stride": [2], "padding": [1], "dim": [128], "input_dim": 384}},
+        "enhancer": {"in_ch": 128}, "message_extractor": {"in_ch": 128, "out_ch": 2},
+        "fusion_method": "att", "att": {"feat_dim": 128}, "in_head": 128, "anchor_number": 2,
+        "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}, "gmatch": True,
+        "gencomm": synth.default_gencomm_cfg(128, T),
+    }
+
+
+def run_shell_case() -> None:
+    """The reference's own stage-1 model shell (heter_model_baseline_w_gencomm_stage1.py) end to end on CPU:
+    PointPillar encoder -> BaseBEVBackbone -> DownsampleConv -> MessageExtractorv2 -> GenComm -> Enhancer ->
+    AttFusion -> heads, on 2 scenes (3 + 1 agents). Everything is reference code except torchvision's DeformConv2d
+    (absent here), which runs the oracle's DCNv1 restatement -- so `message`, and what follows it, is pinned only up
+    to that third-party op (PARITY UNPINNED for the deformable conv itself)."""
+    import copy
+    import json
+    from opencood.models.heter_model_baseline_w_gencomm_stage1 import HeterModelBaselineWGenComm
+    args = shell_args()
+    model = HeterModelBaselineWGenComm(copy.deepcopy(args)).eval()
+    synth.fill_params_(model, WEIGHT_SEED + 40)
+    synth.fill_bn_stats_(model, WEIGHT_SEED + 41)
+    rl = [3, 1]
+    nx, ny = 128, 64
+    pil = synth.make_pillars(5000, sum(rl), nx, ny, DATA_SEED + 40, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
+    ptm = synth.make_pairwise_t_matrix(rl, 5, DATA_SEED + 41, max_shift=8.0)
+    data = {"agent_modality_list": ["m1"] * sum(rl), "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm),
+            "inputs_m1": {"voxel_features": torch.from_numpy(pil["voxel_features"]), "voxel_coords": torch.from_numpy(pil["voxel_coords"]),
+                          "voxel_num_points": torch.from_numpy(pil["voxel_num_points"])}}
+    with torch.no_grad(), PatchedNoise(NOISE_SEED + 40):
+        out = model(data)
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    rec = dict(weight_seed=WEIGHT_SEED + 40, bn_seed=WEIGHT_SEED + 41, data_seed=DATA_SEED + 40, pose_seed=DATA_SEED + 41,
+               noise_seed=NOISE_SEED + 40, record_len=np.asarray(rl), M=5000, nx=nx, ny=ny, max_shift=8.0,
+               out_keys=np.asarray(sorted(out.keys())),
+               message=out["message"].numpy(), gt_feature=sub(out["gt_feature"].numpy(), 5), pred_feature=sub(out["pred_feature"].numpy(), 5),
+               cls_preds=out["cls_preds"].numpy(), reg_preds=out["reg_preds"].numpy(), dir_preds=out["dir_preds"].numpy(),
+               shapes=np.asarray([list(out[k].shape) for k in ("gt_feature", "pred_feature", "cls_preds", "reg_preds", "dir_preds", "message")]))
+    np.savez_compressed(os.path.join(OUT, "shell.npz"), **rec)
+    with open(os.path.join(OUT, "shell_state_dict_keys.json"), "w") as f:
+        json.dump({"args": args, "state_dict": keys}, f, indent=0)
+    print(f"shell: wrote shell.npz ({os.path.getsize(os.path.join(OUT, 'shell.npz')) / 1024:.0f} KiB), {len(keys)} state_dict keys, "
+          f"|cls| mean {out['cls_preds'].abs().mean().item():.4f}")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -286,7 +403,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()

@@ -288,6 +288,17 @@ def att_fusion(xx: Tensor, record_len, affine_matrix: Tensor) -> Tensor:
     return torch.stack(out)
 
 
+def max_fusion(xx: Tensor, record_len, affine_matrix: Tensor) -> Tensor:
+    """MaxFusion.forward, fusion_in_one.py:107-124: warp to the ego frame, element-wise max over the agents."""
+    _, C, H, W = xx.shape
+    out, o = [], 0
+    for b, n in enumerate(regroup_lens(record_len)):
+        x = warp_affine_simple(xx[o:o + n], affine_matrix[b][0, :n], (H, W))
+        out.append(torch.max(x, dim=0)[0])
+        o += n
+    return torch.stack(out)
+
+
 # --------------------------------------------------------------------------------------
 # whole path
 # --------------------------------------------------------------------------------------

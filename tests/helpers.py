@@ -65,3 +65,20 @@ def assert_close(actual, expected, rtol, atol, what):
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.size} elements out of tolerance "
                            f"(rtol {rtol}, atol {atol}); max abs err {err.max():.3e}, "
                            f"max |expected| {np.abs(expected).max():.3e}")
+
+
+from contextlib import contextmanager
+
+
+@contextmanager
+def shell_noise(gencomm, seed, n, C, H, W, device):
+    """Inside a model shell `self.gencomm(feat, msg, record_len)` is called without the parity-only `noise=` keyword:
+    bind the explicit noise of a fixture (same draw order as PatchedNoise in oracle/make_golden.py) for one forward."""
+    n0, sn = synth.make_eval_noise(seed, n, C, H, W, gencomm.num_timesteps)
+    noise = (torch.from_numpy(n0).to(device), torch.from_numpy(sn).to(device))
+    orig = gencomm.forward
+    gencomm.forward = lambda f, c, rl=None: orig(f, c, rl, noise=noise)
+    try:
+        yield
+    finally:
+        del gencomm.forward

@@ -302,3 +302,19 @@ def test_scene_pipeline_token_path_equals_nchw_path():
             outs.append(pipe.run(inp["feat"].contiguous(), inp["cond"].contiguous(), seed=3).clone())
     err = (outs[0] - outs[1]).abs()
     assert (err <= 1e-5 + 1e-5 * outs[1].abs()).all(), err.max().item()
+
+
+def test_max_fusion_vs_oracle():
+    """MaxFusion (fusion_in_one.py:87-124) through the same warp kernel, against the CPU restatement."""
+    from gencomm_amd import normalize_pairwise_tfm, synth
+    from gencomm_amd.fusion import MaxFusion
+    from oracle import torch_port as O
+    C, H, W, rl = 24, 18, 34, [3, 1, 2]
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(rl, C, H, W, 17, max_shift=10.0).items()}
+    x = inp["feat"] - 0.3  # signed values: the zeros of out-of-range samples must win against negatives
+    with torch.no_grad():
+        affine = normalize_pairwise_tfm(inp["pairwise_t_matrix"], H * 0.8, W * 0.8, 1)
+        ref = O.max_fusion(x, rl, affine)
+        got = MaxFusion()(x.to(DEV), torch.tensor(rl), affine).cpu()
+    err = (got - ref).abs()
+    assert (err <= 1e-5 + 1e-4 * ref.abs()).all(), err.max().item()
