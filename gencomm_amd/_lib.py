@@ -55,6 +55,12 @@ _SIGNATURES = {
     "gencomm_conv2d_prepare": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_conv2d_fold": (_i, [_p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _p]),
     "gencomm_conv2d_fwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 13 + [_p]),
+    "gencomm_det_workspace_bytes": (C.c_longlong, [_i, _i, _i]),
+    "gencomm_nms_workspace_bytes": (C.c_longlong, []),
+    "gencomm_nms_max_candidates": (_i, []),
+    "gencomm_det_decode_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, _p, _p, _i, _p, C.c_longlong, _p]),
+    "gencomm_nms_rotated_fwd": (_i, [_p, _p, _p, C.c_float, _i, _p, _p, _p, _p, _p, _p, C.c_longlong, _p]),
+    "gencomm_bbox_overlaps_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_maxfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_attfuse_tok_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

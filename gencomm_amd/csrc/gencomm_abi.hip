@@ -3,6 +3,7 @@
 
 #include "common.h"
 #include "conv_kernels.h"
+#include "detect_kernels.h"
 #include "enhancer_host.h"
 #include "fusion_kernels.h"
 #include "msgext_host.h"
@@ -358,6 +359,52 @@ int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale
   GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
   Conv2dArgs a{x, prepared, scale, shift, y, Cin, H, W, Cout * ups * ups, Ho, Wo, stride, pad, relu, ups, out_ctotal, out_coff};
   return conv2d_enqueue(a, N, KH, KW, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ detection tail
+long long gencomm_det_workspace_bytes(int H, int W, int A) {
+  if (H < 1 || W < 1 || A < 1) { fail(GC_ERR_ARG, "bad H/W/A"); return -1; }
+  return det_workspace_bytes(H, W, A);
+}
+long long gencomm_nms_workspace_bytes(void) { return nms_workspace_bytes(); }
+
+int gencomm_det_decode_fwd(const float* cls_preds, const float* reg_preds, const float* dir_preds, const float* anchors,
+                           const float* transformation_matrix, int H, int W, int A, int num_bins, float score_threshold,
+                           float dir_offset, int order_hwl, float* corners, float* scores, int* anchor_index, int* count,
+                           int capacity, void* workspace, long long workspace_bytes, void* stream) {
+  GC_CHECK_ARG(cls_preds && reg_preds && anchors && transformation_matrix && corners && scores && anchor_index && count && workspace, "null pointer");
+  GC_CHECK_ARG(H >= 1 && W >= 1 && A >= 1 && capacity >= 1 && (dir_preds == nullptr || num_bins >= 1), "bad H/W/A/capacity/num_bins");
+  GC_CHECK_ARG((long long)H * W * A < (1LL << 31), "too many anchors");
+  if (det_workspace_bytes(H, W, A) > workspace_bytes) return fail(GC_ERR_ARG, "workspace too small (gencomm_det_workspace_bytes)");
+  DetArgs a{};
+  a.cls = cls_preds; a.reg = reg_preds; a.dir = dir_preds; a.anchors = anchors; a.T = transformation_matrix;
+  a.corners = corners; a.scores = scores; a.anchor_idx = anchor_index; a.count = count;
+  a.H = H; a.W = W; a.A = A; a.nb = num_bins; a.cap = capacity; a.hwl = order_hwl;
+  a.thr = score_threshold; a.dir_offset = dir_offset;
+  return det_decode_enqueue(a, workspace, (hipStream_t)stream);
+}
+
+int gencomm_nms_rotated_fwd(const float* corners, const float* scores, const int* n_candidates, float iou_threshold, int top,
+                            const float* keep_range6, float* out_boxes, float* out_scores, int* out_index, int* out_count,
+                            void* workspace, long long workspace_bytes, void* stream) {
+  GC_CHECK_ARG(corners && scores && n_candidates && out_boxes && out_scores && out_index && out_count && workspace, "null pointer");
+  GC_CHECK_ARG(top >= 1 && top <= kNmsMaxTop, "top must be in 1..1024");
+  if (nms_workspace_bytes() > workspace_bytes) return fail(GC_ERR_ARG, "workspace too small (gencomm_nms_workspace_bytes)");
+  return nms_rotated_enqueue(corners, scores, n_candidates, iou_threshold, top, keep_range6, out_boxes, out_scores, out_index,
+                             out_count, workspace, (hipStream_t)stream);
+}
+
+int gencomm_nms_max_candidates(void) { return kNmsMaxN; }
+
+int gencomm_bbox_overlaps_fwd(const float* boxes, const float* query_boxes, float* overlaps, int N, int K, void* stream) {
+  GC_CHECK_ARG(N >= 0 && K >= 0, "bad N/K");
+  if (N == 0 || K == 0) return GC_OK;
+  GC_CHECK_ARG(boxes && query_boxes && overlaps, "null pointer");
+  const long long total = (long long)N * K;
+  GC_CHECK_ARG((total + 255) / 256 < (1LL << 31), "N*K too large");
+  bbox_overlaps_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(boxes, query_boxes, overlaps, N, K);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
 }
 
 // ------------------------------------------------------------------------------------ fusion

@@ -191,3 +191,19 @@ def fill_bn_stats_(module, seed: int) -> None:
                 b.copy_(torch.from_numpy(r.normal(0.0, 0.5, tuple(b.shape)).astype(np.float32)))
             elif name.endswith("running_var"):
                 b.copy_(torch.from_numpy(r.uniform(0.5, 2.0, tuple(b.shape)).astype(np.float32)))
+
+
+def make_detection_maps(H: int, W: int, A: int, seed: int, n_obj: int = 60, num_bins: int = 2):
+    """Synthetic head outputs for the detection tail: cls logits [1, A, H, W] (background -5, `n_obj` clusters of
+    overlapping positives), reg deltas [1, 7A, H, W], dir logits [1, A*num_bins, H, W]. float32, numpy-deterministic."""
+    r = np.random.RandomState(seed)
+    cls = np.full((1, A, H, W), -5.0, dtype=np.float32) + r.normal(0, 0.3, (1, A, H, W)).astype(np.float32)
+    for _ in range(n_obj):
+        a, y, x = r.randint(A), r.randint(1, H - 1), r.randint(1, W - 1)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if r.rand() < 0.7:
+                    cls[0, a, y + dy, x + dx] = r.uniform(-1.0, 3.0)
+    reg = r.normal(0, 0.15, (1, 7 * A, H, W)).astype(np.float32)
+    dirp = r.normal(0, 1.0, (1, A * num_bins, H, W)).astype(np.float32)
+    return cls, reg, dirp

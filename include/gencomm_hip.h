@@ -172,6 +172,34 @@ int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale
                        int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
                        int ups, int out_ctotal, int out_coff, void* stream);
 
+/* ---- Detection tail ---------------------------------------------------------------
+ * Replaces, for one agent's head outputs (batch 1), the torch/numpy/shapely chain of
+ *   VoxelPostprocessor.post_process   opencood/data_utils/post_processor/voxel_postprocessor.py:1130-1244
+ * det_decode: sigmoid(cls) > score_threshold, delta_to_boxes3d (:1351-1396), direction classifier fix (:1159-1175),
+ *   boxes_to_corners_3d + project_box3d (box_utils.py:152-204, :278-316), remove_large_pred_bbx / remove_bbx_abnormal_z
+ *   (box_utils.py:1062-1112); survivors are APPENDED in anchor order at position *count (device int, in/out -- zero it
+ *   before the first agent, call once per agent for late fusion). Layouts: cls [A][H][W], reg [7A][H][W],
+ *   dir [A*num_bins][H][W] or NULL, anchors [H][W][A][7] float32, transformation_matrix [16] float32 (device).
+ *   corners [capacity][8][3], scores / anchor_index [capacity]; entries beyond capacity are dropped but still counted:
+ *   the caller must compare *count with capacity.
+ * nms_rotated: box_utils.nms_rotated (:915-960; scores sorted descending, exact ties by descending index; the `top`
+ *   best kept, top <= 1024; IoU of the BEV quadrilaterals = first four corners, in float64, suppressed when
+ *   (float)iou > iou_threshold), then -- when keep_range6 != NULL -- mask_boxes_outside_range_numpy (:384-421, all 8
+ *   corners inside, bounds inclusive). *n_candidates is a DEVICE int (at most gencomm_nms_max_candidates() are
+ *   considered). Outputs in pick order; *out_count device int.
+ * bbox_overlaps: opencood/utils/box_overlaps.pyx:17-57, (N,4) x (K,4) -> (N,K), bit-identical to the compiled source. */
+long long gencomm_det_workspace_bytes(int H, int W, int A);
+long long gencomm_nms_workspace_bytes(void);
+int gencomm_nms_max_candidates(void);
+int gencomm_det_decode_fwd(const float* cls_preds, const float* reg_preds, const float* dir_preds, const float* anchors,
+                           const float* transformation_matrix, int H, int W, int A, int num_bins, float score_threshold,
+                           float dir_offset, int order_hwl, float* corners, float* scores, int* anchor_index, int* count,
+                           int capacity, void* workspace, long long workspace_bytes, void* stream);
+int gencomm_nms_rotated_fwd(const float* corners, const float* scores, const int* n_candidates, float iou_threshold, int top,
+                            const float* keep_range6, float* out_boxes, float* out_scores, int* out_index, int* out_count,
+                            void* workspace, long long workspace_bytes, void* stream);
+int gencomm_bbox_overlaps_fwd(const float* boxes, const float* query_boxes, float* overlaps, int N, int K, void* stream);
+
 /* MaxFusion.forward (opencood/models/fuse_modules/fusion_in_one.py:87-124): same warp, element-wise max over the
  * agents of a scene instead of the attention; arguments as gencomm_warp_attfuse_fwd. */
 int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,

@@ -376,6 +376,58 @@ def run_shell_case() -> None:
           f"|cls| mean {out['cls_preds'].abs().mean().item():.4f}")
 
 
+POSTPROC_PARAMS = {
+    "core_method": "VoxelPostprocessor", "gt_range": [-35.2, -20.0, -3, 35.2, 20.0, 1],
+    "anchor_args": {"cav_lidar_range": [-35.2, -20.0, -3, 35.2, 20.0, 1], "l": 3.9, "w": 1.6, "h": 1.56, "r": [0, 90],
+                    "feature_stride": 2, "num": 2, "vw": 0.4, "vh": 0.4, "vd": 4, "W": 176, "H": 100, "D": 1},
+    "target_args": {"pos_threshold": 0.6, "neg_threshold": 0.45, "score_threshold": 0.2},
+    "order": "hwl", "max_num": 150, "nms_thresh": 0.15,
+    "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]},
+}
+
+
+def run_postproc_case() -> None:
+    """Detection tail: the reference's own VoxelPostprocessor (generate_anchor_box, post_process and the
+    box_utils helpers it calls) on synthetic head outputs, for an identity and a non-identity agent-to-ego transform.
+    shapely is absent: `common_utils.convert_format/compute_iou` (the only shapely users on this path) are bound to the
+    oracle's convex-clipping IoU; the greedy NMS loop itself is the reference's. Also: the compiled reference
+    `bbox_overlaps` (oracle/_ref) on random boxes."""
+    import build_ref
+    import detect_port as D
+    import json
+    assert build_ref.build(), "oracle/_ref/box_overlaps could not be built"
+    bo = build_ref.load_box_overlaps()
+    import opencood.utils as ou
+    sys.modules["opencood.utils.box_overlaps"] = bo
+    ou.box_overlaps = bo
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    from opencood.utils import box_utils, common_utils
+    common_utils.convert_format = lambda boxes: np.asarray(boxes, dtype=np.float64)[:, :4, :2]
+    common_utils.compute_iou = lambda box, boxes: D.quad_iou_one_to_many(box, boxes)
+    pp = VoxelPostprocessor(json.loads(json.dumps(POSTPROC_PARAMS)), train=False)
+    anchors = pp.generate_anchor_box()
+    H, W, A = anchors.shape[:3]
+    rec = dict(anchors=anchors, H=H, W=W, A=A, params=json.dumps(POSTPROC_PARAMS))
+    th = 0.3
+    T2 = np.array([[np.cos(th), -np.sin(th), 0, 1.5], [np.sin(th), np.cos(th), 0, -0.7], [0, 0, 1, 0.1], [0, 0, 0, 1]], dtype=np.float32)
+    for tag, seed, T in (("a", DATA_SEED + 50, np.eye(4, dtype=np.float32)), ("b", DATA_SEED + 51, T2)):
+        cls, reg, dirp = synth.make_detection_maps(H, W, A, seed)
+        data = {"ego": {"transformation_matrix": torch.from_numpy(T), "anchor_box": torch.from_numpy(anchors)}}
+        out = {"ego": {"cls_preds": torch.from_numpy(cls), "reg_preds": torch.from_numpy(reg), "dir_preds": torch.from_numpy(dirp)}}
+        boxes, scores = pp.post_process(data, out)
+        rec.update({f"seed_{tag}": seed, f"T_{tag}": T, f"boxes_{tag}": boxes.numpy(), f"scores_{tag}": scores.numpy(),
+                    f"n_above_thr_{tag}": int((torch.sigmoid(torch.from_numpy(cls)) > 0.2).sum())})
+        print(f"postproc {tag}: {rec[f'n_above_thr_{tag}']} candidates -> {len(scores)} boxes after NMS + range mask")
+    r = np.random.RandomState(DATA_SEED + 52)
+    def rboxes(n):
+        xy, wh = r.uniform(0, 50, (n, 2)), r.uniform(0.5, 20, (n, 2))
+        return np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    qa, qb = rboxes(257), rboxes(61)
+    rec.update(ov_boxes=qa, ov_query=qb, ov=bo.bbox_overlaps(qa, qb))
+    np.savez_compressed(os.path.join(OUT, "postproc.npz"), **rec)
+    print(f"postproc: wrote postproc.npz ({os.path.getsize(os.path.join(OUT, 'postproc.npz')) / 1024:.0f} KiB)")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -403,7 +455,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()
