@@ -214,6 +214,26 @@ class DownsampleConv(nn.Module):  # downsample_conv.py:30-49 ('kernal_size' is t
         return x
 
 
+class NaiveCompressor(nn.Module):
+    """opencood/models/sub_modules/naive_compress.py:5-35 (channel squeeze / expand, three conv3x3 + BN + ReLU); eval-mode
+    BatchNorm only. `compress_raito` is the reference's spelling."""
+
+    def __init__(self, input_dim, compress_raito):
+        super().__init__()
+        mid = input_dim // compress_raito
+        self.encoder = nn.Sequential(nn.Conv2d(input_dim, mid, kernel_size=3, stride=1, padding=1),
+                                     nn.BatchNorm2d(mid, eps=1e-3, momentum=0.01), nn.ReLU())
+        self.decoder = nn.Sequential(nn.Conv2d(mid, input_dim, kernel_size=3, stride=1, padding=1),
+                                     nn.BatchNorm2d(input_dim, eps=1e-3, momentum=0.01), nn.ReLU(),
+                                     nn.Conv2d(input_dim, input_dim, kernel_size=3, stride=1, padding=1),
+                                     nn.BatchNorm2d(input_dim, eps=1e-3, momentum=0.01), nn.ReLU())
+
+    def forward(self, x):
+        x = conv2d_hip(x, self.encoder[0], self.encoder[1], relu=True)
+        x = conv2d_hip(x, self.decoder[0], self.decoder[1], relu=True)
+        return conv2d_hip(x, self.decoder[3], self.decoder[4], relu=True)
+
+
 class HipConv2d(nn.Conv2d):
     """``nn.Conv2d`` whose forward is the HIP kernel (detection heads: 1x1, bias, no activation)."""
 

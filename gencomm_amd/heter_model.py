@@ -6,7 +6,7 @@ fusion_net, shrink_conv, cls_head, reg_head, dir_head``), same forward order and
 of the forward runs in the HIP library.
 
 Scope: lidar modalities encoded by ``point_pillar``; fusion ``att`` or ``max``. SECOND / camera
-encoders, the other fusion nets and ``NaiveCompressor`` are outside this build and raise ``NotImplementedError`` at
+encoders and the other fusion nets are outside this build and raise ``NotImplementedError`` at
 construction with the yaml key that asked for them.
 
 Reference defects absorbed at this boundary: the resolver wants a class whose lower-cased name
@@ -22,7 +22,7 @@ from collections import Counter, OrderedDict
 import torch
 import torch.nn as nn
 
-from .bev_backbone import BaseBEVBackbone, DownsampleConv, HipConv2d
+from .bev_backbone import BaseBEVBackbone, DownsampleConv, HipConv2d, NaiveCompressor
 from .cond_diff import GenComm
 from .enhancer import Enhancer
 from .fusion import AttFusion, MaxFusion, normalize_pairwise_tfm
@@ -115,14 +115,22 @@ class HeterModelBaselineWGenComm(nn.Module):
             if self.STAGE2:
                 self.fix_modules += ["enhancer"]
         self.compress = False
-        if "compressor" in args:
-            raise NotImplementedError("'compressor' (NaiveCompressor) is outside this build")
+        if "compressor" in args:  # inference only here: the reference trains ONLY the compressor in this mode (BatchNorm batch statistics)
+            self.compress = True
+            self.compressor = NaiveCompressor(args["compressor"]["input_dim"], args["compressor"]["compress_ratio"])
+            self.model_train_init()
         if self.STAGE2:
             self.model_train_init_stage2()
 
     # ---- training-mode bookkeeping of the reference
-    def model_train_init(self):  # stage1.py:163-172 (only acts with a compressor, which this build does not have)
-        return None
+    def model_train_init(self):  # stage1.py:163-172 / stage2.py:187-196: freeze everything but the compressor
+        if self.compress:
+            self.eval()
+            for p in self.parameters():
+                p.requires_grad_(False)
+            self.compressor.train()
+            for p in self.compressor.parameters():
+                p.requires_grad_(True)
 
     def model_train_init_stage2(self):  # stage2.py:180-185
         for name in self.fix_modules:
@@ -165,6 +173,9 @@ class HeterModelBaselineWGenComm(nn.Module):
             for i in range(1, heter_message.shape[0]):
                 mask = torch.rand(heter_message.shape[1:], device=heter_message.device) > keep
                 heter_message[i] = heter_message[i] * mask
+
+        if self.compress and self.STAGE2:  # stage2.py:270-271 (the stage-1 forward builds the compressor but never calls it)
+            heter_feature_2d = self.compressor(heter_feature_2d)
 
         if self.supervise_single:
             output_dict.update({"cls_preds_single": self.cls_head_single(heter_feature_2d),

@@ -111,3 +111,16 @@ def test_training_mode_batchnorm_is_refused():
     conv, bn = torch.nn.Conv2d(4, 4, 3, padding=1), torch.nn.BatchNorm2d(4).train()
     with pytest.raises((NotImplementedError, RuntimeError)):
         conv2d_hip(torch.zeros(1, 4, 8, 8), conv, bn)
+
+
+@pytest.mark.gpu
+def test_hip_naive_compressor_vs_torch_fp32():
+    from gencomm_amd.bev_backbone import NaiveCompressor
+    nc = NaiveCompressor(48, 4).eval()
+    synth.fill_params_(nc, 11)
+    synth.fill_bn_stats_(nc, 12)
+    x = torch.randn(2, 48, 14, 22)
+    with torch.no_grad():
+        ref = nc.decoder(nc.encoder(x))          # the torch layers the module owns == naive_compress.py:30-35
+        got = nc.cuda()(x.cuda()).cpu()
+    assert_close(got.numpy(), ref.numpy(), RTOL, ATOL, "compressor")

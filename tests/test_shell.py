@@ -68,9 +68,9 @@ def test_unsupported_blocks_fail_loudly():
     bad = copy.deepcopy(args); bad["m1"]["core_method"] = "second"
     with pytest.raises(NotImplementedError):
         cls(bad)
-    bad = copy.deepcopy(args); bad["compressor"] = {"input_dim": 128, "compress_ratio": 2}
-    with pytest.raises(NotImplementedError):
-        cls(bad)
+    with_comp = copy.deepcopy(args); with_comp["compressor"] = {"input_dim": 128, "compress_ratio": 2}
+    m = cls(with_comp)
+    assert sorted({n.split(".")[0] for n, p in m.named_parameters() if p.requires_grad}) == ["compressor"]  # stage1.py:163-172
 
 
 @pytest.mark.gpu
