@@ -330,6 +330,10 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
 #pragma unroll
   for (int p = 0; p < PPL; ++p) ok[p] = row_ok && (gx + p < a.W);
   const size_t pix = (size_t)gy * a.W + gx;
+  // A wave whose rows all lie below the image (ragged last tile row) only helps staging and keeps the barriers:
+  // it skips the matrix phase and the epilogue arithmetic (wave-uniform branch).
+  constexpr int ROWS_PER_WAVE = 64 / (TW / PPL);
+  const bool wave_live = y0 + (tid >> 6) * ROWS_PER_WAVE < a.H;
 
   GC_STAMP(0);
   // everything that does not depend on the statistics is requested first: weights, bias, tile 0,
@@ -382,65 +386,69 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
     stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   __syncthreads();
   GC_STAMP(2);
-  if (!(GC_EXP & 1)) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[0], acc, tx, ty);
+  if (!(GC_EXP & 1) && wave_live) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[0], acc, tx, ty);
   GC_STAMP(3);
   if (NSRC == 2) {
     __syncthreads();
     if (wvec) stage_store<TW, TH, NT, 8, GN && !(GC_EXP & 2), LS>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid);
     else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
     __syncthreads();
-    if (!(GC_EXP & 1)) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
+    if (!(GC_EXP & 1) && wave_live) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
   }
 
   GC_STAMP(4);
-  // ---- epilogue: bias, residual, store, statistics of the output ----
-  float out[8][PPL];
-#pragma unroll
-  for (int o = 0; o < 8; ++o)
-#pragma unroll
-    for (int p = 0; p < PPL; ++p) out[o][p] = acc[o >> 2][p][o & 3] + bias[o] + (RES == 1 ? resv[o][p] : 0.f);
-
-  if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
-#pragma unroll 4
-    for (int c = 0; c < 16; ++c) {
-      const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + pix;
-      float r[PPL];
-      if (vec_ok) {
-        const float4 t = *reinterpret_cast<const float4*>(rp);
-        r[0] = t.x; r[1 % PPL] = t.y; r[2 % PPL] = t.z; r[3 % PPL] = t.w;
-      } else {
-#pragma unroll
-        for (int p = 0; p < PPL; ++p) r[p] = ok[p] ? rp[p] : 0.f;
-      }
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const float wv = as_const(a.ninw)[c * 8 + o];
-#pragma unroll
-        for (int p = 0; p < PPL; ++p) out[o][p] = fmaf(wv, r[p], out[o][p]);
-      }
-    }
-  }
-
   float part[16];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
-    if ((GC_EXP & 4) && out[o][0] != 1.2345e30f) {
-    } else if (vec_ok) {
-      *reinterpret_cast<float4*>(dp) = make_float4(out[o][0], out[o][1 % PPL], out[o][2 % PPL], out[o][3 % PPL]);
-    } else {
-#pragma unroll
-      for (int p = 0; p < PPL; ++p) if (ok[p]) dp[p] = out[o][p];
+  for (int i = 0; i < 16; ++i) part[i] = 0.f;
+  if (wave_live) {
+    // ---- epilogue: bias, residual, store, statistics of the output ----
+    float out[8][PPL];
+  #pragma unroll
+    for (int o = 0; o < 8; ++o)
+  #pragma unroll
+      for (int p = 0; p < PPL; ++p) out[o][p] = acc[o >> 2][p][o & 3] + bias[o] + (RES == 1 ? resv[o][p] : 0.f);
+
+    if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
+  #pragma unroll 4
+      for (int c = 0; c < 16; ++c) {
+        const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + pix;
+        float r[PPL];
+        if (vec_ok) {
+          const float4 t = *reinterpret_cast<const float4*>(rp);
+          r[0] = t.x; r[1 % PPL] = t.y; r[2 % PPL] = t.z; r[3 % PPL] = t.w;
+        } else {
+  #pragma unroll
+          for (int p = 0; p < PPL; ++p) r[p] = ok[p] ? rp[p] : 0.f;
+        }
+  #pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const float wv = as_const(a.ninw)[c * 8 + o];
+  #pragma unroll
+          for (int p = 0; p < PPL; ++p) out[o][p] = fmaf(wv, r[p], out[o][p]);
+        }
+      }
     }
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int p = 0; p < PPL; ++p) {
-      const float m = ok[p] ? out[o][p] : 0.f;
-      s += m;
-      q = fmaf(m, m, q);
+
+  #pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
+      if ((GC_EXP & 4) && out[o][0] != 1.2345e30f) {
+      } else if (vec_ok) {
+        *reinterpret_cast<float4*>(dp) = make_float4(out[o][0], out[o][1 % PPL], out[o][2 % PPL], out[o][3 % PPL]);
+      } else {
+  #pragma unroll
+        for (int p = 0; p < PPL; ++p) if (ok[p]) dp[p] = out[o][p];
+      }
+      float s = 0.f, q = 0.f;
+  #pragma unroll
+      for (int p = 0; p < PPL; ++p) {
+        const float m = ok[p] ? out[o][p] : 0.f;
+        s += m;
+        q = fmaf(m, m, q);
+      }
+      part[o] = s;
+      part[8 + o] = q;
     }
-    part[o] = s;
-    part[8 + o] = q;
   }
   GC_STAMP(5);
   if (a.dstat != nullptr && (!(GC_EXP & 8) || part[0] == 1.2345e30f)) block_stats_commit<NT>(part, s_red, a.dstat + (size_t)n * 16);
