@@ -1,0 +1,451 @@
+// 8 (or 8+8) -> 8 channel 3x3 convolution of the UNet on the f16 matrix pipe with fp32-grade products.
+//
+// Why: on gfx950 the fp32 MFMA forms (4x4x1, 16x16x4, 32x32x2) and ordinary fp32 VALU work do not overlap --
+// measured with tools/probes/mfma16_probe.hip: a wave's VALU instructions issued beside another wave's fp32 MFMA
+// stream, or interleaved into it, cost their full issue time on top of the MFMA's (32 + 6n cycles for 16x16x4 + n
+// v_fma) -- so conv8_kernel's 576 MFMAs and ~700 VALU instructions per tile-wave simply add up.  The f16/bf16
+// matrix pipe is separate (an MFMA holds the vector issue port for 8 of its 16 cycles) and 16x faster per MAC.
+//
+// Arithmetic: every fp32 operand x is split EXACTLY into x = hi + lo + e with hi = fp16(x), lo = fp16(x - hi),
+// |e| <= 2^-22 |x| (the residual x - hi is exact in fp32).  A product is formed as hi*hi' + hi*lo' + lo*hi'
+// (three v_mfma_f32_16x16x32_f16, each fp16 x fp16 product exact, fp32 accumulation); the dropped lo*lo' term is
+// <= 2^-22 |x||w|.  Relative error of a product <= 3 * 2^-22 = 7e-7 (fp32 FMA: 6e-8): the same parity tolerance
+// (rtol 1e-4 / atol 1e-5 vs the fp32 oracle) is met with the same margin as the exact kernels' reordering error.
+// Weights are pre-scaled by a power of two so that their low parts stay normal fp16 numbers (unscaled in the
+// epilogue, exact).  GENCOMM_CONV8=f32 selects the exact-fp32 conv8_kernel instead (unet_host.h).
+//
+// Mapping (one workgroup = 64x16 output pixels, 4 waves, wave w = rows 4w..4w+3):
+//   MFMA M = 16 = 8 output channels x 2 vertically adjacent output rows (r = 0, 1),
+//        N = 16 pixels: lane n of group j owns pixel x = 4n + j, so a lane ends up with 4 consecutive pixels
+//            (dwordx4 stores / residual loads),
+//        K = 32 = 4 taps x 8 input channels; the 4x3 input window of a row pair is 12 taps = 3 MFMAs with no K
+//            padding (rows of A that a tap does not reach are zero: 75 % of the MACs are useful).
+//   LDS tile: [hi|lo][18 rows][4 phases][18 slots][8 ch] fp16 -- pixel x of a row lives in phase x & 3, slot
+//   (x >> 2) + 1, its 8 channels contiguous (16 B): the B operand of a lane is ONE ds_read_b128, 16 lanes read 256
+//   contiguous bytes (conflict-free) for every tap shift, and the staging pass (a thread holds a 4-pixel quad of all
+//   8 channels) writes one 16-B record per pixel, again 256 contiguous bytes per 16 lanes.
+#pragma once
+#include "unet_kernels.h"
+
+namespace gc {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+constexpr int HC_TW = 64, HC_TH = 16, HC_NT = 256, HC_LH = 18;
+constexpr int HC_SLOTS = 18;
+constexpr int HC_PHASE = HC_SLOTS * 16;  // bytes
+constexpr int HC_ROW = 4 * HC_PHASE;     // 1152
+constexpr int HC_PLANE = HC_LH * HC_ROW; // 20736: hi plane, then lo plane
+constexpr int HC_WTAB = 3 * 2 * 64 * 4;  // dwords of one prepared 8-input-channel weight table (+ 64 for the scale)
+
+// exact two-term fp16 split of a pair of floats: hi = rne16(x), lo = rne16(x - hi)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const half2_t h = __builtin_convertvector((float2_t){a, b}, half2_t);
+  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  const half2_t l = __builtin_convertvector((float2_t){ra, rb}, half2_t);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void split_one(float a, uint16_t& hi, uint16_t& lo) {
+  const _Float16 h = (_Float16)a;
+  const _Float16 l = (_Float16)(a - (float)h);
+  hi = __builtin_bit_cast(uint16_t, h);
+  lo = __builtin_bit_cast(uint16_t, l);
+}
+
+__device__ __forceinline__ int hc_addr(int row, int px /* -1 .. 64 */) {
+  return row * HC_ROW + (px & 3) * HC_PHASE + ((px >> 2) + 1) * 16;
+}
+
+// GroupNorm+SiLU, split, and write this thread's share of the tile (registers filled by stage_load).
+template <bool GN>
+__device__ __forceinline__ void stage_store_h(unsigned char* __restrict__ tile, const TileRegs<HC_TW, HC_TH, HC_NT, 8>& R,
+                                              float2 hreg, int H, int W, int x0, int y0, const float (*ab)[2], int tid) {
+  using TR = TileRegs<HC_TW, HC_TH, HC_NT, 8>;
+  {  // main pass: quad (row r0, quad qx) of every channel
+    const int r0 = tid >> 4, qx = tid & 15;
+    const int gy = y0 - 1 + r0, gx = x0 + 4 * qx;
+    const bool ok = gy >= 0 && gy < H && gx < W;
+    float e[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      e[c][0] = R.v[c].x; e[c][1] = R.v[c].y; e[c][2] = R.v[c].z; e[c][3] = R.v[c].w;
+      if (GN) {
+        const float A = ok ? ab[c][0] : 0.f, B = ok ? ab[c][1] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[c][j] = silu_f(fmaf(A, e[c][j], B));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 hi, lo;
+      split_pair(e[0][j], e[1][j], hi.x, lo.x);
+      split_pair(e[2][j], e[3][j], hi.y, lo.y);
+      split_pair(e[4][j], e[5][j], hi.z, lo.z);
+      split_pair(e[6][j], e[7][j], hi.w, lo.w);
+      const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
+      *reinterpret_cast<uint4*>(tile + addr) = hi;
+      *reinterpret_cast<uint4*>(tile + HC_PLANE + addr) = lo;
+    }
+  }
+  {  // remainder pass: rows 16, 17 -- a thread holds one channel's quad (channel tid / 32); lane ^ 32 holds the other
+     // channel of the pair.  Sub-dword LDS writes of two lanes of ONE instruction to the same dword are not merged
+     // (one lane's half is dropped), so the pair is brought together first and whole dwords are written:
+     // the even channel's thread writes pixels 0, 1 of the quad, the odd channel's thread pixels 2, 3.
+    const int cr = tid >> 5, rr = TR::RPP + ((tid >> 4) & 1), qx = tid & 15;
+    const int gy = y0 - 1 + rr, gx = x0 + 4 * qx;
+    const bool ok = gy >= 0 && gy < H && gx < W;
+    float e[4] = {R.vr.x, R.vr.y, R.vr.z, R.vr.w};
+    if (GN) {
+      const float A = ok ? ab[cr][0] : 0.f, B = ok ? ab[cr][1] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = silu_f(fmaf(A, e[j], B));
+    }
+    const bool odd = (cr & 1) != 0;
+    // send the two pixels the partner writes, receive the partner's values of the two pixels this thread writes
+    const float s0 = odd ? e[0] : e[2], s1 = odd ? e[1] : e[3];
+    const float p0 = __shfl_xor(s0, 32, 64), p1 = __shfl_xor(s1, 32, 64);
+    const float m0 = odd ? e[2] : e[0], m1 = odd ? e[3] : e[1];
+    const int jb = odd ? 2 : 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float mine = k ? m1 : m0, theirs = k ? p1 : p0;
+      uint32_t hi, lo;
+      split_pair(odd ? theirs : mine, odd ? mine : theirs, hi, lo);  // low half = even channel
+      const int addr = rr * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4;
+      *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+      *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
+    }
+  }
+  if (tid < HC_LH * 8) {  // halo columns: pixel -1 (phase 3, slot 0) and pixel 64 (phase 0, slot 17), one channel pair per thread
+    const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
+    float e0 = hreg.x, e1 = hreg.y;
+    if (GN) {
+      const int gy = y0 - 1 + r, gx = side ? x0 + HC_TW : x0 - 1;
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      e0 = ok ? silu_f(fmaf(ab[2 * cp][0], e0, ab[2 * cp][1])) : 0.f;
+      e1 = ok ? silu_f(fmaf(ab[2 * cp + 1][0], e1, ab[2 * cp + 1][1])) : 0.f;
+    }
+    uint32_t hi, lo;
+    split_pair(e0, e1, hi, lo);
+    const int addr = hc_addr(r, side ? HC_TW : -1) + cp * 4;
+    *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+    *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
+  }
+}
+
+// Halo columns of the tile for stage_store_h: thread tid < 144 loads the channel pair (2cp, 2cp+1) of halo pixel
+// (row tid / 8, side (tid / 4) & 1).  (TileRegs::hv, one channel per thread, is not used by this kernel.)
+template <bool UP>
+__device__ __forceinline__ float2 halo_load_h(const float* __restrict__ sp, unsigned plane_in, int Win, int H, int W,
+                                              int x0, int y0, int tid) {
+  float2 out = make_float2(0.f, 0.f);
+  if (tid < HC_LH * 8) {
+    const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
+    const int gy = y0 - 1 + r, gx = side ? x0 + HC_TW : x0 - 1;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const unsigned o = UP ? (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1) : (unsigned)gy * (unsigned)Win + (unsigned)gx;
+      out.x = sp[(unsigned)(2 * cp) * plane_in + o];
+      out.y = sp[(unsigned)(2 * cp + 1) * plane_in + o];
+    }
+  }
+  return out;
+}
+
+// Slow path for widths that are not a multiple of 4 (tests only): one element at a time.
+template <bool GN, bool UP>
+__device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ tile, const float* __restrict__ sp, unsigned plane_in,
+                                                 int Win, int H, int W, int x0, int y0, const float (*ab)[2], int tid) {
+  constexpr int LW = HC_TW + 2;
+  for (int i = tid; i < 8 * HC_LH * LW; i += HC_NT) {
+    const int c = i / (HC_LH * LW), rem = i - c * (HC_LH * LW);
+    const int r = rem / LW, col = rem - r * LW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    float e = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      e = UP ? sp[(unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)]
+             : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
+      if (GN) e = silu_f(fmaf(ab[c][0], e, ab[c][1]));
+    }
+    uint16_t hi, lo;
+    split_one(e, hi, lo);
+    const int addr = hc_addr(r, col - 1) + c * 2;
+    *reinterpret_cast<uint16_t*>(tile + addr) = hi;
+    *reinterpret_cast<uint16_t*>(tile + HC_PLANE + addr) = lo;
+  }
+}
+
+// Per-lane byte offsets of the B operand: off[j][c] for pixel group j (pixel 4n + j) and MFMA c (taps 4c .. 4c+3,
+// this lane's tap t = 4c + lane/16: window row t / 3, column shift t % 3 - 1), row pair 0 of wave `wave`.
+__device__ __forceinline__ void hc_lane_offsets(int (&off)[4][3], int wave, int lane) {
+  const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) off[j][c] = hc_addr(4 * wave + dyp, 4 * n + j + dx - 1);
+  }
+}
+
+// One 8-input-channel source: acc[p][j] (row pair p, pixel group j) += W (*) tile.  wa[c][0/1] = hi/lo A operands.
+// Per (tap group c, row pair p): 8 ds_read_b128 (hi and lo records of the four pixel groups), then three passes of four
+// MFMAs (hi*hi, hi*lo, lo*hi) so that consecutive MFMAs never share an accumulator.
+__device__ __forceinline__ void conv_tile_mfma_h(const unsigned char* tile, const half8_t (&wa)[3][2],
+                                                 f32x4 (&acc)[2][4], const int (&off)[4][3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      half8_t bh[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bh[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c] + p * 2 * HC_ROW);
+        bl[j] = *reinterpret_cast<const half8_t*>(tile + HC_PLANE + off[j][c] + p * 2 * HC_ROW);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bh[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bl[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][1], bh[j], acc[p][j], 0, 0, 0);
+    }
+  }
+}
+
+// prepared weight table of one 8-input-channel source: [c 3][hi/lo 2][lane 64][4 dwords]; after the last table
+// 64 floats: even entries 1 / scale, odd entries scale
+__device__ __forceinline__ void load_wa(half8_t (&wa)[3][2], const float* __restrict__ tab, int lane) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint4 v = *reinterpret_cast<const uint4*>(tab + ((c * 2 + h) * 64 + lane) * 4);
+      wa[c][h] = __builtin_bit_cast(half8_t, v);
+    }
+}
+
+template <int NSRC, bool GN, bool UP, int RES>
+__global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
+  constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
+  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
+  __shared__ float s_ab[16][2];
+  __shared__ float s_red[NT / 64][16];
+#ifdef HC_LDS_PAD  // diagnostic builds: inflate the LDS footprint to limit workgroups per CU
+  __shared__ float s_pad[HC_LDS_PAD / 4];
+  if (a.H < 0) s_pad[threadIdx.x] = 1.f;
+#endif
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const size_t plane_in = (size_t)a.Hin * a.Win;
+  const size_t plane = (size_t)a.H * a.W;
+  const bool wvec = UP ? ((a.Win & 1) == 0) : ((a.W & 3) == 0);
+  // output ownership: pixels x0 + 4*ln .. +3, rows y0 + 4*wave + 2p + rr (p = 0, 1), channels 4*ch + i (i = 0..3)
+  const int ln = lane & 15, g = lane >> 4, ch = g & 1, rr = g >> 1;
+  const int gx = x0 + 4 * ln;
+  const int gy0 = y0 + 4 * wave + rr;
+  const bool vec_ok = (gx + 3 < a.W) && ((a.W & 3) == 0);
+  const bool wave_live = y0 + 4 * wave < a.H;
+
+  half8_t wa[3][2];
+  load_wa(wa, a.wh, lane);
+  const float inv_s = a.wh[NSRC * HC_WTAB];  // one scale for the whole (concatenated) weight tensor
+  const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + 4 * ch);
+  const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+  TileRegs<TW, TH, NT, 8> R;
+  float2 hreg = make_float2(0.f, 0.f);
+  if (wvec) {
+    stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    hreg = halo_load_h<UP>(a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  }
+  if (GN) {
+    if (tid < NSRC * 8) {
+      const int s = tid >> 3, c = tid & 7;
+      float A, B;
+      gn_coeff(a.sstat[s] + (size_t)n * 16, c, 2 * NSRC, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
+      s_ab[tid][0] = A;
+      s_ab[tid][1] = B;
+    }
+    __syncthreads();
+  }
+
+  int off[4][3];
+  hc_lane_offsets(off, wave, lane);
+  // the accumulators start at bias * scale (exact: the scale is a power of two), so the epilogue is one multiply
+  f32x4 acc[2][4];
+  {
+    const float sc = a.wh[NSRC * HC_WTAB + 1];
+    const f32x4 b0 = {bias[0] * sc, bias[1] * sc, bias[2] * sc, bias[3] * sc};
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = b0;
+  }
+
+  if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[0], tid);
+  else stage_tile_scalar_h<GN, UP>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
+  if (NSRC == 2 && wvec) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
+    stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  }
+  __syncthreads();
+  if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+  if (NSRC == 2) {
+    load_wa(wa, a.wh + HC_WTAB, lane);
+    __syncthreads();
+    if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[8], tid);
+    else stage_tile_scalar_h<GN, UP>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
+    __syncthreads();
+    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+  }
+
+  float part[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[i] = 0.f;
+  if (wave_live) {
+    // identity residual: requested here, behind the matrix phase, so that its 32 registers are not live across it
+    float resv[RES == 1 ? 2 : 1][4][4];
+    if (RES == 1) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int gy = gy0 + 2 * p;
+          const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
+          if (vec_ok && gy < a.H) {
+            const float4 r = *reinterpret_cast<const float4*>(rp);
+            resv[p][i][0] = r.x; resv[p][i][1] = r.y; resv[p][i][2] = r.z; resv[p][i][3] = r.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) resv[p][i][j] = (gy < a.H && gx + j < a.W) ? rp[j] : 0.f;
+          }
+        }
+    }
+    float out[2][4][4];  // [row pair][channel i][pixel j]
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[p][i][j] = RES == 1 ? fmaf(acc[p][j][i], inv_s, resv[p][i][j]) : acc[p][j][i] * inv_s;
+
+    if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
+#pragma unroll 2
+      for (int c = 0; c < 16; ++c) {
+        const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + c * 8 + 4 * ch);
+        const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int gy = gy0 + 2 * p;
+          const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + (size_t)gy * a.W + gx;
+          float r[4];
+          if (vec_ok && gy < a.H) {
+            const float4 t = *reinterpret_cast<const float4*>(rp);
+            r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (gy < a.H && gx + j < a.W) ? rp[j] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[p][i][j] = fmaf(wv[i], r[j], out[p][i][j]);
+        }
+      }
+    }
+
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int gy = gy0 + 2 * p;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float* __restrict__ dp = a.dst + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
+        float s = 0.f, q = 0.f;
+        if (vec_ok && gy < a.H) {
+          *reinterpret_cast<float4*>(dp) = make_float4(out[p][i][0], out[p][i][1], out[p][i][2], out[p][i][3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s += out[p][i][j]; q = fmaf(out[p][i][j], out[p][i][j], q); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (gy < a.H && gx + j < a.W) { dp[j] = out[p][i][j]; s += out[p][i][j]; q = fmaf(out[p][i][j], out[p][i][j], q); }
+        }
+        part[i] += s;
+        part[4 + i] += q;
+      }
+    }
+  }
+  if (a.dstat != nullptr) {
+    // sum over the 16 lanes of a row (same channels, different pixels), then over the two rows that hold the same
+    // channels (g and g ^ 2); lane 15 (channels 0..3) and lane 31 (channels 4..7) publish the wave totals
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      float x = part[v];
+      x = dpp_add<0x111, 0xf>(x);
+      x = dpp_add<0x112, 0xf>(x);
+      x = dpp_add<0x114, 0xf>(x);
+      x = dpp_add<0x118, 0xf>(x);
+      x += __shfl_xor(x, 32, 64);
+      part[v] = x;
+    }
+    if (lane == 15 || lane == 31) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_red[wave][4 * ch + i] = part[i];
+        s_red[wave][8 + 4 * ch + i] = part[4 + i];
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) v += s_red[w][tid];
+      atomicAdd(&a.dstat[(size_t)n * 16 + (tid & 7) * 2 + (tid >> 3)], (double)v);
+    }
+  }
+}
+
+// Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 tables of HC_WTAB dwords + 64 floats (1 / scale).
+// A operand of MFMA c, lane l: row m = l % 16 = (r = m / 8, oc = m % 8), K group l / 16 -> tap t = 4c + l/16 of the 4x3
+// window (window row dyp = t / 3, column dx = t % 3), 8 input channels; tap row of the kernel = dyp - r (zero outside 0..2).
+__global__ __launch_bounds__(256) void prep_conv8h_kernel(const float* __restrict__ w, float* __restrict__ dst, int IC) {
+  __shared__ float s_max[256];
+  const int tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < 8 * IC * 9; i += 256) m = fmaxf(m, fabsf(w[i]));
+  s_max[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_max[tid] = fmaxf(s_max[tid], s_max[tid + s]);
+    __syncthreads();
+  }
+  // power-of-two scale that puts the largest weight in [2^7, 2^8): low parts stay normal fp16 numbers down to
+  // |w| ~ 2^-13 of the largest weight; all-zero weights -> scale 1
+  const float wmax = s_max[0];
+  int ex = 0;
+  if (wmax > 0.f) (void)frexpf(wmax, &ex);  // wmax = f * 2^ex, f in [0.5, 1)
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
+  const int nsrc = IC / 8;
+  uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(dst);
+  for (int i = tid; i < nsrc * HC_WTAB; i += 256) {
+    const int s = i / HC_WTAB, rem = i - s * HC_WTAB;
+    const int d = rem & 3, l = (rem >> 2) & 63, h = (rem >> 8) & 1, c = rem >> 9;
+    const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
+    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
+    uint16_t v[2];
+    for (int e = 0; e < 2; ++e) {
+      const int ic = s * 8 + 2 * d + e;
+      const float x = (dy >= 0 && dy <= 2) ? w[((oc * IC + ic) * 3 + dy) * 3 + dx] * scale : 0.f;
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    }
+    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+  }
+  if (tid < 64) dst[nsrc * HC_WTAB + tid] = (tid & 1) ? scale : 1.0f / scale;  // [0] = 1 / scale, [1] = scale
+}
+
+}  // namespace gc

@@ -152,6 +152,28 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
   return unet_enqueue(c, x_t, cond, t, 0, co);
 }
 
+// One plain 8 -> 8 channel 3x3 convolution (stride 1, zero padding 1, bias, no norm, no residual) through the same
+// kernels the UNet layers use -- the unit under test of tests/test_gpu_conv8.py.  `scratch` >= 4096 floats.
+int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, float* dst, double* dstat,
+                      float* scratch, int n, int H, int W, int split, void* stream) {
+  GC_CHECK_ARG(src && w_oihw && bias && dst && scratch, "null pointer");
+  GC_CHECK_ARG(n >= 1 && n <= 65535 && H >= 1 && W >= 1, "bad n/H/W");
+  hipStream_t st = (hipStream_t)stream;
+  float* p_w = scratch;            // [8][9][8]
+  float* p_wh = scratch + 1024;    // fp16 hi/lo tables + scale
+  float* p_b = scratch + 3072;     // bias copy (16-B aligned)
+  prep_conv_w_kernel<<<cdiv(576, 256), 256, 0, st>>>(w_oihw, p_w, 8, 8, 8);
+  prep_conv8h_kernel<<<1, 256, 0, st>>>(w_oihw, p_wh, 8);
+  GC_HIP(hipMemcpyAsync(p_b, bias, 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (dstat) GC_HIP(hipMemsetAsync(dstat, 0, (size_t)n * 16 * sizeof(double), st));
+  Conv8Args a{};
+  a.src[0] = src; a.w = p_w; a.wh = split ? p_wh : nullptr; a.bias = p_b; a.dst = dst; a.dstat = dstat;
+  a.H = a.Hin = H; a.W = a.Win = W;
+  launch_conv8<1, false, false, 0>(pick_tile(n, H, W), a, n, st);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 static void launch_q_sample(const QSampleArgs& q, int n, bool philox, hipStream_t st) {
   TimedLaunch tl(KF_Q_SAMPLE, st);
   const dim3 qgrid((unsigned)std::min<long long>((q.per_agent / 4 + 255) / 256 + 1, 2048), n);

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "attn_kernels.h"
+#include "conv8h_kernels.h"
 #include "latent_kernels.h"
 #include "unet_kernels.h"
 #include "unet_plan.h"
@@ -17,12 +18,16 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // quarter of the serial work per wave (these layers are latency-bound, not throughput-bound).
 enum TileCfg { TILE_64x16 = 0, TILE_32x16 = 1, TILE_32x8 = 2 };
 inline long long tile_want() {
-  // tuning hook (GENCOMM_TILE_WANT): minimum number of workgroups before a larger tile is chosen
-  static const long long v = [] {
-    const char* e = getenv("GENCOMM_TILE_WANT");
-    return e ? atoll(e) : 512LL;
-  }();
-  return v;
+  // tuning / test hook (GENCOMM_TILE_WANT): minimum number of workgroups before a larger tile is chosen; read per call
+  // so that one test process can force the 64x16 kernels onto small maps
+  const char* e = getenv("GENCOMM_TILE_WANT");
+  return e ? atoll(e) : 512LL;
+}
+// GENCOMM_CONV8 = "split" (default): 64x16 tiles of the 8-channel convolutions run conv8h_kernel (fp16 hi/lo split on
+// the f16 matrix pipe, fp32-grade products); "f32": the exact-fp32 conv8_kernel everywhere.  Read per call.
+inline bool conv8_split_mode() {
+  const char* e = getenv("GENCOMM_CONV8");
+  return !(e && strcmp(e, "f32") == 0);
 }
 inline TileCfg pick_tile(int n, int H, int W, int zmul = 1) {
   const long long want = tile_want();
@@ -41,6 +46,12 @@ inline void launch_conv8(TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
   int tw, th;
   tile_dims(t, &tw, &th);
   const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
+  const char* mk = getenv("GENCOMM_CONV8H_MASK");  // diagnostic: restrict the split kernel to some variants
+  const int variant = UP ? 16 : (RES == 2 ? 8 : (RES == 1 ? 4 : (NSRC == 2 ? 2 : 1)));
+  if (t == TILE_64x16 && a.wh != nullptr && conv8_split_mode() && (!mk || (atoi(mk) & variant))) {
+    conv8h_kernel<NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a);
+    return;
+  }
   switch (t) {
     case TILE_64x16: conv8_kernel<64, 16, 4, NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a); break;
     case TILE_32x16: conv8_kernel<32, 16, 4, NSRC, GN, UP, RES><<<grid, 128, 0, st>>>(a); break;
@@ -97,7 +108,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
         if (o.src[1] >= 0) { a.src[1] = c.tensor_ptr(o.src[1]); a.sstat[1] = c.stat_ptr(o.src[1]); }
         a.gamma = P + b.n1w; a.beta = P + b.n1b;
-        a.w = P + b.p_c1w; a.bias = P + b.p_bias1 + (size_t)t * 8;
+        a.w = P + b.p_c1w; a.wh = P + b.p_c1wh; a.bias = P + b.p_bias1 + (size_t)t * 8;
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = a.Hin = Hl; a.W = a.Win = Wl;
         a.inv_cnt = 1.0 / ((b.cin == 8 ? 2.0 : 4.0) * Hl * Wl);
@@ -111,7 +122,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         Conv8Args a{};
         a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
         a.gamma = P + b.n2w; a.beta = P + b.n2b;
-        a.w = P + b.p_c2w; a.bias = P + b.p_bias2;
+        a.w = P + b.p_c2w; a.wh = P + b.p_c2wh; a.bias = P + b.p_bias2;
         a.res[0] = c.tensor_ptr(o.res[0]);
         if (o.res[1] >= 0) { a.res[1] = c.tensor_ptr(o.res[1]); a.ninw = P + b.p_ninw; }
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
@@ -134,7 +145,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         const int lin = o.level + 1;
         Conv8Args a{};
         a.src[0] = c.tensor_ptr(o.src[0]);
-        a.w = P + p.up[lin].p_w; a.bias = P + p.up[lin].b;
+        a.w = P + p.up[lin].p_w; a.wh = P + p.up[lin].p_wh; a.bias = P + p.up[lin].b;
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = Hl; a.W = Wl; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin];
         launch_conv8<1, false, true, 0>(pick_tile(c.n, Hl, Wl), a, c.n, c.st);
@@ -238,7 +249,10 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
   conv_w(p.conv_out.w, p.conv_out.p_w, p.C, 8, 16);
   for (int l = 0; l < p.L; ++l) {
     if (p.down[l].w >= 0) conv_w(p.down[l].w, p.down[l].p_w, 8, 8, 8);
-    if (p.up[l].w >= 0) conv_w(p.up[l].w, p.up[l].p_w, 8, 8, 8);
+    if (p.up[l].w >= 0) {
+      conv_w(p.up[l].w, p.up[l].p_w, 8, 8, 8);
+      prep_conv8h_kernel<<<1, 256, 0, st>>>(raw + p.up[l].w, prepared + p.up[l].p_wh, 8);
+    }
   }
   TembArgs ta{};
   ta.raw = raw; ta.prepared = prepared;
@@ -248,6 +262,8 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
     const ResBlockPlan& b = p.blocks[i];
     conv_w(b.c1w, b.p_c1w, 8, b.cin, 8);
     conv_w(b.c2w, b.p_c2w, 8, 8, 8);
+    prep_conv8h_kernel<<<1, 256, 0, st>>>(raw + b.c1w, prepared + b.p_c1wh, b.cin);
+    prep_conv8h_kernel<<<1, 256, 0, st>>>(raw + b.c2w, prepared + b.p_c2wh, 8);
     if (b.cin != 8) prep_nin_w_kernel<<<1, 256, 0, st>>>(raw + b.ninw, prepared + b.p_ninw, 8, b.cin);
     prep_add_kernel<<<1, 64, 0, st>>>(raw + b.c2b, b.cin != 8 ? raw + b.ninb : nullptr, prepared + b.p_bias2, 8);
     ta.tpw[i] = b.tpw; ta.tpb[i] = b.tpb; ta.c1b[i] = b.c1b; ta.dst[i] = b.p_bias1;

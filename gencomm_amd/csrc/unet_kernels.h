@@ -298,6 +298,7 @@ struct Conv8Args {
   const float* gamma;     // GroupNorm affine of the (concatenated) input [8*NSRC]
   const float* beta;
   const float* w;         // prepared [NSRC*8][9][8] = (ic, tap, oc)
+  const float* wh;        // prepared fp16 hi/lo A-operand tables of conv8h_kernel (conv8h_kernels.h), or null
   const float* bias;      // [8] (conv bias (+ temb_proj(t)) (+ nin_shortcut bias))
   const float* res[2];    // residual sources [n][8][H][W]
   const float* ninw;      // prepared nin_shortcut [16][8] = (ic, oc)

@@ -76,6 +76,13 @@ long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int at
 int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int attn_mask, int T,
                          void* stream);
 
+/* One 8 -> 8 channel 3x3 convolution (pad 1, bias) as the UNet's ResnetBlock / Upsample layers run it
+ * (unet.py:52, :99-118), without norm or residual: dst[n,8,H,W] = conv(src[n,8,H,W], w[8,8,3,3]) + bias; dstat (nullable)
+ * receives per-(sample, channel) {sum, sum of squares} of dst as [n][8][2] doubles. split != 0: fp16 hi/lo split
+ * kernel on 64x16 tiles (conv8h_kernels.h), else the exact-fp32 kernel. scratch >= 4096 floats. Unit-test entry. */
+int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, float* dst, double* dstat,
+                      float* scratch, int n, int H, int W, int split, void* stream);
+
 /* Scratch for one UNet call / the denoise loop on n agents of [C, H, W]. */
 long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask);
 
