@@ -84,8 +84,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    # -packed-fp32-ops: no v_pk_{fma,mul,add}_f32. With them, conv8h_kernel's epilogue `acc * inv_scale + bias` compiled to
+    # `v_pk_fma_f32 v[0:1], v[0:1], s[22:23], v[22:23] op_sel:[0,0,1]` and sporadically lost the bias in the low half on
+    # lanes 48..63 whenever two workgroups shared a SIMD (never with one workgroup per CU); the same source built
+    # without packed ops is exact in every run (tools/conv8_unit.py), and the hot kernels are not slower for it.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", *srcs, "-o", LIB_PATH + ".tmp"]
+           "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+           *srcs, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -59,12 +59,64 @@ __device__ __forceinline__ int hc_addr(int row, int px /* -1 .. 64 */) {
   return row * HC_ROW + (px & 3) * HC_PHASE + ((px >> 2) + 1) * 16;
 }
 
-// GroupNorm+SiLU, split, and write this thread's share of the tile (registers filled by stage_load).
+// ---- LDS writers of the 18-row tile (1-pixel halo); LO = byte offset of the lo plane ----
+// main pass: thread (row r0 = tid / 16, quad qx = tid % 16) holds 4 pixels x 8 channels
+template <int LO>
+__device__ __forceinline__ void hc_store_main(unsigned char* tile, int r0, int qx, const float (&e)[8][4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint4 hi, lo;
+    split_pair(e[0][j], e[1][j], hi.x, lo.x);
+    split_pair(e[2][j], e[3][j], hi.y, lo.y);
+    split_pair(e[4][j], e[5][j], hi.z, lo.z);
+    split_pair(e[6][j], e[7][j], hi.w, lo.w);
+    const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
+    *reinterpret_cast<uint4*>(tile + addr) = hi;
+    *reinterpret_cast<uint4*>(tile + LO + addr) = lo;
+  }
+}
+// rows 16, 17: a thread holds ONE channel's quad (channel tid / 32, row 16 + (tid / 16 & 1), quad tid % 16); lane ^ 32
+// holds the other channel of the pair.  Sub-dword LDS writes of two lanes of one instruction to the same dword must
+// not be relied on, so the pair is brought together first and whole dwords are written: the even channel's thread
+// writes pixels 0, 1 of the quad, the odd channel's thread pixels 2, 3.
+template <int LO>
+__device__ __forceinline__ void hc_store_rem(unsigned char* tile, int tid, const float (&e)[4]) {
+  const int cr = tid >> 5, rr = HC_TH + ((tid >> 4) & 1), qx = tid & 15;
+  const bool odd = (cr & 1) != 0;
+  const float s0 = odd ? e[0] : e[2], s1 = odd ? e[1] : e[3];
+  const float p0 = __shfl_xor(s0, 32, 64), p1 = __shfl_xor(s1, 32, 64);
+  const float m0 = odd ? e[2] : e[0], m1 = odd ? e[3] : e[1];
+  const int jb = odd ? 2 : 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float mine = k ? m1 : m0, theirs = k ? p1 : p0;
+    uint32_t hi, lo;
+    split_pair(odd ? theirs : mine, odd ? mine : theirs, hi, lo);  // low half = even channel
+    const int addr = rr * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4;
+    *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+    *reinterpret_cast<uint32_t*>(tile + LO + addr) = lo;
+  }
+}
+// halo columns: thread tid < 144 = (row tid / 8, side (tid / 4) & 1, channel pair tid % 4) writes pixel -1 (phase 3,
+// slot 0) or pixel 64 (phase 0, slot 17)
+template <int LO>
+__device__ __forceinline__ void hc_store_halo(unsigned char* tile, int tid, float e0, float e1) {
+  const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
+  uint32_t hi, lo;
+  split_pair(e0, e1, hi, lo);
+  const int addr = hc_addr(r, side ? HC_TW : -1) + cp * 4;
+  *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+  *reinterpret_cast<uint32_t*>(tile + LO + addr) = lo;
+}
+
+// GroupNorm+SiLU (GN) or a plain scale (!GN), split, and write this thread's share of the tile (registers filled by
+// stage_load / halo_load_h).
 template <bool GN>
-__device__ __forceinline__ void stage_store_h(unsigned char* __restrict__ tile, const TileRegs<HC_TW, HC_TH, HC_NT, 8>& R,
-                                              float2 hreg, int H, int W, int x0, int y0, const float (*ab)[2], int tid) {
+__device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileRegs<HC_TW, HC_TH, HC_NT, 8>& R,
+                                              float2 hreg, int H, int W, int x0, int y0, const float (*ab)[2], int tid,
+                                              float mul = 1.0f) {
   using TR = TileRegs<HC_TW, HC_TH, HC_NT, 8>;
-  {  // main pass: quad (row r0, quad qx) of every channel
+  {
     const int r0 = tid >> 4, qx = tid & 15;
     const int gy = y0 - 1 + r0, gx = x0 + 4 * qx;
     const bool ok = gy >= 0 && gy < H && gx < W;
@@ -73,27 +125,18 @@ __device__ __forceinline__ void stage_store_h(unsigned char* __restrict__ tile, 
     for (int c = 0; c < 8; ++c) {
       e[c][0] = R.v[c].x; e[c][1] = R.v[c].y; e[c][2] = R.v[c].z; e[c][3] = R.v[c].w;
       if (GN) {
+        // zero padding through the coefficients: out-of-image quads were loaded as 0 and silu(0*0+0) == 0
         const float A = ok ? ab[c][0] : 0.f, B = ok ? ab[c][1] : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[c][j] = silu_f(fmaf(A, e[c][j], B));
+      } else if (mul != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[c][j] *= mul;
       }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint4 hi, lo;
-      split_pair(e[0][j], e[1][j], hi.x, lo.x);
-      split_pair(e[2][j], e[3][j], hi.y, lo.y);
-      split_pair(e[4][j], e[5][j], hi.z, lo.z);
-      split_pair(e[6][j], e[7][j], hi.w, lo.w);
-      const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
-      *reinterpret_cast<uint4*>(tile + addr) = hi;
-      *reinterpret_cast<uint4*>(tile + HC_PLANE + addr) = lo;
-    }
+    hc_store_main<HC_PLANE>(tile, r0, qx, e);
   }
-  {  // remainder pass: rows 16, 17 -- a thread holds one channel's quad (channel tid / 32); lane ^ 32 holds the other
-     // channel of the pair.  Sub-dword LDS writes of two lanes of ONE instruction to the same dword are not merged
-     // (one lane's half is dropped), so the pair is brought together first and whole dwords are written:
-     // the even channel's thread writes pixels 0, 1 of the quad, the odd channel's thread pixels 2, 3.
+  {
     const int cr = tid >> 5, rr = TR::RPP + ((tid >> 4) & 1), qx = tid & 15;
     const int gy = y0 - 1 + rr, gx = x0 + 4 * qx;
     const bool ok = gy >= 0 && gy < H && gx < W;
@@ -102,24 +145,13 @@ __device__ __forceinline__ void stage_store_h(unsigned char* __restrict__ tile, 
       const float A = ok ? ab[cr][0] : 0.f, B = ok ? ab[cr][1] : 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) e[j] = silu_f(fmaf(A, e[j], B));
-    }
-    const bool odd = (cr & 1) != 0;
-    // send the two pixels the partner writes, receive the partner's values of the two pixels this thread writes
-    const float s0 = odd ? e[0] : e[2], s1 = odd ? e[1] : e[3];
-    const float p0 = __shfl_xor(s0, 32, 64), p1 = __shfl_xor(s1, 32, 64);
-    const float m0 = odd ? e[2] : e[0], m1 = odd ? e[3] : e[1];
-    const int jb = odd ? 2 : 0;
+    } else if (mul != 1.0f) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float mine = k ? m1 : m0, theirs = k ? p1 : p0;
-      uint32_t hi, lo;
-      split_pair(odd ? theirs : mine, odd ? mine : theirs, hi, lo);  // low half = even channel
-      const int addr = rr * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4;
-      *reinterpret_cast<uint32_t*>(tile + addr) = hi;
-      *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
+      for (int j = 0; j < 4; ++j) e[j] *= mul;
     }
+    hc_store_rem<HC_PLANE>(tile, tid, e);
   }
-  if (tid < HC_LH * 8) {  // halo columns: pixel -1 (phase 3, slot 0) and pixel 64 (phase 0, slot 17), one channel pair per thread
+  if (tid < HC_LH * 8) {
     const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
     float e0 = hreg.x, e1 = hreg.y;
     if (GN) {
@@ -127,12 +159,11 @@ __device__ __forceinline__ void stage_store_h(unsigned char* __restrict__ tile, 
       const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
       e0 = ok ? silu_f(fmaf(ab[2 * cp][0], e0, ab[2 * cp][1])) : 0.f;
       e1 = ok ? silu_f(fmaf(ab[2 * cp + 1][0], e1, ab[2 * cp + 1][1])) : 0.f;
+    } else if (mul != 1.0f) {
+      e0 *= mul;
+      e1 *= mul;
     }
-    uint32_t hi, lo;
-    split_pair(e0, e1, hi, lo);
-    const int addr = hc_addr(r, side ? HC_TW : -1) + cp * 4;
-    *reinterpret_cast<uint32_t*>(tile + addr) = hi;
-    *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
+    hc_store_halo<HC_PLANE>(tile, tid, e0, e1);
   }
 }
 
@@ -224,6 +255,38 @@ __device__ __forceinline__ void load_wa(half8_t (&wa)[3][2], const float* __rest
       const uint4 v = *reinterpret_cast<const uint4*>(tab + ((c * 2 + h) * 64 + lane) * 4);
       wa[c][h] = __builtin_bit_cast(half8_t, v);
     }
+}
+
+// Per-(sample, channel) sum / sum of squares of the workgroup's output: part[i] / part[4 + i] are this lane's partial
+// sums for channel 4 * ((lane / 16) & 1) + i.  Sum over the 16 lanes of a row (same channels, different pixels), then
+// over the two rows that hold the same channels; lane 15 (channels 0..3) and lane 31 (channels 4..7) publish the wave
+// totals, 16 f64 atomics per workgroup.
+__device__ __forceinline__ void hc_stats_commit(float (&part)[8], float (*s_red)[16], double* __restrict__ dstat, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, ch = (lane >> 4) & 1;
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    float x = part[v];
+    x = dpp_add<0x111, 0xf>(x);
+    x = dpp_add<0x112, 0xf>(x);
+    x = dpp_add<0x114, 0xf>(x);
+    x = dpp_add<0x118, 0xf>(x);
+    x += __shfl_xor(x, 32, 64);
+    part[v] = x;
+  }
+  if (lane == 15 || lane == 31) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s_red[wave][4 * ch + i] = part[i];
+      s_red[wave][8 + 4 * ch + i] = part[4 + i];
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < HC_NT / 64; ++w) v += s_red[w][tid];
+    atomicAdd(&dstat[(tid & 7) * 2 + (tid >> 3)], (double)v);
+  }
 }
 
 template <int NSRC, bool GN, bool UP, int RES>
@@ -378,34 +441,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
       }
     }
   }
-  if (a.dstat != nullptr) {
-    // sum over the 16 lanes of a row (same channels, different pixels), then over the two rows that hold the same
-    // channels (g and g ^ 2); lane 15 (channels 0..3) and lane 31 (channels 4..7) publish the wave totals
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      float x = part[v];
-      x = dpp_add<0x111, 0xf>(x);
-      x = dpp_add<0x112, 0xf>(x);
-      x = dpp_add<0x114, 0xf>(x);
-      x = dpp_add<0x118, 0xf>(x);
-      x += __shfl_xor(x, 32, 64);
-      part[v] = x;
-    }
-    if (lane == 15 || lane == 31) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s_red[wave][4 * ch + i] = part[i];
-        s_red[wave][8 + 4 * ch + i] = part[4 + i];
-      }
-    }
-    __syncthreads();
-    if (tid < 16) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NT / 64; ++w) v += s_red[w][tid];
-      atomicAdd(&a.dstat[(size_t)n * 16 + (tid & 7) * 2 + (tid >> 3)], (double)v);
-    }
-  }
+  if (a.dstat != nullptr) hc_stats_commit(part, s_red, a.dstat + (size_t)n * 16, tid);
 }
 
 // Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 tables of HC_WTAB dwords + 64 floats (1 / scale).

@@ -81,6 +81,8 @@ struct LatentArgs {
   double* hs0_stat;      // [n][8][2], zeroed by the caller
   const float* wc5; const float* wc1; const float* bring; const float* bsum;
   const float* wx;       // prepared conv_in x-part [C][9][8]
+  const float* wc5h;     // fp16 hi/lo tables of wc5 + scale (latenth_kernels.h)
+  const float* wxh;      // fp16 hi/lo tables of the conv_in x-part, same scale
   const float* noise;    // [n][C][H][W] explicit eps (NOISE == 1)
   const float* sched;    // device [5] row of this timestep
   double inv_cnt;        // 1 / (2*H*W)

@@ -1,0 +1,373 @@
+// Latent sampler step (latent_kernels.h: conv_out -> ancestral update -> conv_in of one step, collapsed by linearity)
+// on the f16 matrix pipe with fp16 hi/lo operand splits -- the arithmetic and LDS layout of conv8h_kernels.h.
+//
+//   hs0_{t-1} = k + c2*(hs0_t - k) + c1*[ Wc5 (*) A_t + bsum + fix ] + s*( W_x (*) eps_t )
+//
+// Phase 2 (5x5 composite, 8 -> 8): a row pair sees a 6x5 window = 30 taps = 8 MFMAs of 4 taps x 8 channels (the last
+// two tap slots carry zero weights); phase 3 (3x3, C -> 8 on the noise field, 8 channels per pass through LDS) is
+// conv8h's inner loop unchanged.  Per tile-wave: 192 + C/8 * 72 MFMAs of 16 cycles instead of 1600 + C/8 * 576 fp32
+// MFMAs of ~9 cycles, and they no longer compete with the Philox / Box-Muller VALU work for the issue port.
+#pragma once
+#include "conv8h_kernels.h"
+#include "latent_kernels.h"
+
+namespace gc {
+
+constexpr int HL_LH5 = HC_TH + 4;            // 20 tile rows (2-pixel halo)
+constexpr int HL_PLANE5 = HL_LH5 * HC_ROW;   // 23040 bytes per hi / lo plane
+constexpr int HL_W5TAB = 8 * 2 * 64 * 4;     // dwords: [c 8][hi/lo][lane][4], then 64 floats (even 1/scale, odd scale)
+
+// fp16 hi/lo A-operand tables of the composite kernel and of conv_in's x part, with ONE power-of-two scale (both
+// accumulate into the same registers).  wc5: prepared [8 i][25 d][8 o] (prep_latent_kernel, same stream, earlier).
+__global__ __launch_bounds__(256) void prep_latent_h_kernel(const float* __restrict__ wc5, const float* __restrict__ w_in /*[8][C+2][3][3]*/,
+                                                           float* __restrict__ dst5, float* __restrict__ dstx, int C) {
+  __shared__ float s_max[256];
+  const int tid = threadIdx.x;
+  const int CI = C + 2;
+  float m = 0.f;
+  for (int i = tid; i < 1600; i += 256) m = fmaxf(m, fabsf(wc5[i]));
+  for (int i = tid; i < 8 * C * 9; i += 256) {
+    const int o = i / (C * 9), rem = i - o * C * 9;
+    m = fmaxf(m, fabsf(w_in[((size_t)o * CI + 2) * 9 + rem]));
+  }
+  s_max[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_max[tid] = fmaxf(s_max[tid], s_max[tid + s]);
+    __syncthreads();
+  }
+  const float wmax = s_max[0];
+  int ex = 0;
+  if (wmax > 0.f) (void)frexpf(wmax, &ex);
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
+  auto pack = [&](float x0, float x1, int h) {
+    uint16_t v[2];
+    const float xs[2] = {x0 * scale, x1 * scale};
+    for (int e = 0; e < 2; ++e) {
+      const _Float16 hi = (_Float16)xs[e];
+      const _Float16 lo = (_Float16)(xs[e] - (float)hi);
+      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    }
+    return (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+  };
+  uint32_t* __restrict__ o5 = reinterpret_cast<uint32_t*>(dst5);
+  for (int i = tid; i < HL_W5TAB; i += 256) {
+    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, c = i >> 9;
+    const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
+    const int t = 4 * c + kg, dyp = t / 5, dx = t - 5 * dyp, dy = dyp - r;
+    const bool live = t < 30 && dy >= 0 && dy <= 4;
+    const float x0 = live ? wc5[((2 * d) * 25 + dy * 5 + dx) * 8 + oc] : 0.f;
+    const float x1 = live ? wc5[((2 * d + 1) * 25 + dy * 5 + dx) * 8 + oc] : 0.f;
+    o5[i] = pack(x0, x1, h);
+  }
+  if (tid < 64) dst5[HL_W5TAB + tid] = (tid & 1) ? scale : 1.0f / scale;
+  uint32_t* __restrict__ ox = reinterpret_cast<uint32_t*>(dstx);
+  for (int i = tid; i < (C / 8) * HC_WTAB; i += 256) {
+    const int s = i / HC_WTAB, rem = i - s * HC_WTAB;
+    const int d = rem & 3, l = (rem >> 2) & 63, h = (rem >> 8) & 1, c = rem >> 9;
+    const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
+    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
+    const bool live = dy >= 0 && dy <= 2;
+    const int ic = 2 + s * 8 + 2 * d;
+    const float x0 = live ? w_in[(((size_t)oc * CI + ic) * 3 + dy) * 3 + dx] : 0.f;
+    const float x1 = live ? w_in[(((size_t)oc * CI + ic + 1) * 3 + dy) * 3 + dx] : 0.f;
+    ox[i] = pack(x0, x1, h);
+  }
+}
+
+// value of channel i at (tile row, pixel px in -2..65) of the 20-row A' tile: hi + lo
+__device__ __forceinline__ float hl_tile_value(const unsigned char* tile, int row, int px, int i) {
+  const int addr = hc_addr(row, px) + 2 * i;
+  const _Float16 h = *reinterpret_cast<const _Float16*>(tile + addr);
+  const _Float16 l = *reinterpret_cast<const _Float16*>(tile + HL_PLANE5 + addr);
+  return (float)h + (float)l;
+}
+
+// Border correction of one output row strip (row gy, pixels gx..gx+3, channels oc0..oc0+3) -- the terms of the 5x5
+// composite that would pass through x0_hat positions outside the image (latent_kernels.h, phase 2b, same algebra).
+__device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const unsigned char* tile, float (&fix)[4][4], int gy, int gx,
+                                              int trow /* gy - y0 */, int px0 /* gx - x0 */, int oc0, float c1) {
+  const int H = a.H, W = a.W;
+  const bool mine = gy < H && gx < W && (gy == 0 || gy == H - 1 || gx == 0 || gx + 4 >= W);
+  if (!__any(mine)) return;
+#pragma unroll 1
+  for (int t1 = 0; t1 < 9; ++t1) {
+    const int t1y = t1 / 3, t1x = t1 - t1y * 3;
+    const int qy = gy + t1y - 1;
+    bool outp[4];
+    bool anyo = false;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int qx = gx + p + t1x - 1;
+      outp[p] = mine && (gx + p < W) && (qy < 0 || qy >= H || qx < 0 || qx >= W);
+      anyo |= outp[p];
+    }
+    if (!__any(anyo)) continue;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float b = a.bring[t1 * 8 + oc0 + o] * c1;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) fix[o][p] -= outp[p] ? b : 0.f;
+    }
+#pragma unroll 1
+    for (int t2 = 0; t2 < 9; ++t2) {
+      const int t2y = t2 / 3, t2x = t2 - t2y * 3;
+      const int ry = qy + t2y - 1;
+      bool inp[4];
+      bool anyi = false;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int rx = gx + p + t1x + t2x - 2;
+        inp[p] = outp[p] && ry >= 0 && ry < H && rx >= 0 && rx < W;
+        anyi |= inp[p];
+      }
+      if (!__any(anyi)) continue;
+      const float* __restrict__ w = a.wc1 + (t1 * 9 + t2) * 64;
+#pragma unroll 2
+      for (int i = 0; i < 8; ++i) {
+        float av[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)  // always inside the halo-2 tile
+          av[p] = inp[p] ? hl_tile_value(tile, trow + t1y + t2y, px0 + p + t1x + t2x - 2, i) : 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const float wv = w[i * 8 + oc0 + o];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) fix[o][p] = fmaf(-wv, av[p], fix[o][p]);
+        }
+      }
+    }
+  }
+}
+
+template <int NOISE>
+__global__ __launch_bounds__(HC_NT, 2) void latent_step_h_kernel(const LatentArgs a) {
+  constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
+  __shared__ __align__(16) unsigned char tile[2 * HL_PLANE5];
+  __shared__ float s_ab[8][2];
+  __shared__ float s_red[NT / 64][16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int H = a.H, W = a.W;
+  const unsigned plane = (unsigned)(H * W);
+  const float c1 = a.sched[2], c2 = a.sched[3], sg = a.sched[4];
+  const int ln = lane & 15, g = lane >> 4, ch = g & 1, rr = g >> 1;
+  const int gx = x0 + 4 * ln;
+  const int gy0 = y0 + 4 * wave + rr;
+  const bool wave_live = y0 + 4 * wave < H;
+
+  // ---------------- phase 1: A' = c1 * SiLU(GN(a)) with a 2-pixel halo -> LDS (fp16 hi / lo) ----------------
+  const float* __restrict__ ap = a.a_src + (size_t)n * 8 * plane;
+  float4 qm[8], qr[2];
+  float hh[2][2];
+  const int r0 = tid >> 4, qx = tid & 15;
+  const bool ok_m = (y0 - 2 + r0) >= 0 && (y0 - 2 + r0) < H && (x0 + 4 * qx) < W;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    qm[c] = ok_m ? *reinterpret_cast<const float4*>(ap + ((unsigned)c * plane + (unsigned)(y0 - 2 + r0) * (unsigned)W + (unsigned)(x0 + 4 * qx)))
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  // rows 16..19: thread = (row 16 + (tid & 63) / 16, quad tid % 16, channel pair tid / 64)
+  const int rrow = TH + ((tid & 63) >> 4), cpr = tid >> 6;
+  const bool ok_r = (y0 - 2 + rrow) >= 0 && (y0 - 2 + rrow) < H && (x0 + 4 * qx) < W;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    qr[k] = ok_r ? *reinterpret_cast<const float4*>(ap + ((unsigned)(2 * cpr + k) * plane + (unsigned)(y0 - 2 + rrow) * (unsigned)W + (unsigned)(x0 + 4 * qx)))
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  // halo columns x0-2, x0-1, x0+64, x0+65: item = (row idx / 16, column (idx / 4) & 3, channel pair idx & 3), 320 items
+  bool ok_h[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + j * NT;
+    const int cp = idx & 3, s = (idx >> 2) & 3, r = idx >> 4;
+    const int gy = y0 - 2 + r, gxh = s < 2 ? x0 - 2 + s : x0 + TW + (s - 2);
+    ok_h[j] = idx < HL_LH5 * 16 && gy >= 0 && gy < H && gxh >= 0 && gxh < W;
+    hh[j][0] = hh[j][1] = 0.f;
+    if (ok_h[j]) {
+      hh[j][0] = ap[(unsigned)(2 * cp) * plane + (unsigned)gy * (unsigned)W + (unsigned)gxh];
+      hh[j][1] = ap[(unsigned)(2 * cp + 1) * plane + (unsigned)gy * (unsigned)W + (unsigned)gxh];
+    }
+  }
+  if (tid < 8) {
+    float A, B;
+    gn_coeff(a.a_stat + (size_t)n * 16, tid, 2, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
+    s_ab[tid][0] = A;
+    s_ab[tid][1] = B;
+  }
+  __syncthreads();
+  auto act = [&](int c, float v, bool ok) { return ok ? c1 * silu_f(fmaf(s_ab[c][0], v, s_ab[c][1])) : 0.f; };
+  {
+    float e[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      e[c][0] = act(c, qm[c].x, ok_m); e[c][1] = act(c, qm[c].y, ok_m); e[c][2] = act(c, qm[c].z, ok_m); e[c][3] = act(c, qm[c].w, ok_m);
+    }
+    hc_store_main<HL_PLANE5>(tile, r0, qx, e);
+  }
+  {
+    const float e0[4] = {qr[0].x, qr[0].y, qr[0].z, qr[0].w}, e1[4] = {qr[1].x, qr[1].y, qr[1].z, qr[1].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t hi, lo;
+      split_pair(act(2 * cpr, e0[j], ok_r), act(2 * cpr + 1, e1[j], ok_r), hi, lo);
+      const int addr = rrow * HC_ROW + j * HC_PHASE + (qx + 1) * 16 + cpr * 4;
+      *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+      *reinterpret_cast<uint32_t*>(tile + HL_PLANE5 + addr) = lo;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + j * NT;
+    if (idx < HL_LH5 * 16) {
+      const int cp = idx & 3, s = (idx >> 2) & 3, r = idx >> 4;
+      uint32_t hi, lo;
+      split_pair(act(2 * cp, hh[j][0], ok_h[j]), act(2 * cp + 1, hh[j][1], ok_h[j]), hi, lo);
+      const int addr = hc_addr(r, s < 2 ? s - 2 : TW + (s - 2)) + cp * 4;
+      *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+      *reinterpret_cast<uint32_t*>(tile + HL_PLANE5 + addr) = lo;
+    }
+  }
+  // eps chunk 0 is requested now so that it arrives during the composite phase
+  const float* __restrict__ np_ = NOISE == 1 ? a.noise + (size_t)n * a.C * plane : nullptr;
+  TileRegs<TW, TH, NT, 8> R;
+  float2 hreg = make_float2(0.f, 0.f);
+  if (NOISE == 1) {
+    stage_load<TW, TH, NT, 8, false>(R, np_, plane, W, H, W, x0, y0, tid);
+    hreg = halo_load_h<false>(np_, plane, W, H, W, x0, y0, tid);
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: 5x5 composite on the f16 matrix pipe ----------------
+  const float inv_s = a.wc5h[HL_W5TAB], sc = a.wc5h[HL_W5TAB + 1];
+  f32x4 acc[2][4];
+  {
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bsum + 4 * ch);
+    const float k = c1 * sc;
+    const f32x4 b0 = {b4.x * k, b4.y * k, b4.z * k, b4.w * k};  // + c1 * bsum, in accumulator units
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = b0;
+  }
+  if (wave_live) {
+    static_for<0, 8>([&](auto CC) {
+      constexpr int c = decltype(CC)::value;
+      const int t = min(4 * c + g, 29);  // tap slots 30, 31 carry zero weights: any valid address
+      const int dyp = t / 5, dx = t - 5 * dyp;
+      const uint4 w0 = *reinterpret_cast<const uint4*>(a.wc5h + ((c * 2 + 0) * 64 + lane) * 4);
+      const uint4 w1 = *reinterpret_cast<const uint4*>(a.wc5h + ((c * 2 + 1) * 64 + lane) * 4);
+      const half8_t wa0 = __builtin_bit_cast(half8_t, w0), wa1 = __builtin_bit_cast(half8_t, w1);
+      const int base = (4 * wave + dyp) * HC_ROW + (ln + 1) * 16;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        half8_t bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int po = j + dx - 2;  // pixel 4*ln + po
+          const int addr = base + p * 2 * HC_ROW + (po & 3) * HC_PHASE + (po >> 2) * 16;
+          bh[j] = *reinterpret_cast<const half8_t*>(tile + addr);
+          bl[j] = *reinterpret_cast<const half8_t*>(tile + HL_PLANE5 + addr);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bh[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bl[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, bh[j], acc[p][j], 0, 0, 0);
+      }
+    });
+  }
+
+  // ---------------- phase 2b: border fix (lanes whose strips touch the image border) ----------------
+  float fix[2][4][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fix[p][i][j] = 0.f;
+  if (wave_live) {
+    hl_border_fix(a, tile, fix[0], gy0, gx, gy0 - y0, gx - x0, 4 * ch, c1);
+    hl_border_fix(a, tile, fix[1], gy0 + 2, gx, gy0 + 2 - y0, gx - x0, 4 * ch, c1);
+  }
+
+  // ---------------- phase 3: s * (W_x (*) eps), eps in chunks of 8 channels through LDS ----------------
+  int off[4][3];
+  hc_lane_offsets(off, wave, lane);
+  const int nchunk = a.C / 8;
+#pragma unroll 1
+  for (int cc = 0; cc < nchunk; ++cc) {
+    __syncthreads();  // previous LDS contents (A' tile / previous chunk) are no longer read
+    half8_t wa[3][2];
+    load_wa(wa, a.wxh + (size_t)cc * HC_WTAB, lane);
+    if (NOISE == 1) {
+      stage_store_h<false>(tile, R, hreg, H, W, x0, y0, nullptr, tid, sg);
+      if (cc + 1 < nchunk) {
+        stage_load<TW, TH, NT, 8, false>(R, np_ + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
+        hreg = halo_load_h<false>(np_ + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
+      }
+    } else {
+      // canonical Philox field: one call per aligned quad (counter = element index of the quad's first pixel,
+      // component = pixel within the quad) -- the field the direct sampler's conv_out epilogue draws
+      auto gen_quad = [&](int c, int r, int q, float (&z)[4]) {
+        const int gy2 = y0 - 1 + r, gx2 = x0 + 4 * q;
+        z[0] = z[1] = z[2] = z[3] = 0.f;
+        if (gy2 >= 0 && gy2 < H && gx2 >= 0 && gx2 < W) {
+          normal4((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + c) * plane + (size_t)gy2 * W + gx2), a.stream_id, a.seed, z);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) z[j] *= sg;
+        }
+      };
+      {
+        float e[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) gen_quad(c, r0, qx, e[c]);
+        hc_store_main<HC_PLANE>(tile, r0, qx, e);
+      }
+      {
+        float e[4];
+        gen_quad(tid >> 5, TH + ((tid >> 4) & 1), qx, e);
+        hc_store_rem<HC_PLANE>(tile, tid, e);
+      }
+      if (tid < HC_LH * 8) {
+        const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
+        float z0[4], z1[4];  // the aligned quad that owns the halo pixel: x0-4..x0-1 (component 3) or x0+64.. (component 0)
+        gen_quad(2 * cp, r, side ? 16 : -1, z0);
+        gen_quad(2 * cp + 1, r, side ? 16 : -1, z1);
+        hc_store_halo<HC_PLANE>(tile, tid, side ? z0[0] : z0[3], side ? z1[0] : z1[3]);
+      }
+    }
+    __syncthreads();
+    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+  }
+
+  // ---------------- epilogue: combine, store in place, statistics for the next GroupNorm ----------------
+  float part[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[i] = 0.f;
+  if (wave_live) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int gy = gy0 + 2 * p;
+      if (gy < H && gx + 3 < W) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const size_t e = ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * W + gx;
+          const float4 k4 = *reinterpret_cast<const float4*>(a.kmap + e);
+          const float4 h4 = *reinterpret_cast<const float4*>(a.hs0 + e);
+          const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = kk[j] + c2 * (hv[j] - kk[j]) + fmaf(acc[p][j][i], inv_s, fix[p][i][j]);
+          *reinterpret_cast<float4*>(a.hs0 + e) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { part[i] += v[j]; part[4 + i] = fmaf(v[j], v[j], part[4 + i]); }
+        }
+      }
+    }
+  }
+  hc_stats_commit(part, s_red, a.hs0_stat + (size_t)n * 16, tid);
+}
+
+}  // namespace gc

@@ -5,6 +5,7 @@
 #include "attn_kernels.h"
 #include "conv8h_kernels.h"
 #include "latent_kernels.h"
+#include "latenth_kernels.h"
 #include "unet_kernels.h"
 #include "unet_plan.h"
 
@@ -222,10 +223,15 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   a.hs0 = c.tensor_ptr(p.hs0_tensor); a.hs0_stat = c.stat_ptr(p.hs0_tensor);
   a.wc5 = P + p.p_wc5; a.wc1 = P + p.p_wc1; a.bring = P + p.p_bring; a.bsum = P + p.p_bsum;
   a.wx = P + p.conv_in.p_w + 144;
+  a.wc5h = P + p.p_wc5h; a.wxh = P + p.p_wxh;
   a.noise = noise; a.sched = sched_row; a.inv_cnt = 1.0 / (2.0 * c.H * c.W);
   a.seed = seed; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
   TimedLaunch tl(KF_LATENT_STEP, c.st);
-  if (pick_tile(c.n, c.H, c.W) == TILE_64x16) {
+  if (pick_tile(c.n, c.H, c.W) == TILE_64x16 && conv8_split_mode()) {
+    const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
+    if (noise) latent_step_h_kernel<1><<<grid, 256, 0, c.st>>>(a);
+    else latent_step_h_kernel<2><<<grid, 256, 0, c.st>>>(a);
+  } else if (pick_tile(c.n, c.H, c.W) == TILE_64x16) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
     if (noise) latent_step_kernel<64, 16, 1><<<grid, 256, 0, c.st>>>(a);
     else latent_step_kernel<64, 16, 2><<<grid, 256, 0, c.st>>>(a);
@@ -273,6 +279,7 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
     PrepLatentArgs la{raw + p.conv_in.w, raw + p.conv_out.w, raw + p.conv_out.b, prepared + p.p_wc5, prepared + p.p_wc1,
                       prepared + p.p_bring, prepared + p.p_bsum, p.C};
     prep_latent_kernel<<<cdiv(1600 + 5184 + 72 + 8, 256), 256, 0, st>>>(la);
+    prep_latent_h_kernel<<<1, 256, 0, st>>>(prepared + p.p_wc5, raw + p.conv_in.w, prepared + p.p_wc5h, prepared + p.p_wxh, p.C);
   }
   GC_HIP(hipGetLastError());
   return GC_OK;

@@ -1,0 +1,105 @@
+"""The 8 -> 8 channel 3x3 convolution kernels of the UNet, one layer at a time through the C ABI
+(gencomm_conv8_fwd), and the whole path with the 64x16-tile kernels forced onto the small golden cases.
+
+Two kernels implement these layers (csrc/unet_kernels.h conv8_kernel: exact fp32 on v_mfma_f32_4x4x1;
+csrc/conv8h_kernels.h conv8h_kernel: fp16 hi/lo operand split on v_mfma_f32_16x16x32_f16, fp32-grade
+products). Both must meet the same bar: rtol 1e-4 / atol 1e-5 against the reference's golden vectors, and for a
+single layer 2e-5 absolute against a float64 convolution of O(1) data. Launches with several workgroups per CU
+are part of the matrix on purpose: a scheduling-dependent fault of an early conv8h_kernel only showed there.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, build_inputs, build_modules, eval_noise, load_case, sub
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _env(monkeypatch):
+    monkeypatch.delenv("GENCOMM_CONV8", raising=False)
+    monkeypatch.delenv("GENCOMM_CONV8H_MASK", raising=False)
+    monkeypatch.delenv("GENCOMM_TILE_WANT", raising=False)
+
+
+def _conv8(x, w, b, split):
+    from gencomm_amd import _lib
+    from gencomm_amd.runtime import ptr, stream_ptr
+    n, _, H, W = x.shape
+    y = torch.full_like(x, float("nan"))
+    st = torch.zeros(n, 8, 2, dtype=torch.float64, device=DEV)
+    scratch = torch.zeros(4096, device=DEV)
+    _lib.check(_lib.lib().gencomm_conv8_fwd(ptr(x), ptr(w), ptr(b), ptr(y), ptr(st), ptr(scratch), n, H, W, split,
+                                            stream_ptr(DEV)), "gencomm_conv8_fwd")
+    torch.cuda.synchronize()
+    return y, st
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 32, 64), (3, 18, 26), (2, 50, 130), (64, 64, 128), (4, 200, 704), (16, 100, 352)])
+def test_single_layer_vs_float64(monkeypatch, shape, split):
+    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")  # 64x16 tiles whatever the size (ragged widths take the scalar staging)
+    n, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(100 + n + H)
+    x = torch.randn(n, 8, H, W, generator=g, device=DEV)
+    w = torch.randn(8, 8, 3, 3, generator=g, device=DEV) * 0.2
+    b = torch.randn(8, generator=g, device=DEV)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    y0, st0 = _conv8(x, w, b, split)
+    assert float((y0.double() - ref).abs().max()) < 2e-5
+    s_ref = torch.stack([ref.sum(dim=(2, 3)), (ref * ref).sum(dim=(2, 3))], dim=-1)
+    assert float(((st0 - s_ref).abs() / (s_ref.abs() + 1.0)).max()) < 1e-5
+    for _ in range(2):  # bit-identical from launch to launch (statistics: f64 atomics, order-dependent in the last bits)
+        y1, _ = _conv8(x, w, b, split)
+        assert torch.equal(y0, y1)
+
+
+def test_split_operands_cover_the_fp16_range(monkeypatch):
+    """Tiny and large weights / activations: the power-of-two weight scale keeps low parts normal; activations far below
+    1 lose only absolute accuracy (fp16 subnormal steps of 6e-8)."""
+    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
+    g = torch.Generator(device=DEV).manual_seed(7)
+    for wscale, xscale in [(1e-3, 1.0), (30.0, 1.0), (0.2, 1e-3), (0.2, 200.0)]:
+        x = torch.randn(2, 8, 32, 64, generator=g, device=DEV) * xscale
+        w = torch.randn(8, 8, 3, 3, generator=g, device=DEV) * wscale
+        b = torch.zeros(8, device=DEV)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None, padding=1)
+        y, _ = _conv8(x, w, b, 1)
+        tol = 1e-5 * wscale * max(xscale, 1.0) * 10 + 2e-6 * float(ref.abs().max())
+        assert float((y.double() - ref).abs().max()) < tol, (wscale, xscale)
+
+
+@pytest.mark.parametrize("mode", ["f32", "split"])
+@pytest.mark.parametrize("name", ["tiny", "ragged", "mid", "shipped"])
+def test_golden_path_with_64x16_tiles_forced(monkeypatch, name, mode):
+    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
+    monkeypatch.setenv("GENCOMM_CONV8", mode)
+    g = load_case(name)
+    _, gen, _ = build_modules(g, "cuda:0")
+    inp = build_inputs(g, "cuda:0")
+    with torch.no_grad():
+        pred = gen(inp["feat"], inp["cond"], inp["record_len"], noise=eval_noise(g, "cuda:0"))["pred_feature"]
+    assert_close(sub(pred, int(g["stride"])), g["pred_feature"], 1e-4, 1e-5, f"pred_feature ({mode}, forced tiles)")
+
+
+def test_full_size_unet_call_modes_agree_and_repeat(monkeypatch):
+    from gencomm_amd import GenComm, synth
+    gen = GenComm(synth.default_gencomm_cfg(64, 20)).eval()
+    synth.fill_params_(gen, 0)
+    gen = gen.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(8, 66, 200, 704, generator=g, device=DEV)
+    t = torch.full((8,), 7.0, device=DEV)
+    ys = {}
+    for mode in ("f32", "split", "split"):
+        monkeypatch.setenv("GENCOMM_CONV8", mode)
+        with torch.no_grad():
+            y = gen.denoiser(x, t, T=20).clone()
+        if mode in ys:
+            assert float((y - ys[mode]).abs().max()) < 1e-6  # GroupNorm statistics: f64 atomics in any order
+        ys[mode] = y
+    assert float((ys["f32"] - ys["split"]).abs().max()) < 2e-5
