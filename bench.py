@@ -38,8 +38,11 @@ PX_M = 0.4           # metres per BEV pixel at 200x704 (OPV2V range +-140.8 x +-
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 
-# dominant kernel (profiles/r1_bench_default_kernel_stats.csv: 22 % of kernel time): family id in the library's timer
+# dominant kernel (profiles/r1_bench_default_kernel_stats.csv: 19 % of kernel time, the largest single kernel): family id
+# in the library's timer.  The 8-channel convolutions together are 59 % (five conv8h_kernel variants): the largest of
+# them, the 16 -> 8 layers (family 2), is reported beside it against the HBM roof in a separate pass.
 DOMINANT = {"family": 15, "name": "latent_step_kernel"}
+SECONDARY_FAMILY = 2
 
 
 def algorithmic_work(N, C, HW, T):
@@ -132,7 +135,7 @@ def main():
     ap.add_argument("--no-enhancer", action="store_true")
     ap.add_argument("--timer-family", type=int, default=DOMINANT["family"])
     ap.add_argument("--batch", type=int, default=4, help="scenes per step (batched in one launch sequence, record_len=[N]*B)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
     args = ap.parse_args()
 
@@ -203,6 +206,14 @@ def main():
                 pipes[0].run(scenes[0][0], scenes[0][1], seed=3000 + i)
             torch.cuda.synchronize(device)
             _lib.check(lib.gencomm_timer_stop(ctypes.byref(iso_ms), ctypes.byref(iso_n)), "gencomm_timer_stop")
+    sec_ms, sec_n = ctypes.c_double(0.0), ctypes.c_int(0)
+    if timed:
+        with torch.no_grad():  # same single-stream pass for the 16 -> 8 channel layers (HBM-bound)
+            _lib.check(lib.gencomm_timer_start(SECONDARY_FAMILY, 4 * (T + 4) * 16), "gencomm_timer_start")
+            for i in range(2):
+                pipes[0].run(scenes[0][0], scenes[0][1], seed=3100 + i)
+            torch.cuda.synchronize(device)
+            _lib.check(lib.gencomm_timer_stop(ctypes.byref(sec_ms), ctypes.byref(sec_n)), "gencomm_timer_stop")
     for pipe in pipes:
         assert torch.isfinite(pipe.fused).all(), "non-finite output"
 
@@ -257,10 +268,28 @@ def main():
                                             "achieved": fl / (per_launch_ms * 1e-3) / 1e12,
                                             "frac": fl / (per_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                                             "note": f"event pairs with {S} streams sharing the chip: includes queueing behind the other stream"},
-                        "note": "latent_step_kernel = conv_out + sampler update + conv_in of one step fused by linearity; "
-                                "executed FLOPs = 2*(1600 + 72*C) per agent-pixel; v_mfma_f32_4x4x1 (exact fp32) priced against "
-                                "the 157.3 TFLOP/s fp32 matrix/vector peak; duration = HIP events on the launch stream, one "
-                                "scene batch in flight (agrees with the rocprofv3 --kernel-trace --stats average)"}
+                        "note": "latent_step_h_kernel = conv_out + sampler update + conv_in of one step fused by linearity; "
+                                "algorithmic FLOPs = 2*(1600 + 72*C) per agent-pixel, priced against the 157.3 TFLOP/s fp32 "
+                                "matrix/vector peak (the dtype of the path). The products run on the f16 matrix pipe from exact "
+                                "fp16 hi/lo operand splits (3 v_mfma_f32_16x16x32_f16 per fp32 product block, fp32 accumulate, "
+                                "22-bit products: same parity tolerance as the exact-fp32 kernel, GENCOMM_CONV8=f32); the kernel "
+                                "is now bound by the in-kernel Philox4x32-10 + Box-Muller VALU work, not by the matrix pipe. "
+                                "duration = HIP events on the launch stream, one scene batch in flight (agrees with the "
+                                "rocprofv3 --kernel-trace --stats average)"}
+                if sec_n.value > 0:
+                    # 16 -> 8 channel layers (conv1 of the up blocks): per UNet call 3 launches per level, level l at 1/4^l of the
+                    # pixels; algorithmic bytes = read 16 channels + write 8 channels, fp32
+                    L = len(gen.denoiser.ch_mult) if hasattr(gen.denoiser, "ch_mult") else 2
+                    lvl = sum(0.25 ** l for l in range(L)) / L
+                    bytes_launch = 4.0 * 24 * HW * N * B * lvl
+                    s_ms = sec_ms.value / sec_n.value
+                    out["roofline_conv16"] = {
+                        "kernel": "conv8h_kernel<NSRC=2> (16 -> 8 ch 3x3 + GroupNorm + SiLU, all levels)", "bound": "hbm",
+                        "achieved": bytes_launch / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_launch / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "launches": sec_n.value, "avg_launch_ms": s_ms, "bytes_per_launch_avg": bytes_launch,
+                        "note": "average over the launches of one scene batch (full- and half-resolution levels); algorithmic "
+                                "bytes = 4 B * (16 read + 8 written channels) * pixels * agents"}
             else:
                 roof = {"kernel": name, "launches": k_n.value, "avg_launch_ms": per_launch_ms}
         out["roofline"] = roof
