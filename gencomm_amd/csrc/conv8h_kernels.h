@@ -350,6 +350,24 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
 
   if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[0], tid);
   else stage_tile_scalar_h<GN, UP>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
+  // identity residual: requested once the staging registers are free, so that it arrives during the matrix phase
+  float resv[RES == 1 ? 2 : 1][4][4];
+  if (RES == 1 && wave_live) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gy = gy0 + 2 * p;
+        const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
+        if (vec_ok && gy < a.H) {
+          const float4 r = *reinterpret_cast<const float4*>(rp);
+          resv[p][i][0] = r.x; resv[p][i][1] = r.y; resv[p][i][2] = r.z; resv[p][i][3] = r.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) resv[p][i][j] = (gy < a.H && gx + j < a.W) ? rp[j] : 0.f;
+        }
+      }
+  }
   if (NSRC == 2 && wvec) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
     stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
@@ -369,24 +387,6 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) part[i] = 0.f;
   if (wave_live) {
-    // identity residual: requested here, behind the matrix phase, so that its 32 registers are not live across it
-    float resv[RES == 1 ? 2 : 1][4][4];
-    if (RES == 1) {
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int gy = gy0 + 2 * p;
-          const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
-          if (vec_ok && gy < a.H) {
-            const float4 r = *reinterpret_cast<const float4*>(rp);
-            resv[p][i][0] = r.x; resv[p][i][1] = r.y; resv[p][i][2] = r.z; resv[p][i][3] = r.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) resv[p][i][j] = (gy < a.H && gx + j < a.W) ? rp[j] : 0.f;
-          }
-        }
-    }
     float out[2][4][4];  // [row pair][channel i][pixel j]
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
         for (int j = 0; j < 4; ++j) out[p][i][j] = RES == 1 ? fmaf(acc[p][j][i], inv_s, resv[p][i][j]) : acc[p][j][i] * inv_s;
 
     if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
-#pragma unroll 2
+#pragma unroll 4
       for (int c = 0; c < 16; ++c) {
         const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + c * 8 + 4 * ch);
         const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
