@@ -313,6 +313,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   const bool vec_ok = (gx + 3 < a.W) && ((a.W & 3) == 0);
   const bool wave_live = y0 + 4 * wave < a.H;
 
+  GC_STAMP(0);
   half8_t wa[3][2];
   load_wa(wa, a.wh, lane);
   const float inv_s = a.wh[NSRC * HC_WTAB];  // one scale for the whole (concatenated) weight tensor
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
     __syncthreads();
   }
 
+  GC_STAMP(1);
   int off[4][3];
   hc_lane_offsets(off, wave, lane);
   // the accumulators start at bias * scale (exact: the scale is a power of two), so the epilogue is one multiply
@@ -373,7 +375,9 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   }
   __syncthreads();
+  GC_STAMP(2);
   if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+  GC_STAMP(3);
   if (NSRC == 2) {
     load_wa(wa, a.wh + HC_WTAB, lane);
     __syncthreads();
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
     if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
   }
 
+  GC_STAMP(4);
   float part[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) part[i] = 0.f;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
         for (int j = 0; j < 4; ++j) out[p][i][j] = RES == 1 ? fmaf(acc[p][j][i], inv_s, resv[p][i][j]) : acc[p][j][i] * inv_s;
 
     if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
-#pragma unroll 4
+#pragma unroll 8
       for (int c = 0; c < 16; ++c) {
         const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + c * 8 + 4 * ch);
         const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
@@ -441,7 +446,9 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
       }
     }
   }
+  GC_STAMP(5);
   if (a.dstat != nullptr) hc_stats_commit(part, s_red, a.dstat + (size_t)n * 16, tid);
+  GC_STAMP(6);
 }
 
 // Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 tables of HC_WTAB dwords + 64 floats (1 / scale).
