@@ -18,17 +18,19 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // smaller still run 32x8 px / 256 threads / ONE pixel per lane, which has 4x the waves and a
 // quarter of the serial work per wave (these layers are latency-bound, not throughput-bound).
 enum TileCfg { TILE_64x16 = 0, TILE_32x16 = 1, TILE_32x8 = 2 };
-inline long long tile_want() {
-  // tuning / test hook (GENCOMM_TILE_WANT): minimum number of workgroups before a larger tile is chosen; read per call
-  // so that one test process can force the 64x16 kernels onto small maps
-  const char* e = getenv("GENCOMM_TILE_WANT");
-  return e ? atoll(e) : 512LL;
-}
 // GENCOMM_CONV8 = "split" (default): 64x16 tiles of the 8-channel convolutions run conv8h_kernel (fp16 hi/lo split on
 // the f16 matrix pipe, fp32-grade products); "f32": the exact-fp32 conv8_kernel everywhere.  Read per call.
 inline bool conv8_split_mode() {
   const char* e = getenv("GENCOMM_CONV8");
   return !(e && strcmp(e, "f32") == 0);
+}
+inline long long tile_want() {
+  // minimum number of 64x16 workgroups before the 64x16-tile kernels are chosen.  512 for the fp32 kernels (two
+  // workgroups per CU); 160 for the f16-pipe kernels, whose workgroups are short enough that a partly filled chip beats
+  // the smaller fp32 tiles (1 scene x 1 stream 80.9 -> 86.4 scenes/s, 2 x 2 131.6 -> 141.3, 4 x 3 unchanged).
+  // GENCOMM_TILE_WANT overrides (tuning / tests: 1 forces the 64x16 kernels onto small maps); read per call.
+  const char* e = getenv("GENCOMM_TILE_WANT");
+  return e ? atoll(e) : (conv8_split_mode() ? 160LL : 512LL);
 }
 inline TileCfg pick_tile(int n, int H, int W, int zmul = 1) {
   const long long want = tile_want();
