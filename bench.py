@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="scenes per step (batched in one launch sequence, record_len=[N]*B)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the scene's launch sequence as a captured HIP graph")
     args = ap.parse_args()
 
     from gencomm_amd import dist as gdist
@@ -164,7 +165,7 @@ def main():
     scenes, pipes = [], []
     for si in range(S):
         feat, cond, ptm = make_scene(N, C, H, W, 1 + rank * S + si, device, B)
-        pipe = ScenePipeline(gen, None if args.no_enhancer else enh, [N] * B, C, H, W, device)
+        pipe = ScenePipeline(gen, None if args.no_enhancer else enh, [N] * B, C, H, W, device, graph=bool(args.graph))
         pipe.set_affine(normalize_pairwise_tfm(ptm, H * PX_M, W * PX_M, 1))
         scenes.append((feat, cond))
         pipes.append(pipe)
@@ -186,7 +187,7 @@ def main():
             run_scene(i, 1000 + i)
         barrier()
         # arm the kernel timer for the dominant kernel on rank 0 (HIP events on the launch stream)
-        timed = rank == 0 and args.timer_family >= 0
+        timed = rank == 0 and args.timer_family >= 0 and not args.graph  # event pairs cannot be recorded into a replayed graph
         if timed:
             _lib.check(lib.gencomm_timer_start(args.timer_family, args.steps * (T + 4) * 16), "gencomm_timer_start")
         t0 = time.perf_counter()
@@ -231,7 +232,7 @@ def main():
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
                                    f"T={T} x0-param ancestral steps, {B} scene(s)/step/GPU",
                        "agents": N, "C": C, "H": H, "W": W, "T": T, "enhancer": not args.no_enhancer,
-                       "noise": "in-kernel Philox4x32-10", "streams_per_gpu": S, "scenes_per_step": B, "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+                       "noise": "in-kernel Philox4x32-10", "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph), "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
             "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
                                   "achieved_tflops": flops * args.steps * B / elapsed / 1e12,
                                   "achieved_gbs": byts * args.steps * B / elapsed / 1e9},

@@ -40,6 +40,8 @@ _SIGNATURES = {
     "gencomm_unet_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_denoise_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, C.c_ulonglong,
                                  _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_denoise_fwd_dseed": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, C.c_ulonglong, _p,
+                                       _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_q_sample_fwd": (_i, [_p, _p, _i, _p, _p, C.c_ulonglong, C.c_uint, _p, _i, _i, _i, _i, _p]),
     "gencomm_enhancer_num_params": (_i, [_i]),
     "gencomm_enhancer_param_info": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),

@@ -197,6 +197,16 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
                         float* out, const float* noise0, const float* step_noise, unsigned long long seed,
                         int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
                         void* workspace, long long workspace_bytes, void* stream) {
+  return gencomm_denoise_fwd_dseed(prepared, sched, feat, n_feat_rows, src_row, cond, out, noise0, step_noise, seed, nullptr,
+                                   n, C, H, W, levels, res_blocks, attn_mask, T, workspace, workspace_bytes, stream);
+}
+
+int gencomm_denoise_fwd_dseed(const float* prepared, const float* sched,
+                              const float* feat, int n_feat_rows, const int* src_row, const float* cond,
+                              float* out, const float* noise0, const float* step_noise, unsigned long long seed,
+                              const unsigned long long* seed_dev,
+                              int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
+                              void* workspace, long long workspace_bytes, void* stream) {
   UNetPlan p;
   if (const char* e = p.build(C, levels, res_blocks, attn_mask, T)) return fail(GC_ERR_ARG, e);
   if (int rc = check_dims(n, C, H, W)) return rc;
@@ -210,7 +220,7 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
   const bool philox = noise0 == nullptr;
   const long long per_agent = (long long)C * H * W;
 
-  QSampleArgs q{feat, src_row, noise0, sched + (size_t)(T - 1) * 5, out, seed, (unsigned)T, per_agent};
+  QSampleArgs q{feat, src_row, noise0, sched + (size_t)(T - 1) * 5, out, seed, (unsigned)T, per_agent, seed_dev};
   launch_q_sample(q, n, philox, st);
 
   UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st};
@@ -228,6 +238,7 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
       co.sched = sched + (size_t)t * 5;
       co.noise = philox ? nullptr : step_noise + (size_t)i * n * per_agent;
       co.seed = seed;
+      co.seed_dev = seed_dev;
       co.stream_id = (unsigned)t;
       const int post = t == 0 ? 0 : (philox ? 2 : 1);
       if (int rc = unet_enqueue(c, out, cond, t, post, co)) return rc;
@@ -244,7 +255,7 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
     if (int rc = unet_enqueue_range(c, out, cond, t, 0, co, i == 0 ? 0 : 1, t == 0 ? nops : nops - 1, i != 0)) return rc;
     if (t > 0) {
       const float* nz = philox ? nullptr : step_noise + (size_t)i * n * per_agent;
-      if (int rc = latent_step_enqueue(c, sched + (size_t)t * 5, nz, seed, (unsigned)t)) return rc;
+      if (int rc = latent_step_enqueue(c, sched + (size_t)t * 5, nz, seed, (unsigned)t, seed_dev)) return rc;
     }
   }
   return GC_OK;

@@ -89,6 +89,7 @@ struct LatentArgs {
   unsigned long long seed;
   unsigned int stream_id;
   int C, H, W;
+  const unsigned long long* seed_dev;  // optional device-resident Philox key
 };
 
 template <int TW, int TH, int NOISE>
@@ -109,6 +110,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void latent_step_kernel(const Latent
   const int H = a.H, W = a.W;
   const unsigned plane = (unsigned)(H * W);
   const float c1 = as_const(a.sched)[2], c2 = as_const(a.sched)[3], sg = as_const(a.sched)[4];
+  const unsigned long long seed = (NOISE == 2 && a.seed_dev) ? *a.seed_dev : a.seed;
 
   // ---------------- phase 1: A' = c1 * SiLU(GN(a)) with a 2-pixel halo -> LDS ----------------
   float wc[25];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void latent_step_kernel(const Latent
         const int gy2 = y0 - 1 + r, gx2 = x0 + 4 * qx;
         float z[4] = {0.f, 0.f, 0.f, 0.f};
         if (gy2 >= 0 && gy2 < H && gx2 < W) {
-          normal4((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + c) * plane + (size_t)gy2 * W + gx2), a.stream_id, a.seed, z);
+          normal4((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + c) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, z);
         }
         *reinterpret_cast<float4*>(&tileE[c][r][4 + 4 * qx]) = make_float4(sg * z[0], sg * z[1], sg * z[2], sg * z[3]);
       };
@@ -318,7 +320,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void latent_step_kernel(const Latent
           const int gy2 = y0 - 1 + r, gxq = side ? x0 + TW : x0 - 4;  // the aligned quad that owns the halo pixel
           float z[4] = {0.f, 0.f, 0.f, 0.f};
           if (gy2 >= 0 && gy2 < H && gxq >= 0 && gxq < W)
-            normal4((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + c) * plane + (size_t)gy2 * W + gxq), a.stream_id, a.seed, z);
+            normal4((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + c) * plane + (size_t)gy2 * W + gxq), a.stream_id, seed, z);
           tileE[c][r][side ? TW + 4 : 3] = sg * (side ? z[0] : z[3]);
         }
       }

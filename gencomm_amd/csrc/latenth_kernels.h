@@ -153,6 +153,7 @@ __global__ __launch_bounds__(HC_NT, 2) void latent_step_h_kernel(const LatentArg
   const int H = a.H, W = a.W;
   const unsigned plane = (unsigned)(H * W);
   const float c1 = a.sched[2], c2 = a.sched[3], sg = a.sched[4];
+  const unsigned long long seed = (NOISE == 2 && a.seed_dev) ? *a.seed_dev : a.seed;
   const int ln = lane & 15, g = lane >> 4, ch = g & 1, rr = g >> 1;
   const int gx = x0 + 4 * ln;
   const int gy0 = y0 + 4 * wave + rr;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(HC_NT, 2) void latent_step_h_kernel(const LatentArg
         const int gy2 = y0 - 1 + r, gx2 = x0 + 4 * q;
         z[0] = z[1] = z[2] = z[3] = 0.f;
         if (gy2 >= 0 && gy2 < H && gx2 >= 0 && gx2 < W) {
-          normal4((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + c) * plane + (size_t)gy2 * W + gx2), a.stream_id, a.seed, z);
+          normal4((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + c) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, z);
 #pragma unroll
           for (int j = 0; j < 4; ++j) z[j] *= sg;
         }

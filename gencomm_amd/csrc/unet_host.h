@@ -214,7 +214,7 @@ inline void kmap_enqueue(const UNetCall& c, const float* cond) {
 
 // one latent step: hs0 <- k + c2 (hs0 - k) + c1 [Wc5 (*) A + bsum + fix] + s (W_x (*) eps)
 inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const float* noise, unsigned long long seed,
-                               unsigned stream_id) {
+                               unsigned stream_id, const unsigned long long* seed_dev = nullptr) {
   const UNetPlan& p = *c.plan;
   const float* P = c.prepared;
   GC_HIP(hipMemsetAsync(c.stat_ptr(p.hs0_tensor), 0, (size_t)c.n * 16 * sizeof(double), c.st));
@@ -227,7 +227,7 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   a.wx = P + p.conv_in.p_w + 144;
   a.wc5h = P + p.p_wc5h; a.wxh = P + p.p_wxh;
   a.noise = noise; a.sched = sched_row; a.inv_cnt = 1.0 / (2.0 * c.H * c.W);
-  a.seed = seed; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
+  a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
   TimedLaunch tl(KF_LATENT_STEP, c.st);
   if (pick_tile(c.n, c.H, c.W) == TILE_64x16 && conv8_split_mode()) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);

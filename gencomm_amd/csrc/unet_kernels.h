@@ -636,6 +636,7 @@ struct ConvOutArgs {
   unsigned long long seed;
   unsigned int stream_id;
   int C, H, W;
+  const unsigned long long* seed_dev;  // optional: the Philox key is read from device memory (graph replay with a new seed)
 };
 
 template <int TW, int TH, int PPL, int POST>
@@ -679,6 +680,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOut
   const bool row_ok = gy < a.H;
   const bool vec_ok = PPL == 4 && row_ok && (gx + 3 < a.W) && ((a.W & 3) == 0);
   const size_t pix = (size_t)gy * a.W + gx;
+  const unsigned long long seed = (POST == 2 && a.seed_dev) ? *a.seed_dev : a.seed;
   float c1 = 0.f, c2 = 0.f, sg = 0.f;
   if (POST != 0) { c1 = as_const(a.sched)[2]; c2 = as_const(a.sched)[3]; sg = as_const(a.sched)[4]; }
 #pragma unroll
@@ -713,10 +715,10 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOut
         // counter is the element index of the aligned quad (x & ~3) -- independent of the tiling and
         // shared with the latent sampler (latent_kernels.h)
         if (PPL == 4) {
-          normal4((uint64_t)e, a.stream_id, a.seed, z);
+          normal4((uint64_t)e, a.stream_id, seed, z);
         } else {
           float zz[4];
-          normal4((uint64_t)(e - (size_t)(gx & 3)), a.stream_id, a.seed, zz);
+          normal4((uint64_t)(e - (size_t)(gx & 3)), a.stream_id, seed, zz);
           z[0] = zz[gx & 3];
         }
       }
@@ -745,12 +747,14 @@ struct QSampleArgs {
   unsigned long long seed;
   unsigned int stream_id;
   long long per_agent; // C*H*W
+  const unsigned long long* seed_dev;  // optional device-resident Philox key
 };
 
 template <bool PHILOX>
 __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
   const int n = blockIdx.y;
   const float sa = as_const(a.sched)[0], sb = as_const(a.sched)[1];
+  const unsigned long long seed = (PHILOX && a.seed_dev) ? *a.seed_dev : a.seed;
   const float* __restrict__ fp = a.feat + (size_t)a.src_row[n] * a.per_agent;
   float* __restrict__ op = a.out + (size_t)n * a.per_agent;
   const long long nvec = (a.per_agent & 3) ? 0 : (a.per_agent >> 2);  // rows stay 16-B aligned only then
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
     const float4 f = reinterpret_cast<const float4*>(fp)[i];
     float z[4];
     if (PHILOX) {
-      normal4((uint64_t)((size_t)n * a.per_agent + i * 4), a.stream_id, a.seed, z);
+      normal4((uint64_t)((size_t)n * a.per_agent + i * 4), a.stream_id, seed, z);
     } else {
       const float4 z4 = reinterpret_cast<const float4*>(a.noise + (size_t)n * a.per_agent)[i];
       z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
     float z;
     if (PHILOX) {
       float zz[4];
-      normal4((uint64_t)((size_t)n * a.per_agent + i), a.stream_id, a.seed, zz);
+      normal4((uint64_t)((size_t)n * a.per_agent + i), a.stream_id, seed, zz);
       z = zz[0];
     } else {
       z = a.noise[(size_t)n * a.per_agent + i];

@@ -103,6 +103,15 @@ int gencomm_denoise_fwd(const float* prepared, const float* sched,
                         int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
                         void* workspace, long long workspace_bytes, void* stream);
 
+/* gencomm_denoise_fwd with the Philox key optionally read from DEVICE memory at kernel run time (seed_dev != NULL
+ * overrides `seed`): a captured hipGraph of the call can be replayed with fresh noise by rewriting one 8-byte word. */
+int gencomm_denoise_fwd_dseed(const float* prepared, const float* sched,
+                              const float* feat, int n_feat_rows, const int* src_row, const float* cond,
+                              float* out, const float* noise0, const float* step_noise, unsigned long long seed,
+                              const unsigned long long* seed_dev,
+                              int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
+                              void* workspace, long long workspace_bytes, void* stream);
+
 /* q_sample alone (cond_diff.py:262-264 with the ego repeat of :332-337 folded in):
  *   out[i] = sched_row[0] * feat[src_row[i]] + sched_row[1] * eps[i]
  * sched_row: device float[5] (one row of the table above).  noise NULL = Philox stream `stream_id`

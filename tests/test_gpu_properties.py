@@ -134,3 +134,31 @@ def test_full_size_stages_vs_cpu_oracle():
         err = (got - ref).abs()
         tol = 1e-5 + 1e-4 * ref.abs()
         assert (err <= tol).all(), f"{name}: max abs err {err.max().item():.3e}, |ref| max {ref.abs().max().item():.3e}"
+
+
+def test_scene_pipeline_graph_replay_matches_eager_and_reseeds():
+    """ScenePipeline(graph=True): the captured HIP graph reproduces the eager launch sequence for the same
+    Philox key (read from device memory at replay) and draws different noise for a different key."""
+    from gencomm_amd import Enhancer, GenComm, normalize_pairwise_tfm, synth
+    from gencomm_amd.pipeline import ScenePipeline
+    Cc, Hh, Ww, Tt, rl = 32, 32, 64, 3, [2, 1]
+    gen_, enh_ = GenComm(synth.default_gencomm_cfg(Cc, Tt)).eval(), Enhancer(Cc, [8, 8], 4).eval()
+    synth.fill_params_(gen_, 21)
+    synth.fill_params_(enh_, 22)
+    gen_, enh_ = gen_.to(DEV), enh_.to(DEV)
+    inp = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_inputs(rl, Cc, Hh, Ww, 23, max_shift=6.0).items()}
+    aff = normalize_pairwise_tfm(inp["pairwise_t_matrix"], Hh * 0.8, Ww * 0.8, 1)
+    outs = {}
+    for graph in (False, True):
+        pipe = ScenePipeline(gen_, enh_, rl, Cc, Hh, Ww, torch.device(DEV), graph=graph)
+        pipe.set_affine(aff)
+        with torch.no_grad():
+            a = pipe.run(inp["feat"], inp["cond"], seed=5).clone()
+            b = pipe.run(inp["feat"], inp["cond"], seed=6).clone()
+            c = pipe.run(inp["feat"], inp["cond"], seed=5).clone()
+        torch.cuda.synchronize()
+        # same key -> same noise (GroupNorm statistics are f64 atomics in any order: last-bit differences only)
+        assert torch.allclose(a, c, rtol=0, atol=1e-6) and float((a - b).abs().max()) > 1e-3
+        outs[graph] = (a, b)
+    assert torch.allclose(outs[False][0], outs[True][0], rtol=0, atol=1e-6)  # GroupNorm statistics: atomics in any order
+    assert torch.allclose(outs[False][1], outs[True][1], rtol=0, atol=1e-6)
