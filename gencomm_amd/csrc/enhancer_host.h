@@ -1,5 +1,7 @@
 // Host side of the Enhancer: live-parameter enumeration, workspace carve-up, launch sequence.
 #pragma once
+#include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -48,6 +50,12 @@ struct EnhancerPlan {
 struct EnhancerWs {
   size_t Y, Z, Zc, Hd, G, O, colsum, gate, wT, total;
 };
+// GENCOMM_CONV8=f32 keeps the exact-fp32 GEMMs (read per call, as in unet_host.h)
+inline bool enh_split_mode() {
+  const char* e = getenv("GENCOMM_CONV8");
+  return !(e && strcmp(e, "f32") == 0);
+}
+
 inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
   const size_t M = (size_t)n * H * W;
   EnhancerWs w{};
@@ -97,7 +105,8 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   {  // K3: linear1 + GELU
     GemmArgs a{F(w.Z), raw + p.l1w, raw + p.l1b, nullptr, F(w.Hd), nullptr, HW, 2 * p.hid, C};
     TimedLaunch tl(KF_ENH_GEMM1, st);
-    gemm_f32_mfma_kernel<0><<<dim3((HW + 127) / 128, (2 * p.hid + 63) / 64, n), 256, 0, st>>>(a);
+    if (enh_split_mode() && (C & 3) == 0) gemm_f16s_mfma_kernel<0><<<dim3((HW + 127) / 128, (2 * p.hid + 63) / 64, n), 256, 0, st>>>(a);
+    else gemm_f32_mfma_kernel<0><<<dim3((HW + 127) / 128, (2 * p.hid + 63) / 64, n), 256, 0, st>>>(a);
   }
   {  // K4: dwconv + GELU, gate
     constexpr int SL = 8;
@@ -109,7 +118,8 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   {  // K5: linear2 + residual, column sums for the global average pool
     GemmArgs a{F(w.G), raw + p.l2w, raw + p.l2b, F(w.Y), F(w.O), F(w.colsum), HW, C, p.hid};
     TimedLaunch tl(KF_ENH_GEMM2, st);
-    gemm_f32_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
+    if (enh_split_mode() && (p.hid & 3) == 0) gemm_f16s_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
+    else gemm_f32_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
   }
   {  // K6
     EnhGateArgs a{F(w.colsum), raw + p.fc1, raw + p.bnw, raw + p.bnb, raw + p.fc2, F(w.gate), C, 1.0f / (float)HW};

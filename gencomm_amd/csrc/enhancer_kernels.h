@@ -260,6 +260,111 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same GEMM on the f16 matrix pipe with exact fp16 hi/lo splits of both operands (the arithmetic of
+// conv8h_kernels.h: three v_mfma_f32_32x32x16_f16 per product block -- hi*hi, hi*lo, lo*hi -- fp32 accumulation, 22-bit
+// products).  Tokens are split while they are staged into LDS; the weights (pre-multiplied by 2^6 so that their low parts
+// stay normal fp16 numbers, undone exactly in the epilogue) likewise.  K = 64 costs 24 MFMAs of 32 cycles per wave
+// instead of 64 fp32 MFMAs of 64, beside -- not in front of -- the GELU / residual epilogue's VALU work.
+// LDS rows are 32 halves + 8 pad (80 B): the 16 lanes of a ds_read_b128 phase hit 64 distinct banks.
+// Operand maps of v_mfma_f32_32x32x16_f16: A[i = lane & 31][k = 8 * (lane >> 5) .. +7], B[k same][j = lane & 31],
+// D as in the fp32 kernel.  K must be a multiple of 4 (it is C or 2C).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 eh8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 eh2_t __attribute__((ext_vector_type(2)));
+typedef float ef2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void enh_split4(float4 v, float mul, uint2& hi, uint2& lo) {
+  const float x[4] = {v.x * mul, v.y * mul, v.z * mul, v.w * mul};
+  const eh2_t h0 = __builtin_convertvector((ef2_t){x[0], x[1]}, eh2_t), h1 = __builtin_convertvector((ef2_t){x[2], x[3]}, eh2_t);
+  const eh2_t l0 = __builtin_convertvector((ef2_t){x[0] - (float)h0[0], x[1] - (float)h0[1]}, eh2_t);
+  const eh2_t l1 = __builtin_convertvector((ef2_t){x[2] - (float)h1[0], x[3] - (float)h1[1]}, eh2_t);
+  hi = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+  lo = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f16s_mfma_kernel(const GemmArgs a) {
+  constexpr int BM = 128, BN = 64, KC = 32, RB = 80;  // row bytes
+  constexpr float WS = 64.0f, WSI = 1.0f / 64.0f;
+  __shared__ __align__(16) unsigned char Ah[BM * RB], Al[BM * RB], Bh[BN * RB], Bl[BN * RB];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int ag = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const float* __restrict__ Ap = a.A + (size_t)ag * a.M * a.K;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    __syncthreads();
+    {
+      const int kq = tid & 7, gk = k0 + 4 * kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i, gm = m0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < a.M && gk + 3 < a.K) v = *reinterpret_cast<const float4*>(Ap + (size_t)gm * a.K + gk);
+        uint2 hi, lo;
+        enh_split4(v, 1.0f, hi, lo);
+        *reinterpret_cast<uint2*>(Ah + row * RB + 8 * kq) = hi;
+        *reinterpret_cast<uint2*>(Al + row * RB + 8 * kq) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i, gn = n0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gn < a.N && gk + 3 < a.K) v = *reinterpret_cast<const float4*>(a.Bw + (size_t)gn * a.K + gk);
+        uint2 hi, lo;
+        enh_split4(v, WS, hi, lo);
+        *reinterpret_cast<uint2*>(Bh + row * RB + 8 * kq) = hi;
+        *reinterpret_cast<uint2*>(Bl + row * RB + 8 * kq) = lo;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      const int ko = 32 * ks + 16 * h;  // byte offset of this lane's 8 halves in the row
+      const eh8_t ah = *reinterpret_cast<const eh8_t*>(Ah + (32 * w + r) * RB + ko);
+      const eh8_t al = *reinterpret_cast<const eh8_t*>(Al + (32 * w + r) * RB + ko);
+      const eh8_t b0h = *reinterpret_cast<const eh8_t*>(Bh + r * RB + ko);
+      const eh8_t b0l = *reinterpret_cast<const eh8_t*>(Bl + r * RB + ko);
+      const eh8_t b1h = *reinterpret_cast<const eh8_t*>(Bh + (32 + r) * RB + ko);
+      const eh8_t b1l = *reinterpret_cast<const eh8_t*>(Bl + (32 + r) * RB + ko);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+    }
+  }
+
+  float* __restrict__ op = a.out + (size_t)ag * a.M * a.N;
+  const float* __restrict__ rp = EPI == 1 ? a.res + (size_t)ag * a.M * a.N : nullptr;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = n0 + 32 * t + r;
+    const bool cok = col < a.N;
+    const float b = cok ? a.bias[col] : 0.f;
+    float cs = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      float v = fmaf(t == 0 ? acc0[reg] : acc1[reg], WSI, b);
+      if (cok && m < a.M) {
+        if (EPI == 0) v = gelu_erf_f(v);
+        else { v += rp[(size_t)m * a.N + col]; cs += v; }
+        op[(size_t)m * a.N + col] = v;
+      }
+    }
+    if (EPI == 1) {
+      cs += __shfl_xor(cs, 32, 64);
+      if (h == 0 && cok) atomicAdd(&a.colsum[(size_t)ag * a.N + col], cs);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: depthwise 3x3 (+bias) + GELU on the first 2C hidden channels, times the other 2C
 // (enhancer.py:241-246).  Lanes run over channels (contiguous in NHWC); each thread slides a
 // 3x3 register window along a strip of SL pixels.
