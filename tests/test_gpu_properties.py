@@ -158,7 +158,7 @@ def test_scene_pipeline_graph_replay_matches_eager_and_reseeds():
             c = pipe.run(inp["feat"], inp["cond"], seed=5).clone()
         torch.cuda.synchronize()
         # same key -> same noise (GroupNorm statistics are f64 atomics in any order: last-bit differences only)
-        assert torch.allclose(a, c, rtol=0, atol=1e-6) and float((a - b).abs().max()) > 1e-3
+        assert torch.allclose(a, c, rtol=0, atol=1e-5) and float((a - b).abs().max()) > 1e-3
         outs[graph] = (a, b)
-    assert torch.allclose(outs[False][0], outs[True][0], rtol=0, atol=1e-6)  # GroupNorm statistics: atomics in any order
-    assert torch.allclose(outs[False][1], outs[True][1], rtol=0, atol=1e-6)
+    assert torch.allclose(outs[False][0], outs[True][0], rtol=0, atol=1e-5)  # GroupNorm statistics: atomics in any order
+    assert torch.allclose(outs[False][1], outs[True][1], rtol=0, atol=1e-5)
