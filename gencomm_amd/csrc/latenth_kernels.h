@@ -141,7 +141,7 @@ __device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const unsigne
 }
 
 template <int NOISE>
-__global__ __launch_bounds__(HC_NT, 2) void latent_step_h_kernel(const LatentArgs a) {
+__global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArgs a) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
   __shared__ __align__(16) unsigned char tile[2 * HL_PLANE5];
   __shared__ float s_ab[8][2];
@@ -291,6 +291,13 @@ __global__ __launch_bounds__(HC_NT, 2) void latent_step_h_kernel(const LatentArg
   if (wave_live) {
     hl_border_fix(a, tile, fix[0], gy0, gx, gy0 - y0, gx - x0, 4 * ch, c1);
     hl_border_fix(a, tile, fix[1], gy0 + 2, gx, gy0 + 2 - y0, gx - x0, 4 * ch, c1);
+    // folded into the accumulators (in accumulator units) so that the 32 registers are free during phase 3
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j][i] = fmaf(fix[p][i][j], sc, acc[p][j][i]);
   }
 
   // ---------------- phase 3: s * (W_x (*) eps), eps in chunks of 8 channels through LDS ----------------
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(HC_NT, 2) void latent_step_h_kernel(const LatentArg
           const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = kk[j] + c2 * (hv[j] - kk[j]) + fmaf(acc[p][j][i], inv_s, fix[p][i][j]);
+          for (int j = 0; j < 4; ++j) v[j] = kk[j] + c2 * (hv[j] - kk[j]) + acc[p][j][i] * inv_s;
           *reinterpret_cast<float4*>(a.hs0 + e) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { part[i] += v[j]; part[4 + i] = fmaf(v[j], v[j], part[4 + i]); }
