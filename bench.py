@@ -215,6 +215,26 @@ def main():
                 pipes[0].run(scenes[0][0], scenes[0][1], seed=3100 + i)
             torch.cuda.synchronize(device)
             _lib.check(lib.gencomm_timer_stop(ctypes.byref(sec_ms), ctypes.byref(sec_n)), "gencomm_timer_stop")
+    # the same workload with the exact-fp32 MFMA kernels everywhere (GENCOMM_CONV8=f32, read per call by the library): a short
+    # untimed-region pass so that the JSON line carries both arithmetic modes
+    exact = None
+    if rank == 0 and not os.environ.get("GENCOMM_CONV8"):
+        os.environ["GENCOMM_CONV8"] = "f32"
+        try:
+            with torch.no_grad():
+                for i in range(S):
+                    run_scene(i, 4000 + i)
+                torch.cuda.synchronize(device)
+                te = time.perf_counter()
+                ne = 2 * S
+                for i in range(ne):
+                    run_scene(i, 4100 + i)
+                torch.cuda.synchronize(device)
+                te = time.perf_counter() - te
+            exact = {"value": ne * B / te, "unit": "scenes/sec", "steps": ne, "n_gpus": 1,
+                     "note": "rank 0 only, same pipelines and streams, exact-fp32 v_mfma_f32_4x4x1 / 32x32x2 kernels"}
+        finally:
+            os.environ.pop("GENCOMM_CONV8", None)
     for pipe in pipes:
         assert torch.isfinite(pipe.fused).all(), "non-finite output"
 
@@ -232,7 +252,12 @@ def main():
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
                                    f"T={T} x0-param ancestral steps, {B} scene(s)/step/GPU",
                        "agents": N, "C": C, "H": H, "W": W, "T": T, "enhancer": not args.no_enhancer,
-                       "noise": "in-kernel Philox4x32-10", "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph), "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+                       "noise": "in-kernel Philox4x32-10",
+                       "arithmetic": "fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
+                                     "exact two-term fp16 splits of both operands (22-bit products, same parity tolerance as the exact-fp32 "
+                                     "kernels; GENCOMM_CONV8=f32 selects those: see exact_fp32_mode)" if not os.environ.get("GENCOMM_CONV8") == "f32"
+                                     else "exact fp32 MFMA kernels (GENCOMM_CONV8=f32)",
+                       "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph), "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
             "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
                                   "achieved_tflops": flops * args.steps * B / elapsed / 1e12,
                                   "achieved_gbs": byts * args.steps * B / elapsed / 1e9},
@@ -294,6 +319,7 @@ def main():
             else:
                 roof = {"kernel": name, "launches": k_n.value, "avg_launch_ms": per_launch_ms}
         out["roofline"] = roof
+        out["exact_fp32_mode"] = exact
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, N, C, H, W, T, gen, enh, ptm)
         else:
