@@ -1,5 +1,6 @@
 // Host side of the Enhancer: live-parameter enumeration, workspace carve-up, launch sequence.
 #pragma once
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -63,7 +64,8 @@ inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
   auto take = [&](size_t floats) { const size_t o = off; off += align_up(floats * sizeof(float), 256); return o; };
   w.colsum = take((size_t)n * p.C);
   w.gate = take((size_t)n * p.C);
-  w.wT = take((size_t)9 * p.dc * p.dcp);
+  // pconv weights: fp32 [9][dc][dcp] or the fp16 hi/lo A-operand table (oc blocks x k slices x 512 dwords + 64)
+  w.wT = take(std::max((size_t)9 * p.dc * p.dcp, (size_t)(p.dc / 16) * ((9 * p.dc + 31) / 32) * 512 + 64));
   w.Y = take(M * p.C);
   w.Z = take(M * p.C);
   w.Zc = take(M * p.dc);
@@ -89,6 +91,15 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     TimedLaunch tl(KF_ENH_LN, st);
     enh_ln_kernel<<<dim3((HW + 63) / 64, n), 256, sh, st>>>(a);
   }
+  if (enh_split_mode() && (p.dc == 16 || p.dc == 32) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
+    const int nslice = (9 * p.dc + 31) / 32;
+    enh_prep_pconv_h_kernel<<<1, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, nslice);
+    TimedLaunch tl(KF_ENH_PCONV, st);
+    EnhPconvHArgs a{F(w.Zc), F(w.wT), F(w.Z), C, p.dc, H, W, nslice};
+    const size_t sh = (size_t)2 * 18 * 34 * p.dc * 2;
+    if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)enh_pconv_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    enh_pconv_h_kernel<<<dim3((W + 31) / 32, (H + 15) / 16, n), 256, sh, st>>>(a);
+  } else
   {  // K2
     enh_prep_pconv_kernel<<<(9 * p.dc * p.dcp + 255) / 256, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, p.dcp);
     TimedLaunch tl(KF_ENH_PCONV, st);

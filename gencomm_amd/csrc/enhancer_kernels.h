@@ -12,6 +12,7 @@
 namespace gc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using ef32x4 = __attribute__((ext_vector_type(4))) float;
 
 // ---------------------------------------------------------------------------------------------
 // K1: x NCHW -> Y = x + LN1(x), Z = LN2(Y) (token-major), Zc = Z[:, :dc] (compact copy that the
@@ -360,6 +361,114 @@ __global__ __launch_bounds__(256) void gemm_f16s_mfma_kernel(const GemmArgs a) {
     if (EPI == 1) {
       cs += __shfl_xor(cs, 32, 64);
       if (h == 0 && cok) atomicAdd(&a.colsum[(size_t)ag * a.N + col], cs);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 on the f16 matrix pipe (dc = 16 or 32): the partial 3x3 convolution as an implicit GEMM with the hi/lo split
+// arithmetic of the GEMM above.  M = 16 output channels, N = 16 consecutive pixels of a row, K = 32 consecutive
+// (tap, input channel) pairs; the tile (32x16 pixels + halo) is staged token-major in fp16 hi / lo planes, so a B
+// operand is one 16-B read at (pixel + tap shift, channel offset).  Table: [oc block][k slice][hi/lo][lane][4 dwords],
+// then 64 floats (even 1 / scale, odd scale).
+// ---------------------------------------------------------------------------------------------
+struct EnhPconvHArgs {
+  const float* Zc;   // [n][H][W][dc]
+  const float* tab;  // prepared A operands
+  float* Z;          // [n][H][W][C]
+  int C, dc, H, W, nslice;
+};
+
+__global__ __launch_bounds__(256) void enh_prep_pconv_h_kernel(const float* __restrict__ w /*[dc][dc][3][3]*/, float* __restrict__ tab,
+                                                              int dc, int nslice) {
+  __shared__ float s_max[256];
+  const int tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < dc * dc * 9; i += 256) m = fmaxf(m, fabsf(w[i]));
+  s_max[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_max[tid] = fmaxf(s_max[tid], s_max[tid + s]);
+    __syncthreads();
+  }
+  const float wmax = s_max[0];
+  int ex = 0;
+  if (wmax > 0.f) (void)frexpf(wmax, &ex);
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
+  const int nob = dc / 16, total = nob * nslice * 512;
+  uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
+  for (int i = tid; i < total; i += 256) {
+    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, sl = (i >> 9) % nslice, ob = (i >> 9) / nslice;
+    const int mrow = l & 15, kg = l >> 4, oc = 16 * ob + mrow;
+    uint16_t v[2];
+    for (int e = 0; e < 2; ++e) {
+      const int kidx = 32 * sl + 8 * kg + 2 * d + e, tap = kidx / dc, ic = kidx - tap * dc;
+      const float x = tap < 9 ? w[((size_t)oc * dc + ic) * 9 + tap] * scale : 0.f;
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    }
+    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+  }
+  if (tid < 64) tab[total + tid] = (tid & 1) ? scale : 1.0f / scale;
+}
+
+__global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a) {
+  constexpr int TW = 32, TH = 16, LW = TW + 2, LH = TH + 2;
+  extern __shared__ __align__(16) unsigned char pch_smem[];
+  const int dc = a.dc, PB = dc * 2, plane = LH * LW * PB, q4 = dc >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const float* __restrict__ zp = a.Zc + (size_t)n * a.H * a.W * dc;
+  for (int i = tid; i < LH * LW * q4; i += 256) {
+    const int pix = i / q4, q = i - pix * q4;
+    const int r = pix / LW, col = pix - r * LW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(zp + ((size_t)gy * a.W + gx) * dc + 4 * q);
+    uint2 hi, lo;
+    enh_split4(v, 1.0f, hi, lo);
+    *reinterpret_cast<uint2*>(pch_smem + pix * PB + 8 * q) = hi;
+    *reinterpret_cast<uint2*>(pch_smem + plane + pix * PB + 8 * q) = lo;
+  }
+  __syncthreads();
+  const int ln = lane & 15, kg = lane >> 4;
+  const int nob = dc >> 4;
+  const float inv_s = a.tab[nob * a.nslice * 512];
+  for (int ob = 0; ob < nob; ++ob) {
+    ef32x4 acc[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[g] = ef32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int sl = 0; sl < a.nslice; ++sl) {
+      const int kidx0 = 32 * sl + 8 * kg;
+      const int tap = min(kidx0 / dc, 8), ic0 = kidx0 - (kidx0 / dc) * dc;  // slices past tap 8 carry zero weights
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const uint4 w0 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(ob * a.nslice + sl) * 2 + 0) * 64 + lane) * 4);
+      const uint4 w1 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(ob * a.nslice + sl) * 2 + 1) * 64 + lane) * 4);
+      const eh8_t wa0 = __builtin_bit_cast(eh8_t, w0), wa1 = __builtin_bit_cast(eh8_t, w1);
+      const int base = ((4 * wave + dy) * LW + ln + dx) * PB + ic0 * 2;
+      eh8_t bh[8], bl[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int ad = base + ((g >> 1) * LW + 16 * (g & 1)) * PB;
+        bh[g] = *reinterpret_cast<const eh8_t*>(pch_smem + ad);
+        bl[g] = *reinterpret_cast<const eh8_t*>(pch_smem + plane + ad);
+      }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bl[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, bh[g], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int gy = y0 + 4 * wave + (g >> 1), gx = x0 + 16 * (g & 1) + ln;
+      if (gy < a.H && gx < a.W) {
+        float* __restrict__ op = a.Z + ((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * a.C + 16 * ob + 4 * kg;
+        *reinterpret_cast<float4*>(op) = make_float4(acc[g][0] * inv_s, acc[g][1] * inv_s, acc[g][2] * inv_s, acc[g][3] * inv_s);
+      }
     }
   }
 }
