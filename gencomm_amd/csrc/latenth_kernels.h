@@ -20,16 +20,14 @@ constexpr int HL_W5TAB = 8 * 2 * 64 * 4;     // dwords: [c 8][hi/lo][lane][4], t
 // fp16 hi/lo A-operand tables of the composite kernel and of conv_in's x part, with ONE power-of-two scale (both
 // accumulate into the same registers).  wc5: prepared [8 i][25 d][8 o] (prep_latent_kernel, same stream, earlier).
 __global__ __launch_bounds__(256) void prep_latent_h_kernel(const float* __restrict__ wc5, const float* __restrict__ w_in /*[8][C+2][3][3]*/,
-                                                           float* __restrict__ dst5, float* __restrict__ dstx, int C) {
+                                                           float* __restrict__ dst5, float* __restrict__ dstx,
+                                                           float* __restrict__ dstc, int C) {
   __shared__ float s_max[256];
   const int tid = threadIdx.x;
   const int CI = C + 2;
   float m = 0.f;
   for (int i = tid; i < 1600; i += 256) m = fmaxf(m, fabsf(wc5[i]));
-  for (int i = tid; i < 8 * C * 9; i += 256) {
-    const int o = i / (C * 9), rem = i - o * C * 9;
-    m = fmaxf(m, fabsf(w_in[((size_t)o * CI + 2) * 9 + rem]));
-  }
+  for (int i = tid; i < 8 * CI * 9; i += 256) m = fmaxf(m, fabsf(w_in[i]));  // message channels included (conv_in_h_kernel)
   s_max[tid] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -72,6 +70,17 @@ __global__ __launch_bounds__(256) void prep_latent_h_kernel(const float* __restr
     const float x0 = live ? w_in[(((size_t)oc * CI + ic) * 3 + dy) * 3 + dx] : 0.f;
     const float x1 = live ? w_in[(((size_t)oc * CI + ic + 1) * 3 + dy) * 3 + dx] : 0.f;
     ox[i] = pack(x0, x1, h);
+  }
+  // the two message channels as an 8-channel chunk (channels 2..7 zero): chunk 0 of conv_in_h_kernel
+  uint32_t* __restrict__ oc_ = reinterpret_cast<uint32_t*>(dstc);
+  for (int i = tid; i < HC_WTAB; i += 256) {
+    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, c = i >> 9;
+    const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
+    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
+    const bool live = d == 0 && dy >= 0 && dy <= 2;
+    const float x0 = live ? w_in[(((size_t)oc * CI + 0) * 3 + dy) * 3 + dx] : 0.f;
+    const float x1 = live ? w_in[(((size_t)oc * CI + 1) * 3 + dy) * 3 + dx] : 0.f;
+    oc_[i] = pack(x0, x1, h);
   }
 }
 
@@ -138,6 +147,127 @@ __device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const unsigne
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// conv_in on the f16 matrix pipe: cat[cond(2), x_t(C)] -> 8 channels, 3x3 pad 1 (unet.py:229-233; channel order cond
+// first, cond_diff.py:318) -- conv8h's inner loop over 1 + C/8 eight-channel chunks streamed through LDS (the message
+// chunk carries six zero channels), next chunk's tile and weights in flight during the current chunk's MFMAs.
+// C == 0: message channels only (the sampler's constant map k).  Needs W % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+struct ConvInHArgs {
+  const float* cond;    // [n][2][H][W]
+  const float* x;       // [n][C][H][W]
+  const float* wch;     // message-chunk table
+  const float* wxh;     // C/8 tables of the x part
+  const float* scales;  // [0] = 1 / scale, [1] = scale
+  const float* bias;    // [8]
+  float* dst;           // [n][8][H][W]
+  double* dstat;
+  int C, H, W;
+};
+
+__global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a) {
+  constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
+  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
+  __shared__ float s_red[NT / 64][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int H = a.H, W = a.W;
+  const unsigned plane = (unsigned)(H * W);
+  const int ln = lane & 15, g = lane >> 4, ch = g & 1, rr = g >> 1;
+  const int gx = x0 + 4 * ln, gy0 = y0 + 4 * wave + rr;
+  const bool wave_live = y0 + 4 * wave < H;
+  const int r0 = tid >> 4, qx = tid & 15;
+  const float inv_s = a.scales[0], sc = a.scales[1];
+
+  f32x4 acc[2][4];
+  {
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 4 * ch);
+    const f32x4 b0 = {b4.x * sc, b4.y * sc, b4.z * sc, b4.w * sc};
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = b0;
+  }
+  int off[4][3];
+  hc_lane_offsets(off, wave, lane);
+  const int nchunk = a.C / 8;
+  const float* __restrict__ xp = a.x + (size_t)n * a.C * plane;
+  TileRegs<TW, TH, NT, 8> R;
+  float2 hreg = make_float2(0.f, 0.f);
+  {  // chunk 0: the two message channels
+    const float* __restrict__ sp = a.cond + (size_t)n * 2 * plane;
+    TileRegs<TW, TH, NT, 2> Rc;
+    stage_load<TW, TH, NT, 2, false>(Rc, sp, plane, W, H, W, x0, y0, tid);
+    float2 hc = make_float2(0.f, 0.f);
+    if (tid < HC_LH * 8 && (tid & 3) == 0) {
+      const int side = (tid >> 2) & 1, r = tid >> 3;
+      const int gy = y0 - 1 + r, gxh = side ? x0 + TW : x0 - 1;
+      if (gy >= 0 && gy < H && gxh >= 0 && gxh < W) {
+        hc.x = sp[(unsigned)gy * (unsigned)W + (unsigned)gxh];
+        hc.y = sp[plane + (unsigned)gy * (unsigned)W + (unsigned)gxh];
+      }
+    }
+    half8_t wa[3][2];
+    load_wa(wa, a.wch, lane);
+    if (nchunk > 0) {  // first x chunk requested behind the message tile
+      stage_load<TW, TH, NT, 8, false>(R, xp, plane, W, H, W, x0, y0, tid);
+      hreg = halo_load_h<false>(xp, plane, W, H, W, x0, y0, tid);
+    }
+    float e[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[c][j] = 0.f;
+    e[0][0] = Rc.v[0].x; e[0][1] = Rc.v[0].y; e[0][2] = Rc.v[0].z; e[0][3] = Rc.v[0].w;
+    e[1][0] = Rc.v[1].x; e[1][1] = Rc.v[1].y; e[1][2] = Rc.v[1].z; e[1][3] = Rc.v[1].w;
+    hc_store_main<HC_PLANE>(tile, r0, qx, e);
+    const float er[4] = {Rc.vr.x, Rc.vr.y, Rc.vr.z, Rc.vr.w};  // zero for threads whose channel (tid / 32) is not 0 or 1
+    hc_store_rem<HC_PLANE>(tile, tid, er);
+    if (tid < HC_LH * 8) hc_store_halo<HC_PLANE>(tile, tid, hc.x, hc.y);  // pairs 1..3: zeros
+    __syncthreads();
+    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+  }
+#pragma unroll 1
+  for (int cc = 0; cc < nchunk; ++cc) {
+    __syncthreads();
+    half8_t wa[3][2];
+    load_wa(wa, a.wxh + (size_t)cc * HC_WTAB, lane);
+    stage_store_h<false>(tile, R, hreg, H, W, x0, y0, nullptr, tid);
+    if (cc + 1 < nchunk) {
+      stage_load<TW, TH, NT, 8, false>(R, xp + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
+      hreg = halo_load_h<false>(xp + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
+    }
+    __syncthreads();
+    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+  }
+
+  float part[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[i] = 0.f;
+  if (wave_live) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int gy = gy0 + 2 * p;
+      if (gy < H && gx + 3 < W) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[p][j][i] * inv_s;
+            part[i] += v[j];
+            part[4 + i] = fmaf(v[j], v[j], part[4 + i]);
+          }
+          *reinterpret_cast<float4*>(a.dst + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * W + gx) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  }
+  if (a.dstat != nullptr) hc_stats_commit(part, s_red, a.dstat + (size_t)n * 16, tid);
 }
 
 template <int NOISE>

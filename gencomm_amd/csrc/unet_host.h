@@ -100,7 +100,11 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         tile_dims(tc, &tw, &th);
         const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n);
         TimedLaunch tl(KF_CONV_IN, c.st);
-        if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
+        if (tc == TILE_64x16 && conv8_split_mode() && (Wl & 3) == 0) {
+          ConvInHArgs ah{cond, x_t, P + p.p_wch, P + p.p_wxh, P + p.p_wc5h + HL_W5TAB, P + p.conv_in.b, c.tensor_ptr(o.dst),
+                         c.stat_ptr(o.dst), p.C, Hl, Wl};
+          conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
+        } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
         else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
         else conv_in_kernel<32, 8, 1><<<grid, 256, 0, c.st>>>(a);
         break;
@@ -207,7 +211,11 @@ inline void kmap_enqueue(const UNetCall& c, const float* cond) {
   int tw, th;
   tile_dims(tc, &tw, &th);
   const dim3 grid(cdiv(c.W, tw), cdiv(c.H, th), c.n);
-  if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
+  if (tc == TILE_64x16 && conv8_split_mode() && (c.W & 3) == 0) {
+    ConvInHArgs ah{cond, nullptr, c.prepared + p.p_wch, c.prepared + p.p_wxh, c.prepared + p.p_wc5h + HL_W5TAB, c.prepared + p.conv_in.b,
+                   reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W};
+    conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
+  } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
   else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
   else conv_in_kernel<32, 8, 1><<<grid, 256, 0, c.st>>>(a);
 }
@@ -281,7 +289,8 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
     PrepLatentArgs la{raw + p.conv_in.w, raw + p.conv_out.w, raw + p.conv_out.b, prepared + p.p_wc5, prepared + p.p_wc1,
                       prepared + p.p_bring, prepared + p.p_bsum, p.C};
     prep_latent_kernel<<<cdiv(1600 + 5184 + 72 + 8, 256), 256, 0, st>>>(la);
-    prep_latent_h_kernel<<<1, 256, 0, st>>>(prepared + p.p_wc5, raw + p.conv_in.w, prepared + p.p_wc5h, prepared + p.p_wxh, p.C);
+    prep_latent_h_kernel<<<1, 256, 0, st>>>(prepared + p.p_wc5, raw + p.conv_in.w, prepared + p.p_wc5h, prepared + p.p_wxh,
+                                           prepared + p.p_wch, p.C);
   }
   GC_HIP(hipGetLastError());
   return GC_OK;

@@ -64,7 +64,7 @@ struct UNetPlan {
   ConvPlan conv_in, conv_out;
   long long nout_w, nout_b;
   long long p_wc5, p_wc1, p_bring, p_bsum;  // latent sampler tables (latent_kernels.h)
-  long long p_wc5h, p_wxh;                  // their fp16 hi/lo A-operand forms (latenth_kernels.h)
+  long long p_wc5h, p_wxh, p_wch;           // their fp16 hi/lo A-operand forms + conv_in's message chunk (latenth_kernels.h)
   int hs0_tensor = 0, last_body_tensor = 0;
   std::vector<ConvPlan> down, up;  // indexed by level (down[l] valid for l < L-1, up[l] for l > 0)
   std::vector<ResBlockPlan> blocks;
@@ -193,7 +193,7 @@ struct UNetPlan {
       if (up[l].w >= 0) { up[l].p_w = padd(8 * 8 * 9); up[l].p_wh = padd(1536 + 64); }
     }
     p_wc5 = padd(1600); p_wc1 = padd(5184); p_bring = padd(72); p_bsum = padd(8);
-    p_wc5h = padd(4096 + 64); p_wxh = padd((long long)(C / 8) * 1536);
+    p_wc5h = padd(4096 + 64); p_wxh = padd((long long)(C / 8) * 1536); p_wch = padd(1536);
     for (auto& b : blocks) {
       b.p_c1w = padd(8LL * b.cin * 9);
       b.p_c2w = padd(8 * 8 * 9);
