@@ -270,6 +270,151 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
   if (a.dstat != nullptr) hc_stats_commit(part, s_red, a.dstat + (size_t)n * 16, tid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_out on the f16 matrix pipe: GroupNorm(norm_out)+SiLU -> 3x3 8 -> C with the sampler's update in the epilogue
+// (conv_out_kernel's contract, unet_kernels.h: POST 0 x0_hat, 1 explicit noise, 2 in-kernel Philox).  M = 16 output
+// channels (no row pairing needed), N = 16 pixels (lane n of group j owns pixel 4n + j), K = 4 taps x 8 channels: the 9
+// taps are 3 MFMAs (three zero tap slots).  One workgroup stages its 64x16 tile ONCE and walks all C/16 channel blocks
+// (the fp32 kernel stages it once per block).  Table: [block][c 3][hi/lo][lane][4 dwords], then 64 scale floats.
+// Needs W % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_conv_out_h_kernel(const float* __restrict__ w /*[C][8][3][3]*/, float* __restrict__ tab, int C) {
+  __shared__ float s_max[256];
+  const int tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < C * 72; i += 256) m = fmaxf(m, fabsf(w[i]));
+  s_max[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_max[tid] = fmaxf(s_max[tid], s_max[tid + s]);
+    __syncthreads();
+  }
+  const float wmax = s_max[0];
+  int ex = 0;
+  if (wmax > 0.f) (void)frexpf(wmax, &ex);
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
+  const int nocb = (C + 15) / 16;
+  uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
+  for (int i = tid; i < nocb * HC_WTAB; i += 256) {
+    const int ob = i / HC_WTAB, rem = i - ob * HC_WTAB;
+    const int d = rem & 3, l = (rem >> 2) & 63, h = (rem >> 8) & 1, c = rem >> 9;
+    const int oc = 16 * ob + (l & 15), t = 4 * c + (l >> 4);
+    uint16_t v[2];
+    for (int e = 0; e < 2; ++e) {
+      const int ic = 2 * d + e;
+      const float x = (t < 9 && oc < C) ? w[((size_t)oc * 8 + ic) * 9 + t] * scale : 0.f;
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    }
+    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+  }
+  if (tid < 64) tab[nocb * HC_WTAB + tid] = (tid & 1) ? scale : 1.0f / scale;
+}
+
+template <int POST>
+__global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs a) {
+  constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
+  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
+  __shared__ float s_ab[8][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int H = a.H, W = a.W, C = a.C;
+  const unsigned plane = (unsigned)(H * W);
+  const int ln = lane & 15, g = lane >> 4;
+  const int gx = x0 + 4 * ln;
+  const bool wave_live = y0 + 4 * wave < H;
+  const int nocb = (C + 15) / 16;
+
+  TileRegs<TW, TH, NT, 8> R;
+  const float* __restrict__ sp = a.src + (size_t)n * 8 * plane;
+  stage_load<TW, TH, NT, 8, false>(R, sp, plane, W, H, W, x0, y0, tid);
+  const float2 hreg = halo_load_h<false>(sp, plane, W, H, W, x0, y0, tid);
+  if (tid < 8) {
+    float A, B;
+    gn_coeff(a.sstat + (size_t)n * 16, tid, 2, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
+    s_ab[tid][0] = A;
+    s_ab[tid][1] = B;
+  }
+  __syncthreads();
+  stage_store_h<true>(tile, R, hreg, H, W, x0, y0, s_ab, tid);
+  __syncthreads();
+  if (!wave_live) return;  // no barrier below
+
+  // B addressing: tap t = 4c + lane/16 (slots 9..11 carry zero weights: clamp), output row 4*wave + rrow
+  int off[4][3];
+  {
+    const int kg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int t = min(4 * c + kg, 8), dy = t / 3, dx = t - 3 * dy;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) off[j][c] = hc_addr(4 * wave + dy, 4 * ln + j + dx - 1);
+    }
+  }
+  const float inv_s = a.wh[nocb * HC_WTAB], sc = a.wh[nocb * HC_WTAB + 1];
+  const unsigned long long seed = (POST == 2 && a.seed_dev) ? *a.seed_dev : a.seed;
+  float c1 = 0.f, c2 = 0.f, sg = 0.f;
+  if (POST != 0) { c1 = a.sched[2]; c2 = a.sched[3]; sg = a.sched[4]; }
+
+#pragma unroll 1
+  for (int ob = 0; ob < nocb; ++ob) {
+    half8_t wa[3][2];
+    load_wa(wa, a.wh + (size_t)ob * HC_WTAB, lane);
+    const int oc0 = 16 * ob + 4 * g;
+    f32x4 b0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b0[i] = (oc0 + i < C) ? a.bias[oc0 + i] * sc : 0.f;
+    // one output row at a time (16 accumulator registers live; the whole 4-row block at once spilled 1.6 KB per thread)
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      f32x4 acc[4] = {b0, b0, b0, b0};
+      const unsigned char* trow = tile + r * HC_ROW;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        half8_t bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = *reinterpret_cast<const half8_t*>(trow + off[j][c]);
+          bl[j] = *reinterpret_cast<const half8_t*>(trow + HC_PLANE + off[j][c]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][1], bh[j], acc[j], 0, 0, 0);
+      }
+      const int gy = y0 + 4 * wave + r;
+      if (gy >= H || gx + 3 >= W) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oc = oc0 + i;
+        if (oc >= C) continue;
+        const size_t e = ((size_t)n * C + oc) * plane + (size_t)gy * W + gx;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[j][i] * inv_s;
+        if (POST != 0) {
+          const float4 t4 = *reinterpret_cast<const float4*>(a.xt + e);
+          const float xt[4] = {t4.x, t4.y, t4.z, t4.w};
+          float z[4];
+          if (POST == 1) {
+            const float4 z4 = *reinterpret_cast<const float4*>(a.noise + e);
+            z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
+          } else {
+            normal4((uint64_t)e, a.stream_id, seed, z);  // canonical field: counter = element index of the aligned quad
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaf(sg, z[j], fmaf(c1, v[j], c2 * xt[j]));
+        }
+        *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
 template <int NOISE>
 __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArgs a) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;

@@ -172,7 +172,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
       case OP_CONV_OUT: {
         co.src = c.tensor_ptr(o.src[0]); co.sstat = c.stat_ptr(o.src[0]);
         co.gamma = P + p.nout_w; co.beta = P + p.nout_b;
-        co.w = P + p.conv_out.p_w; co.bias = P + p.conv_out.b;
+        co.w = P + p.conv_out.p_w; co.wh = P + p.conv_out.p_wh; co.bias = P + p.conv_out.b;
         co.C = p.C; co.H = Hl; co.W = Wl;
         co.inv_cnt = 1.0 / (2.0 * Hl * Wl);
         const int nocb = (p.C + 15) / 16;
@@ -186,7 +186,12 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
     else conv_out_kernel<32, 8, 1, POST><<<grid, 256, 0, c.st>>>(co);                  \
   } while (0)
         TimedLaunch tl(KF_CONV_OUT, c.st);
-        if (post == 0) GC_LAUNCH_CO(0);
+        if (conv8_split_mode() && (Wl & 3) == 0 && pick_tile(c.n, Hl, Wl) == TILE_64x16) {
+          const dim3 gh(cdiv(Wl, 64), cdiv(Hl, 16), c.n);
+          if (post == 0) conv_out_h_kernel<0><<<gh, 256, 0, c.st>>>(co);
+          else if (post == 1) conv_out_h_kernel<1><<<gh, 256, 0, c.st>>>(co);
+          else conv_out_h_kernel<2><<<gh, 256, 0, c.st>>>(co);
+        } else if (post == 0) GC_LAUNCH_CO(0);
         else if (post == 1) GC_LAUNCH_CO(1);
         else GC_LAUNCH_CO(2);
 #undef GC_LAUNCH_CO
@@ -263,6 +268,7 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
   conv_w(p.conv_in.w, p.conv_in.p_w, 8, p.C + 2, 8);
   GC_HIP(hipMemsetAsync(prepared + p.conv_out.p_w, 0, (size_t)((p.C + 15) / 16 * 16) * 72 * sizeof(float), st));
   conv_w(p.conv_out.w, p.conv_out.p_w, p.C, 8, 16);
+  prep_conv_out_h_kernel<<<1, 256, 0, st>>>(raw + p.conv_out.w, prepared + p.conv_out.p_wh, p.C);
   for (int l = 0; l < p.L; ++l) {
     if (p.down[l].w >= 0) conv_w(p.down[l].w, p.down[l].p_w, 8, 8, 8);
     if (p.up[l].w >= 0) {

@@ -627,6 +627,7 @@ struct ConvOutArgs {
   const float* gamma;   // [8]
   const float* beta;
   const float* w;       // prepared [ceil(C/16)][8][9][16], zero padded
+  const float* wh;      // fp16 hi/lo A-operand tables of conv_out_h_kernel (latenth_kernels.h), or null
   const float* bias;    // [C]
   const float* xt;      // [n][C][H][W] (POST != 0)
   const float* noise;   // [n][C][H][W] (POST == 1)

@@ -188,6 +188,7 @@ struct UNetPlan {
     prepared_floats = (raw_floats + 63) / 64 * 64;
     conv_in.p_w = padd(8LL * (C + 2) * 9);
     conv_out.p_w = padd((long long)((C + 15) / 16 * 16) * 8 * 9);
+    conv_out.p_wh = padd((long long)((C + 15) / 16) * 1536 + 64);
     for (int l = 0; l < L; ++l) {
       if (down[l].w >= 0) down[l].p_w = padd(8 * 8 * 9);
       if (up[l].w >= 0) { up[l].p_w = padd(8 * 8 * 9); up[l].p_wh = padd(1536 + 64); }

@@ -103,3 +103,17 @@ def test_full_size_unet_call_modes_agree_and_repeat(monkeypatch):
             assert float((y - ys[mode]).abs().max()) < 1e-6  # GroupNorm statistics: f64 atomics in any order
         ys[mode] = y
     assert float((ys["f32"] - ys["split"]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_golden_path_direct_sampler_with_64x16_tiles_forced(monkeypatch, name):
+    """The literal sampler (conv_in ... conv_out + update per step, explicit noise in conv_out's epilogue) through
+    conv_in_h_kernel / conv8h_kernel / conv_out_h_kernel<POST=1>."""
+    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
+    monkeypatch.setenv("GENCOMM_SAMPLER", "direct")
+    g = load_case(name)
+    _, gen, _ = build_modules(g, "cuda:0")
+    inp = build_inputs(g, "cuda:0")
+    with torch.no_grad():
+        pred = gen(inp["feat"], inp["cond"], inp["record_len"], noise=eval_noise(g, "cuda:0"))["pred_feature"]
+    assert_close(sub(pred, int(g["stride"])), g["pred_feature"], 1e-4, 1e-5, "pred_feature (direct sampler, forced tiles)")
