@@ -117,3 +117,33 @@ def test_golden_path_direct_sampler_with_64x16_tiles_forced(monkeypatch, name):
     with torch.no_grad():
         pred = gen(inp["feat"], inp["cond"], inp["record_len"], noise=eval_noise(g, "cuda:0"))["pred_feature"]
     assert_close(sub(pred, int(g["stride"])), g["pred_feature"], 1e-4, 1e-5, "pred_feature (direct sampler, forced tiles)")
+
+
+@pytest.mark.parametrize("shape", [(32, 22, 46, 5, [5, 1]), (256, 16, 24, 2, [2]), (16, 34, 68, 3, [1, 3])])
+def test_forced_tiles_vs_oracle_on_odd_shapes(monkeypatch, shape):
+    """The 64x16-tile f16-pipe kernels on shapes no fixture has: a width that is not a multiple of 4 (scalar staging,
+    fp32 conv_in / conv_out / sampler fall-backs mixed with conv8h layers), 5 agents in a scene, C = 256 (V2X-Real:
+    16 channel blocks in conv_out_h, 32 chunks in conv_in_h, C/4 = 64 partial conv on the fp32 kernel), and a map whose
+    half-resolution level is 17 x 34 (partial tiles at both levels) -- each stage against the CPU oracle."""
+    from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, synth
+    from oracle import torch_port as O
+    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
+    C, H, W, T, rl = shape
+    n = sum(rl)
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen, enh = GenComm(cfg).eval(), Enhancer(C, [8, 8], 4).eval()
+    synth.fill_params_(gen, 31)
+    synth.fill_params_(enh, 32)
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(rl, C, H, W, 33, max_shift=6.0).items()}
+    n0, sn = (torch.from_numpy(a) for a in synth.make_eval_noise(34, n, C, H, W, T))
+    ref = O.path_forward({k: v.detach() for k, v in gen.state_dict().items()}, {k: v.detach() for k, v in enh.state_dict().items()},
+                         cfg, inp["feat"], inp["cond"], inp["record_len"], inp["pairwise_t_matrix"], H * 0.8, W * 0.8, n0, sn)
+    gen, enh = gen.to(DEV), enh.to(DEV)
+    with torch.no_grad():
+        affine = normalize_pairwise_tfm(inp["pairwise_t_matrix"], H * 0.8, W * 0.8, 1)
+        pred = gen(inp["feat"].to(DEV), inp["cond"].to(DEV), inp["record_len"], noise=(n0.to(DEV), sn.to(DEV)))["pred_feature"]
+        assert_close(pred.cpu().numpy(), ref["pred_feature"].numpy(), 1e-4, 1e-5, "pred_feature")
+        e = enh(ref["pred_feature"].to(DEV), affine, inp["record_len"])
+        assert_close(e.cpu().numpy(), ref["enhanced"].numpy(), 1e-4, 1e-5, "enhanced (oracle input)")
+        f = AttFusion(C)(ref["enhanced"].to(DEV), inp["record_len"], affine)
+        assert_close(f.cpu().numpy(), ref["fused"].numpy(), 1e-4, 1e-5, "fused (oracle input)")
