@@ -223,24 +223,43 @@ __device__ __forceinline__ void hc_lane_offsets(int (&off)[4][3], int wave, int 
 // One 8-input-channel source: acc[p][j] (row pair p, pixel group j) += W (*) tile.  wa[c][0/1] = hi/lo A operands.
 // Per (tap group c, row pair p): 8 ds_read_b128 (hi and lo records of the four pixel groups), then three passes of four
 // MFMAs (hi*hi, hi*lo, lo*hi) so that consecutive MFMAs never share an accumulator.
+template <bool LOWREG = false>
 __device__ __forceinline__ void conv_tile_mfma_h(const unsigned char* tile, const half8_t (&wa)[3][2],
                                                  f32x4 (&acc)[2][4], const int (&off)[4][3]) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      half8_t bh[4], bl[4];
+      if constexpr (!LOWREG) {
+        half8_t bh[4], bl[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bh[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c] + p * 2 * HC_ROW);
-        bl[j] = *reinterpret_cast<const half8_t*>(tile + HC_PLANE + off[j][c] + p * 2 * HC_ROW);
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c] + p * 2 * HC_ROW);
+          bl[j] = *reinterpret_cast<const half8_t*>(tile + HC_PLANE + off[j][c] + p * 2 * HC_ROW);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bh[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bl[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][1], bh[j], acc[p][j], 0, 0, 0);
+      } else {
+        // 16 instead of 32 operand registers in flight: the hi records feed two passes, the lo records are fetched behind
+        // them (fenced, or the scheduler hoists the reads and the kernel that asks for this spills instead)
+        half8_t b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c] + p * 2 * HC_ROW);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][1], b[j], acc[p][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + HC_PLANE + off[j][c] + p * 2 * HC_ROW);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], b[j], acc[p][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bh[j], acc[p][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bl[j], acc[p][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][1], bh[j], acc[p][j], 0, 0, 0);
     }
   }
 }
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
 
   GC_STAMP(0);
   half8_t wa[3][2];
-  load_wa(wa, a.wh, lane);
+  if (NSRC == 1) load_wa(wa, a.wh, lane);  // two-source layers: behind the first staging (register pressure)
   const float inv_s = a.wh[NSRC * HC_WTAB];  // one scale for the whole (concatenated) weight tensor
   const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + 4 * ch);
   const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
@@ -337,8 +356,6 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   }
 
   GC_STAMP(1);
-  int off[4][3];
-  hc_lane_offsets(off, wave, lane);
   // the accumulators start at bias * scale (exact: the scale is a power of two), so the epilogue is one multiply
   f32x4 acc[2][4];
   {
@@ -352,6 +369,9 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
 
   if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[0], tid);
   else stage_tile_scalar_h<GN, UP>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
+  if (NSRC == 2) load_wa(wa, a.wh, lane);
+  int off[4][3];
+  hc_lane_offsets(off, wave, lane);
   // identity residual: requested once the staging registers are free, so that it arrives during the matrix phase
   float resv[RES == 1 ? 2 : 1][4][4];
   if (RES == 1 && wave_live) {
@@ -376,13 +396,13 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   }
   __syncthreads();
   GC_STAMP(2);
-  if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+  if (wave_live) conv_tile_mfma_h<NSRC == 2>(tile, wa, acc, off);
   GC_STAMP(3);
   if (NSRC == 2) {
-    load_wa(wa, a.wh + HC_WTAB, lane);
     __syncthreads();
     if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[8], tid);
     else stage_tile_scalar_h<GN, UP>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
+    load_wa(wa, a.wh + HC_WTAB, lane);  // behind the staging: 24 fewer live registers while the tile is converted
     __syncthreads();
     if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
   }
