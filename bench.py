@@ -32,7 +32,8 @@ WORKLOADS = {
     # name: (agents, C, H, W, T)
     "metric": (4, 64, 200, 704, 20),   # BASELINE.json metric: 4 agents, 64x200x704 BEV, 20 steps
     "cfg2": (2, 64, 200, 704, 10),     # BASELINE.json configs[1]
-    "shipped": (2, 128, 64, 128, 3),   # shape of every shipped yaml (control)
+    "shipped": (2, 128, 64, 128, 3),   # shape of every shipped OPV2V / DAIR-V2X yaml (control)
+    "v2xreal": (2, 256, 64, 128, 3),   # V2X-Real yamls: 256 feature channels
 }
 PX_M = 0.4           # metres per BEV pixel at 200x704 (OPV2V range +-140.8 x +-40 m)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s

@@ -162,3 +162,30 @@ def test_scene_pipeline_graph_replay_matches_eager_and_reseeds():
         outs[graph] = (a, b)
     assert torch.allclose(outs[False][0], outs[True][0], rtol=0, atol=1e-5)  # GroupNorm statistics: atomics in any order
     assert torch.allclose(outs[False][1], outs[True][1], rtol=0, atol=1e-5)
+
+
+def test_full_size_enhancer_and_fusion_modes_agree(monkeypatch):
+    """Enhancer (f16-pipe GEMMs and partial conv vs the exact-fp32 kernels) and the token-major fusion behind it at the
+    benchmark geometry: the two arithmetic modes agree to 1e-5 on O(5) outputs."""
+    from gencomm_amd import Enhancer, GenComm, normalize_pairwise_tfm, synth
+    from gencomm_amd.pipeline import ScenePipeline
+    gen_ = GenComm(synth.default_gencomm_cfg(C, T)).eval()
+    enh_ = Enhancer(C, [8, 8], 4).eval()
+    synth.fill_params_(gen_, 41)
+    synth.fill_params_(enh_, 42)
+    gen_, enh_ = gen_.to(DEV), enh_.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(43)
+    feat = torch.randn(N, C, H, W, generator=g, device=DEV).clamp_(min=0)
+    cond = torch.randn(N, 2, H, W, generator=g, device=DEV)
+    ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N], 5, 44, 40.0))
+    pipe = ScenePipeline(gen_, enh_, [N], C, H, W, torch.device(DEV))
+    pipe.set_affine(normalize_pairwise_tfm(ptm, H * 0.4, W * 0.4, 1))
+    outs = {}
+    for mode in ("f32", "split"):
+        monkeypatch.setenv("GENCOMM_CONV8", mode)
+        with torch.no_grad():
+            outs[mode] = pipe.run(feat, cond, seed=9).clone()
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs["split"]).all()
+    d = (outs["f32"] - outs["split"]).abs().max().item()
+    assert d < 2e-4 * max(1.0, outs["f32"].abs().max().item()), d  # T = 20 sampler steps + Enhancer + fusion end to end
