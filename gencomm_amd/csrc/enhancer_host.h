@@ -113,6 +113,14 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
       enh_pconv_kernel<16, 8><<<dim3((W + 15) / 16, (H + 7) / 8, n), 128, sh, st>>>(a);
     }
   }
+  const char* fuse_env = getenv("GENCOMM_ENH_FUSE");  // "0": separate Linear1 / depthwise launches (A/B runs)
+  if (enh_split_mode() && C == 64 && !(fuse_env && fuse_env[0] == '0')) {
+    // K3 + K4 fused: the hidden tensor never reaches HBM; its slot in the workspace holds the 64 KB operand table
+    enh_prep_front_kernel<<<32, 256, 0, st>>>(raw + p.l1w, F(w.Hd), C, p.hid);
+    EnhFrontArgs a{F(w.Z), F(w.Hd), raw + p.l1b, raw + p.dww, raw + p.dwb, F(w.G), C, p.hid, H, W};
+    TimedLaunch tl(KF_ENH_GEMM1, st);
+    enh_front_h_kernel<<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);
+  } else {
   {  // K3: linear1 + GELU
     GemmArgs a{F(w.Z), raw + p.l1w, raw + p.l1b, nullptr, F(w.Hd), nullptr, HW, 2 * p.hid, C};
     TimedLaunch tl(KF_ENH_GEMM1, st);
@@ -125,6 +133,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     const long long total = (long long)H * ((W + SL - 1) / SL) * p.hid;
     TimedLaunch tl(KF_ENH_DWGATE, st);
     enh_dwgate_kernel<SL><<<dim3((unsigned)((total + 255) / 256), n), 256, 0, st>>>(a);
+  }
   }
   {  // K5: linear2 + residual, column sums for the global average pool
     GemmArgs a{F(w.G), raw + p.l2w, raw + p.l2b, F(w.Y), F(w.O), F(w.colsum), HW, C, p.hid};

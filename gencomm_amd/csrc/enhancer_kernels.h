@@ -474,6 +474,131 @@ __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3 + K4 fused on the f16 matrix pipe (C = 64): Linear1 + GELU -> depthwise 3x3 + GELU on the first half -> times the
+// second half, per 8x8-pixel tile with the Linear1 outputs of its 10x10 halo region RECOMPUTED instead of written to and
+// read back from HBM (the hidden tensor is 4C floats per pixel: 2.3 GB written and 2.3 GB read per 16 agents at the
+// benchmark geometry; with the GEMM on the f16 pipe 1.56x of it is ~0.1 ms of MFMA time).
+//   per workgroup (256 threads): stage the 100 tokens (C channels) as fp16 hi / lo planes; for each of the hid / 16 chunks
+//   of 16 gate-branch channels q: M = 32 rows = Linear1 rows {16q..16q+15} (x1) and {hid + 16q ..} (x2), N = 4 blocks of
+//   32 region pixels (one per wave), K = C: 4 k-steps x 3 split products of v_mfma_f32_32x32x16_f16; + bias, GELU, zero
+//   outside the image (the depthwise conv pads its INPUT with zeros) -> LDS [100][32]; then 64 pixels x 16 channels:
+//   dw3x3 + bias, GELU, times x2 at the centre -> G[pixel][16q + ch].
+// Table (prep kernel): [chunk][k-step 4][hi/lo][lane 64][4 dwords], weights pre-multiplied by 2^6.
+// ---------------------------------------------------------------------------------------------
+struct EnhFrontArgs {
+  const float* Z;     // [n][H][W][C] tokens (LayerNorm2 output, partial conv applied)
+  const float* tab;   // prepared Linear1 A operands
+  const float* b1;    // [2*hid]
+  const float* dww;   // [hid][9]
+  const float* dwb;   // [hid]
+  float* G;           // [n][H][W][hid]
+  int C, hid, H, W;
+};
+
+__global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __restrict__ w1 /*[2*hid][C]*/, float* __restrict__ tab, int C, int hid) {
+  const int ksteps = C / 16, total = (hid / 16) * ksteps * 512;
+  uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, ks = (i >> 9) % ksteps, q = (i >> 9) / ksteps;
+    const int m = l & 31, kg = l >> 5;
+    const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
+    uint16_t v[2];
+    for (int e = 0; e < 2; ++e) {
+      const float x = w1[(size_t)row * C + 16 * ks + 8 * kg + 2 * d + e] * 64.0f;
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    }
+    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+  }
+}
+
+__global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) {
+  constexpr int TP = 8, RP = TP + 2, NPX = RP * RP, C = 64, RB = C * 2 + 16, HS = 33;  // region 10x10, row bytes, hb stride
+  __shared__ __align__(16) unsigned char zh[NPX * RB], zl[NPX * RB];
+  __shared__ float hb[NPX * HS];
+  __shared__ float s_b1[4 * C], s_dww[2 * C * 9], s_dwb[2 * C];  // Linear1 bias, depthwise weights / bias: read per chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
+  const int x0 = blockIdx.x * TP, y0 = blockIdx.y * TP;
+  const int hid = a.hid;  // == 2 * C
+  for (int i = tid; i < 4 * C; i += 256) s_b1[i] = a.b1[i];
+  for (int i = tid; i < 2 * C * 9; i += 256) s_dww[i] = a.dww[i];
+  for (int i = tid; i < 2 * C; i += 256) s_dwb[i] = a.dwb[i];
+  // ---- stage the region's tokens: item = (pixel, float4 of 4 channels): 100 * 16 items
+  for (int i = tid; i < NPX * (C / 4); i += 256) {
+    const int p = i >> 4, q4 = i & 15;
+    const int gy = y0 - 1 + p / RP, gx = x0 - 1 + p % RP;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(a.Z + ((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * C + 4 * q4);
+    uint2 hi, lo;
+    enh_split4(v, 1.0f, hi, lo);
+    *reinterpret_cast<uint2*>(zh + p * RB + 8 * q4) = hi;
+    *reinterpret_cast<uint2*>(zl + p * RB + 8 * q4) = lo;
+  }
+  __syncthreads();
+  const int r = lane & 31, h = lane >> 5;
+  const int pb = min(32 * wave + r, NPX - 1);  // this lane's region pixel as B column (padding columns repeat the last pixel)
+  const int pcol = 32 * wave + r;
+  const bool pvalid = pcol < NPX;
+  const int pgy = y0 - 1 + pcol / RP, pgx = x0 - 1 + pcol % RP;
+  const bool inimg = pvalid && pgy >= 0 && pgy < a.H && pgx >= 0 && pgx < a.W;
+  // the gate branch x2 is only read at the tile's own 8x8 pixels: no GELU for it on the halo ring
+  const int prow = pcol / RP, pcl = pcol - prow * RP;
+  const bool centre = inimg && prow >= 1 && prow <= TP && pcl >= 1 && pcl <= TP;
+  // second phase ownership: channel tid % 16, tile row (tid / 16) % 8, pixels 4 * (tid / 128) .. +3 of that row
+  const int dch = tid & 15, dpy = (tid >> 4) & 7, dx0 = 4 * (tid >> 7);
+  const int nchunk = hid / 16;
+#pragma unroll 1
+  for (int q = 0; q < nchunk; ++q) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ++ks) {
+      const uint4 w0 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(q * (C / 16) + ks) * 2 + 0) * 64 + lane) * 4);
+      const uint4 w1 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(q * (C / 16) + ks) * 2 + 1) * 64 + lane) * 4);
+      const eh8_t ah = __builtin_bit_cast(eh8_t, w0), al = __builtin_bit_cast(eh8_t, w1);
+      const int ko = 32 * ks + 16 * h;
+      const eh8_t bh = *reinterpret_cast<const eh8_t*>(zh + pb * RB + ko);
+      const eh8_t bl = *reinterpret_cast<const eh8_t*>(zl + pb * RB + ko);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    }
+    if (q > 0) __syncthreads();  // the previous chunk's depthwise phase has finished reading hb
+    if (pvalid) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // row of the chunk: < 16 gate-branch x1, >= 16 x2
+        const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
+        const bool need = m < 16 ? inimg : centre;  // compile-time m per register: uniform branch per lane group
+        hb[pcol * HS + m] = need ? gelu_erf_f(fmaf(acc[reg], 1.0f / 64.0f, s_b1[row])) : 0.f;
+      }
+    }
+    __syncthreads();
+    {
+      const int ch = 16 * q + dch;
+      float wd[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wd[t] = s_dww[ch * 9 + t];
+      const float bd = s_dwb[ch];
+      const int gy = y0 + dpy;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = dx0 + j, gx = x0 + x;
+        float s = bd;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) s = fmaf(wd[dy * 3 + dx], hb[((dpy + dy) * RP + x + dx) * HS + dch], s);
+        const float g = gelu_erf_f(s) * hb[((dpy + 1) * RP + x + 1) * HS + 16 + dch];
+        if (gy < a.H && gx < a.W) a.G[((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * hid + ch] = g;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: depthwise 3x3 (+bias) + GELU on the first 2C hidden channels, times the other 2C
 // (enhancer.py:241-246).  Lanes run over channels (contiguous in NHWC); each thread slides a
 // 3x3 register window along a strip of SL pixels.
