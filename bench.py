@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the scene's launch sequence as a captured HIP graph")
+    ap.add_argument("--mode", action="append", default=[], metavar="KEY=VALUE",
+                    help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd), e.g. --mode xcd=0")
     args = ap.parse_args()
 
     from gencomm_amd import dist as gdist
@@ -155,6 +157,11 @@ def main():
     from gencomm_amd import _lib, normalize_pairwise_tfm
     from gencomm_amd.pipeline import ScenePipeline
     lib = _lib.lib()
+    mode_keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
+                 "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP}
+    for kv in args.mode:
+        k, v = kv.split("=")
+        _lib.check(lib.gencomm_set_mode(mode_keys[k], int(v)), "gencomm_set_mode")
 
     N, C, H, W, T = WORKLOADS[args.workload]
     gen, enh = build_modules(C, T, device)
@@ -219,9 +226,8 @@ def main():
     # the same workload with the exact-fp32 MFMA kernels everywhere (GENCOMM_CONV8=f32, read per call by the library): a short
     # untimed-region pass so that the JSON line carries both arithmetic modes
     exact = None
-    if rank == 0 and not os.environ.get("GENCOMM_CONV8"):
-        os.environ["GENCOMM_CONV8"] = "f32"
-        try:
+    if rank == 0 and lib.gencomm_get_mode(_lib.MODE_ARITH) == 0:
+        with _lib.mode(_lib.MODE_ARITH, 1):
             with torch.no_grad():
                 for i in range(S):
                     run_scene(i, 4000 + i)
@@ -234,8 +240,6 @@ def main():
                 te = time.perf_counter() - te
             exact = {"value": ne * B / te, "unit": "scenes/sec", "steps": ne, "n_gpus": 1,
                      "note": "rank 0 only, same pipelines and streams, exact-fp32 v_mfma_f32_4x4x1 / 32x32x2 kernels"}
-        finally:
-            os.environ.pop("GENCOMM_CONV8", None)
     for pipe in pipes:
         assert torch.isfinite(pipe.fused).all(), "non-finite output"
 
@@ -256,8 +260,8 @@ def main():
                        "noise": "in-kernel Philox4x32-10",
                        "arithmetic": "fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
                                      "exact two-term fp16 splits of both operands (22-bit products, same parity tolerance as the exact-fp32 "
-                                     "kernels; GENCOMM_CONV8=f32 selects those: see exact_fp32_mode)" if not os.environ.get("GENCOMM_CONV8") == "f32"
-                                     else "exact fp32 MFMA kernels (GENCOMM_CONV8=f32)",
+                                     "kernels; gencomm_set_mode(GENCOMM_MODE_ARITH, 1) selects those: see exact_fp32_mode)" if lib.gencomm_get_mode(_lib.MODE_ARITH) == 0
+                                     else "exact fp32 MFMA kernels (GENCOMM_MODE_ARITH = 1)",
                        "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph), "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
             "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
                                   "achieved_tflops": flops * args.steps * B / elapsed / 1e12,

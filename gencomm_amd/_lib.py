@@ -15,7 +15,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
+MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP = range(6)
 
 _lock = threading.Lock()
 _lib = None
@@ -26,6 +27,8 @@ _i, _ll, _p = C.c_int, C.c_longlong, C.c_void_p
 _SIGNATURES = {
     "gencomm_abi_version": (_i, []),
     "gencomm_last_error": (C.c_char_p, []),
+    "gencomm_set_mode": (_i, [_i, _ll]),
+    "gencomm_get_mode": (_ll, [_i]),
     "gencomm_timer_num_kernels": (_i, []),
     "gencomm_timer_kernel_name": (C.c_char_p, [_i]),
     "gencomm_timer_start": (_i, [_i, _i]),
@@ -121,6 +124,24 @@ def lib() -> C.CDLL:
                 raise GenCommHipError(f"ABI version mismatch: library {l.gencomm_abi_version()}, binding {ABI_VERSION}")
             _lib = l
     return _lib
+
+
+class mode:
+    """``with _lib.mode(_lib.MODE_ARITH, 1): ...`` -- set a library mode (include/gencomm_hip.h) for a block, restoring the
+    previous value afterwards. Modes are process-wide: do not flip them while another thread is inside the library."""
+
+    def __init__(self, key: int, value: int):
+        self.key, self.value = key, int(value)
+
+    def __enter__(self):
+        l = lib()
+        self.prev = l.gencomm_get_mode(self.key)
+        check(l.gencomm_set_mode(self.key, self.value), "gencomm_set_mode")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().gencomm_set_mode(self.key, self.prev), "gencomm_set_mode")
+        return False
 
 
 def check(rc: int, what: str) -> None:

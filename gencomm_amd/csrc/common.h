@@ -41,6 +41,26 @@ inline int fail(int code, const char* msg) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------
+// Library modes (gencomm_set_mode / gencomm_get_mode in the C ABI): explicit, atomic, read ONCE per entry-point call
+// into a Modes snapshot that travels with the call -- never an environment variable, never re-read per launch.
+// ---------------------------------------------------------------------------------------------
+enum ModeKey : int {
+  MODE_ARITH = 0,        // 0: products on the f16 matrix pipe from exact fp16 hi/lo splits (default); 1: exact-fp32 kernels
+  MODE_SAMPLER = 1,      // 0: latent sampler structure (default); 1: literal conv_in .. conv_out + update per step
+  MODE_TILE_WANT = 2,    // 0: automatic; > 0: minimum number of 64x16 workgroups before the 64x16-tile kernels are chosen
+  MODE_ENH_FUSE = 3,     // 1: Enhancer Linear1 + depthwise stage fused at C = 64 (default); 0: separate launches
+  MODE_CONV8H_MASK = 4,  // diagnostic: bit mask of conv8h variants allowed on the f16 pipe (-1: all)
+  MODE_XCD_REMAP = 5,    // 1: workgroup -> tile mapping keeps neighbouring tiles on one XCD (default); 0: plain grid order
+  MODE_COUNT = 6
+};
+struct Modes {
+  long long v[MODE_COUNT];
+  bool split() const { return v[MODE_ARITH] == 0; }
+  int xcd() const { return v[MODE_XCD_REMAP] != 0 ? 1 : 0; }
+};
+Modes modes_snapshot();  // defined in gencomm_abi.hip
+
+// ---------------------------------------------------------------------------------------------
 // Diagnostic kernel timer (gencomm_timer_start / gencomm_timer_stop): while armed for one kernel
 // family, every launch of that family is bracketed by a pair of HIP events recorded on the launch
 // stream. Off by default; the only process-global state in the library.
@@ -89,6 +109,32 @@ struct TimedLaunch {
 // ---------------------------------------------------------------------------------------------
 typedef const float __attribute__((address_space(4)))* cfloat_p;
 __device__ __forceinline__ cfloat_p as_const(const float* p) { return (cfloat_p)(p); }
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware workgroup -> tile mapping.  The dispatcher deals workgroups to the 8 XCDs round-robin by linear workgroup
+// id, and every XCD has its own 4 MiB L2 (not coherent with the others): with the plain mapping the tiles left/right of
+// a tile run on OTHER XCDs, so every halo row/column a tile shares with its neighbours is fetched across the fabric
+// once per XCD that touches it.  Remapped, XCD k walks the k-th contiguous eighth of the (x fastest, then y, then
+// sample) tile order, so horizontally and vertically adjacent tiles are resident on the same XCD at about the same
+// time and their shared lines are L2 hits.  Bijective for any grid size (XCD k gets total/8 tiles, +1 for k < total%8).
+// ---------------------------------------------------------------------------------------------
+struct BlockId { int x, y, z; };
+__device__ __forceinline__ BlockId xcd_block(int remap) {
+  BlockId b{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  if (remap) {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned nl = xcd * q + (xcd < r ? xcd : r) + j;
+    const unsigned row = nl / gx;
+    b.x = (int)(nl - row * gx);
+    b.z = (int)(row / gy);
+    b.y = (int)(row - (unsigned)b.z * gy);
+  }
+  return b;
+}
 
 // ---------------------------------------------------------------------------------------------
 // device math

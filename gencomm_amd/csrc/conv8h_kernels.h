@@ -320,8 +320,9 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
 #endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const size_t plane_in = (size_t)a.Hin * a.Win;
   const size_t plane = (size_t)a.H * a.W;
   const bool wvec = UP ? ((a.Win & 1) == 0) : ((a.W & 3) == 0);

@@ -51,11 +51,6 @@ struct EnhancerPlan {
 struct EnhancerWs {
   size_t Y, Z, Zc, Hd, G, O, colsum, gate, wT, total;
 };
-// GENCOMM_CONV8=f32 keeps the exact-fp32 GEMMs (read per call, as in unet_host.h)
-inline bool enh_split_mode() {
-  const char* e = getenv("GENCOMM_CONV8");
-  return !(e && strcmp(e, "f32") == 0);
-}
 
 inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
   const size_t M = (size_t)n * H * W;
@@ -78,7 +73,7 @@ inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
 inline size_t enhancer_workspace_bytes(const EnhancerPlan& p, int n, int H, int W) { return enhancer_ws(p, n, H, W).total; }
 
 inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float* x, float* out,
-                            int n, int H, int W, char* wsp, hipStream_t st) {
+                            int n, int H, int W, char* wsp, hipStream_t st, const Modes& m) {
   const EnhancerWs w = enhancer_ws(p, n, H, W);
   const int HW = H * W, C = p.C;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(wsp + off); };
@@ -91,7 +86,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     TimedLaunch tl(KF_ENH_LN, st);
     enh_ln_kernel<<<dim3((HW + 63) / 64, n), 256, sh, st>>>(a);
   }
-  if (enh_split_mode() && (p.dc == 16 || p.dc == 32) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
+  if (m.split() && (p.dc == 16 || p.dc == 32) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
     const int nslice = (9 * p.dc + 31) / 32;
     enh_prep_pconv_h_kernel<<<1, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, nslice);
     TimedLaunch tl(KF_ENH_PCONV, st);
@@ -113,8 +108,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
       enh_pconv_kernel<16, 8><<<dim3((W + 15) / 16, (H + 7) / 8, n), 128, sh, st>>>(a);
     }
   }
-  const char* fuse_env = getenv("GENCOMM_ENH_FUSE");  // "0": separate Linear1 / depthwise launches (A/B runs)
-  if (enh_split_mode() && C == 64 && !(fuse_env && fuse_env[0] == '0')) {
+  if (m.split() && C == 64 && m.v[MODE_ENH_FUSE] != 0) {  // MODE_ENH_FUSE 0: separate Linear1 / depthwise launches (A/B runs)
     // K3 + K4 fused: the hidden tensor never reaches HBM; its slot in the workspace holds the 64 KB operand table
     enh_prep_front_kernel<<<32, 256, 0, st>>>(raw + p.l1w, F(w.Hd), C, p.hid);
     EnhFrontArgs a{F(w.Z), F(w.Hd), raw + p.l1b, raw + p.dww, raw + p.dwb, F(w.G), C, p.hid, H, W};
@@ -124,7 +118,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   {  // K3: linear1 + GELU
     GemmArgs a{F(w.Z), raw + p.l1w, raw + p.l1b, nullptr, F(w.Hd), nullptr, HW, 2 * p.hid, C};
     TimedLaunch tl(KF_ENH_GEMM1, st);
-    if (enh_split_mode() && (C & 3) == 0) gemm_f16s_mfma_kernel<0><<<dim3((HW + 127) / 128, (2 * p.hid + 63) / 64, n), 256, 0, st>>>(a);
+    if (m.split() && (C & 3) == 0) gemm_f16s_mfma_kernel<0><<<dim3((HW + 127) / 128, (2 * p.hid + 63) / 64, n), 256, 0, st>>>(a);
     else gemm_f32_mfma_kernel<0><<<dim3((HW + 127) / 128, (2 * p.hid + 63) / 64, n), 256, 0, st>>>(a);
   }
   {  // K4: dwconv + GELU, gate
@@ -138,7 +132,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   {  // K5: linear2 + residual, column sums for the global average pool
     GemmArgs a{F(w.G), raw + p.l2w, raw + p.l2b, F(w.Y), F(w.O), F(w.colsum), HW, C, p.hid};
     TimedLaunch tl(KF_ENH_GEMM2, st);
-    if (enh_split_mode() && (p.hid & 3) == 0) gemm_f16s_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
+    if (m.split() && (p.hid & 3) == 0) gemm_f16s_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
     else gemm_f32_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
   }
   {  // K6

@@ -11,6 +11,7 @@
 #include "unet_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -23,6 +24,12 @@ KernelTimer& kernel_timer() {
   static KernelTimer t;
   return t;
 }
+static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {1}, {-1}, {1}};  // defaults, see ModeKey
+Modes modes_snapshot() {
+  Modes m;
+  for (int i = 0; i < MODE_COUNT; ++i) m.v[i] = g_modes[i].load(std::memory_order_relaxed);
+  return m;
+}
 }  // namespace gc
 
 using namespace gc;
@@ -31,6 +38,20 @@ extern "C" {
 
 int gencomm_abi_version(void) { return GENCOMM_ABI_VERSION; }
 const char* gencomm_last_error(void) { return last_error_buf(); }
+
+// ------------------------------------------------------------------------------------ modes
+int gencomm_set_mode(int key, long long value) {
+  GC_CHECK_ARG(key >= 0 && key < MODE_COUNT, "unknown mode key");
+  GC_CHECK_ARG(key != MODE_ARITH || value == 0 || value == 1, "GENCOMM_MODE_ARITH: 0 (f16-pipe split) or 1 (exact fp32)");
+  GC_CHECK_ARG(key != MODE_SAMPLER || value == 0 || value == 1, "GENCOMM_MODE_SAMPLER: 0 (latent) or 1 (direct)");
+  GC_CHECK_ARG(key != MODE_TILE_WANT || value >= 0, "GENCOMM_MODE_TILE_WANT: 0 (automatic) or a positive workgroup count");
+  g_modes[key].store(value, std::memory_order_relaxed);
+  return GC_OK;
+}
+long long gencomm_get_mode(int key) {
+  if (key < 0 || key >= MODE_COUNT) { fail(GC_ERR_ARG, "unknown mode key"); return -1; }
+  return g_modes[key].load(std::memory_order_relaxed);
+}
 
 // ------------------------------------------------------------------------------------ timer
 int gencomm_timer_num_kernels(void) { return KF_COUNT; }
@@ -146,7 +167,7 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
   UNetWorkspace w;
   if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
   if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_denoise_workspace_bytes)");
-  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream};
+  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()};
   ConvOutArgs co{};
   co.out = x0_out;
   return unet_enqueue(c, x_t, cond, t, 0, co);
@@ -166,10 +187,12 @@ int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, 
   prep_conv8h_kernel<<<1, 256, 0, st>>>(w_oihw, p_wh, 8);
   GC_HIP(hipMemcpyAsync(p_b, bias, 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (dstat) GC_HIP(hipMemsetAsync(dstat, 0, (size_t)n * 16 * sizeof(double), st));
+  const Modes m = modes_snapshot();
   Conv8Args a{};
   a.src[0] = src; a.w = p_w; a.wh = split ? p_wh : nullptr; a.bias = p_b; a.dst = dst; a.dstat = dstat;
   a.H = a.Hin = H; a.W = a.Win = W;
-  launch_conv8<1, false, false, 0>(pick_tile(n, H, W), a, n, st);
+  a.xcd = m.xcd();
+  launch_conv8<1, false, false, 0>(m, pick_tile(m, n, H, W), a, n, st);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -223,11 +246,10 @@ int gencomm_denoise_fwd_dseed(const float* prepared, const float* sched,
   QSampleArgs q{feat, src_row, noise0, sched + (size_t)(T - 1) * 5, out, seed, (unsigned)T, per_agent, seed_dev};
   launch_q_sample(q, n, philox, st);
 
-  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st};
+  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st, modes_snapshot()};
   // Sampler structure: "latent" (default) carries the loop on the 8-channel map hs0 = conv_in(x_t)
   // (latent_kernels.h); "direct" is the literal conv_in ... conv_out + update per step.
-  const char* mode_env = getenv("GENCOMM_SAMPLER");  // read per call so that tests can compare both structures
-  const bool force_direct = mode_env && strcmp(mode_env, "direct") == 0;
+  const bool force_direct = c.m.v[MODE_SAMPLER] == 1;  // tests compare both structures
   const bool latent = !force_direct && T >= 2 && (W % 4) == 0;
   if (!latent) {
     for (int i = 0; i < T; ++i) {
@@ -296,7 +318,7 @@ int gencomm_enhancer_fwd(const float* raw, const float* x, float* out, int n, in
   GC_CHECK_ARG(n >= 1 && n <= 65535 && H >= 1 && W >= 1, "bad n/H/W");
   if ((long long)enhancer_workspace_bytes(p, n, H, W) > workspace_bytes)
     return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_enhancer_workspace_bytes)");
-  return enhancer_enqueue(p, raw, x, out, n, H, W, (char*)workspace, (hipStream_t)stream);
+  return enhancer_enqueue(p, raw, x, out, n, H, W, (char*)workspace, (hipStream_t)stream, modes_snapshot());
 }
 
 // ------------------------------------------------------------------------------------ message extractor

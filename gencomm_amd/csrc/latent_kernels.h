@@ -90,6 +90,7 @@ struct LatentArgs {
   unsigned int stream_id;
   int C, H, W;
   const unsigned long long* seed_dev;  // optional device-resident Philox key
+  int xcd;
 };
 
 template <int TW, int TH, int NOISE>
@@ -104,8 +105,9 @@ __global__ __launch_bounds__((TW / 4) * TH) void latent_step_kernel(const Latent
   float (*tileE)[LH][LS] = reinterpret_cast<float (*)[LH][LS]>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int tx = tid % QPR, ty = tid / QPR;
   const int H = a.H, W = a.W;
   const unsigned plane = (unsigned)(H * W);

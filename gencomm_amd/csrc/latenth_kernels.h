@@ -166,6 +166,7 @@ struct ConvInHArgs {
   float* dst;           // [n][8][H][W]
   double* dstat;
   int C, H, W;
+  int xcd;
 };
 
 __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a) {
@@ -173,8 +174,9 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
   __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
   __shared__ float s_red[NT / 64][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int H = a.H, W = a.W;
   const unsigned plane = (unsigned)(H * W);
   const int ln = lane & 15, g = lane >> 4, ch = g & 1, rr = g >> 1;
@@ -318,8 +320,9 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
   __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
   __shared__ float s_ab[8][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int H = a.H, W = a.W, C = a.C;
   const unsigned plane = (unsigned)(H * W);
   const int ln = lane & 15, g = lane >> 4;
@@ -423,8 +426,9 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
   __shared__ float s_red[NT / 64][16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int H = a.H, W = a.W;
   const unsigned plane = (unsigned)(H * W);
   const float c1 = a.sched[2], c2 = a.sched[3], sg = a.sched[4];

@@ -61,7 +61,7 @@ inline int msgext_enqueue(const MsgExtPlan& p, const float* raw, const float* x,
   prep_nin_w_kernel<<<16, 256, 0, st>>>(raw + p.f0w, F(w.wFuse), 64, 64);
   {
     ConvNArgs a{x, F(w.wOff), raw + p.ob, F(w.off), C, 18, H, W};
-    const TileCfg tc = pick_tile(n, H, W);
+    const TileCfg tc = pick_tile(modes_snapshot(), n, H, W);
     int tw, th;
     tile_dims(tc, &tw, &th);
     const dim3 grid(cdiv(W, tw), cdiv(H, th), n);

@@ -18,22 +18,17 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // smaller still run 32x8 px / 256 threads / ONE pixel per lane, which has 4x the waves and a
 // quarter of the serial work per wave (these layers are latency-bound, not throughput-bound).
 enum TileCfg { TILE_64x16 = 0, TILE_32x16 = 1, TILE_32x8 = 2 };
-// GENCOMM_CONV8 = "split" (default): 64x16 tiles of the 8-channel convolutions run conv8h_kernel (fp16 hi/lo split on
-// the f16 matrix pipe, fp32-grade products); "f32": the exact-fp32 conv8_kernel everywhere.  Read per call.
-inline bool conv8_split_mode() {
-  const char* e = getenv("GENCOMM_CONV8");
-  return !(e && strcmp(e, "f32") == 0);
-}
-inline long long tile_want() {
+// Arithmetic mode (Modes, common.h): split (default) = 64x16 tiles of the 8-channel convolutions run conv8h_kernel (fp16 hi/lo
+// split on the f16 matrix pipe, fp32-grade products); exact = the fp32 conv8_kernel everywhere.
+inline long long tile_want(const Modes& m) {
   // minimum number of 64x16 workgroups before the 64x16-tile kernels are chosen.  512 for the fp32 kernels (two
   // workgroups per CU); 160 for the f16-pipe kernels, whose workgroups are short enough that a partly filled chip beats
   // the smaller fp32 tiles (1 scene x 1 stream 80.9 -> 86.4 scenes/s, 2 x 2 131.6 -> 141.3, 4 x 3 unchanged).
-  // GENCOMM_TILE_WANT overrides (tuning / tests: 1 forces the 64x16 kernels onto small maps); read per call.
-  const char* e = getenv("GENCOMM_TILE_WANT");
-  return e ? atoll(e) : (conv8_split_mode() ? 160LL : 512LL);
+  // MODE_TILE_WANT overrides (tuning / tests: 1 forces the 64x16 kernels onto small maps).
+  return m.v[MODE_TILE_WANT] > 0 ? m.v[MODE_TILE_WANT] : (m.split() ? 160LL : 512LL);
 }
-inline TileCfg pick_tile(int n, int H, int W, int zmul = 1) {
-  const long long want = tile_want();
+inline TileCfg pick_tile(const Modes& m, int n, int H, int W, int zmul = 1) {
+  const long long want = tile_want(m);
   if ((long long)cdiv(W, 64) * cdiv(H, 16) * n * zmul >= want) return TILE_64x16;
   if ((long long)cdiv(W, 32) * cdiv(H, 16) * n * zmul >= want) return TILE_32x16;
   return TILE_32x8;
@@ -44,14 +39,13 @@ inline void tile_dims(TileCfg t, int* tw, int* th) {
 }
 
 template <int NSRC, bool GN, bool UP, int RES>
-inline void launch_conv8(TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
+inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
   TimedLaunch tl(UP ? KF_UP : (NSRC == 2 ? KF_CONV16 : KF_CONV8), st);
   int tw, th;
   tile_dims(t, &tw, &th);
   const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
-  const char* mk = getenv("GENCOMM_CONV8H_MASK");  // diagnostic: restrict the split kernel to some variants
-  const int variant = UP ? 16 : (RES == 2 ? 8 : (RES == 1 ? 4 : (NSRC == 2 ? 2 : 1)));
-  if (t == TILE_64x16 && a.wh != nullptr && conv8_split_mode() && (!mk || (atoi(mk) & variant))) {
+  const int variant = UP ? 16 : (RES == 2 ? 8 : (RES == 1 ? 4 : (NSRC == 2 ? 2 : 1)));  // MODE_CONV8H_MASK: diagnostic
+  if (t == TILE_64x16 && a.wh != nullptr && m.split() && (m.v[MODE_CONV8H_MASK] & variant)) {
     conv8h_kernel<NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a);
     return;
   }
@@ -69,6 +63,7 @@ struct UNetCall {
   char* wsp;  // workspace base
   int n, H, W;
   hipStream_t st;
+  Modes m;
 
   float* tensor_ptr(int id) const {
     const TensorPlan& t = plan->tensors[id];
@@ -94,15 +89,15 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
     const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level];
     switch (o.kind) {
       case OP_CONV_IN: {
-        ConvInArgs a{cond, x_t, P + p.conv_in.p_w, P + p.conv_in.b, c.tensor_ptr(o.dst), c.stat_ptr(o.dst), p.C, Hl, Wl};
-        const TileCfg tc = pick_tile(c.n, Hl, Wl);
+        ConvInArgs a{cond, x_t, P + p.conv_in.p_w, P + p.conv_in.b, c.tensor_ptr(o.dst), c.stat_ptr(o.dst), p.C, Hl, Wl, c.m.xcd()};
+        const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl);
         int tw, th;
         tile_dims(tc, &tw, &th);
         const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n);
         TimedLaunch tl(KF_CONV_IN, c.st);
-        if (tc == TILE_64x16 && conv8_split_mode() && (Wl & 3) == 0) {
+        if (tc == TILE_64x16 && c.m.split() && (Wl & 3) == 0) {
           ConvInHArgs ah{cond, x_t, P + p.p_wch, P + p.p_wxh, P + p.p_wc5h + HL_W5TAB, P + p.conv_in.b, c.tensor_ptr(o.dst),
-                         c.stat_ptr(o.dst), p.C, Hl, Wl};
+                         c.stat_ptr(o.dst), p.C, Hl, Wl, c.m.xcd()};
           conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
         } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
         else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
@@ -119,9 +114,10 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = a.Hin = Hl; a.W = a.Win = Wl;
         a.inv_cnt = 1.0 / ((b.cin == 8 ? 2.0 : 4.0) * Hl * Wl);
-        const TileCfg tc = pick_tile(c.n, Hl, Wl);
-        if (b.cin == 8) launch_conv8<1, true, false, 0>(tc, a, c.n, c.st);
-        else launch_conv8<2, true, false, 0>(tc, a, c.n, c.st);
+        a.xcd = c.m.xcd();
+        const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl);
+        if (b.cin == 8) launch_conv8<1, true, false, 0>(c.m, tc, a, c.n, c.st);
+        else launch_conv8<2, true, false, 0>(c.m, tc, a, c.n, c.st);
         break;
       }
       case OP_RES_CONV2: {
@@ -135,9 +131,10 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = a.Hin = Hl; a.W = a.Win = Wl;
         a.inv_cnt = 1.0 / (2.0 * Hl * Wl);
-        const TileCfg tc = pick_tile(c.n, Hl, Wl);
-        if (b.cin == 8) launch_conv8<1, true, false, 1>(tc, a, c.n, c.st);
-        else launch_conv8<1, true, false, 2>(tc, a, c.n, c.st);
+        a.xcd = c.m.xcd();
+        const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl);
+        if (b.cin == 8) launch_conv8<1, true, false, 1>(c.m, tc, a, c.n, c.st);
+        else launch_conv8<1, true, false, 2>(c.m, tc, a, c.n, c.st);
         break;
       }
       case OP_DOWN: {
@@ -155,7 +152,8 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         a.w = P + p.up[lin].p_w; a.wh = P + p.up[lin].p_wh; a.bias = P + p.up[lin].b;
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = Hl; a.W = Wl; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin];
-        launch_conv8<1, false, true, 0>(pick_tile(c.n, Hl, Wl), a, c.n, c.st);
+        a.xcd = c.m.xcd();
+        launch_conv8<1, false, true, 0>(c.m, pick_tile(c.m, c.n, Hl, Wl), a, c.n, c.st);
         break;
       }
       case OP_ATTN: {
@@ -175,8 +173,9 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         co.w = P + p.conv_out.p_w; co.wh = P + p.conv_out.p_wh; co.bias = P + p.conv_out.b;
         co.C = p.C; co.H = Hl; co.W = Wl;
         co.inv_cnt = 1.0 / (2.0 * Hl * Wl);
+        co.xcd = c.m.xcd();
         const int nocb = (p.C + 15) / 16;
-        const TileCfg tc = pick_tile(c.n, Hl, Wl, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
+        const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
         int tw, th;
         tile_dims(tc, &tw, &th);
         const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n * nocb);
@@ -186,7 +185,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
     else conv_out_kernel<32, 8, 1, POST><<<grid, 256, 0, c.st>>>(co);                  \
   } while (0)
         TimedLaunch tl(KF_CONV_OUT, c.st);
-        if (conv8_split_mode() && (Wl & 3) == 0 && pick_tile(c.n, Hl, Wl) == TILE_64x16) {
+        if (c.m.split() && (Wl & 3) == 0 && pick_tile(c.m, c.n, Hl, Wl) == TILE_64x16) {
           const dim3 gh(cdiv(Wl, 64), cdiv(Hl, 16), c.n);
           if (post == 0) conv_out_h_kernel<0><<<gh, 256, 0, c.st>>>(co);
           else if (post == 1) conv_out_h_kernel<1><<<gh, 256, 0, c.st>>>(co);
@@ -211,14 +210,14 @@ inline int unet_enqueue(const UNetCall& c, const float* x_t, const float* cond, 
 inline void kmap_enqueue(const UNetCall& c, const float* cond) {
   const UNetPlan& p = *c.plan;
   ConvInArgs a{cond, nullptr, c.prepared + p.conv_in.p_w, c.prepared + p.conv_in.b,
-               reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W};
-  const TileCfg tc = pick_tile(c.n, c.H, c.W);
+               reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W, c.m.xcd()};
+  const TileCfg tc = pick_tile(c.m, c.n, c.H, c.W);
   int tw, th;
   tile_dims(tc, &tw, &th);
   const dim3 grid(cdiv(c.W, tw), cdiv(c.H, th), c.n);
-  if (tc == TILE_64x16 && conv8_split_mode() && (c.W & 3) == 0) {
+  if (tc == TILE_64x16 && c.m.split() && (c.W & 3) == 0) {
     ConvInHArgs ah{cond, nullptr, c.prepared + p.p_wch, c.prepared + p.p_wxh, c.prepared + p.p_wc5h + HL_W5TAB, c.prepared + p.conv_in.b,
-                   reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W};
+                   reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W, c.m.xcd()};
     conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
   } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
   else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
@@ -241,12 +240,13 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   a.wc5h = P + p.p_wc5h; a.wxh = P + p.p_wxh;
   a.noise = noise; a.sched = sched_row; a.inv_cnt = 1.0 / (2.0 * c.H * c.W);
   a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
+  a.xcd = c.m.xcd();
   TimedLaunch tl(KF_LATENT_STEP, c.st);
-  if (pick_tile(c.n, c.H, c.W) == TILE_64x16 && conv8_split_mode()) {
+  if (pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16 && c.m.split()) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
     if (noise) latent_step_h_kernel<1><<<grid, 256, 0, c.st>>>(a);
     else latent_step_h_kernel<2><<<grid, 256, 0, c.st>>>(a);
-  } else if (pick_tile(c.n, c.H, c.W) == TILE_64x16) {
+  } else if (pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
     if (noise) latent_step_kernel<64, 16, 1><<<grid, 256, 0, c.st>>>(a);
     else latent_step_kernel<64, 16, 2><<<grid, 256, 0, c.st>>>(a);

@@ -306,6 +306,7 @@ struct Conv8Args {
   double* dstat;          // [n][8][2] accumulators for dst (may be null)
   double inv_cnt;         // 1 / (channels per group * Hin * Win)
   int H, W, Hin, Win;
+  int xcd;                // 1: XCD-aware workgroup -> tile mapping (common.h xcd_block)
 };
 
 template <int TW, int TH, int PPL, int NSRC, bool GN, bool UP, int RES>
@@ -318,8 +319,9 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
   __shared__ float s_red[NT / 64][16];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int tx = tid % (TW / PPL), ty = tid / (TW / PPL);
   const size_t plane_in = (size_t)a.Hin * a.Win;
   const size_t plane = (size_t)a.H * a.W;
@@ -519,6 +521,7 @@ struct ConvInArgs {
   float* dst;         // [n][8][H][W]
   double* dstat;
   int C, H, W;
+  int xcd;
 };
 
 template <int TW, int TH, int PPL>
@@ -528,8 +531,9 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_in_kernel(const ConvInAr
   __shared__ __align__(16) float tile[8][LH][LS];
   __shared__ float s_red[NT / 64][16];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int tx = tid % (TW / PPL), ty = tid / (TW / PPL);
   const size_t plane = (size_t)a.H * a.W;
   const bool wvec = (a.W & 3) == 0;
@@ -638,6 +642,7 @@ struct ConvOutArgs {
   unsigned int stream_id;
   int C, H, W;
   const unsigned long long* seed_dev;  // optional: the Philox key is read from device memory (graph replay with a new seed)
+  int xcd;
 };
 
 template <int TW, int TH, int PPL, int POST>
@@ -649,8 +654,9 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOut
   __shared__ float s_ab[8][2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int nocb = (a.C + OCB - 1) / OCB;
-  const int n = blockIdx.z / nocb, ocb = blockIdx.z - n * nocb;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const BlockId bid = xcd_block(a.xcd);
+  const int n = bid.z / nocb, ocb = bid.z - n * nocb;
+  const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int tx = tid % (TW / PPL), ty = tid / (TW / PPL);
   const size_t plane = (size_t)a.H * a.W;
   const bool wvec = (a.W & 3) == 0;

@@ -44,10 +44,30 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 2
+#define GENCOMM_ABI_VERSION 3
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
+
+/* Library modes.  Explicit, atomic process-wide settings that every entry point reads ONCE when it is called (they
+ * travel with the call from there on); the library reads no environment variable.  gencomm_set_mode returns 0 or 1
+ * (unknown key / value out of range); gencomm_get_mode returns the value, -1 for an unknown key.
+ *   GENCOMM_MODE_ARITH        0 (default): 3x3 / 5x5 / Linear products on the f16 matrix pipe from exact two-term fp16
+ *                             splits of the fp32 operands (22-bit products, fp32 accumulation); 1: exact-fp32 kernels
+ *   GENCOMM_MODE_SAMPLER      0 (default): the loop is carried on conv_in's 8-channel output (one fused kernel per
+ *                             step replaces conv_out + update + conv_in); 1: literal per-step structure of
+ *                             cond_diff.py:321-329 (tests compare the two)
+ *   GENCOMM_MODE_TILE_WANT    0 (default): automatic tile choice; > 0: minimum number of 64x16 workgroups before the
+ *                             64x16-tile kernels are used (1 forces them onto small maps: tests)
+ *   GENCOMM_MODE_ENH_FUSE     1 (default): Enhancer Linear1 + depthwise stage fused at C = 64; 0: separate launches
+ *   GENCOMM_MODE_CONV8H_MASK  diagnostic bit mask of 8-channel layer variants allowed on the f16 pipe (-1: all)
+ *   GENCOMM_MODE_XCD_REMAP    1 (default): workgroup -> tile mapping keeps neighbouring tiles on one XCD; 0: grid order */
+enum {
+  GENCOMM_MODE_ARITH = 0, GENCOMM_MODE_SAMPLER = 1, GENCOMM_MODE_TILE_WANT = 2, GENCOMM_MODE_ENH_FUSE = 3,
+  GENCOMM_MODE_CONV8H_MASK = 4, GENCOMM_MODE_XCD_REMAP = 5
+};
+int gencomm_set_mode(int key, long long value);
+long long gencomm_get_mode(int key);
 
 /* Diagnostic kernel timer: gencomm_timer_start(family, capacity) arms it for ONE kernel family
  * (0 <= family < gencomm_timer_num_kernels(), name via gencomm_timer_kernel_name); until

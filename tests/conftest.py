@@ -15,3 +15,23 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(REPO, "tests", "golden")
+
+
+@pytest.fixture
+def modes():
+    """Setter for the library modes of include/gencomm_hip.h (gencomm_set_mode), restored after the test:
+    ``modes(arith="f32", sampler="direct", tile_want=1, xcd=0, enh_fuse=0, conv8h_mask=-1)``."""
+    from gencomm_amd import _lib
+    l = _lib.lib()
+    keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
+            "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP}
+    names = {"split": 0, "f32": 1, "latent": 0, "direct": 1}
+    prev = {k: l.gencomm_get_mode(k) for k in keys.values()}
+
+    def set_(**kw):
+        for name, value in kw.items():
+            _lib.check(l.gencomm_set_mode(keys[name], names.get(value, value)), "gencomm_set_mode")
+
+    yield set_
+    for k, v in prev.items():
+        _lib.check(l.gencomm_set_mode(k, v), "gencomm_set_mode")

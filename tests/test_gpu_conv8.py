@@ -7,8 +7,6 @@ products). Both must meet the same bar: rtol 1e-4 / atol 1e-5 against the refere
 single layer 2e-5 absolute against a float64 convolution of O(1) data. Launches with several workgroups per CU
 are part of the matrix on purpose: a scheduling-dependent fault of an early conv8h_kernel only showed there.
 """
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -17,13 +15,6 @@ from helpers import assert_close, build_inputs, build_modules, eval_noise, load_
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
-
-
-@pytest.fixture(autouse=True)
-def _env(monkeypatch):
-    monkeypatch.delenv("GENCOMM_CONV8", raising=False)
-    monkeypatch.delenv("GENCOMM_CONV8H_MASK", raising=False)
-    monkeypatch.delenv("GENCOMM_TILE_WANT", raising=False)
 
 
 def _conv8(x, w, b, split):
@@ -41,8 +32,8 @@ def _conv8(x, w, b, split):
 
 @pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("shape", [(1, 32, 64), (3, 18, 26), (2, 50, 130), (64, 64, 128), (4, 200, 704), (16, 100, 352)])
-def test_single_layer_vs_float64(monkeypatch, shape, split):
-    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")  # 64x16 tiles whatever the size (ragged widths take the scalar staging)
+def test_single_layer_vs_float64(modes, shape, split):
+    modes(tile_want=1)  # 64x16 tiles whatever the size (ragged widths take the scalar staging)
     n, H, W = shape
     g = torch.Generator(device=DEV).manual_seed(100 + n + H)
     x = torch.randn(n, 8, H, W, generator=g, device=DEV)
@@ -58,10 +49,10 @@ def test_single_layer_vs_float64(monkeypatch, shape, split):
         assert torch.equal(y0, y1)
 
 
-def test_split_operands_cover_the_fp16_range(monkeypatch):
+def test_split_operands_cover_the_fp16_range(modes):
     """Tiny and large weights / activations: the power-of-two weight scale keeps low parts normal; activations far below
     1 lose only absolute accuracy (fp16 subnormal steps of 6e-8)."""
-    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
+    modes(tile_want=1)
     g = torch.Generator(device=DEV).manual_seed(7)
     for wscale, xscale in [(1e-3, 1.0), (30.0, 1.0), (0.2, 1e-3), (0.2, 200.0)]:
         x = torch.randn(2, 8, 32, 64, generator=g, device=DEV) * xscale
@@ -75,9 +66,9 @@ def test_split_operands_cover_the_fp16_range(monkeypatch):
 
 @pytest.mark.parametrize("mode", ["f32", "split"])
 @pytest.mark.parametrize("name", ["tiny", "ragged", "mid", "shipped"])
-def test_golden_path_with_64x16_tiles_forced(monkeypatch, name, mode):
-    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
-    monkeypatch.setenv("GENCOMM_CONV8", mode)
+def test_golden_path_with_64x16_tiles_forced(modes, name, mode):
+    modes(tile_want=1)
+    modes(arith=mode)
     g = load_case(name)
     _, gen, _ = build_modules(g, "cuda:0")
     inp = build_inputs(g, "cuda:0")
@@ -86,7 +77,7 @@ def test_golden_path_with_64x16_tiles_forced(monkeypatch, name, mode):
     assert_close(sub(pred, int(g["stride"])), g["pred_feature"], 1e-4, 1e-5, f"pred_feature ({mode}, forced tiles)")
 
 
-def test_full_size_unet_call_modes_agree_and_repeat(monkeypatch):
+def test_full_size_unet_call_modes_agree_and_repeat(modes):
     from gencomm_amd import GenComm, synth
     gen = GenComm(synth.default_gencomm_cfg(64, 20)).eval()
     synth.fill_params_(gen, 0)
@@ -96,7 +87,7 @@ def test_full_size_unet_call_modes_agree_and_repeat(monkeypatch):
     t = torch.full((8,), 7.0, device=DEV)
     ys = {}
     for mode in ("f32", "split", "split"):
-        monkeypatch.setenv("GENCOMM_CONV8", mode)
+        modes(arith=mode)
         with torch.no_grad():
             y = gen.denoiser(x, t, T=20).clone()
         if mode in ys:
@@ -106,11 +97,11 @@ def test_full_size_unet_call_modes_agree_and_repeat(monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["tiny", "mid"])
-def test_golden_path_direct_sampler_with_64x16_tiles_forced(monkeypatch, name):
+def test_golden_path_direct_sampler_with_64x16_tiles_forced(modes, name):
     """The literal sampler (conv_in ... conv_out + update per step, explicit noise in conv_out's epilogue) through
     conv_in_h_kernel / conv8h_kernel / conv_out_h_kernel<POST=1>."""
-    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
-    monkeypatch.setenv("GENCOMM_SAMPLER", "direct")
+    modes(tile_want=1)
+    modes(sampler="direct")
     g = load_case(name)
     _, gen, _ = build_modules(g, "cuda:0")
     inp = build_inputs(g, "cuda:0")
@@ -120,14 +111,14 @@ def test_golden_path_direct_sampler_with_64x16_tiles_forced(monkeypatch, name):
 
 
 @pytest.mark.parametrize("shape", [(32, 22, 46, 5, [5, 1]), (256, 16, 24, 2, [2]), (16, 34, 68, 3, [1, 3])])
-def test_forced_tiles_vs_oracle_on_odd_shapes(monkeypatch, shape):
+def test_forced_tiles_vs_oracle_on_odd_shapes(modes, shape):
     """The 64x16-tile f16-pipe kernels on shapes no fixture has: a width that is not a multiple of 4 (scalar staging,
     fp32 conv_in / conv_out / sampler fall-backs mixed with conv8h layers), 5 agents in a scene, C = 256 (V2X-Real:
     16 channel blocks in conv_out_h, 32 chunks in conv_in_h, C/4 = 64 partial conv on the fp32 kernel), and a map whose
     half-resolution level is 17 x 34 (partial tiles at both levels) -- each stage against the CPU oracle."""
     from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, synth
     from oracle import torch_port as O
-    monkeypatch.setenv("GENCOMM_TILE_WANT", "1")
+    modes(tile_want=1)
     C, H, W, T, rl = shape
     n = sum(rl)
     cfg = synth.default_gencomm_cfg(C, T)

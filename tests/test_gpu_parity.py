@@ -229,7 +229,7 @@ def test_message_extractor_vs_oracle(C, H, W, n):
     assert_close(got.numpy(), ref.numpy(), RTOL, ATOL, "message")
 
 
-def test_latent_and_direct_samplers_agree():
+def test_latent_and_direct_samplers_agree(modes):
     """The default 'latent' sampler (loop carried on hs0 = conv_in(x_t), latent_kernels.h) against the
     literal conv_in..conv_out+update structure: same explicit noise, and same Philox seed (both draw the
     same counter-indexed noise field). Includes a map that is one tile wide/high and one with many tiles,
@@ -244,14 +244,11 @@ def test_latent_and_direct_samplers_agree():
         feat, cond = torch.from_numpy(inp["feat"]).to(DEV), torch.from_numpy(inp["cond"]).to(DEV)
         noise = tuple(torch.from_numpy(a).to(DEV) for a in synth.make_eval_noise(9, n, C, H, W, T))
         outs = {}
-        try:
-            for mode in ("latent", "direct"):
-                os.environ["GENCOMM_SAMPLER"] = mode
-                with torch.no_grad():
-                    outs[mode, "explicit"] = gen(feat, cond, [n], noise=noise)["pred_feature"].cpu()
-                    outs[mode, "philox"] = gen(feat, cond, [n], seed=77)["pred_feature"].cpu()
-        finally:
-            os.environ.pop("GENCOMM_SAMPLER", None)
+        for mode in ("latent", "direct"):
+            modes(sampler=mode)
+            with torch.no_grad():
+                outs[mode, "explicit"] = gen(feat, cond, [n], noise=noise)["pred_feature"].cpu()
+                outs[mode, "philox"] = gen(feat, cond, [n], seed=77)["pred_feature"].cpu()
         for kind in ("explicit", "philox"):
             a, b = outs["latent", kind], outs["direct", kind]
             err = (a - b).abs()

@@ -164,7 +164,7 @@ def test_scene_pipeline_graph_replay_matches_eager_and_reseeds():
     assert torch.allclose(outs[False][1], outs[True][1], rtol=0, atol=1e-5)
 
 
-def test_full_size_enhancer_and_fusion_modes_agree(monkeypatch):
+def test_full_size_enhancer_and_fusion_modes_agree(modes):
     """Enhancer (f16-pipe GEMMs and partial conv vs the exact-fp32 kernels) and the token-major fusion behind it at the
     benchmark geometry: the two arithmetic modes agree to 1e-5 on O(5) outputs."""
     from gencomm_amd import Enhancer, GenComm, normalize_pairwise_tfm, synth
@@ -182,7 +182,7 @@ def test_full_size_enhancer_and_fusion_modes_agree(monkeypatch):
     pipe.set_affine(normalize_pairwise_tfm(ptm, H * 0.4, W * 0.4, 1))
     outs = {}
     for mode in ("f32", "split"):
-        monkeypatch.setenv("GENCOMM_CONV8", mode)
+        modes(arith=mode)
         with torch.no_grad():
             outs[mode] = pipe.run(feat, cond, seed=9).clone()
         torch.cuda.synchronize()

@@ -10,6 +10,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
+from gencomm_amd import _lib as _L
+def _set(key, v): _L.check(_L.lib().gencomm_set_mode(key, int(v)), 'gencomm_set_mode')
 
 from gencomm_amd import GenComm, synth
 
@@ -19,14 +21,14 @@ gen = GenComm(synth.default_gencomm_cfg(C, T)).eval()
 synth.fill_params_(gen, 0)
 gen = gen.to(DEV)
 for mask in ("1", "2", "4", "8", "16", "31"):
-    os.environ["GENCOMM_CONV8H_MASK"] = mask
+    _set(_L.MODE_CONV8H_MASK, mask)
     for (N, H, W) in [(64, 64, 128), (4, 200, 704), (16, 200, 704)]:
         g = torch.Generator(device=DEV).manual_seed(3)
         x = torch.randn(N, C + 2, H, W, generator=g, device=DEV)
         t = torch.full((N,), 7.0, device=DEV)
         ys = {}
         for mode in ("f32", "split", "split2", "split3"):
-            os.environ["GENCOMM_CONV8"] = "f32" if mode == "f32" else "split"
+            _set(_L.MODE_ARITH, mode == "f32")
             with torch.no_grad():
                 ys[mode] = gen.denoiser(x, t, T=T).clone()
         torch.cuda.synchronize()

@@ -13,6 +13,8 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np
 import torch
+from gencomm_amd import _lib as _L
+def _set(key, v): _L.check(_L.lib().gencomm_set_mode(key, int(v)), 'gencomm_set_mode')
 
 from gencomm_amd import GenComm, synth
 from helpers import build_inputs, build_modules, eval_noise, load_case, sub
@@ -35,13 +37,13 @@ def golden_err(name):
 
 def main():
     for tile in ("512", "1"):
-        os.environ["GENCOMM_TILE_WANT"] = tile
+        _set(_L.MODE_TILE_WANT, tile)
         for mode in ("f32", "split"):
-            os.environ["GENCOMM_CONV8"] = mode
+            _set(_L.MODE_ARITH, mode == "f32")
             for name in ("tiny", "ragged", "mid", "shipped"):
                 e, r = golden_err(name)
                 print(f"tile_want {tile:>3} conv8 {mode:5} {name:8}: max abs err {e:.3e}  worst err/tol {r:.3f}", flush=True)
-    os.environ["GENCOMM_TILE_WANT"] = "512"
+    _set(_L.MODE_TILE_WANT, 512)
     n, C, H, W, T = 16, 64, 200, 704, 20
     torch.manual_seed(0)
     gen = GenComm(synth.default_gencomm_cfg(C, T)).eval().to(DEV)
@@ -50,7 +52,7 @@ def main():
     outs = {}
     for rep in range(2):
         for mode in ("f32", "split"):
-            os.environ["GENCOMM_CONV8"] = mode
+            _set(_L.MODE_ARITH, mode == "f32")
             with torch.no_grad():
                 y = gen.denoiser(x, t, T=T)
                 torch.cuda.synchronize()

@@ -4,12 +4,12 @@ import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
+from gencomm_amd import _lib as _L
+def _set(key, v): _L.check(_L.lib().gencomm_set_mode(key, int(v)), 'gencomm_set_mode')
 from gencomm_amd import _lib
 from gencomm_amd.runtime import ptr, stream_ptr
 DEV = torch.device("cuda:0")
-os.environ["GENCOMM_TILE_WANT"] = "1"
-os.environ.pop("GENCOMM_CONV8", None)
-os.environ.pop("GENCOMM_CONV8H_MASK", None)
+_set(_L.MODE_TILE_WANT, 1)
 l = _lib.lib()
 g = torch.Generator(device=DEV).manual_seed(5)
 CASES = [(1, 32, 64), (2, 64, 128), (16, 64, 128), (64, 64, 128), (1, 200, 704), (4, 200, 704), (16, 200, 704)]
