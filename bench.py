@@ -257,7 +257,7 @@ def main():
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
                                    f"T={T} x0-param ancestral steps, {B} scene(s)/step/GPU",
                        "agents": N, "C": C, "H": H, "W": W, "T": T, "enhancer": not args.no_enhancer,
-                       "noise": "in-kernel Philox4x32-10",
+                       "noise": "in-kernel Philox4x32-7 + Box-Muller (16-bit uniforms), step noise rounded to fp16",
                        "arithmetic": "fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
                                      "exact two-term fp16 splits of both operands (22-bit products, same parity tolerance as the exact-fp32 "
                                      "kernels; gencomm_set_mode(GENCOMM_MODE_ARITH, 1) selects those: see exact_fp32_mode)" if lib.gencomm_get_mode(_lib.MODE_ARITH) == 0

@@ -5,7 +5,7 @@ HIP kernels through ``gencomm_denoise_fwd``.
 Same constructor (``GenComm(model_cfg)``), same 12 persistent schedule buffers, same forward /
 forward_single signatures and returned dict keys, same ``state_dict`` layout as the reference.
 Extra, optional keyword ``noise=(noise0, step_noise)`` injects explicit N(0,1) tensors (parity
-tests); by default noise comes from an in-kernel Philox4x32-10 stream keyed by a seed drawn from
+tests); by default noise comes from an in-kernel Philox4x32-7 stream keyed by a seed drawn from
 torch's default generator (so ``torch.manual_seed`` makes runs reproducible).
 """
 from __future__ import annotations

@@ -219,12 +219,18 @@ __device__ __forceinline__ void wave_reduce16(const float (&part)[16], float (&t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 counter RNG + Box-Muller: 4 N(0,1) floats per (counter, key)
+// Noise: Philox4x32-7 counter RNG (Salmon et al., SC'11: 7 rounds is the fewest that passes BigCrush; the customary
+// 10 are a safety margin a sampler's noise field does not need) + Box-Muller.  One call yields four 32-bit words =
+// four Box-Muller pairs: word j -> radius from its low 16 bits (u = (k + 1/2) / 65536: |z| <= 4.85, the tail mass
+// beyond is 1.2e-6), angle from its high 16 bits (in revolutions, the unit of v_sin_f32 / v_cos_f32).
+// Round 1 used Philox4x32-10 with 32-bit uniforms, one call per FOUR normals: 20 quarter-rate v_mad_u64_u32 + 8
+// transcendentals per 4 normals made the sampler step VALU-bound (56 k of 70 k issue cycles per tile-wave); this
+// form spends 14 multiplies + 16 transcendentals per EIGHT normals.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+__device__ __forceinline__ void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                             uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < 7; ++r) {
     // one v_mad_u64_u32 per 32x32->64 product (integer multiplies are quarter-rate on CDNA:
     // a separate mul_hi + mul_lo pair would cost twice as much)
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -237,20 +243,53 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ void normal4(uint64_t elem, uint32_t stream, uint64_t seed, float z[4]) {
+// Box-Muller pair of one word, scaled by sg: (sg * r * cos, sg * r * sin) on the raw hardware transcendentals
+// (-2 ln u = (-2 ln 2) * v_log_f32(u) with u in [2^-17, 1): never 0, never denormal).
+__device__ __forceinline__ void bm_pair(uint32_t w, float sg, float& zc, float& zs) {
+  const float k = 1.52587890625e-5f;  // 2^-16
+  const float ur = fmaf((float)(w & 0xffffu), k, 0.5f * k), ut = (float)(w >> 16) * k;
+  const float m = sg * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ur));
+  zc = m * __builtin_amdgcn_cosf(ut);
+  zs = m * __builtin_amdgcn_sinf(ut);
+}
+
+// 8 N(0,1) floats of one counter: z[2j], z[2j+1] = the pair of word j (q_sample's initial noise: element index / 8)
+__device__ __forceinline__ void normal8(uint64_t ctr, uint32_t stream, uint64_t seed, float z[8]) {
   uint32_t r[4];
-  philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  // Box-Muller on the raw hardware transcendentals: the radius uniform lies in [2^-33, 1) (never denormal, never 0),
-  // -2 ln u = (-2 ln 2) * v_log_f32(u) >= 1.2e-7, and v_sin/v_cos take their argument in REVOLUTIONS, i.e. the angle
-  // uniform itself.  The library versions (sqrtf, __logf, __sincosf) spend ~10 extra VALU instructions per normal on
-  // denormal scaling and correctly-rounded square roots that a noise field does not need.
-  const float k = 2.3283064365386963e-10f;  // 2^-32
-  const float u0 = fminf(((float)r[0] + 0.5f) * k, 0.99999994f), u1 = ((float)r[1]) * k;
-  const float u2 = fminf(((float)r[2] + 0.5f) * k, 0.99999994f), u3 = ((float)r[3]) * k;
-  const float m0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
-  const float m1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
-  z[0] = m0 * __builtin_amdgcn_cosf(u1); z[1] = m0 * __builtin_amdgcn_sinf(u1);
-  z[2] = m1 * __builtin_amdgcn_cosf(u3); z[3] = m1 * __builtin_amdgcn_sinf(u3);
+  philox4x32_7((uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bm_pair(r[j], 1.0f, z[2 * j], z[2 * j + 1]);
+}
+
+// The sampler's step noise, CANONICAL FIELD (identical in the latent and the literal sampler structure, independent of
+// tiling): nu_t(n, c, y, x) = fp16( sigma_t * z ), z ~ N(0,1).  One call serves the channel pair (c & ~1, c | 1) at the
+// aligned pixel quad x & ~3: counter = element index of (n, c & ~1, y, x & ~3) in the [n][C][H][W] tensor, stream = t;
+// word j belongs to pixel (x & ~3) + j, its cosine branch to the even channel, its sine branch to the odd one.
+// Rounding sigma*z to fp16 (relative 2^-11, unbiased) is what lets the noise convolution run on the f16 matrix pipe
+// with ONE operand term; both sampler structures add exactly this value.
+// h[j] = packed (even channel, odd channel) fp16 pair of pixel j -- one dword of the LDS record of that pixel.
+typedef _Float16 nz_half2_t __attribute__((ext_vector_type(2)));
+typedef float nz_float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void noise_pair_quad_h(uint64_t elem, uint32_t stream, uint64_t seed, float sg, uint32_t (&h)[4]) {
+  uint32_t r[4];
+  philox4x32_7((uint32_t)elem, (uint32_t)(elem >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float zc, zs;
+    bm_pair(r[j], sg, zc, zs);
+    h[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector((nz_float2_t){zc, zs}, nz_half2_t));
+  }
+}
+// the same values as floats: z[j] = even channel, pixel j; z[4 + j] = odd channel, pixel j
+__device__ __forceinline__ void noise_pair_quad(uint64_t elem, uint32_t stream, uint64_t seed, float sg, float (&z)[8]) {
+  uint32_t h[4];
+  noise_pair_quad_h(elem, stream, seed, sg, h);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const nz_half2_t v = __builtin_bit_cast(nz_half2_t, h[j]);
+    z[j] = (float)v[0];
+    z[4 + j] = (float)v[1];
+  }
 }
 
 }  // namespace gc

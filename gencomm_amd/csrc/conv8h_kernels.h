@@ -264,6 +264,24 @@ __device__ __forceinline__ void conv_tile_mfma_h(const unsigned char* tile, cons
   }
 }
 
+// B operand is an fp16 number already (the sampler's step noise): hi plane only, two MFMA passes (w_hi, w_lo).
+__device__ __forceinline__ void conv_tile_mfma_hionly(const unsigned char* tile, const half8_t (&wa)[3][2],
+                                                      f32x4 (&acc)[2][4], const int (&off)[4][3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      half8_t b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c] + p * 2 * HC_ROW);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][1], b[j], acc[p][j], 0, 0, 0);
+    }
+  }
+}
+
 // prepared weight table of one 8-input-channel source: [c 3][hi/lo 2][lane 64][4 dwords]; after the last table
 // 64 floats: even entries 1 / scale, odd entries scale
 __device__ __forceinline__ void load_wa(half8_t (&wa)[3][2], const float* __restrict__ tab, int lane) {

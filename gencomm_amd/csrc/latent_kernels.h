@@ -297,21 +297,30 @@ __global__ __launch_bounds__((TW / 4) * TH) void latent_step_kernel(const Latent
         }
       }
     } else {
-      // Philox: one call per aligned quad (counter = element index of the quad's first pixel,
-      // component = pixel within the quad) -- the field the direct sampler's conv_out epilogue draws
-      auto gen_quad = [&](int c, int r, int qx) {
-        const int gy2 = y0 - 1 + r, gx2 = x0 + 4 * qx;
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gy2 >= 0 && gy2 < H && gx2 < W) {
-          normal4((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + c) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, z);
-        }
-        *reinterpret_cast<float4*>(&tileE[c][r][4 + 4 * qx]) = make_float4(sg * z[0], sg * z[1], sg * z[2], sg * z[3]);
+      // canonical step-noise field (common.h noise_pair_quad): one call per (channel pair, aligned quad), already scaled
+      // by sigma_t and rounded to fp16 -- the field the direct sampler's conv_out epilogue adds
+      auto pair_quad = [&](int cp, int r, int gxq, float (&z)[8]) {
+        const int gy2 = y0 - 1 + r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = 0.f;
+        if (gy2 >= 0 && gy2 < H && gxq >= 0 && gxq < W)
+          noise_pair_quad((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + 2 * cp) * plane + (size_t)gy2 * W + gxq), a.stream_id, seed, sg, z);
       };
 #pragma unroll
-      for (int c = 0; c < 8; ++c) gen_quad(c, ty, tx);
+      for (int cp = 0; cp < 4; ++cp) {
+        float z[8];
+        pair_quad(cp, ty, x0 + 4 * tx, z);
+        *reinterpret_cast<float4*>(&tileE[2 * cp][ty][4 + 4 * tx]) = make_float4(z[0], z[1], z[2], z[3]);
+        *reinterpret_cast<float4*>(&tileE[2 * cp + 1][ty][4 + 4 * tx]) = make_float4(z[4], z[5], z[6], z[7]);
+      }
       {
         const int cr = tid / (2 * QPR), rr = TH + ((tid / QPR) & 1);
-        if (cr < 8) gen_quad(cr, rr, tx);
+        if (cr < 8) {
+          float z[8];
+          pair_quad(cr >> 1, rr, x0 + 4 * tx, z);
+          const int o = 4 * (cr & 1);
+          *reinterpret_cast<float4*>(&tileE[cr][rr][4 + 4 * tx]) = make_float4(z[o], z[o + 1], z[o + 2], z[o + 3]);
+        }
       }
       constexpr int NH = (8 * LH * 2 + NT - 1) / NT;
 #pragma unroll
@@ -319,11 +328,9 @@ __global__ __launch_bounds__((TW / 4) * TH) void latent_step_kernel(const Latent
         const int hq = tid + k * NT;
         if (hq < 8 * LH * 2) {
           const int row = hq >> 1, side = hq & 1, c = row / LH, r = row - c * LH;
-          const int gy2 = y0 - 1 + r, gxq = side ? x0 + TW : x0 - 4;  // the aligned quad that owns the halo pixel
-          float z[4] = {0.f, 0.f, 0.f, 0.f};
-          if (gy2 >= 0 && gy2 < H && gxq >= 0 && gxq < W)
-            normal4((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + c) * plane + (size_t)gy2 * W + gxq), a.stream_id, seed, z);
-          tileE[c][r][side ? TW + 4 : 3] = sg * (side ? z[0] : z[3]);
+          float z[8];
+          pair_quad(c >> 1, r, side ? x0 + TW : x0 - 4, z);  // the aligned quad that owns the halo pixel
+          tileE[c][r][side ? TW + 4 : 3] = z[4 * (c & 1) + (side ? 0 : 3)];
         }
       }
     }

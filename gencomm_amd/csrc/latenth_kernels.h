@@ -392,27 +392,33 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
       const int gy = y0 + 4 * wave + r;
       if (gy >= H || gx + 3 >= W) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int oc = oc0 + i;
-        if (oc >= C) continue;
-        const size_t e = ((size_t)n * C + oc) * plane + (size_t)gy * W + gx;
-        float v[4];
+      for (int ip = 0; ip < 2; ++ip) {  // channel pairs (oc0 + 2 ip, oc0 + 2 ip + 1): one noise call each
+        if (oc0 + 2 * ip >= C) continue;
+        float z8[8];
+        if (POST == 2)  // canonical step-noise field, already scaled by sigma_t and rounded to fp16 (common.h)
+          noise_pair_quad((uint64_t)(((size_t)n * C + oc0 + 2 * ip) * plane + (size_t)gy * W + gx), a.stream_id, seed, sg, z8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[j][i] * inv_s;
-        if (POST != 0) {
-          const float4 t4 = *reinterpret_cast<const float4*>(a.xt + e);
-          const float xt[4] = {t4.x, t4.y, t4.z, t4.w};
-          float z[4];
-          if (POST == 1) {
-            const float4 z4 = *reinterpret_cast<const float4*>(a.noise + e);
-            z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
-          } else {
-            normal4((uint64_t)e, a.stream_id, seed, z);  // canonical field: counter = element index of the aligned quad
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = 2 * ip + ii, oc = oc0 + i;
+          const size_t e = ((size_t)n * C + oc) * plane + (size_t)gy * W + gx;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[j][i] * inv_s;
+          if (POST != 0) {
+            const float4 t4 = *reinterpret_cast<const float4*>(a.xt + e);
+            const float xt[4] = {t4.x, t4.y, t4.z, t4.w};
+            if (POST == 1) {
+              const float4 z4 = *reinterpret_cast<const float4*>(a.noise + e);
+              const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = fmaf(sg, z[j], fmaf(c1, v[j], c2 * xt[j]));
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = z8[4 * ii + j] + fmaf(c1, v[j], c2 * xt[j]);
+            }
           }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaf(sg, z[j], fmaf(c1, v[j], c2 * xt[j]));
+          *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -595,38 +601,45 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
         hreg = halo_load_h<false>(np_ + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
       }
     } else {
-      // canonical Philox field: one call per aligned quad (counter = element index of the quad's first pixel,
-      // component = pixel within the quad) -- the field the direct sampler's conv_out epilogue draws
-      auto gen_quad = [&](int c, int r, int q, float (&z)[4]) {
-        const int gy2 = y0 - 1 + r, gx2 = x0 + 4 * q;
-        z[0] = z[1] = z[2] = z[3] = 0.f;
-        if (gy2 >= 0 && gy2 < H && gx2 >= 0 && gx2 < W) {
-          normal4((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + c) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, z);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) z[j] *= sg;
-        }
+      // canonical step-noise field (common.h): nu = fp16(sigma_t * z), one Philox call per (channel pair, aligned quad)
+      // gives the packed (even, odd channel) dword of each of the quad's four pixel records.  Only the hi plane is
+      // written: nu IS an fp16 number, so the noise convolution needs one operand term (conv_tile_mfma_hionly).
+      auto pair_quad = [&](int cp, int r, int gx2, uint32_t (&h)[4]) {
+        const int gy2 = y0 - 1 + r;
+        h[0] = h[1] = h[2] = h[3] = 0u;
+        if (gy2 >= 0 && gy2 < H && gx2 >= 0 && gx2 < W)
+          noise_pair_quad_h((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + 2 * cp) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, sg, h);
       };
       {
-        float e[8][4];
+        uint32_t h[4][4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) gen_quad(c, r0, qx, e[c]);
-        hc_store_main<HC_PLANE>(tile, r0, qx, e);
+        for (int cp = 0; cp < 4; ++cp) pair_quad(cp, r0, x0 + 4 * qx, h[cp]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<uint4*>(tile + r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16) = make_uint4(h[0][j], h[1][j], h[2][j], h[3][j]);
       }
-      {
-        float e[4];
-        gen_quad(tid >> 5, TH + ((tid >> 4) & 1), qx, e);
-        hc_store_rem<HC_PLANE>(tile, tid, e);
+      {  // rows 16, 17: thread = (channel tid / 32, row 16 + (tid / 16 & 1), quad); the even channel's thread writes
+         // the pair's dwords of pixels 0, 1, the odd channel's thread those of pixels 2, 3 (whole dwords, see hc_store_rem)
+        const int cr = tid >> 5, rrw = TH + ((tid >> 4) & 1);
+        uint32_t h[4];
+        pair_quad(cr >> 1, rrw, x0 + 4 * qx, h);
+        const int jb = (cr & 1) ? 2 : 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          *reinterpret_cast<uint32_t*>(tile + rrw * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4) = h[jb + k];
       }
       if (tid < HC_LH * 8) {
         const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
-        float z0[4], z1[4];  // the aligned quad that owns the halo pixel: x0-4..x0-1 (component 3) or x0+64.. (component 0)
-        gen_quad(2 * cp, r, side ? 16 : -1, z0);
-        gen_quad(2 * cp + 1, r, side ? 16 : -1, z1);
-        hc_store_halo<HC_PLANE>(tile, tid, side ? z0[0] : z0[3], side ? z1[0] : z1[3]);
+        uint32_t h[4];  // the aligned quad that owns the halo pixel: x0-4..x0-1 (pixel 3) or x0+64.. (pixel 0)
+        pair_quad(cp, r, side ? x0 + TW : x0 - 4, h);
+        *reinterpret_cast<uint32_t*>(tile + hc_addr(r, side ? HC_TW : -1) + cp * 4) = side ? h[0] : h[3];
       }
     }
     __syncthreads();
-    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+    if (wave_live) {
+      if (NOISE == 1) conv_tile_mfma_h(tile, wa, acc, off);
+      else conv_tile_mfma_hionly(tile, wa, acc, off);
+    }
   }
 
   // ---------------- epilogue: combine, store in place, statistics for the next GroupNorm ----------------

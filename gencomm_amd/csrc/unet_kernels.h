@@ -621,7 +621,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_in_kernel(const ConvInAr
 // update fused into the epilogue (cond_diff.py:272-279, :302-315):
 //   POST 0: out = x0_hat                                  (t == 0, or a bare UNet call)
 //   POST 1: out = c1*x0_hat + c2*x_t + sigma*noise[elem]  (explicit noise tensor)
-//   POST 2: same with in-kernel Philox4x32-10 N(0,1)
+//   POST 2: same with the in-kernel step noise (common.h noise_pair_quad)
 // x_t is read from `xt` at the element being written, so xt == out (in place) is allowed.
 // One workgroup = one spatial tile x 16 output channels.
 // ---------------------------------------------------------------------------------------------
@@ -718,19 +718,17 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOut
           for (int p = 0; p < PPL; ++p) if (row_ok && gx + p < a.W) z[p] = a.noise[e + p];
         }
       } else {
-        // canonical noise field: element (n, c, y, x) = component (x & 3) of the Philox block whose
-        // counter is the element index of the aligned quad (x & ~3) -- independent of the tiling and
-        // shared with the latent sampler (latent_kernels.h)
-        if (PPL == 4) {
-          normal4((uint64_t)e, a.stream_id, seed, z);
-        } else {
-          float zz[4];
-          normal4((uint64_t)(e - (size_t)(gx & 3)), a.stream_id, seed, zz);
-          z[0] = zz[gx & 3];
-        }
+        // canonical step-noise field (common.h noise_pair_quad): already scaled by sigma_t and rounded to fp16,
+        // independent of the tiling and shared with the latent sampler (latent_kernels.h, latenth_kernels.h)
+        float z8[8];
+        const size_t e_even = e - (size_t)(oc & 1) * plane - (PPL == 4 ? 0 : (size_t)(gx & 3));
+        noise_pair_quad((uint64_t)e_even, a.stream_id, seed, sg, z8);
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) z[p] = z8[4 * (oc & 1) + (PPL == 4 ? p : (gx & 3))];
       }
 #pragma unroll
-      for (int p = 0; p < PPL; ++p) v[p] = fmaf(sg, z[p], fmaf(c1, v[p], c2 * xt[p]));
+      for (int p = 0; p < PPL; ++p)
+        v[p] = POST == 1 ? fmaf(sg, z[p], fmaf(c1, v[p], c2 * xt[p])) : z[p] + fmaf(c1, v[p], c2 * xt[p]);
     }
     if (vec_ok) {
       *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1 % PPL], v[2 % PPL], v[3 % PPL]);
@@ -764,25 +762,29 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
   const unsigned long long seed = (PHILOX && a.seed_dev) ? *a.seed_dev : a.seed;
   const float* __restrict__ fp = a.feat + (size_t)a.src_row[n] * a.per_agent;
   float* __restrict__ op = a.out + (size_t)n * a.per_agent;
-  const long long nvec = (a.per_agent & 3) ? 0 : (a.per_agent >> 2);  // rows stay 16-B aligned only then
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-    const float4 f = reinterpret_cast<const float4*>(fp)[i];
-    float z[4];
+  // octets of consecutive elements: one Philox call (normal8, counter = octet index) per 8 outputs
+  const long long noct = (a.per_agent & 7) ? 0 : (a.per_agent >> 3);  // rows stay 16-B aligned only then
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < noct; i += (long long)gridDim.x * 256) {
+    const float4 f0 = reinterpret_cast<const float4*>(fp)[2 * i], f1 = reinterpret_cast<const float4*>(fp)[2 * i + 1];
+    float z[8];
     if (PHILOX) {
-      normal4((uint64_t)((size_t)n * a.per_agent + i * 4), a.stream_id, seed, z);
+      normal8((uint64_t)(((size_t)n * a.per_agent >> 3) + i), a.stream_id, seed, z);
     } else {
-      const float4 z4 = reinterpret_cast<const float4*>(a.noise + (size_t)n * a.per_agent)[i];
-      z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
+      const float4 z0 = reinterpret_cast<const float4*>(a.noise + (size_t)n * a.per_agent)[2 * i];
+      const float4 z1 = reinterpret_cast<const float4*>(a.noise + (size_t)n * a.per_agent)[2 * i + 1];
+      z[0] = z0.x; z[1] = z0.y; z[2] = z0.z; z[3] = z0.w; z[4] = z1.x; z[5] = z1.y; z[6] = z1.z; z[7] = z1.w;
     }
-    reinterpret_cast<float4*>(op)[i] = make_float4(fmaf(sa, f.x, sb * z[0]), fmaf(sa, f.y, sb * z[1]),
-                                                   fmaf(sa, f.z, sb * z[2]), fmaf(sa, f.w, sb * z[3]));
+    reinterpret_cast<float4*>(op)[2 * i] = make_float4(fmaf(sa, f0.x, sb * z[0]), fmaf(sa, f0.y, sb * z[1]),
+                                                       fmaf(sa, f0.z, sb * z[2]), fmaf(sa, f0.w, sb * z[3]));
+    reinterpret_cast<float4*>(op)[2 * i + 1] = make_float4(fmaf(sa, f1.x, sb * z[4]), fmaf(sa, f1.y, sb * z[5]),
+                                                           fmaf(sa, f1.z, sb * z[6]), fmaf(sa, f1.w, sb * z[7]));
   }
-  // tail (per_agent not a multiple of 4)
-  for (long long i = (nvec << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < a.per_agent; i += (long long)gridDim.x * 256) {
+  // per_agent not a multiple of 8 (no shipped shape: C % 8 == 0): one element at a time, counter = element index
+  for (long long i = (noct << 3) + (long long)blockIdx.x * 256 + threadIdx.x; i < a.per_agent; i += (long long)gridDim.x * 256) {
     float z;
     if (PHILOX) {
-      float zz[4];
-      normal4((uint64_t)((size_t)n * a.per_agent + i), a.stream_id, seed, zz);
+      float zz[8];
+      normal8((uint64_t)((size_t)n * a.per_agent + i), a.stream_id ^ 0x80000000u, seed, zz);
       z = zz[0];
     } else {
       z = a.noise[(size_t)n * a.per_agent + i];

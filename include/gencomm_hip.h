@@ -115,7 +115,7 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
  * posterior_mean_coef1, posterior_mean_coef2, exp(0.5*posterior_log_variance_clipped)}.
  * x_start of agent i = feat[src_row[i]] (src_row: device int32[n]; the ego row of i's scene).
  * noise0 [n,C,H,W] and step_noise [T,n,C,H,W] (loop order t = T-1..0; entry T-1 unused) are either
- * both given (explicit noise: parity tests) or both NULL (in-kernel Philox4x32-10 keyed by `seed`).
+ * both given (explicit noise: parity tests) or both NULL (in-kernel Philox4x32-7 + Box-Muller keyed by `seed`; the step noise is sigma_t z rounded to fp16).
  * out [n,C,H,W] receives pred_feature; it is also the in-place x_t buffer of the loop. */
 int gencomm_denoise_fwd(const float* prepared, const float* sched,
                         const float* feat, int n_feat_rows, const int* src_row, const float* cond,

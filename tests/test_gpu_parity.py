@@ -105,7 +105,7 @@ def test_train_mode_forward_matches_reference_train_branch():
 
 
 def test_philox_noise_statistics_and_determinism():
-    """Production mode draws N(0,1) in-kernel (Philox4x32-10 + Box-Muller). q_sample with a zero
+    """Production mode draws N(0,1) in-kernel (Philox4x32-7 + Box-Muller on 16-bit uniforms, csrc/common.h). q_sample with a zero
     x_start returns sqrt(1-ac) * eps, so eps can be read back: moments of N(0,1), independent
     streams, seed determinism. The same generator feeds the fused step update in conv_out."""
     from gencomm_amd import GenComm, _lib, synth
