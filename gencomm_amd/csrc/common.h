@@ -163,6 +163,41 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return fmaf(h, copysignf(erf_abs, x), h);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Range guard of the fp16 hi/lo operand splits (conv8h_kernels.h).  A two-term split x = hi + lo needs |x| < 65504:
+//  * kernels whose operands are RAW tensors (conv_in's x_t / message channels, the Upsample conv's input, the unit-test
+//    entry) scale them by an exact power of two 2^-k chosen from a device-side bound on max|x| (act_scale: k = 0, i.e. no
+//    change at all, while the bound is below 2^14) and undo it in the epilogue -- the result is the fp32 one at any
+//    input magnitude a float can hold;
+//  * operands that are GroupNorm / LayerNorm outputs are bounded by |gamma| sqrt(group size) + |beta| whatever the
+//    input; every split kernel additionally runs with MODE.FP16_OVFL = 1, under which an overflowing f32 -> f16
+//    conversion saturates to +-65504 instead of producing inf: a pathological gamma degrades accuracy, it cannot
+//    create inf / NaN out of finite inputs.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fp16_ovfl_clamp() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+__device__ __forceinline__ float act_scale(float bound) {
+  if (!(bound >= 16384.f)) return 1.0f;
+  int ex = 0;
+  (void)frexpf(bound, &ex);  // bound = f * 2^ex, f in [0.5, 1)
+  return ldexpf(1.0f, 14 - ex);
+}
+// non-negative floats order like their bit patterns: max|x| over many workgroups with one integer atomic per wave
+__device__ __forceinline__ void wave_amax_commit(float v, float* __restrict__ dst) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(v));
+}
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long count, float* __restrict__ dst) {
+  float m = 0.f;
+  const long long nvec = (count & 3) ? 0 : (count >> 2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (long long i = (nvec << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  wave_amax_commit(m, dst);
+}
+
 // Butterfly sum, result in every lane (ds_bpermute based).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -188,7 +188,8 @@ __device__ __forceinline__ float2 halo_load_h(const float* __restrict__ sp, unsi
 // Slow path for widths that are not a multiple of 4 (tests only): one element at a time.
 template <bool GN, bool UP>
 __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ tile, const float* __restrict__ sp, unsigned plane_in,
-                                                 int Win, int H, int W, int x0, int y0, const float (*ab)[2], int tid) {
+                                                 int Win, int H, int W, int x0, int y0, const float (*ab)[2], int tid,
+                                                 float mul = 1.0f) {
   constexpr int LW = HC_TW + 2;
   for (int i = tid; i < 8 * HC_LH * LW; i += HC_NT) {
     const int c = i / (HC_LH * LW), rem = i - c * (HC_LH * LW);
@@ -199,6 +200,7 @@ __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ til
       e = UP ? sp[(unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)]
              : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
       if (GN) e = silu_f(fmaf(ab[c][0], e, ab[c][1]));
+      else e *= mul;
     }
     uint16_t hi, lo;
     split_one(e, hi, lo);
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   if (a.H < 0) s_pad[threadIdx.x] = 1.f;
 #endif
 
+  fp16_ovfl_clamp();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const BlockId bid = xcd_block(a.xcd);
   const int n = bid.z;
@@ -354,7 +357,22 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   GC_STAMP(0);
   half8_t wa[3][2];
   if (NSRC == 1) load_wa(wa, a.wh, lane);  // two-source layers: behind the first staging (register pressure)
-  const float inv_s = a.wh[NSRC * HC_WTAB];  // one scale for the whole (concatenated) weight tensor
+  // raw (not normalised) input: exact power-of-two range reduction from a device-side bound on max|src| (common.h)
+  float mul = 1.0f;
+  if (!GN) {
+    float bound = 0.f;
+    if (a.amax != nullptr) {
+      bound = *a.amax;
+    } else if (a.sstat[0] != nullptr) {  // max|x| <= sqrt(sum x^2) of the largest channel of this sample
+      const double* __restrict__ st = a.sstat[0] + (size_t)n * 16;
+      double q = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) q = fmax(q, st[2 * c + 1]);
+      bound = sqrtf((float)q) * 1.0001f;
+    }
+    mul = act_scale(bound);
+  }
+  const float inv_s = a.wh[NSRC * HC_WTAB] / mul;  // one scale for the whole (concatenated) weight tensor
   const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + 4 * ch);
   const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
   TileRegs<TW, TH, NT, 8> R;
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   // the accumulators start at bias * scale (exact: the scale is a power of two), so the epilogue is one multiply
   f32x4 acc[2][4];
   {
-    const float sc = a.wh[NSRC * HC_WTAB + 1];
+    const float sc = a.wh[NSRC * HC_WTAB + 1] * mul;
     const f32x4 b0 = {bias[0] * sc, bias[1] * sc, bias[2] * sc, bias[3] * sc};
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -386,8 +404,8 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
       for (int j = 0; j < 4; ++j) acc[p][j] = b0;
   }
 
-  if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[0], tid);
-  else stage_tile_scalar_h<GN, UP>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
+  if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[0], tid, mul);
+  else stage_tile_scalar_h<GN, UP>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid, mul);
   if (NSRC == 2) load_wa(wa, a.wh, lane);
   int off[4][3];
   hc_lane_offsets(off, wave, lane);

@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256) void enh_prep_pconv_h_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a) {
   constexpr int TW = 32, TH = 16, LW = TW + 2, LH = TH + 2;
+  fp16_ovfl_clamp();  // operands are LayerNorm outputs (bounded by the affine); saturate rather than overflow (common.h)
   extern __shared__ __align__(16) unsigned char pch_smem[];
   const int dc = a.dc, PB = dc * 2, plane = LH * LW * PB, q4 = dc >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) {
+  fp16_ovfl_clamp();
   constexpr int TP = 8, RP = TP + 2, NPX = RP * RP, C = 64, RB = C * 2 + 16, HS = 33;  // region 10x10, row bytes, hb stride
   __shared__ __align__(16) unsigned char zh[NPX * RB], zl[NPX * RB];
   __shared__ float hb[NPX * HS];

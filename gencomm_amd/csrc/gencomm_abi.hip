@@ -168,6 +168,9 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
   if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
   if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_denoise_workspace_bytes)");
   UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()};
+  GC_HIP(hipMemsetAsync(c.amax(), 0, 256, c.st));
+  amax_kernel<<<256, 256, 0, c.st>>>(cond, (long long)n * 2 * H * W, c.amax());
+  amax_kernel<<<1024, 256, 0, c.st>>>(x_t, (long long)n * C * H * W, c.amax() + 1);
   ConvOutArgs co{};
   co.out = x0_out;
   return unet_enqueue(c, x_t, cond, t, 0, co);
@@ -187,11 +190,15 @@ int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, 
   prep_conv8h_kernel<<<1, 256, 0, st>>>(w_oihw, p_wh, 8);
   GC_HIP(hipMemcpyAsync(p_b, bias, 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (dstat) GC_HIP(hipMemsetAsync(dstat, 0, (size_t)n * 16 * sizeof(double), st));
+  float* p_amax = scratch + 3088;  // device bound on max|src|: the f16-pipe kernel's range guard
+  GC_HIP(hipMemsetAsync(p_amax, 0, sizeof(float), st));
+  amax_kernel<<<256, 256, 0, st>>>(src, (long long)n * 8 * H * W, p_amax);
   const Modes m = modes_snapshot();
   Conv8Args a{};
   a.src[0] = src; a.w = p_w; a.wh = split ? p_wh : nullptr; a.bias = p_b; a.dst = dst; a.dstat = dstat;
   a.H = a.Hin = H; a.W = a.Win = W;
   a.xcd = m.xcd();
+  a.amax = p_amax;
   launch_conv8<1, false, false, 0>(m, pick_tile(m, n, H, W), a, n, st);
   GC_HIP(hipGetLastError());
   return GC_OK;
@@ -209,7 +216,7 @@ int gencomm_q_sample_fwd(const float* sched_row, const float* feat, int n_feat_r
                          float* out, int n, int C, int H, int W, void* stream) {
   GC_CHECK_ARG(sched_row && feat && src_row && out, "null pointer");
   GC_CHECK_ARG(n >= 1 && n <= 65535 && n_feat_rows >= 1 && C >= 1 && H >= 1 && W >= 1, "bad n/C/H/W");
-  QSampleArgs q{feat, src_row, noise, sched_row, out, seed, stream_id, (long long)C * H * W};
+  QSampleArgs q{feat, src_row, noise, sched_row, out, seed, stream_id, (long long)C * H * W, nullptr, nullptr};
   launch_q_sample(q, n, noise == nullptr, (hipStream_t)stream);
   GC_HIP(hipGetLastError());
   return GC_OK;
@@ -243,10 +250,13 @@ int gencomm_denoise_fwd_dseed(const float* prepared, const float* sched,
   const bool philox = noise0 == nullptr;
   const long long per_agent = (long long)C * H * W;
 
-  QSampleArgs q{feat, src_row, noise0, sched + (size_t)(T - 1) * 5, out, seed, (unsigned)T, per_agent, seed_dev};
+  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st, modes_snapshot()};
+  // range guard of conv_in on the f16 pipe: device bounds {max|cond|, max|x_T|} (common.h act_scale)
+  GC_HIP(hipMemsetAsync(c.amax(), 0, 256, st));
+  amax_kernel<<<256, 256, 0, st>>>(cond, (long long)n * 2 * H * W, c.amax());
+  QSampleArgs q{feat, src_row, noise0, sched + (size_t)(T - 1) * 5, out, seed, (unsigned)T, per_agent, seed_dev, c.amax() + 1};
   launch_q_sample(q, n, philox, st);
 
-  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st, modes_snapshot()};
   // Sampler structure: "latent" (default) carries the loop on the 8-channel map hs0 = conv_in(x_t)
   // (latent_kernels.h); "direct" is the literal conv_in ... conv_out + update per step.
   const bool force_direct = c.m.v[MODE_SAMPLER] == 1;  // tests compare both structures

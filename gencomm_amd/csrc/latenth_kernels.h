@@ -167,12 +167,14 @@ struct ConvInHArgs {
   double* dstat;
   int C, H, W;
   int xcd;
+  const float* amax;    // optional device bounds {max|cond|, max|x|}: exact power-of-two range reduction (common.h)
 };
 
 __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
   __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
   __shared__ float s_red[NT / 64][16];
+  fp16_ovfl_clamp();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const BlockId bid = xcd_block(a.xcd);
   const int n = bid.z;
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
   const int gx = x0 + 4 * ln, gy0 = y0 + 4 * wave + rr;
   const bool wave_live = y0 + 4 * wave < H;
   const int r0 = tid >> 4, qx = tid & 15;
-  const float inv_s = a.scales[0], sc = a.scales[1];
+  const float mul = a.amax != nullptr ? act_scale(fmaxf(a.amax[0], a.C > 0 ? a.amax[1] : 0.f)) : 1.0f;
+  const float inv_s = a.scales[0] / mul, sc = a.scales[1] * mul;
 
   f32x4 acc[2][4];
   {
@@ -224,12 +227,12 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
     for (int c = 0; c < 8; ++c)
 #pragma unroll
       for (int j = 0; j < 4; ++j) e[c][j] = 0.f;
-    e[0][0] = Rc.v[0].x; e[0][1] = Rc.v[0].y; e[0][2] = Rc.v[0].z; e[0][3] = Rc.v[0].w;
-    e[1][0] = Rc.v[1].x; e[1][1] = Rc.v[1].y; e[1][2] = Rc.v[1].z; e[1][3] = Rc.v[1].w;
+    e[0][0] = Rc.v[0].x * mul; e[0][1] = Rc.v[0].y * mul; e[0][2] = Rc.v[0].z * mul; e[0][3] = Rc.v[0].w * mul;
+    e[1][0] = Rc.v[1].x * mul; e[1][1] = Rc.v[1].y * mul; e[1][2] = Rc.v[1].z * mul; e[1][3] = Rc.v[1].w * mul;
     hc_store_main<HC_PLANE>(tile, r0, qx, e);
-    const float er[4] = {Rc.vr.x, Rc.vr.y, Rc.vr.z, Rc.vr.w};  // zero for threads whose channel (tid / 32) is not 0 or 1
+    const float er[4] = {Rc.vr.x * mul, Rc.vr.y * mul, Rc.vr.z * mul, Rc.vr.w * mul};  // zero for threads whose channel (tid / 32) is not 0 or 1
     hc_store_rem<HC_PLANE>(tile, tid, er);
-    if (tid < HC_LH * 8) hc_store_halo<HC_PLANE>(tile, tid, hc.x, hc.y);  // pairs 1..3: zeros
+    if (tid < HC_LH * 8) hc_store_halo<HC_PLANE>(tile, tid, hc.x * mul, hc.y * mul);  // pairs 1..3: zeros
     __syncthreads();
     if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
   }
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
     __syncthreads();
     half8_t wa[3][2];
     load_wa(wa, a.wxh + (size_t)cc * HC_WTAB, lane);
-    stage_store_h<false>(tile, R, hreg, H, W, x0, y0, nullptr, tid);
+    stage_store_h<false>(tile, R, hreg, H, W, x0, y0, nullptr, tid, mul);
     if (cc + 1 < nchunk) {
       stage_load<TW, TH, NT, 8, false>(R, xp + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
       hreg = halo_load_h<false>(xp + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
   __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
   __shared__ float s_ab[8][2];
+  fp16_ovfl_clamp();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const BlockId bid = xcd_block(a.xcd);
   const int n = bid.z;
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
   const unsigned long long seed = (POST == 2 && a.seed_dev) ? *a.seed_dev : a.seed;
   float c1 = 0.f, c2 = 0.f, sg = 0.f;
   if (POST != 0) { c1 = a.sched[2]; c2 = a.sched[3]; sg = a.sched[4]; }
+  float amax = 0.f;
 
 #pragma unroll 1
   for (int ob = 0; ob < nocb; ++ob) {
@@ -418,10 +423,12 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
             }
           }
           *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1], v[2], v[3]);
+          if (POST != 0) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
       }
     }
   }
+  if (POST != 0 && a.amax_out != nullptr) wave_amax_commit(amax, a.amax_out);
 }
 
 template <int NOISE>
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
   __shared__ float s_ab[8][2];
   __shared__ float s_red[NT / 64][16];
 
+  fp16_ovfl_clamp();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const BlockId bid = xcd_block(a.xcd);
   const int n = bid.z;

@@ -64,6 +64,7 @@ struct UNetCall {
   int n, H, W;
   hipStream_t st;
   Modes m;
+  float* amax() const { return reinterpret_cast<float*>(wsp + ws->amax_off); }  // {max|cond|, max|x_t|}, set by the caller
 
   float* tensor_ptr(int id) const {
     const TensorPlan& t = plan->tensors[id];
@@ -97,7 +98,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         TimedLaunch tl(KF_CONV_IN, c.st);
         if (tc == TILE_64x16 && c.m.split() && (Wl & 3) == 0) {
           ConvInHArgs ah{cond, x_t, P + p.p_wch, P + p.p_wxh, P + p.p_wc5h + HL_W5TAB, P + p.conv_in.b, c.tensor_ptr(o.dst),
-                         c.stat_ptr(o.dst), p.C, Hl, Wl, c.m.xcd()};
+                         c.stat_ptr(o.dst), p.C, Hl, Wl, c.m.xcd(), c.amax()};
           conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
         } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
         else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
@@ -142,13 +143,15 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         DownArgs a{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst),
                    c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin]};
         TimedLaunch tl(KF_DOWN, c.st);
-        down8_kernel<<<dim3(cdiv(Hl * Wl, 256), 1, c.n), 256, 0, c.st>>>(a);
+        if ((a.Win & 3) == 0) down8x2_kernel<<<dim3(cdiv(Hl * ((Wl + 1) / 2), 256), 1, c.n), 256, 0, c.st>>>(a);
+        else down8_kernel<<<dim3(cdiv(Hl * Wl, 256), 1, c.n), 256, 0, c.st>>>(a);
         break;
       }
       case OP_UP: {
         const int lin = o.level + 1;
         Conv8Args a{};
         a.src[0] = c.tensor_ptr(o.src[0]);
+        a.sstat[0] = c.stat_ptr(o.src[0]);  // raw input: range bound from its sum of squares (conv8h_kernel)
         a.w = P + p.up[lin].p_w; a.wh = P + p.up[lin].p_wh; a.bias = P + p.up[lin].b;
         a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
         a.H = Hl; a.W = Wl; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin];
@@ -174,6 +177,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         co.C = p.C; co.H = Hl; co.W = Wl;
         co.inv_cnt = 1.0 / (2.0 * Hl * Wl);
         co.xcd = c.m.xcd();
+        co.amax_out = post != 0 ? c.amax() + 1 : nullptr;  // literal sampler: x_{t-1} feeds the next step's conv_in
         const int nocb = (p.C + 15) / 16;
         const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
         int tw, th;
@@ -217,7 +221,7 @@ inline void kmap_enqueue(const UNetCall& c, const float* cond) {
   const dim3 grid(cdiv(c.W, tw), cdiv(c.H, th), c.n);
   if (tc == TILE_64x16 && c.m.split() && (c.W & 3) == 0) {
     ConvInHArgs ah{cond, nullptr, c.prepared + p.p_wch, c.prepared + p.p_wxh, c.prepared + p.p_wc5h + HL_W5TAB, c.prepared + p.conv_in.b,
-                   reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W, c.m.xcd()};
+                   reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W, c.m.xcd(), c.amax()};
     conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
   } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
   else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);

@@ -307,6 +307,7 @@ struct Conv8Args {
   double inv_cnt;         // 1 / (channels per group * Hin * Win)
   int H, W, Hin, Win;
   int xcd;                // 1: XCD-aware workgroup -> tile mapping (common.h xcd_block)
+  const float* amax;      // !GN on the f16 pipe: device bound on max|src| (or null: bound from sstat[0], or none)
 };
 
 template <int TW, int TH, int PPL, int NSRC, bool GN, bool UP, int RES>
@@ -509,6 +510,65 @@ __global__ __launch_bounds__(256) void down8_kernel(const DownArgs a) {
   if (a.dstat != nullptr) block_stats_commit<256>(part, s_red, a.dstat + (size_t)n * 16);
 }
 
+// Same layer, two horizontally adjacent outputs per thread: the 3x5 input window of the pair is one aligned float4 + one
+// scalar per (channel, row) -- 48 load instructions per thread instead of 72 stride-2 scalar gathers PER OUTPUT (the
+// scalar form moved 2.7 TB/s: 33 us per 16-agent launch at 200x704).  Needs Win % 4 == 0 (16-B aligned rows).
+__global__ __launch_bounds__(256) void down8x2_kernel(const DownArgs a) {
+  __shared__ float s_red[4][16];
+  const int n = blockIdx.z;
+  const int Wp = (a.W + 1) >> 1;  // output pairs per row
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = i < a.H * Wp;
+  const int oy = ok ? i / Wp : 0, op = ok ? i - oy * Wp : 0;
+  const int ox = 2 * op, ix = 4 * op;
+  const bool ok1 = ok && ox + 1 < a.W;
+  const size_t plane_in = (size_t)a.Hin * a.Win;
+  float acc[2][8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[0][o] = acc[1][o] = as_const(a.bias)[o];
+  const float* __restrict__ sp = a.src + (size_t)n * 8 * plane_in;
+#pragma unroll 2
+  for (int ic = 0; ic < 8; ++ic) {
+    float in[3][5];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy + dy;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float e = 0.f;
+      if (ok && iy < a.Hin) {
+        const float* __restrict__ rp = sp + (size_t)ic * plane_in + (size_t)iy * a.Win + ix;
+        v = *reinterpret_cast<const float4*>(rp);  // ix + 3 < Win: Win % 4 == 0 and ix < Win
+        if (ix + 4 < a.Win) e = rp[4];
+      }
+      in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = e;
+    }
+    const cfloat_p wp = as_const(a.w) + ic * 72;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const float w = wp[t * 8 + o];
+        acc[0][o] = fmaf(w, in[t / 3][t % 3], acc[0][o]);
+        acc[1][o] = fmaf(w, in[t / 3][t % 3 + 2], acc[1][o]);
+      }
+  }
+  float part[16];
+  const size_t total = (size_t)a.H * a.W;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * total + (size_t)oy * a.W + ox;
+    if (ok1 && (a.W & 1) == 0) *reinterpret_cast<float2*>(dp) = make_float2(acc[0][o], acc[1][o]);
+    else {
+      if (ok) dp[0] = acc[0][o];
+      if (ok1) dp[1] = acc[1][o];
+    }
+    const float v0 = ok ? acc[0][o] : 0.f, v1 = ok1 ? acc[1][o] : 0.f;
+    part[o] = v0 + v1;
+    part[8 + o] = fmaf(v0, v0, v1 * v1);
+  }
+  if (a.dstat != nullptr) block_stats_commit<256>(part, s_red, a.dstat + (size_t)n * 16);
+}
+
 // ---------------------------------------------------------------------------------------------
 // conv_in: cat[cond(2), x_t(C)] -> 8 channels, 3x3 pad 1 (unet.py:229-233; channel order cond
 // first, cond_diff.py:318). Input channels are streamed through LDS in chunks of 8.
@@ -643,6 +703,7 @@ struct ConvOutArgs {
   int C, H, W;
   const unsigned long long* seed_dev;  // optional: the Philox key is read from device memory (graph replay with a new seed)
   int xcd;
+  float* amax_out;      // optional (POST != 0, f16-pipe kernel): max|out| is folded into it (bound for the next conv_in)
 };
 
 template <int TW, int TH, int PPL, int POST>
@@ -753,6 +814,7 @@ struct QSampleArgs {
   unsigned int stream_id;
   long long per_agent; // C*H*W
   const unsigned long long* seed_dev;  // optional device-resident Philox key
+  float* amax;         // optional: max|out| is folded into it (range guard of conv_in on the f16 pipe)
 };
 
 template <bool PHILOX>
@@ -762,6 +824,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
   const unsigned long long seed = (PHILOX && a.seed_dev) ? *a.seed_dev : a.seed;
   const float* __restrict__ fp = a.feat + (size_t)a.src_row[n] * a.per_agent;
   float* __restrict__ op = a.out + (size_t)n * a.per_agent;
+  float amax = 0.f;
   // octets of consecutive elements: one Philox call (normal8, counter = octet index) per 8 outputs
   const long long noct = (a.per_agent & 7) ? 0 : (a.per_agent >> 3);  // rows stay 16-B aligned only then
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < noct; i += (long long)gridDim.x * 256) {
@@ -774,10 +837,12 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
       const float4 z1 = reinterpret_cast<const float4*>(a.noise + (size_t)n * a.per_agent)[2 * i + 1];
       z[0] = z0.x; z[1] = z0.y; z[2] = z0.z; z[3] = z0.w; z[4] = z1.x; z[5] = z1.y; z[6] = z1.z; z[7] = z1.w;
     }
-    reinterpret_cast<float4*>(op)[2 * i] = make_float4(fmaf(sa, f0.x, sb * z[0]), fmaf(sa, f0.y, sb * z[1]),
-                                                       fmaf(sa, f0.z, sb * z[2]), fmaf(sa, f0.w, sb * z[3]));
-    reinterpret_cast<float4*>(op)[2 * i + 1] = make_float4(fmaf(sa, f1.x, sb * z[4]), fmaf(sa, f1.y, sb * z[5]),
-                                                           fmaf(sa, f1.z, sb * z[6]), fmaf(sa, f1.w, sb * z[7]));
+    const float4 o0 = make_float4(fmaf(sa, f0.x, sb * z[0]), fmaf(sa, f0.y, sb * z[1]), fmaf(sa, f0.z, sb * z[2]), fmaf(sa, f0.w, sb * z[3]));
+    const float4 o1 = make_float4(fmaf(sa, f1.x, sb * z[4]), fmaf(sa, f1.y, sb * z[5]), fmaf(sa, f1.z, sb * z[6]), fmaf(sa, f1.w, sb * z[7]));
+    reinterpret_cast<float4*>(op)[2 * i] = o0;
+    reinterpret_cast<float4*>(op)[2 * i + 1] = o1;
+    amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(o0.x), fabsf(o0.y)), fmaxf(fabsf(o0.z), fabsf(o0.w))),
+                             fmaxf(fmaxf(fabsf(o1.x), fabsf(o1.y)), fmaxf(fabsf(o1.z), fabsf(o1.w)))));
   }
   // per_agent not a multiple of 8 (no shipped shape: C % 8 == 0): one element at a time, counter = element index
   for (long long i = (noct << 3) + (long long)blockIdx.x * 256 + threadIdx.x; i < a.per_agent; i += (long long)gridDim.x * 256) {
@@ -790,7 +855,9 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
       z = a.noise[(size_t)n * a.per_agent + i];
     }
     op[i] = fmaf(sa, fp[i], sb * z);
+    amax = fmaxf(amax, fabsf(op[i]));
   }
+  if (a.amax != nullptr) wave_amax_commit(amax, a.amax);
 }
 
 // ---------------------------------------------------------------------------------------------

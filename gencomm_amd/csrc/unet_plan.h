@@ -284,7 +284,7 @@ struct UNetPlan {
 struct UNetWorkspace {
   std::vector<int> Hl, Wl;
   std::vector<size_t> level_base, slot_bytes;
-  size_t stats_bytes = 0, total = 0, kmap_off = 0;
+  size_t stats_bytes = 0, total = 0, kmap_off = 0, amax_off = 0;
 
   const char* build(const UNetPlan& p, int n, int H, int W) {
     Hl.assign(p.L, 0); Wl.assign(p.L, 0);
@@ -305,6 +305,8 @@ struct UNetWorkspace {
     }
     kmap_off = off;  // persistent k = W_cond (*) cond + b_in of the latent sampler
     off += slot_bytes[0];
+    amax_off = off;  // two floats: device bounds on max|cond|, max|x_t| (range guard of conv_in on the f16 pipe)
+    off += 256;
     total = off;
     return nullptr;
   }

@@ -115,7 +115,7 @@ def unet_forward(sd: SD, p: str, x: Tensor, t: Tensor, mcfg: dict) -> Tensor:
     ch = mcfg["ch"]
     nres = len(mcfg["ch_mult"])
     nblk = mcfg["num_res_blocks"]
-    temb = timestep_embedding(t, ch)
+    temb = timestep_embedding(t, ch).to(x.dtype)  # float32 in the reference; follows x so that a float64 evaluation is possible
     temb = F.linear(temb, sd[p + ".temb.dense.0.weight"], sd[p + ".temb.dense.0.bias"])
     temb = F.linear(_silu(temb), sd[p + ".temb.dense.1.weight"], sd[p + ".temb.dense.1.bias"])
     hs = [_conv(sd, p + ".conv_in", x)]

