@@ -33,6 +33,8 @@ _SIGNATURES = {
     "gencomm_timer_kernel_name": (C.c_char_p, [_i]),
     "gencomm_timer_start": (_i, [_i, _i]),
     "gencomm_timer_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+    "gencomm_timer_start_mask": (_i, [C.c_ulonglong, _i]),
+    "gencomm_timer_stop_families": (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), _i]),
     "gencomm_unet_num_params": (_i, [_i, _i, _i, _i]),
     "gencomm_unet_param_info": (_i, [_i, _i, _i, _i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
     "gencomm_unet_raw_floats": (_ll, [_i, _i, _i, _i]),

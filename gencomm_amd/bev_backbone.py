@@ -28,12 +28,62 @@ def _versions(*tensors):
     return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
 
 
+def _torch_expr(x, conv, bn, relu, pad):
+    """The same layer as differentiable torch ops (backward of ``_Conv2dHipFn`` only -- never the forward result)."""
+    import torch.nn.functional as F
+    if isinstance(conv, nn.ConvTranspose2d):
+        y = F.conv_transpose2d(x, conv.weight, conv.bias, stride=conv.stride)
+    else:
+        y = F.conv2d(x, conv.weight, conv.bias, stride=conv.stride, padding=conv.padding[0] if pad is None else pad)
+    if bn is not None:
+        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    return F.relu(y) if relu else y
+
+
+class _Conv2dHipFn(torch.autograd.Function):
+    """HIP forward; backward re-evaluates the layer with differentiable torch ops from the saved input (the recompute
+    scheme of gencomm_amd/autograd.py), so gradients reach the input and the conv / BatchNorm-affine parameters."""
+
+    @staticmethod
+    def forward(ctx, x, conv, bn, relu, pad, *params):
+        ctx.conv, ctx.bn, ctx.relu, ctx.pad = conv, bn, relu, pad
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return conv2d_hip(x, conv, bn, relu=relu, pad=pad)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        params = [p for p in (ctx.conv.weight, ctx.conv.bias) + ((ctx.bn.weight, ctx.bn.bias) if ctx.bn is not None else ()) if p is not None]
+        with torch.enable_grad():
+            xd = x.detach().requires_grad_(True)
+            y = _torch_expr(xd, ctx.conv, ctx.bn, ctx.relu, ctx.pad)
+            wanted = [xd] + [p for p in params if p.requires_grad]
+            grads = torch.autograd.grad(y, wanted, gy.contiguous(), allow_unused=True)
+        gx = grads[0] if ctx.needs_input_grad[0] else None
+        it = iter(grads[1:])
+        gp = [next(it) if p.requires_grad else None for p in params]
+        return (gx, None, None, None, None, *gp)
+
+
 def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
                pad: Optional[int] = None, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
     """act(BN(conv(x))) as one HIP launch. ``conv`` is an ``nn.Conv2d`` (3x3 stride 1|2, or 1x1) or an
     ``nn.ConvTranspose2d`` whose kernel equals its stride; ``pad`` overrides ``conv.padding`` (ZeroPad2d(1)
-    in front of a padding-0 conv). ``out``/``out_coff``: write into a channel slice of a larger tensor."""
+    in front of a padding-0 conv). ``out``/``out_coff``: write into a channel slice of a larger tensor.
+    With gradients enabled and anything differentiable among the input and the layer's parameters the call goes
+    through ``_Conv2dHipFn`` (HIP forward, recompute backward): the graph is never cut silently."""
     require_gpu(x, "conv2d_hip")
+    if torch.is_grad_enabled():
+        params = [p for p in (conv.weight, conv.bias) + ((bn.weight, bn.bias) if bn is not None else ()) if p is not None]
+        if x.requires_grad or any(p.requires_grad for p in params):
+            if bn is not None and bn.training:
+                raise NotImplementedError("BatchNorm2d in training mode (batch statistics) is not implemented on the HIP path; call .eval()")
+            y = _Conv2dHipFn.apply(x, conv, bn, relu, pad, *params)
+            if out is None:
+                return y
+            out[:, out_coff:out_coff + y.shape[1]] = y  # differentiable slice assignment (training only)
+            return out
     x = f32c(x)
     transposed = isinstance(conv, nn.ConvTranspose2d)
     w = conv.weight

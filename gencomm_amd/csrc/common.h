@@ -68,29 +68,39 @@ Modes modes_snapshot();  // defined in gencomm_abi.hip
 enum KernelFamily : int {
   KF_CONV_IN = 0, KF_CONV8 = 1, KF_CONV16 = 2, KF_DOWN = 3, KF_UP = 4, KF_CONV_OUT = 5, KF_Q_SAMPLE = 6,
   KF_ENH_LN = 7, KF_ENH_PCONV = 8, KF_ENH_GEMM1 = 9, KF_ENH_DWGATE = 10, KF_ENH_GEMM2 = 11,
-  KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_LATENT_STEP = 15, KF_COUNT = 16
+  KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_LATENT_STEP = 15, KF_CONV8_RES1 = 16, KF_CONV8_RES2 = 17,
+  KF_COUNT = 18
 };
 inline const char* kernel_family_name(int id) {
-  static const char* names[KF_COUNT] = {"conv_in_kernel", "conv8_kernel<NSRC=1>", "conv8_kernel<NSRC=2>", "down8_kernel",
-                                        "conv8_kernel<UP>", "conv_out_kernel", "q_sample_kernel", "enh_ln_kernel",
-                                        "enh_pconv_kernel", "gemm_f32_mfma_kernel<0>", "enh_dwgate_kernel",
-                                        "gemm_f32_mfma_kernel<1>", "enh_gate_kernel", "enh_scale_transpose_kernel",
-                                        "warp_attfuse_kernel", "latent_step_kernel"};
+  static const char* names[KF_COUNT] = {
+      "conv_in_h_kernel | conv_in_kernel", "conv8h_kernel<1,GN,0> | conv8_kernel (ResnetBlock conv1, 8 -> 8)",
+      "conv8h_kernel<2,GN,0> | conv8_kernel (ResnetBlock conv1, 16 -> 8)", "down8x2_kernel | down8_kernel",
+      "conv8h_kernel<UP> | conv8_kernel<UP>", "conv_out_h_kernel | conv_out_kernel", "q_sample_kernel", "enh_ln_kernel",
+      "enh_pconv_h_kernel | enh_pconv_kernel", "enh_front_h_kernel | gemm_*_mfma_kernel<0>", "enh_dwgate_kernel",
+      "gemm_*_mfma_kernel<1>", "enh_gate_kernel", "enh_scale_transpose_kernel", "warp_attfuse_kernel | warp_attfuse_tok_kernel",
+      "latent_step_h_kernel | latent_step_kernel", "conv8h_kernel<1,GN,RES=1> | conv8_kernel (ResnetBlock conv2 + identity)",
+      "conv8h_kernel<1,GN,RES=2> | conv8_kernel (ResnetBlock conv2 + nin_shortcut)"};
   return (id >= 0 && id < KF_COUNT) ? names[id] : "?";
 }
 struct KernelTimer {
-  int family = -1;
+  unsigned long long mask = 0;  // families armed (bit per KernelFamily)
   int cap = 0, count = 0;
   hipEvent_t* ev = nullptr;  // 2 * cap
+  int* fam = nullptr;        // family of each recorded launch
+  double* bytes = nullptr;   // ALGORITHMIC bytes of each recorded launch (tensor bytes the layer must read + write)
 };
 KernelTimer& kernel_timer();  // defined in gencomm_abi.hip
 struct TimedLaunch {
   bool armed;
   hipStream_t st;
-  TimedLaunch(int family, hipStream_t s) : st(s) {
+  TimedLaunch(int family, hipStream_t s, double algorithmic_bytes = 0.0) : st(s) {
     KernelTimer& t = kernel_timer();
-    armed = t.family == family && t.count < t.cap;
-    if (armed) (void)hipEventRecord(t.ev[2 * t.count], st);
+    armed = ((t.mask >> family) & 1ull) && t.count < t.cap;
+    if (armed) {
+      t.fam[t.count] = family;
+      t.bytes[t.count] = algorithmic_bytes;
+      (void)hipEventRecord(t.ev[2 * t.count], st);
+    }
   }
   ~TimedLaunch() {
     if (armed) {
@@ -185,7 +195,13 @@ __device__ __forceinline__ float act_scale(float bound) {
 __device__ __forceinline__ void wave_amax_commit(float v, float* __restrict__ dst) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(v));
+  // the maximum saturates after the first few waves: look before adding (a stale smaller value read here only costs a
+  // redundant atomic; 131 k unconditional atomics on one address took 1.3 ms in q_sample_kernel)
+  if ((threadIdx.x & 63) == 0) {
+    unsigned int* __restrict__ p = reinterpret_cast<unsigned int*>(dst);
+    const unsigned int bits = __float_as_uint(v);
+    if (bits > __builtin_nontemporal_load(p)) atomicMax(p, bits);
+  }
 }
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long count, float* __restrict__ dst) {
   float m = 0.f;

@@ -57,10 +57,10 @@ long long gencomm_get_mode(int key) {
 int gencomm_timer_num_kernels(void) { return KF_COUNT; }
 const char* gencomm_timer_kernel_name(int family) { return kernel_family_name(family); }
 
-int gencomm_timer_start(int family, int capacity) {
+int gencomm_timer_start_mask(unsigned long long mask, int capacity) {
   KernelTimer& t = kernel_timer();
   GC_CHECK_ARG(t.ev == nullptr, "timer already armed");
-  GC_CHECK_ARG(family >= 0 && family < KF_COUNT && capacity >= 1 && capacity <= (1 << 20), "bad family/capacity");
+  GC_CHECK_ARG(mask != 0 && (mask >> KF_COUNT) == 0 && capacity >= 1 && capacity <= (1 << 20), "bad family mask / capacity");
   t.ev = new hipEvent_t[2 * (size_t)capacity];
   for (int i = 0; i < 2 * capacity; ++i) {
     if (hipEventCreate(&t.ev[i]) != hipSuccess) {
@@ -70,26 +70,54 @@ int gencomm_timer_start(int family, int capacity) {
       return fail(GC_ERR_HIP, "hipEventCreate failed");
     }
   }
-  t.family = family; t.cap = capacity; t.count = 0;
+  t.fam = new int[capacity];
+  t.bytes = new double[capacity];
+  t.mask = mask; t.cap = capacity; t.count = 0;
   return GC_OK;
+}
+int gencomm_timer_start(int family, int capacity) {
+  GC_CHECK_ARG(family >= 0 && family < KF_COUNT, "bad family");
+  return gencomm_timer_start_mask(1ull << family, capacity);
+}
+
+int gencomm_timer_stop_families(double* ms, int* launches, double* algorithmic_bytes, int n_families) {
+  KernelTimer& t = kernel_timer();
+  GC_CHECK_ARG(t.ev != nullptr, "timer not armed");
+  GC_CHECK_ARG(n_families >= 0 && n_families <= KF_COUNT, "bad n_families");
+  for (int f = 0; f < n_families; ++f) {
+    if (ms) ms[f] = 0.0;
+    if (launches) launches[f] = 0;
+    if (algorithmic_bytes) algorithmic_bytes[f] = 0.0;
+  }
+  int rc = GC_OK;
+  for (int i = 0; i < t.count; ++i) {
+    float e = 0.f;
+    if (hipEventSynchronize(t.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&e, t.ev[2 * i], t.ev[2 * i + 1]) != hipSuccess)
+      rc = fail(GC_ERR_HIP, "event timing failed");
+    const int f = t.fam[i];
+    if (f < n_families) {
+      if (ms) ms[f] += e;
+      if (launches) launches[f] += 1;
+      if (algorithmic_bytes) algorithmic_bytes[f] += t.bytes[i];
+    }
+  }
+  for (int i = 0; i < 2 * t.cap; ++i) (void)hipEventDestroy(t.ev[i]);
+  delete[] t.ev;
+  delete[] t.fam;
+  delete[] t.bytes;
+  t = KernelTimer{};
+  return rc;
 }
 
 int gencomm_timer_stop(double* total_ms, int* launches) {
-  KernelTimer& t = kernel_timer();
-  GC_CHECK_ARG(t.ev != nullptr, "timer not armed");
+  double ms[KF_COUNT];
+  int n[KF_COUNT];
+  const int rc = gencomm_timer_stop_families(ms, n, nullptr, KF_COUNT);
   double sum = 0.0;
-  int rc = GC_OK;
-  for (int i = 0; i < t.count; ++i) {
-    float ms = 0.f;
-    if (hipEventSynchronize(t.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]) != hipSuccess)
-      rc = fail(GC_ERR_HIP, "event timing failed");
-    sum += ms;
-  }
+  int cnt = 0;
+  for (int f = 0; f < KF_COUNT; ++f) { sum += ms[f]; cnt += n[f]; }
   if (total_ms) *total_ms = sum;
-  if (launches) *launches = t.count;
-  for (int i = 0; i < 2 * t.cap; ++i) (void)hipEventDestroy(t.ev[i]);
-  delete[] t.ev;
-  t = KernelTimer{};
+  if (launches) *launches = cnt;
   return rc;
 }
 

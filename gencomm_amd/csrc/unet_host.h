@@ -40,7 +40,9 @@ inline void tile_dims(TileCfg t, int* tw, int* th) {
 
 template <int NSRC, bool GN, bool UP, int RES>
 inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
-  TimedLaunch tl(UP ? KF_UP : (NSRC == 2 ? KF_CONV16 : KF_CONV8), st);
+  // algorithmic bytes: the source map(s), the residual source(s) and the destination, once each, fp32
+  const double abytes = 4.0 * n * ((double)NSRC * 8 * a.Hin * a.Win + (RES == 1 ? 8.0 : RES == 2 ? 16.0 : 0.0) * a.H * a.W + 8.0 * a.H * a.W);
+  TimedLaunch tl(UP ? KF_UP : (NSRC == 2 ? KF_CONV16 : (RES == 1 ? KF_CONV8_RES1 : RES == 2 ? KF_CONV8_RES2 : KF_CONV8)), st, abytes);
   int tw, th;
   tile_dims(t, &tw, &th);
   const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
@@ -142,7 +144,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         const int lin = o.level - 1;
         DownArgs a{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst),
                    c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin]};
-        TimedLaunch tl(KF_DOWN, c.st);
+        TimedLaunch tl(KF_DOWN, c.st, 4.0 * c.n * 8.0 * ((double)a.Hin * a.Win + (double)Hl * Wl));
         if ((a.Win & 3) == 0) down8x2_kernel<<<dim3(cdiv(Hl * ((Wl + 1) / 2), 256), 1, c.n), 256, 0, c.st>>>(a);
         else down8_kernel<<<dim3(cdiv(Hl * Wl, 256), 1, c.n), 256, 0, c.st>>>(a);
         break;
@@ -245,7 +247,8 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   a.noise = noise; a.sched = sched_row; a.inv_cnt = 1.0 / (2.0 * c.H * c.W);
   a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
   a.xcd = c.m.xcd();
-  TimedLaunch tl(KF_LATENT_STEP, c.st);
+  // algorithmic bytes: last block's output (read), k map (read), hs0 (read + write): 4 eight-channel maps
+  TimedLaunch tl(KF_LATENT_STEP, c.st, 4.0 * c.n * 32.0 * c.H * c.W);
   if (pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16 && c.m.split()) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
     if (noise) latent_step_h_kernel<1><<<grid, 256, 0, c.st>>>(a);

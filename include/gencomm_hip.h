@@ -69,16 +69,20 @@ enum {
 int gencomm_set_mode(int key, long long value);
 long long gencomm_get_mode(int key);
 
-/* Diagnostic kernel timer: gencomm_timer_start(family, capacity) arms it for ONE kernel family
- * (0 <= family < gencomm_timer_num_kernels(), name via gencomm_timer_kernel_name); until
- * gencomm_timer_stop every launch of that family (up to `capacity`) is bracketed by a pair of HIP
- * events on the stream it is launched on. stop() synchronises those events and returns the summed
- * device time and the number of launches. This is the only process-global state in the library;
- * do not arm it while capturing a graph. */
+/* Diagnostic kernel timer: gencomm_timer_start(family, capacity) arms it for ONE kernel family, gencomm_timer_start_mask
+ * for a set (bit f = family f; 0 <= f < gencomm_timer_num_kernels(), name via gencomm_timer_kernel_name); until it is
+ * stopped every launch of an armed family (up to `capacity` launches) is bracketed by a pair of HIP events on the stream
+ * it is launched on, and its ALGORITHMIC byte count (the tensor bytes the layer has to read and write, computed by the
+ * host from the launch shape) is recorded with it. gencomm_timer_stop synchronises those events and returns the summed
+ * device time and the number of launches; gencomm_timer_stop_families returns them per family (arrays of n_families
+ * entries, any may be NULL) together with the summed algorithmic bytes. Process-global diagnostic state (with the modes
+ * above the only one); do not arm it while capturing a graph. */
 int gencomm_timer_num_kernels(void);
 const char* gencomm_timer_kernel_name(int family);
 int gencomm_timer_start(int family, int capacity);
+int gencomm_timer_start_mask(unsigned long long family_mask, int capacity);
 int gencomm_timer_stop(double* total_ms, int* launches);
+int gencomm_timer_stop_families(double* ms, int* launches, double* algorithmic_bytes, int n_families);
 
 /* ----------------------------------------------------------------------------------------------
  * UNet parameters.  The "raw" blob is the concatenation of the module's parameters in EXECUTION

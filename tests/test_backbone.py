@@ -124,3 +124,38 @@ def test_hip_naive_compressor_vs_torch_fp32():
         ref = nc.decoder(nc.encoder(x))          # the torch layers the module owns == naive_compress.py:30-35
         got = nc.cuda()(x.cuda()).cpu()
     assert_close(got.numpy(), ref.numpy(), RTOL, ATOL, "compressor")
+
+
+@pytest.mark.gpu
+def test_grad_mode_keeps_the_autograd_graph_through_the_conv_stacks():
+    """Backbone -> shrink -> heads in grad mode: the HIP forward must not cut the graph (the reference's detection loss
+    back-propagates through these frozen or trainable layers into fusion / enhancer / gencomm). Gradients against the
+    same layers as plain torch modules."""
+    import copy
+    g = load_case("backbone")
+    bb, sh, heads, x = _modules(g, "cuda:0")
+    x = x[:, :, :32, :48].contiguous().requires_grad_(True)
+    y = bb({"spatial_features": x})["spatial_features_2d"]
+    out = heads[0](sh(y))
+    assert out.requires_grad and y.requires_grad
+    out.square().mean().backward()
+    got = {"x": x.grad.clone(), "w0": bb.blocks[0][1].weight.grad.clone(), "bn": bb.blocks[1][2].weight.grad.clone(),
+           "de": bb.deblocks[2][0].weight.grad.clone(), "head": heads[0].weight.grad.clone(), "sh_b": sh.layers[0].double_conv[0].bias.grad.clone()}
+    # the same computation with the torch layers the modules own
+    x2 = x.detach().clone().requires_grad_(True)
+    for m in (bb, sh, heads):
+        m.zero_grad()
+    feats, h = [], x2
+    for blk in bb.blocks:
+        h = blk(h)
+        feats.append(h)
+    y2 = torch.cat([bb.deblocks[i](f) for i, f in enumerate(feats)], dim=1)
+    z2 = sh.layers[0].double_conv(y2)
+    out2 = torch.nn.functional.conv2d(z2, heads[0].weight, heads[0].bias)
+    out2.square().mean().backward()
+    want = {"x": x2.grad, "w0": bb.blocks[0][1].weight.grad, "bn": bb.blocks[1][2].weight.grad,
+            "de": bb.deblocks[2][0].weight.grad, "head": heads[0].weight.grad, "sh_b": sh.layers[0].double_conv[0].bias.grad}
+    assert_close(out.detach().cpu().numpy(), out2.detach().cpu().numpy(), 1e-3, 1e-4, "forward (HIP vs torch/MIOpen)")
+    for k in got:
+        scale = float(want[k].abs().max())
+        assert float((got[k] - want[k]).abs().max()) <= 2e-3 * scale + 1e-7, (k, float((got[k] - want[k]).abs().max()), scale)
