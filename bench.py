@@ -39,11 +39,14 @@ PX_M = 0.4           # metres per BEV pixel at 200x704 (OPV2V range +-140.8 x +-
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 
-# dominant kernel (profiles/r1_bench_default_kernel_stats.csv: 19 % of kernel time, the largest single kernel): family id
-# in the library's timer.  The 8-channel convolutions together are 59 % (five conv8h_kernel variants): the largest of
-# them, the 16 -> 8 layers (family 2), is reported beside it against the HBM roof in a separate pass.
-DOMINANT = {"family": 15, "name": "latent_step_kernel"}
-SECONDARY_FAMILY = 2
+# Kernel families of the library's timer (include/gencomm_hip.h, csrc/common.h KernelFamily).  The dominant kernel is the
+# conv8h_kernel template -- the 8-channel 3x3 layers of the UNet (ResnetBlock conv1 / conv2, Upsample), ~55 % of kernel time in
+# profiles/r2_*_kernel_stats*.csv, HBM-bound: the headline `roofline`.  The latent sampler step (the largest single
+# instantiation, ~14 %, VALU/MFMA-bound) is reported beside it as `roofline_latent_step`.
+CONV8_FAMILIES = {1: "conv1 8->8 (GN+SiLU)", 16: "conv2 + identity residual", 17: "conv2 + 1x1 nin_shortcut", 2: "conv1 16->8 (skip concat)",
+                  4: "Upsample conv (nearest x2)"}
+LATENT_FAMILY = 15
+N_FAMILIES = 18
 
 
 def algorithmic_work(N, C, HW, T):
@@ -73,11 +76,11 @@ def build_modules(C, T, device):
     return gen.to(device), enh.to(device)
 
 
-def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, sample_steps=2):
-    """The CPU oracle (plain PyTorch restatement of the reference, oracle/torch_port.py) on this
-    host's cores, on a bounded sample: q_sample + `sample_steps` of the T denoise steps + Enhancer +
-    fusion at full tensor size; the per-step time is extrapolated to T steps (every step has
-    identical cost)."""
+def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, timed_steps=5):
+    """The CPU oracle (plain PyTorch restatement of the reference, oracle/torch_port.py) on this host's cores, on a bounded
+    sample of the same workload: after one untimed warm-up step, `timed_steps` of the T denoise steps are timed one by one
+    at full tensor size (every step has identical cost), q_sample once, Enhancer and fusion twice each; the scene time is
+    q_sample + T * mean(step) + enhancer + fusion, reported with the 95 % interval that the step-to-step spread implies."""
     from gencomm_amd import synth
     from oracle import torch_port as O
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -89,9 +92,9 @@ def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, sample_steps=2):
     cond = torch.randn(N, 2, H, W, generator=g)
     noise = torch.randn(N, C, H, W, generator=g)
     sched = O.make_schedule(T)
-    # thread count: ATen's CPU convolutions on these 8-channel maps stop scaling (and then slow down
-    # badly) well below the core count of a 2-socket host, so calibrate on one denoise step and
-    # keep the fastest of a few candidates; `cores` reports the threads actually used
+    # thread count: ATen's CPU convolutions on these 8-channel maps stop scaling (and then slow down badly) well below the
+    # core count of a 2-socket host, so calibrate on one denoise step and keep the fastest of a few candidates (this doubles
+    # as the warm-up); `cores` reports the threads actually used
     best = None
     with torch.no_grad():
         for th in [c for c in (8, 16, 32, 64) if c <= avail] or [avail]:
@@ -105,24 +108,37 @@ def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, sample_steps=2):
                 break
     cores = best[0]
     torch.set_num_threads(cores)
+    steps = []
     with torch.no_grad():
         t0 = time.perf_counter()
         x = O.q_sample(sched, O.ego_repeat(feat, [N]), T - 1, noise)
-        t1 = time.perf_counter()
-        for i in range(sample_steps):
-            x = O.p_sample(sd_g, sched, cfg["model"], cond, x, T - 1 - i, noise)
-        t2 = time.perf_counter()
-        e = O.enhancer_forward(sd_e, x, [N])
-        t3 = time.perf_counter()
+        t_q = time.perf_counter() - t0
+        x = O.p_sample(sd_g, sched, cfg["model"], cond, x, T - 1, noise)  # warm-up at the chosen thread count
+        for i in range(timed_steps):
+            t0 = time.perf_counter()
+            x = O.p_sample(sd_g, sched, cfg["model"], cond, x, T - 2 - i, noise)
+            steps.append(time.perf_counter() - t0)
+        t_e, t_f = [], []
         affine = O.normalize_pairwise_tfm(ptm, H * PX_M, W * PX_M, 1.0)
-        O.att_fusion(e, [N], affine)
-        t4 = time.perf_counter()
-    per_step = (t2 - t1) / sample_steps
-    scene_s = (t1 - t0) + per_step * T + (t3 - t2) + (t4 - t3)
+        for _ in range(2):
+            t0 = time.perf_counter()
+            e = O.enhancer_forward(sd_e, x, [N])
+            t_e.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            O.att_fusion(e, [N], affine)
+            t_f.append(time.perf_counter() - t0)
+    mean = float(np.mean(steps))
+    sem = float(np.std(steps, ddof=1) / np.sqrt(len(steps))) if len(steps) > 1 else 0.0
+    tcrit = {2: 12.71, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365}.get(len(steps), 2.0)  # Student t, 95 %
+    rest = t_q + min(t_e) + min(t_f)
+    scene_s = rest + T * mean
+    lo, hi = rest + T * (mean - tcrit * sem), rest + T * (mean + tcrit * sem)
     return {"value": 1.0 / scene_s, "unit": "scenes/sec", "cores": cores, "kind": "port",
-            "sample": f"workload '{name}': q_sample + {sample_steps} of {T} denoise steps ({per_step:.2f} s each, extrapolated x{T}) "
-                      f"+ enhancer {t3 - t2:.2f} s + fusion {t4 - t3:.2f} s, torch {torch.__version__} CPU, {cores} threads "
-                      f"(fastest of 8/16/32/64 on one step; host exposes {avail} logical CPUs)",
+            "ci95": [1.0 / hi, 1.0 / max(lo, 1e-9)],
+            "sample": f"workload '{name}': q_sample {t_q:.2f} s + 1 warm-up and {len(steps)} individually timed denoise steps of {T} "
+                      f"(mean {mean:.3f} s, standard error {sem:.3f} s, extrapolated x{T}) + enhancer {min(t_e):.2f} s + fusion {min(t_f):.2f} s "
+                      f"(best of 2), torch {torch.__version__} CPU, {cores} threads (fastest of 8/16/32/64 on one step; host exposes "
+                      f"{avail} logical CPUs); value = 1 / scene time, ci95 from the step-to-step spread",
             "scene_seconds": scene_s}
 
 
@@ -134,7 +150,8 @@ def main():
     ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-enhancer", action="store_true")
-    ap.add_argument("--timer-family", type=int, default=DOMINANT["family"])
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 pass (profiling runs)")
+    ap.add_argument("--no-timer", action="store_true", help="skip the per-kernel HIP-event passes")
     ap.add_argument("--batch", type=int, default=4, help="scenes per step (batched in one launch sequence, record_len=[N]*B)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
@@ -164,10 +181,10 @@ def main():
         _lib.check(lib.gencomm_set_mode(mode_keys[k], int(v)), "gencomm_set_mode")
 
     N, C, H, W, T = WORKLOADS[args.workload]
+    HW = H * W
     gen, enh = build_modules(C, T, device)
-    # S scenes in flight: the path is a chain of ~600 short dependent launches per scene, so two
-    # independent scenes on two streams fill each other's latency gaps (memory phases of one overlap
-    # compute phases of the other). Every stream has its own inputs, workspace and outputs.
+    # S scene batches in flight: the path is a chain of ~600 short dependent launches per scene batch, so independent
+    # batches on separate streams fill each other's latency gaps. Every stream has its own inputs, workspace and outputs.
     S, B = max(1, args.streams), max(1, args.batch)
     streams = [torch.cuda.Stream(device=device) for _ in range(S)]
     scenes, pipes = [], []
@@ -190,64 +207,101 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def timed_region(steps, seed0, use_barrier=True):
+        """`steps` steps bracketed by barrier + synchronize on both sides; returns elapsed seconds."""
+        (barrier if use_barrier else (lambda: torch.cuda.synchronize(device)))()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run_scene(i, seed0 + i)
+        (barrier if use_barrier else (lambda: torch.cuda.synchronize(device)))()
+        return time.perf_counter() - t0
+
+    def family_pass(runs=2):
+        """Per-kernel-family device time, launches and algorithmic bytes (HIP events on the launch stream, one scene
+        batch in flight so that an event pair brackets the kernel alone)."""
+        ms = (ctypes.c_double * N_FAMILIES)()
+        cnt = (ctypes.c_int * N_FAMILIES)()
+        byt = (ctypes.c_double * N_FAMILIES)()
+        _lib.check(lib.gencomm_timer_start_mask((1 << N_FAMILIES) - 1, runs * (T + 4) * 40), "gencomm_timer_start_mask")
+        with torch.no_grad():
+            for i in range(runs):
+                pipes[0].run(scenes[0][0], scenes[0][1], seed=3000 + i)
+        torch.cuda.synchronize(device)
+        _lib.check(lib.gencomm_timer_stop_families(ms, cnt, byt, N_FAMILIES), "gencomm_timer_stop_families")
+        return {f: {"ms": ms[f], "launches": cnt[f], "bytes": byt[f], "name": lib.gencomm_timer_kernel_name(f).decode()}
+                for f in range(N_FAMILIES) if cnt[f] > 0}
+
+    def rooflines(fam, arith_note):
+        """Headline roofline of the conv8h_kernel template (HBM) and the latent step beside it, from one family pass."""
+        out = {}
+        tot_ms = sum(v["ms"] for v in fam.values())
+        conv = {f: fam[f] for f in CONV8_FAMILIES if f in fam}
+        if conv:
+            c_ms, c_b, c_n = sum(v["ms"] for v in conv.values()), sum(v["bytes"] for v in conv.values()), sum(v["launches"] for v in conv.values())
+            traffic = None
+            pmc = os.path.join(REPO, "profiles", "r2_pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    tj = json.load(open(pmc))
+                    if tj.get("workload") == args.workload and tj.get("scenes_per_launch") == B:
+                        traffic = tj["conv8h_family"]["hbm_bytes_per_launch"]
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "kernel": "conv8h_kernel<NSRC, GN, UP, RES> (8-channel 3x3 layers of the UNet: ResnetBlock conv1 / conv2, Upsample; all levels)",
+                "bound": "hbm", "achieved": c_b / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": c_b / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "launches": c_n, "avg_launch_ms": c_ms / c_n, "algorithmic_bytes_per_launch": c_b / c_n,
+                "share_of_kernel_time": c_ms / tot_ms,
+                "variants": [{"variant": CONV8_FAMILIES[f], "launches": v["launches"], "avg_launch_ms": v["ms"] / v["launches"],
+                              "achieved_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for f, v in conv.items()],
+                "note": "achieved = ALGORITHMIC bytes (source maps + residual sources + destination of each launch, fp32, computed by the "
+                        "host from the launch shape) / HIP-event time of the launches, one scene batch in flight; averages over the full- "
+                        "and half-resolution levels. traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from the committed rocprofv3 --pmc "
+                        "passes of this command (profiles/r2_pmc_traffic.json, tools/pmc_pass.sh), null when none matches this workload. " + arith_note}
+        if LATENT_FAMILY in fam:
+            v = fam[LATENT_FAMILY]
+            fl = 2.0 * (1600.0 + 72.0 * C) * HW * N * B
+            ms1 = v["ms"] / v["launches"]
+            out["roofline_latent_step"] = {
+                "kernel": "latent_step_h_kernel (conv_out + sampler update + conv_in of one step fused by linearity, in-kernel noise)",
+                "bound": "mfma", "achieved": fl / (ms1 * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / (ms1 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": v["launches"], "avg_launch_ms": ms1,
+                "flops_per_launch": fl, "share_of_kernel_time": v["ms"] / tot_ms,
+                "achieved_algorithmic_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                "note": "algorithmic FLOPs = 2*(1600 + 72*C) per agent-pixel against the 157.3 TFLOP/s fp32 matrix/vector peak (the dtype of "
+                        "the path); bound by the in-kernel Philox4x32-7 + Box-Muller VALU work, not by the matrix pipe or HBM"}
+        out["kernel_time_shares"] = {v["name"]: round(v["ms"] / tot_ms, 4) for f, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        return out
+
     with torch.no_grad():
         for i in range(args.warmup):
             run_scene(i, 1000 + i)
-        barrier()
-        # arm the kernel timer for the dominant kernel on rank 0 (HIP events on the launch stream)
-        timed = rank == 0 and args.timer_family >= 0 and not args.graph  # event pairs cannot be recorded into a replayed graph
-        if timed:
-            _lib.check(lib.gencomm_timer_start(args.timer_family, args.steps * (T + 4) * 16), "gencomm_timer_start")
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            run_scene(i, 2000 + i)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    k_ms, k_n = ctypes.c_double(0.0), ctypes.c_int(0)
-    iso_ms, iso_n = ctypes.c_double(0.0), ctypes.c_int(0)
-    if timed:
-        _lib.check(lib.gencomm_timer_stop(ctypes.byref(k_ms), ctypes.byref(k_n)), "gencomm_timer_stop")
-        # the same kernel with nothing else in flight (one stream, outside the timed region): what
-        # the kernel itself achieves when it does not share the chip with another scene
-        with torch.no_grad():
-            _lib.check(lib.gencomm_timer_start(args.timer_family, 4 * (T + 4) * 16), "gencomm_timer_start")
-            for i in range(2):
-                pipes[0].run(scenes[0][0], scenes[0][1], seed=3000 + i)
-            torch.cuda.synchronize(device)
-            _lib.check(lib.gencomm_timer_stop(ctypes.byref(iso_ms), ctypes.byref(iso_n)), "gencomm_timer_stop")
-    sec_ms, sec_n = ctypes.c_double(0.0), ctypes.c_int(0)
-    if timed:
-        with torch.no_grad():  # same single-stream pass for the 16 -> 8 channel layers (HBM-bound)
-            _lib.check(lib.gencomm_timer_start(SECONDARY_FAMILY, 4 * (T + 4) * 16), "gencomm_timer_start")
-            for i in range(2):
-                pipes[0].run(scenes[0][0], scenes[0][1], seed=3100 + i)
-            torch.cuda.synchronize(device)
-            _lib.check(lib.gencomm_timer_stop(ctypes.byref(sec_ms), ctypes.byref(sec_n)), "gencomm_timer_stop")
-    # the same workload with the exact-fp32 MFMA kernels everywhere (GENCOMM_CONV8=f32, read per call by the library): a short
-    # untimed-region pass so that the JSON line carries both arithmetic modes
+        elapsed = timed_region(args.steps, 2000)
+    timed = rank == 0 and not args.graph and not args.no_timer  # event pairs cannot be recorded into a replayed graph
+    split_default = lib.gencomm_get_mode(_lib.MODE_ARITH) == 0
+    roofs = rooflines(family_pass(), "Arithmetic: see config.arithmetic.") if timed else {}
+    # the same workload with the exact-fp32 MFMA kernels everywhere, the arithmetic that is identical to the reference's:
+    # the full step count, timed the same way (rank 0), with its own family pass
     exact = None
-    if rank == 0 and lib.gencomm_get_mode(_lib.MODE_ARITH) == 0:
-        with _lib.mode(_lib.MODE_ARITH, 1):
-            with torch.no_grad():
-                for i in range(S):
-                    run_scene(i, 4000 + i)
-                torch.cuda.synchronize(device)
-                te = time.perf_counter()
-                ne = 2 * S
-                for i in range(ne):
-                    run_scene(i, 4100 + i)
-                torch.cuda.synchronize(device)
-                te = time.perf_counter() - te
-            exact = {"value": ne * B / te, "unit": "scenes/sec", "steps": ne, "n_gpus": 1,
-                     "note": "rank 0 only, same pipelines and streams, exact-fp32 v_mfma_f32_4x4x1 / 32x32x2 kernels"}
+    if rank == 0 and split_default and not args.no_exact:
+        with _lib.mode(_lib.MODE_ARITH, 1), torch.no_grad():
+            for i in range(S):
+                run_scene(i, 4000 + i)
+            te = timed_region(args.steps, 4100, use_barrier=False)
+            exact = {"value": args.steps * B / te, "unit": "scenes/sec", "steps": args.steps, "ms_per_step": 1e3 * te / args.steps,
+                     "n_gpus": 1, "dtype": "f32",
+                     "note": "rank 0, same pipelines and streams, gencomm_set_mode(GENCOMM_MODE_ARITH, 1): exact-fp32 "
+                             "v_mfma_f32_4x4x1 / 32x32x2 kernels everywhere"}
+            if timed:
+                exact.update({k: v for k, v in rooflines(family_pass(), "Exact-fp32 kernels (conv8_kernel).").items() if k.startswith("roofline")})
     for pipe in pipes:
         assert torch.isfinite(pipe.fused).all(), "non-finite output"
 
-    # every rank ran `steps` scenes of its own; whole-job rate = all scenes / slowest rank
+    # every rank ran `steps` steps of B scenes of its own; whole-job rate = all scenes / slowest rank
     value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed, dist, device)
 
     if rank == 0:
-        HW = H * W
         flops, byts = algorithmic_work(N, C, HW, T)
         out = {
             "metric": "scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world,
@@ -258,72 +312,20 @@ def main():
                                    f"T={T} x0-param ancestral steps, {B} scene(s)/step/GPU",
                        "agents": N, "C": C, "H": H, "W": W, "T": T, "enhancer": not args.no_enhancer,
                        "noise": "in-kernel Philox4x32-7 + Box-Muller (16-bit uniforms), step noise rounded to fp16",
-                       "arithmetic": "fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
-                                     "exact two-term fp16 splits of both operands (22-bit products, same parity tolerance as the exact-fp32 "
-                                     "kernels; gencomm_set_mode(GENCOMM_MODE_ARITH, 1) selects those: see exact_fp32_mode)" if lib.gencomm_get_mode(_lib.MODE_ARITH) == 0
-                                     else "exact fp32 MFMA kernels (GENCOMM_MODE_ARITH = 1)",
-                       "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph), "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+                       "arithmetic": ("fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
+                                      "exact two-term fp16 splits of both operands (22-bit products: slightly narrower than an fp32 FMA, same parity "
+                                      "tolerance; range-guarded, see DESIGN.md section 4); the arithmetic-identical-to-the-reference mode is "
+                                      "exact_fp32_mode") if split_default else "exact fp32 MFMA kernels (GENCOMM_MODE_ARITH = 1)",
+                       "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph),
+                       "modes": {k: lib.gencomm_get_mode(v) for k, v in mode_keys.items()},
+                       "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
             "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
                                   "achieved_tflops": flops * args.steps * B / elapsed / 1e12,
                                   "achieved_gbs": byts * args.steps * B / elapsed / 1e9},
         }
-        # roofline of the dominant kernel: algorithmic FLOPs per launch / measured launch time
-        roof = None
-        if timed and k_n.value > 0:
-            fam = args.timer_family
-            name = lib.gencomm_timer_kernel_name(fam).decode()
-            per_launch_ms = k_ms.value / k_n.value
-            # MACs per agent-pixel the kernel executes: conv_in 72(C+2); conv_out 72C; latent step = 5x5 composite
-            # (8*8*25) + noise conv (72C) -- DESIGN.md section 4
-            macs_px = {0: 72.0 * (C + 2), 5: 72.0 * C, 15: 1600.0 + 72.0 * C}.get(fam)
-            traffic = None
-            pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")  # measured at 1 scene/launch
-                    traffic = traffic * B if traffic is not None else None
-                except Exception:
-                    traffic = None
-            if macs_px is not None:
-                fl = 2.0 * macs_px * HW * N * B
-                # primary figure = the kernel's own duration: HIP events around every launch of two extra pipeline runs
-                # with ONE scene batch in flight. Inside the timed region two streams share the chip, so an event pair
-                # there also counts the time a launch waits for the other stream's kernels to drain; rocprofv3 (which
-                # serialises dispatches) reports the same duration as the single-stream pass, see profiles/.
-                own_ms = iso_ms.value / iso_n.value if iso_n.value else per_launch_ms
-                roof = {"kernel": name, "bound": "mfma", "achieved": fl / (own_ms * 1e-3) / 1e12,
-                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (own_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "traffic": traffic, "launches": iso_n.value if iso_n.value else k_n.value, "avg_launch_ms": own_ms,
-                        "flops_per_launch": fl,
-                        "in_timed_region": {"launches": k_n.value, "avg_launch_ms": per_launch_ms,
-                                            "achieved": fl / (per_launch_ms * 1e-3) / 1e12,
-                                            "frac": fl / (per_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                            "note": f"event pairs with {S} streams sharing the chip: includes queueing behind the other stream"},
-                        "note": "latent_step_h_kernel = conv_out + sampler update + conv_in of one step fused by linearity; "
-                                "algorithmic FLOPs = 2*(1600 + 72*C) per agent-pixel, priced against the 157.3 TFLOP/s fp32 "
-                                "matrix/vector peak (the dtype of the path). The products run on the f16 matrix pipe from exact "
-                                "fp16 hi/lo operand splits (3 v_mfma_f32_16x16x32_f16 per fp32 product block, fp32 accumulate, "
-                                "22-bit products: same parity tolerance as the exact-fp32 kernel, GENCOMM_CONV8=f32); the kernel "
-                                "is now bound by the in-kernel Philox4x32-10 + Box-Muller VALU work, not by the matrix pipe. "
-                                "duration = HIP events on the launch stream, one scene batch in flight (agrees with the "
-                                "rocprofv3 --kernel-trace --stats average)"}
-                if sec_n.value > 0:
-                    # 16 -> 8 channel layers (conv1 of the up blocks): per UNet call 3 launches per level, level l at 1/4^l of the
-                    # pixels; algorithmic bytes = read 16 channels + write 8 channels, fp32
-                    L = len(gen.denoiser.ch_mult) if hasattr(gen.denoiser, "ch_mult") else 2
-                    lvl = sum(0.25 ** l for l in range(L)) / L
-                    bytes_launch = 4.0 * 24 * HW * N * B * lvl
-                    s_ms = sec_ms.value / sec_n.value
-                    out["roofline_conv16"] = {
-                        "kernel": "conv8h_kernel<NSRC=2> (16 -> 8 ch 3x3 + GroupNorm + SiLU, all levels)", "bound": "hbm",
-                        "achieved": bytes_launch / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_launch / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "launches": sec_n.value, "avg_launch_ms": s_ms, "bytes_per_launch_avg": bytes_launch,
-                        "note": "average over the launches of one scene batch (full- and half-resolution levels); algorithmic "
-                                "bytes = 4 B * (16 read + 8 written channels) * pixels * agents"}
-            else:
-                roof = {"kernel": name, "launches": k_n.value, "avg_launch_ms": per_launch_ms}
-        out["roofline"] = roof
+        out["roofline"] = roofs.get("roofline")
+        out["roofline_latent_step"] = roofs.get("roofline_latent_step")
+        out["kernel_time_shares"] = roofs.get("kernel_time_shares")
         out["exact_fp32_mode"] = exact
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, N, C, H, W, T, gen, enh, ptm)

@@ -27,6 +27,7 @@ _i, _ll, _p = C.c_int, C.c_longlong, C.c_void_p
 _SIGNATURES = {
     "gencomm_abi_version": (_i, []),
     "gencomm_last_error": (C.c_char_p, []),
+    "gencomm_build_info": (C.c_char_p, []),
     "gencomm_set_mode": (_i, [_i, _ll]),
     "gencomm_get_mode": (_ll, [_i]),
     "gencomm_timer_num_kernels": (_i, []),
@@ -87,7 +88,7 @@ def hip_sources() -> List[str]:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU)."""
     srcs = hip_sources()
-    deps = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)] + [os.path.join(REPO_DIR, "include", "gencomm_hip.h")]
+    deps = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)] + [os.path.join(REPO_DIR, "include", "gencomm_hip.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -95,9 +96,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # `v_pk_fma_f32 v[0:1], v[0:1], s[22:23], v[22:23] op_sel:[0,0,1]` and sporadically lost the bias in the low half on
     # lanes 48..63 whenever two workgroups shared a SIMD (never with one workgroup per CU); the same source built
     # without packed ops is exact in every run (tools/conv8_unit.py), and the hot kernels are not slower for it.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
-           *srcs, "-o", LIB_PATH + ".tmp"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+             "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+    cmd = [hipcc, *flags, '-DGENCOMM_BUILD_FLAGS="' + " ".join(flags) + '"', *srcs, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -124,6 +125,9 @@ def lib() -> C.CDLL:
                 fn.restype, fn.argtypes = res, args
             if l.gencomm_abi_version() != ABI_VERSION:
                 raise GenCommHipError(f"ABI version mismatch: library {l.gencomm_abi_version()}, binding {ABI_VERSION}")
+            if b"-packed-fp32-ops" not in l.gencomm_build_info():
+                raise GenCommHipError(f"{LIB_PATH} was not built with '-Xclang -target-feature -Xclang -packed-fp32-ops' "
+                                      f"(build info: {l.gencomm_build_info().decode()!r}); rebuild with gencomm_amd._lib.build(force=True)")
             _lib = l
     return _lib
 

@@ -147,8 +147,12 @@ class GenComm(nn.Module):
         return out
 
     def _needs_grad(self, *tensors) -> bool:
-        return torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
-                                            any(p.requires_grad for p in self.denoiser.parameters()))
+        """The autograd path (explicit noise tensors, recompute backward) is taken only when something can receive a gradient:
+        a differentiable input, or -- in training mode -- a trainable denoiser parameter. An eval-mode module called with
+        plain inputs outside ``torch.no_grad()`` still runs the allocation-free HIP-only path."""
+        if not torch.is_grad_enabled():
+            return False
+        return any(t.requires_grad for t in tensors) or (self.training and any(p.requires_grad for p in self.denoiser.parameters()))
 
     def _run(self, feat, cond, src_rows, noise, seed) -> torch.Tensor:
         """HIP forward; when gradients are required, wrap it in the recompute-based autograd

@@ -37,6 +37,10 @@ using namespace gc;
 extern "C" {
 
 int gencomm_abi_version(void) { return GENCOMM_ABI_VERSION; }
+#ifndef GENCOMM_BUILD_FLAGS
+#define GENCOMM_BUILD_FLAGS "unknown"
+#endif
+const char* gencomm_build_info(void) { return GENCOMM_BUILD_FLAGS; }
 const char* gencomm_last_error(void) { return last_error_buf(); }
 
 // ------------------------------------------------------------------------------------ modes

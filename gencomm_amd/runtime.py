@@ -32,18 +32,23 @@ def stream_ptr(device: torch.device) -> int:
 
 
 class _Workspaces:
-    """One growable byte buffer per (device, tag). Kernels are stream-ordered on the caller's
-    current stream, so reuse across calls on that stream is safe."""
+    """One growable byte buffer per (device, HIP stream, tag). Kernels are stream-ordered on the caller's current stream, so
+    reuse across calls on that stream is safe; two streams (or threads on different streams) never share scratch. A buffer
+    that is outgrown is released only after the stream that used it has drained."""
 
     def __init__(self):
-        self._bufs: Dict[Tuple[int, str], torch.Tensor] = {}
+        self._bufs: Dict[Tuple[int, int, str], torch.Tensor] = {}
 
     def get(self, device: torch.device, nbytes: int, tag: str = "main") -> torch.Tensor:
-        key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(device)
+        key = (dev, stream.cuda_stream, tag)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = None
-            self._bufs.pop(key, None)
+            if buf is not None:
+                stream.synchronize()  # kernels already enqueued on this stream may still use the old buffer
+                self._bufs.pop(key, None)
+                del buf
             buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
             self._bufs[key] = buf
         return buf

@@ -48,6 +48,11 @@ extern "C" {
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
+/* The code-generation flags the library was compiled with (set by the build: -DGENCOMM_BUILD_FLAGS). The kernels must be
+ * built WITHOUT packed fp32 instructions (-Xclang -target-feature -Xclang -packed-fp32-ops): a v_pk_fma_f32 in
+ * conv8h_kernel's epilogue returned wrong values under multi-workgroup occupancy; the Python binding
+ * refuses a library whose build info lacks that switch and tests/test_abi.py disassembles the code object to check. */
+const char* gencomm_build_info(void);
 
 /* Library modes.  Explicit, atomic process-wide settings that every entry point reads ONCE when it is called (they
  * travel with the call from there on); the library reads no environment variable.  gencomm_set_mode returns 0 or 1

@@ -96,3 +96,68 @@ def test_attnblock_params_are_enumerated_when_present(lib):
     table = _lib.unet_param_table(8, 2, 2, 0b10)
     assert sorted(n for n, _, _ in table) == sorted(named)
     assert lib.gencomm_unet_raw_floats(8, 2, 2, 0b100) == -1  # bit beyond the number of levels
+
+
+def test_integration_md_example_matches_the_binding():
+    """INTEGRATION.md section 2 shows a maintainer how to call the C ABI: every `lib.<fn>(...)` call and every `argtypes`
+    list in it must have exactly as many entries as the binding the package itself uses (a stale example shifts arguments
+    and corrupts the call)."""
+    import re
+    from gencomm_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = text[text.index("```python\nimport ctypes as C, torch"):]
+    block = block[:block.index("```", 10)]
+    assert f"gencomm_abi_version() == {_lib.ABI_VERSION}" in block
+
+    def top_level_args(s):
+        depth, n, seen = 0, 0, False
+        for ch in s:
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+            elif ch == "," and depth == 0:
+                n += 1
+            if not ch.isspace():
+                seen = True
+        return n + 1 if seen else 0
+
+    checked = 0
+    for m in re.finditer(r"lib\.(gencomm_\w+)\.argtypes = \[([^\]]*)\]", block):
+        assert top_level_args(m.group(2)) == len(_lib._SIGNATURES[m.group(1)][1]), m.group(1)
+        checked += 1
+    for m in re.finditer(r"lib\.(gencomm_\w+)\(", block):
+        name, start = m.group(1), m.end()
+        if name == "gencomm_abi_version" or name == "gencomm_last_error":
+            continue
+        depth, i = 1, start
+        while depth:
+            depth += {"(": 1, ")": -1}.get(block[i], 0)
+            i += 1
+        nargs = top_level_args(block[start:i - 1])
+        want = len(_lib._SIGNATURES[name][1])
+        if name == "gencomm_unet_num_params" or nargs == want:
+            assert nargs == want, (name, nargs, want)
+            checked += 1
+        else:
+            raise AssertionError((name, nargs, want))
+    assert checked >= 8
+
+
+def test_code_object_has_no_packed_fp32_instructions(tmp_path):
+    """Disassemble the gfx950 code object of the built library: no v_pk_{fma,mul,add}_f32 anywhere (see gencomm_build_info
+    in include/gencomm_hip.h), and the matrix-core instructions the design rests on are there."""
+    import shutil, subprocess
+    from gencomm_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("llvm-objdump or the built library is not available")
+    assert b"-packed-fp32-ops" in _lib.lib().gencomm_build_info()
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert objs, os.listdir(tmp_path)
+    asm = subprocess.run([objdump, "-d", str(tmp_path / objs[0])], check=True, capture_output=True, text=True).stdout
+    import re
+    assert not re.search(r"v_pk_(fma|mul|add)_f32", asm)
+    assert "v_mfma_f32_16x16x32_f16" in asm and "v_mfma_f32_4x4x1" in asm
