@@ -428,6 +428,78 @@ def run_postproc_case() -> None:
     print(f"postproc: wrote postproc.npz ({os.path.getsize(os.path.join(OUT, 'postproc.npz')) / 1024:.0f} KiB)")
 
 
+def make_eval_frames(seed: int, n_frames: int = 6):
+    """Synthetic detection frames for the AP fixture: ground-truth BEV boxes (corners (K, 8, 3)), detections = jittered
+    ground truth (some well inside IoU 0.7, some between the thresholds) + false positives, scores; one frame with no
+    detection (det_boxes None), one with no ground truth."""
+    r = np.random.RandomState(seed)
+
+    def corners(c, size, yaw):
+        l, w = size
+        loc = np.array([[l / 2, w / 2], [l / 2, -w / 2], [-l / 2, -w / 2], [-l / 2, w / 2]])
+        R = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        xy = loc @ R.T + c
+        top = np.concatenate([xy, np.full((4, 1), 1.0)], 1)
+        bot = np.concatenate([xy, np.full((4, 1), -1.0)], 1)
+        return np.concatenate([bot, top], 0).astype(np.float32)
+
+    frames = []
+    for f in range(n_frames):
+        K = 0 if f == 4 else r.randint(6, 14)
+        gts, dets, scores = [], [], []
+        for _ in range(K):
+            c, size, yaw = r.uniform(-60, 60, 2), (r.uniform(3.5, 5.5), r.uniform(1.6, 2.2)), r.uniform(-np.pi, np.pi)
+            gts.append(corners(c, size, yaw))
+            u = r.rand()
+            if u < 0.8:  # detected, with jitter that lands on either side of the 0.5 / 0.7 thresholds
+                j = r.choice([0.05, 0.3, 0.8])
+                dets.append(corners(c + r.normal(0, j, 2), (size[0] * r.uniform(0.9, 1.1), size[1] * r.uniform(0.9, 1.1)), yaw + r.normal(0, 0.05)))
+                scores.append(r.uniform(0.3, 0.99))
+                if r.rand() < 0.2:  # duplicate detection of the same object (must become a false positive)
+                    dets.append(corners(c + r.normal(0, 0.05, 2), size, yaw))
+                    scores.append(r.uniform(0.2, 0.9))
+        for _ in range(r.randint(1, 5)):  # false positives
+            dets.append(corners(r.uniform(-60, 60, 2), (4.5, 1.9), r.uniform(-np.pi, np.pi)))
+            scores.append(r.uniform(0.2, 0.7))
+        gt = np.stack(gts) if gts else np.zeros((0, 8, 3), np.float32)
+        if f == 2:
+            frames.append((None, None, gt))
+        else:
+            frames.append((np.stack(dets), np.asarray(scores, dtype=np.float32), gt))
+    return frames
+
+
+def run_eval_case() -> None:
+    """AP harness (SURVEY 8d parity metric): the reference's own caluclate_tp_fp / calculate_ap / voc_ap
+    (opencood/utils/eval_utils.py) on synthetic frames. shapely is absent: `common_utils.convert_format/compute_iou` are bound
+    to the oracle's float64 convex-clipping IoU (PARITY UNPINNED for that call, see oracle/eval_port.py); the matching, the
+    cumulative sums and the precision envelope are the reference's."""
+    import detect_port as D
+    from opencood.utils import common_utils, eval_utils
+    common_utils.convert_format = lambda boxes: np.asarray(boxes, dtype=np.float64)[:, :4, :2]
+    common_utils.compute_iou = lambda box, boxes: D.quad_iou_one_to_many(box, np.asarray(boxes).reshape(-1, 4, 2))
+    seed = DATA_SEED + 60
+    frames = make_eval_frames(seed)
+    stat = {0.3: {'tp': [], 'fp': [], 'gt': 0, 'score': []}, 0.5: {'tp': [], 'fp': [], 'gt': 0, 'score': []}, 0.7: {'tp': [], 'fp': [], 'gt': 0, 'score': []}}
+    for det, score, gt in frames:
+        for thr in (0.3, 0.5, 0.7):
+            eval_utils.caluclate_tp_fp(None if det is None else torch.from_numpy(det), None if det is None else torch.from_numpy(score),
+                                       torch.from_numpy(gt), stat, thr)
+    rec = {"seed": seed, "n_frames": len(frames)}
+    for thr in (0.3, 0.5, 0.7):
+        k = str(thr)
+        rec["tp_" + k], rec["fp_" + k] = np.array(stat[thr]["tp"]), np.array(stat[thr]["fp"])
+        rec["score_" + k], rec["gt_" + k] = np.array(stat[thr]["score"], dtype=np.float64), stat[thr]["gt"]
+    import copy
+    for gs in (True, False):  # inference.py:231-234 order; the second call cumulates the stored lists in place, so copy
+        for thr in (0.3, 0.5, 0.7):
+            ap, mrec, mpre = eval_utils.calculate_ap(copy.deepcopy(stat), thr, gs)
+            rec[f"ap_{thr}_{int(gs)}"], rec[f"mrec_{thr}_{int(gs)}"], rec[f"mpre_{thr}_{int(gs)}"] = ap, np.array(mrec), np.array(mpre)
+    np.savez_compressed(os.path.join(OUT, "eval.npz"), **rec)
+    print("eval: AP@0.3/0.5/0.7 global-sort", [round(float(rec[f'ap_{t}_1']), 4) for t in (0.3, 0.5, 0.7)],
+          "per-frame order", [round(float(rec[f'ap_{t}_0']), 4) for t in (0.3, 0.5, 0.7)])
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -455,7 +527,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()
