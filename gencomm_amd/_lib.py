@@ -70,6 +70,12 @@ _SIGNATURES = {
     "gencomm_det_decode_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, _p, _p, _i, _p, C.c_longlong, _p]),
     "gencomm_nms_rotated_fwd": (_i, [_p, _p, _p, C.c_float, _i, _p, _p, _p, _p, _p, _p, C.c_longlong, _p]),
     "gencomm_bbox_overlaps_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
+    "gencomm_iou3d_pairwise_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p]),
+    "gencomm_iou3d_max_boxes": (_i, []),
+    "gencomm_iou3d_nms_workspace_bytes": (_ll, [_i]),
+    "gencomm_iou3d_nms_fwd": (_i, [_p, _i, C.c_float, _i, _p, _p, _p, _ll, _p]),
+    "gencomm_voxelize_workspace_bytes": (_ll, [_i]),
+    "gencomm_voxelize_fwd": (_i, [_p, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p, _p, _p, _p, _p, _ll, _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_maxfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_attfuse_tok_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -82,7 +88,7 @@ class GenCommHipError(RuntimeError):
 
 
 def hip_sources() -> List[str]:
-    return [os.path.join(CSRC_DIR, "gencomm_abi.hip")]
+    return [os.path.join(CSRC_DIR, "gencomm_abi.hip"), os.path.join(CSRC_DIR, "gencomm_abi_aux.hip")]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -96,9 +102,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # `v_pk_fma_f32 v[0:1], v[0:1], s[22:23], v[22:23] op_sel:[0,0,1]` and sporadically lost the bias in the low half on
     # lanes 48..63 whenever two workgroups shared a SIMD (never with one workgroup per CU); the same source built
     # without packed ops is exact in every run (tools/conv8_unit.py), and the hot kernels are not slower for it.
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
              "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-    cmd = [hipcc, *flags, '-DGENCOMM_BUILD_FLAGS="' + " ".join(flags) + '"', *srcs, "-o", LIB_PATH + ".tmp"]
+    define = '-DGENCOMM_BUILD_FLAGS="' + " ".join(flags) + '"'
+    obj_dir = os.path.join(PKG_DIR, "_build")
+    os.makedirs(obj_dir, exist_ok=True)
+    # one object per translation unit, compiled concurrently (the hot path's unit takes ~2 min, the rocPRIM one ~1 min)
+    procs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        cmd = [hipcc, *flags, define, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

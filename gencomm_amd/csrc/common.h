@@ -203,7 +203,7 @@ __device__ __forceinline__ void wave_amax_commit(float v, float* __restrict__ ds
     if (bits > __builtin_nontemporal_load(p)) atomicMax(p, bits);
   }
 }
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long count, float* __restrict__ dst) {
+static __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long count, float* __restrict__ dst) {
   float m = 0.f;
   const long long nvec = (count & 3) ? 0 : (count >> 2);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {

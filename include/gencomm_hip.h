@@ -257,6 +257,36 @@ int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* sce
 int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* theta, const int* scene_off, float* out,
                                  int B, int n, int C, int H, int W, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * iou3d_nms with the reference extension's own semantics (opencood/pcdet_utils/iou3d_nms: src/iou3d_nms_kernel.cu:104-372,
+ * src/iou3d_nms.cpp:30-135; Python wrappers iou3d_nms_utils.py:32-46, :147-181, :255-289). Boxes are [n][7] float32
+ * (x, y, z, dx, dy, dz, heading). gencomm_iou3d_pairwise_fwd: out[num_a][num_b] = BEV overlap area (mode 0,
+ * boxes_overlap_bev_gpu) or BEV IoU (mode 1, boxes_iou_bev_gpu). gencomm_iou3d_nms_fwd: boxes already in descending
+ * score order (as nms_gpu / nms_normal_gpu pass them); keep[0..*count) = indices kept, ascending -- the reference returns
+ * the count on the host after a blocking copy of the masks, here masks, greedy reduction, keep list and count all stay on
+ * the device and the call is asynchronous. normal != 0 ignores the heading (nms_normal_gpu). At most
+ * gencomm_iou3d_max_boxes() boxes. (The live GenComm post-processor uses the shapely-semantics NMS below,
+ * gencomm_nms_rotated_fwd; this API serves the FPV-RCNN / iou-loss callers of the extension.)
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_iou3d_pairwise_fwd(const float* boxes_a, int num_a, const float* boxes_b, int num_b, int mode, float* out, void* stream);
+int gencomm_iou3d_max_boxes(void);
+long long gencomm_iou3d_nms_workspace_bytes(int n);
+int gencomm_iou3d_nms_fwd(const float* boxes, int n, float thresh, int normal, long long* keep, int* count,
+                          void* workspace, long long workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Point cloud -> voxels with the semantics of spconv's CPU point-to-voxel as the reference's dataloader uses it
+ * (opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:25-29, :54-68): points [n][nfeat] (x, y, z first), voxels
+ * in order of first appearance, points in input order, at most max_points per voxel / max_voxels voxels,
+ * coords (z, y, x), grid = round((range[3:6] - range[0:3]) / voxel_size). Outputs are sized for max_voxels
+ * (voxels [max_voxels][max_points][nfeat] zero-padded, coords_zyx [max_voxels][3], num_points [max_voxels]); *count = the
+ * number of voxels produced (device int). Deterministic (stable radix sort + scans, no order-dependent atomics).
+ * -------------------------------------------------------------------------------------------- */
+long long gencomm_voxelize_workspace_bytes(int n);
+int gencomm_voxelize_fwd(const float* points, int n, int nfeat, const float* voxel_size3, const float* range6, int max_points,
+                         int max_voxels, float* voxels, int* coords_zyx, int* num_points, int* count,
+                         void* workspace, long long workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
