@@ -1,12 +1,15 @@
-"""Training support for the hot path: HIP forward, gradients by differentiable recomputation.
+"""Training support for the hot path.
 
-Forward always runs the hand-written HIP kernels. For backward, this round re-evaluates the same
-maths with differentiable torch ops ON THE GPU (activation-checkpoint style: nothing but the
-inputs and the explicit noise is saved) and lets autograd produce the gradients -- the first
-pass SURVEY.md section 7 step 6 plans before dedicated HIP backward kernels. Nothing here touches
-the CPU or the oracle. Gradients reach what the reference's do (training-branch row):
-the UNet weights, every row of ``conditions`` and -- through the ego repeat -- the ego rows of
-``spatial_features``; for the Enhancer and AttFusion the usual dense gradients.
+GenComm (the T-step chain of UNet calls the reference's training branch back-propagates through, cond_diff.py:342-360):
+HIP forward AND HIP backward -- ``UNetFunction`` wraps one UNet call (``gencomm_unet_fwd`` / ``gencomm_unet_bwd``: conv dgrad
+and wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample backward; only the call's inputs are saved, the backward
+re-runs the HIP forward with every intermediate kept), the sampler's affine updates between the calls are elementwise torch
+ops that autograd composes. The one piece of the UNet's backward that is not a HIP kernel is the timestep MLP on 32-vectors.
+Gradients reach what the reference's do (training-branch row): the UNet weights, every row of ``conditions``
+and -- through the ego repeat -- the ego rows of ``spatial_features``.
+
+Enhancer and AttFusion: HIP forward; backward still re-evaluates the stage with differentiable torch ops on the GPU from
+the saved input (activation-checkpoint style). Nothing here touches the CPU or the oracle.
 
 The functional forms below follow the reference line by line:
   UNet            opencood/models/gencomm_modules/unet.py:307-344, :119-138, :71-75, :51-56
@@ -23,100 +26,81 @@ import torch
 import torch.nn.functional as F
 
 
-# ----------------------------------------------------------------------------------------- UNet
+# ----------------------------------------------------------------------------------------- UNet + sampler
 def _silu(x):
     return x * torch.sigmoid(x)
 
 
-def _resblock(blk, x, temb):
-    h = F.conv2d(_silu(F.group_norm(x, 4, blk.norm1.weight, blk.norm1.bias, 1e-6)), blk.conv1.weight, blk.conv1.bias, padding=1)
-    h = h + F.linear(_silu(temb), blk.temb_proj.weight, blk.temb_proj.bias)[:, :, None, None]
-    h = F.conv2d(_silu(F.group_norm(h, 4, blk.norm2.weight, blk.norm2.bias, 1e-6)), blk.conv2.weight, blk.conv2.bias, padding=1)
-    if hasattr(blk, "nin_shortcut"):
-        x = F.conv2d(x, blk.nin_shortcut.weight, blk.nin_shortcut.bias)
-    return x + h
+def _resblocks_in_execution_order(unet):
+    """(key prefix, module) of every ResnetBlock in the order the library enumerates them (down, mid, up from the deepest level)."""
+    out, L = [], unet.num_resolutions
+    for l in range(L):
+        out += [(f"down.{l}.block.{i}", blk) for i, blk in enumerate(unet.down[l].block)]
+    out += [("mid.block_1", unet.mid.block_1), ("mid.block_2", unet.mid.block_2)]
+    for l in reversed(range(L)):
+        out += [(f"up.{l}.block.{i}", blk) for i, blk in enumerate(unet.up[l].block)]
+    return out
 
 
-def _attnblock(ab, x):
-    h = F.group_norm(x, 4, ab.norm.weight, ab.norm.bias, 1e-6)
-    q, k, v = (F.conv2d(h, m.weight, m.bias) for m in (ab.q, ab.k, ab.v))
-    b, c, hh, ww = q.shape
-    w_ = torch.bmm(q.reshape(b, c, hh * ww).permute(0, 2, 1), k.reshape(b, c, hh * ww)) * (int(c) ** (-0.5))
-    w_ = F.softmax(w_, dim=2)
-    o = torch.bmm(v.reshape(b, c, hh * ww), w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
-    return x + F.conv2d(o, ab.proj_out.weight, ab.proj_out.bias)
+class UNetFunction(torch.autograd.Function):
+    """x0_hat = DiffusionUNet(cat[cond, x_t], t): HIP forward (gencomm_unet_fwd) and HIP backward (gencomm_unet_bwd: conv
+    dgrad / wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample backward kernels, csrc/unet_bwd_kernels.h). Only the
+    inputs are saved; the backward pass re-runs the HIP forward with every intermediate kept."""
 
+    @staticmethod
+    def forward(ctx, unet, t_int, T, x_t, cond, *params):
+        with torch.no_grad():
+            out = unet(torch.cat([cond, x_t], dim=1), torch.full((x_t.shape[0],), float(t_int), device=x_t.device), T=T)
+        ctx.unet, ctx.t_int, ctx.T = unet, int(t_int), int(T)
+        ctx.save_for_backward(x_t, cond)
+        return out
 
-def unet_forward(unet, x, t_int: int):
-    half = unet.ch // 2
-    freq = torch.exp(torch.arange(half, dtype=torch.float32, device=x.device) * -(math.log(10000) / (half - 1)))
-    ang = float(t_int) * freq
-    temb = torch.cat([torch.sin(ang), torch.cos(ang)])[None, :].expand(x.shape[0], -1)
-    temb = F.linear(temb, unet.temb.dense[0].weight, unet.temb.dense[0].bias)
-    temb = F.linear(_silu(temb), unet.temb.dense[1].weight, unet.temb.dense[1].bias)
-    hs = [F.conv2d(x, unet.conv_in.weight, unet.conv_in.bias, padding=1)]
-    L = unet.num_resolutions
-    for lvl in range(L):
-        for i, blk in enumerate(unet.down[lvl].block):
-            h = _resblock(blk, hs[-1], temb)
-            if len(unet.down[lvl].attn) > 0:
-                h = _attnblock(unet.down[lvl].attn[i], h)
-            hs.append(h)
-        if lvl != L - 1:
-            c = unet.down[lvl].downsample.conv
-            hs.append(F.conv2d(F.pad(hs[-1], (0, 1, 0, 1)), c.weight, c.bias, stride=2))
-    h = _resblock(unet.mid.block_2, _resblock(unet.mid.block_1, hs[-1], temb), temb)
-    for lvl in reversed(range(L)):
-        for i, blk in enumerate(unet.up[lvl].block):
-            h = _resblock(blk, torch.cat([h, hs.pop()], dim=1), temb)
-            if len(unet.up[lvl].attn) > 0:
-                h = _attnblock(unet.up[lvl].attn[i], h)
-        if lvl != 0:
-            c = unet.up[lvl].upsample.conv
-            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), c.weight, c.bias, padding=1)
-    return F.conv2d(_silu(F.group_norm(h, 4, unet.norm_out.weight, unet.norm_out.bias, 1e-6)),
-                    unet.conv_out.weight, unet.conv_out.bias, padding=1)
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_t, cond = ctx.saved_tensors
+        unet = ctx.unet
+        gx, gc, graw = unet.backward_call(x_t.detach().float().contiguous(), cond.detach().float().contiguous(), ctx.t_int,
+                                          grad_out.float().contiguous(), ctx.T)
+        named = dict(unet.named_parameters())
+        off = {name: (o, numel) for name, numel, o in unet._packed.table}
+        grads = {name: graw[o:o + numel].view_as(named[name]) for name, (o, numel) in off.items()}
+        # timestep path: d conv1.bias of every block is also the gradient of temb_proj(SiLU(temb)) (same for every sample)
+        blocks = _resblocks_in_execution_order(unet)
+        with torch.enable_grad():
+            leaves = [unet.temb.dense[0].weight, unet.temb.dense[0].bias, unet.temb.dense[1].weight, unet.temb.dense[1].bias]
+            leaves += [p for _, blk in blocks for p in (blk.temb_proj.weight, blk.temb_proj.bias)]
+            local = [p.detach().requires_grad_(True) for p in leaves]
+            half = unet.ch // 2
+            freq = torch.exp(torch.arange(half, dtype=torch.float32, device=x_t.device) * -(math.log(10000) / (half - 1)))
+            ang = float(ctx.t_int) * freq
+            temb = torch.cat([torch.sin(ang), torch.cos(ang)])
+            temb = F.linear(temb, local[0], local[1])
+            temb = _silu(F.linear(_silu(temb), local[2], local[3]))
+            outs = [F.linear(temb, local[4 + 2 * i], local[5 + 2 * i]) for i in range(len(blocks))]
+            gouts = [grads[f"{key}.conv1.bias"] for key, _ in blocks]
+            tg = torch.autograd.grad(outs, local, gouts)
+        tnames = ["temb.dense.0.weight", "temb.dense.0.bias", "temb.dense.1.weight", "temb.dense.1.bias"]
+        tnames += [f"{key}.temb_proj.{w}" for key, _ in blocks for w in ("weight", "bias")]
+        for name, g in zip(tnames, tg):
+            grads[name] = g
+        gp = [grads[name] if p.requires_grad else None for name, p in unet.named_parameters()]
+        return (None, None, None, gx if ctx.needs_input_grad[3] else None, gc if ctx.needs_input_grad[4] else None, *gp)
 
 
 def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise):
+    """The training branch's maths (cond_diff.py:342-360, :262-264, :272-315) as a chain of `UNetFunction` calls and
+    elementwise torch ops; autograd composes the T steps. `step_noise[i]` is the noise of the i-th loop iteration."""
     T = gen.num_timesteps
     idx = torch.as_tensor(list(src_rows), dtype=torch.long, device=feat.device)
+    params = list(gen.denoiser.parameters())
     x = gen.sqrt_alphas_cumprod[T - 1] * feat.index_select(0, idx) + gen.sqrt_one_minus_alphas_cumprod[T - 1] * noise0
     for i, t in enumerate(reversed(range(T))):
-        x0 = unet_forward(gen.denoiser, torch.cat([cond, x], dim=1), t)
+        x0 = UNetFunction.apply(gen.denoiser, t, T, x, cond, *params)
         if t == 0:
             return x0
         x = gen.posterior_mean_coef1[t] * x0 + gen.posterior_mean_coef2[t] * x \
             + (0.5 * gen.posterior_log_variance_clipped[t]).exp() * step_noise[i]
     return x
-
-
-class DenoiseFunction(torch.autograd.Function):
-    """pred = HIP denoise loop; backward = autograd through `sampler_forward` recomputed on the GPU."""
-
-    @staticmethod
-    def forward(ctx, gen, src_rows, feat, cond, noise0, step_noise, *params):
-        with torch.no_grad():
-            pred = gen._denoise(feat, cond, src_rows, (noise0, step_noise), None)
-        ctx.gen, ctx.src_rows = gen, list(src_rows)
-        ctx.save_for_backward(feat, cond, noise0, step_noise)
-        return pred
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        feat, cond, noise0, step_noise = ctx.saved_tensors
-        gen = ctx.gen
-        params = [p for p in gen.denoiser.parameters()]
-        with torch.enable_grad():
-            f = feat.detach().float().requires_grad_(ctx.needs_input_grad[2])
-            c = cond.detach().float().requires_grad_(ctx.needs_input_grad[3])
-            out = sampler_forward(gen, f, c, ctx.src_rows, noise0, step_noise)
-            wanted = [t for t in [f, c] if t.requires_grad] + [p for p in params if p.requires_grad]
-            grads = list(torch.autograd.grad(out, wanted, grad_out.float().contiguous(), allow_unused=True)) if wanted else []
-        gf = grads.pop(0) if f.requires_grad else None
-        gc = grads.pop(0) if c.requires_grad else None
-        gp = [grads.pop(0) if p.requires_grad else None for p in params]
-        return (None, None, gf, gc, None, None, *gp)
 
 
 # ----------------------------------------------------------------------------------------- Enhancer

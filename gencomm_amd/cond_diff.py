@@ -155,12 +155,13 @@ class GenComm(nn.Module):
         return any(t.requires_grad for t in tensors) or (self.training and any(p.requires_grad for p in self.denoiser.parameters()))
 
     def _run(self, feat, cond, src_rows, noise, seed) -> torch.Tensor:
-        """HIP forward; when gradients are required, wrap it in the recompute-based autograd
-        Function (explicit noise so that the recomputation sees the same draws)."""
+        """HIP forward; when gradients are required, the chain of per-step HIP UNet calls with HIP backward
+        (``autograd.sampler_forward``: ``gencomm_unet_fwd`` / ``gencomm_unet_bwd`` per step, T saved x_t maps)."""
         if not self._needs_grad(feat, cond):
             return self._denoise(feat, cond, src_rows, noise, seed)
-        from .autograd import DenoiseFunction
+        from .autograd import sampler_forward
         require_gpu(feat, "GenComm.forward(spatial_features)")
+        require_gpu(cond, "GenComm.forward(conditions)")
         n, (C, H, W), T = cond.shape[0], feat.shape[1:], self.num_timesteps
         if noise is None:
             g = None
@@ -169,8 +170,7 @@ class GenComm(nn.Module):
                 g.manual_seed(int(seed))
             noise = (torch.randn(n, C, H, W, device=feat.device, generator=g),
                      torch.randn(T, n, C, H, W, device=feat.device, generator=g))
-        params = list(self.denoiser.parameters())
-        return DenoiseFunction.apply(self, list(src_rows), f32c(feat), f32c(cond), f32c(noise[0]), f32c(noise[1]), *params)
+        return sampler_forward(self, f32c(feat), f32c(cond), list(src_rows), f32c(noise[0]), f32c(noise[1]))
 
     def _debug_t1_t2(self, spatial_features: torch.Tensor, data_dict: dict) -> None:
         """'t1' / 't2': the eval branch's two unused q_samples of the first ego map

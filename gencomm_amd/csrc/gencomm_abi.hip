@@ -8,6 +8,7 @@
 #include "fusion_kernels.h"
 #include "msgext_host.h"
 #include "pillar_kernels.h"
+#include "unet_bwd_host.h"
 #include "unet_host.h"
 
 #include <algorithm>
@@ -206,6 +207,32 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
   ConvOutArgs co{};
   co.out = x0_out;
   return unet_enqueue(c, x_t, cond, t, 0, co);
+}
+
+long long gencomm_unet_bwd_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, 1, true)) { fail(GC_ERR_ARG, e); return -1; }
+  if (n < 1 || H < 1 || W < 1) { fail(GC_ERR_ARG, "n, H, W must be positive"); return -1; }
+  UNetWorkspace w;
+  if (const char* e = w.build(p, n, H, W)) { fail(GC_ERR_ARG, e); return -1; }
+  return (long long)unet_bwd_ws(p, w, n, H, W).total;
+}
+
+int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
+                     float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
+                     int attn_mask, int T, void* workspace, long long workspace_bytes, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, T, true)) return fail(GC_ERR_ARG, e);
+  if (int rc = check_dims(n, C, H, W)) return rc;
+  GC_CHECK_ARG(attn_mask == 0, "gencomm_unet_bwd: AttnBlock backward is not implemented (attn_mask must be 0)");
+  GC_CHECK_ARG(prepared && raw && x_t && cond && grad_x0 && grad_xt && grad_cond && grad_raw && workspace, "null pointer");
+  GC_CHECK_ARG(t >= 0 && t < T, "timestep out of range");
+  UNetWorkspace w;
+  if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
+  const UNetBwdWs bw = unet_bwd_ws(p, w, n, H, W);
+  if ((long long)bw.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_unet_bwd_workspace_bytes)");
+  UNetBwdCall b{UNetCall{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()}, &bw, raw, grad_raw};
+  return unet_bwd_enqueue(b, x_t, cond, t, grad_x0, grad_xt, grad_cond);
 }
 
 // One plain 8 -> 8 channel 3x3 convolution (stride 1, zero padding 1, bias, no norm, no residual) through the same

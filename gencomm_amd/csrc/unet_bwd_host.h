@@ -1,0 +1,183 @@
+// Host logic of gencomm_unet_bwd: one DiffusionUNet call backwards (reference: autograd through unet.py:307-344 inside the
+// training branch cond_diff.py:342-360).  Re-runs the HIP forward with every intermediate kept, then walks the launch
+// program in reverse.  Attention blocks are not differentiated here (no shipped config has one): attn_mask must be 0.
+#pragma once
+#include "conv_kernels.h"
+#include "unet_bwd_kernels.h"
+#include "unet_host.h"
+
+namespace gc {
+
+struct UNetBwdWs {
+  size_t fwd_total, g_base, A, DA, red, wtmp, ones, zeros, total;
+  std::vector<size_t> g_level_base;
+};
+inline UNetBwdWs unet_bwd_ws(const UNetPlan& p, const UNetWorkspace& w, int n, int H, int W) {
+  UNetBwdWs b{};
+  size_t off = align_up(w.total, 256);
+  b.fwd_total = off;
+  b.g_base = off;
+  b.g_level_base.assign(p.L, 0);
+  for (int l = 0; l < p.L; ++l) {
+    b.g_level_base[l] = off;
+    off += w.slot_bytes[l] * p.slots_per_level[l];
+  }
+  auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+  const size_t map16 = (size_t)n * 16 * H * W * sizeof(float);
+  b.A = take(map16);
+  b.DA = take(map16);
+  b.red = take((size_t)n * 16 * 2 * sizeof(double));
+  b.wtmp = take((size_t)(p.C + 16) * 9 * 16 * sizeof(float));
+  b.ones = take((size_t)(p.C + 16) * sizeof(float));
+  b.zeros = take((size_t)(p.C + 16) * sizeof(float));
+  b.total = off;
+  return b;
+}
+
+struct UNetBwdCall {
+  UNetCall c;            // forward call (keep_all plan)
+  const UNetBwdWs* bw;
+  const float* raw;      // raw parameter blob (reference layouts)
+  float* graw;           // gradient of the raw blob (+=)
+  float* G(int id) const {
+    const TensorPlan& t = c.plan->tensors[id];
+    return reinterpret_cast<float*>(c.wsp + bw->g_level_base[t.level] + c.ws->slot_bytes[t.level] * t.slot);
+  }
+  float* F(size_t off) const { return reinterpret_cast<float*>(c.wsp + off); }
+};
+
+// out[n][Cout][H][W] = 3x3 stride-1 pad-1 convolution of dy[n][Cin_d][H][W] with the input-gradient weights of a forward
+// layer w [Cout_f = Cin_d][Cin_f][3][3], restricted to forward input channels [ic0, ic0 + nic)
+inline int dgrad3x3_enqueue(const UNetBwdCall& b, const float* dy, const float* w_fwd, int Cout_f, int Cin_f, int ic0, int nic,
+                            float* out, int out_ctotal, int out_coff, int n, int H, int W) {
+  hipStream_t st = b.c.st;
+  float* P = b.F(b.bw->wtmp);
+  prep_dgrad_w_kernel<<<cdiv(Cout_f * nic * 9, 256), 256, 0, st>>>(w_fwd, P, Cout_f, Cin_f, ic0, nic);
+  Conv2dArgs a{dy, P, b.F(b.bw->ones), b.F(b.bw->zeros), out, Cout_f, H, W, nic, H, W, 1, 1, 0, 1, out_ctotal, out_coff};
+  return conv2d_enqueue(a, n, 3, 3, st);
+}
+
+// SiLU(GN(x)) of one 8-channel source into A at channel offset coff (ctotal channels)
+inline void gn_fwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, const float* beta, int gs, int HW, float* A, int ctotal, int coff) {
+  GnArgs g{};
+  g.x = b.c.tensor_ptr(src_id); g.stat = b.c.stat_ptr(src_id); g.gamma = gamma; g.beta = beta; g.out = A;
+  g.inv_cnt = 1.0 / ((double)gs * HW); g.gs = gs; g.HW = HW; g.out_ctotal = ctotal; g.out_coff = coff;
+  gn_silu_fwd_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, b.c.st>>>(g);
+}
+// G[src] += backward of SiLU(GN(src)) given dA (channels coff.. of a ctotal-channel tensor); d gamma / d beta accumulated
+inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, const float* beta, int gs, int HW, const float* dA, int ctotal,
+                          int coff, float* dgamma, float* dbeta) {
+  hipStream_t st = b.c.st;
+  double* red = reinterpret_cast<double*>(b.c.wsp + b.bw->red);
+  GC_HIP(hipMemsetAsync(red, 0, (size_t)b.c.n * 16 * sizeof(double), st));
+  GnArgs g{};
+  g.x = b.c.tensor_ptr(src_id); g.stat = b.c.stat_ptr(src_id); g.gamma = gamma; g.beta = beta; g.da = dA; g.out = b.G(src_id); g.red = red;
+  g.inv_cnt = 1.0 / ((double)gs * HW); g.gs = gs; g.HW = HW; g.da_ctotal = ctotal; g.da_coff = coff;
+  gn_silu_bwd_reduce_kernel<<<dim3(std::min(cdiv(HW, 256), 64), 8, b.c.n), 256, 0, st>>>(g);
+  gn_silu_bwd_apply_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, st>>>(g);
+  gn_param_grad_kernel<<<1, 64, 0, st>>>(red, b.c.n, dgamma, dbeta);
+  return GC_OK;
+}
+
+inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float* cond, int t, const float* grad_x0,
+                            float* grad_xt, float* grad_cond) {
+  const UNetCall& c = b.c;
+  const UNetPlan& p = *c.plan;
+  hipStream_t st = c.st;
+  const int n = c.n, C = p.C;
+  // ---- forward with every intermediate kept (x0_hat itself is not needed: it lands in grad_xt, overwritten below)
+  GC_HIP(hipMemsetAsync(c.amax(), 0, 256, st));
+  amax_kernel<<<256, 256, 0, st>>>(cond, (long long)n * 2 * c.H * c.W, c.amax());
+  amax_kernel<<<1024, 256, 0, st>>>(x_t, (long long)n * C * c.H * c.W, c.amax() + 1);
+  ConvOutArgs co{};
+  co.out = grad_xt;
+  if (int rc = unet_enqueue(c, x_t, cond, t, 0, co)) return rc;
+  // ---- gradient buffers, constants
+  size_t gbytes = 0;
+  for (int l = 0; l < p.L; ++l) gbytes += c.ws->slot_bytes[l] * p.slots_per_level[l];
+  GC_HIP(hipMemsetAsync(c.wsp + b.bw->g_base, 0, gbytes, st));
+  fill_kernel<<<cdiv(C + 16, 256), 256, 0, st>>>(b.F(b.bw->ones), 1.0f, C + 16);
+  GC_HIP(hipMemsetAsync(b.F(b.bw->zeros), 0, (size_t)(C + 16) * sizeof(float), st));
+  float* A = b.F(b.bw->A);
+  float* DA = b.F(b.bw->DA);
+
+  for (int oi = (int)p.ops.size() - 1; oi >= 0; --oi) {
+    const Op& o = p.ops[oi];
+    const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level], HW = Hl * Wl;
+    switch (o.kind) {
+      case OP_CONV_OUT: {
+        // y = conv_out(SiLU(GN_out(h))) + b
+        gn_fwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, A, 8, 0);
+        WgradArgs wa{grad_x0, A, nullptr, b.graw + p.conv_out.w, b.graw + p.conv_out.b, C, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
+        if (int rc = dgrad3x3_enqueue(b, grad_x0, b.raw + p.conv_out.w, C, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
+        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, DA, 8, 0, b.graw + p.nout_w, b.graw + p.nout_b)) return rc;
+        break;
+      }
+      case OP_RES_CONV2: {
+        // out = shortcut(in) + conv2(SiLU(GN2(tmp))) + b2 (+ nin bias)
+        const ResBlockPlan& rb = p.blocks[o.blk];
+        const float* go = b.G(o.dst);
+        gn_fwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, A, 8, 0);
+        WgradArgs wa{go, A, nullptr, b.graw + rb.c2w, b.graw + rb.c2b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
+        if (int rc = dgrad3x3_enqueue(b, go, b.raw + rb.c2w, 8, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
+        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, b.graw + rb.n2w, b.graw + rb.n2b)) return rc;
+        if (rb.cin == 8) {
+          axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
+        } else {
+          WgradArgs wn{go, c.tensor_ptr(o.res[0]), c.tensor_ptr(o.res[1]), b.graw + rb.ninw, b.graw + rb.ninb, 8, 8, 8, Hl, Wl, Hl, Wl, 1, 1, 0, 0};
+          if (int rc = conv_wgrad_enqueue(wn, n, st)) return rc;
+          nin_dgrad_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW);
+        }
+        break;
+      }
+      case OP_RES_CONV1: {
+        // tmp = conv1(SiLU(GN1(cat in))) + b1 + temb_proj(...)  (the timestep term only shifts the bias: its gradient is d b1)
+        const ResBlockPlan& rb = p.blocks[o.blk];
+        const float* gt = b.G(o.dst);
+        const int nsrc = rb.cin / 8, gs = rb.cin == 8 ? 2 : 4;
+        for (int s = 0; s < nsrc; ++s) gn_fwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, A, rb.cin, 8 * s);
+        WgradArgs wa{gt, A, nullptr, b.graw + rb.c1w, b.graw + rb.c1b, 8, rb.cin, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
+        if (int rc = dgrad3x3_enqueue(b, gt, b.raw + rb.c1w, 8, rb.cin, 0, rb.cin, DA, rb.cin, 0, n, Hl, Wl)) return rc;
+        for (int s = 0; s < nsrc; ++s)
+          if (int rc = gn_bwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, DA, rb.cin, 8 * s,
+                                      b.graw + rb.n1w + 8 * s, b.graw + rb.n1b + 8 * s)) return rc;
+        break;
+      }
+      case OP_DOWN: {
+        const int lin = o.level - 1, Hi = c.ws->Hl[lin], Wi = c.ws->Wl[lin];
+        const float* gd = b.G(o.dst);
+        WgradArgs wa{gd, c.tensor_ptr(o.src[0]), nullptr, b.graw + p.down[lin].w, b.graw + p.down[lin].b, 8, 8, 0, Hl, Wl, Hi, Wi, 3, 2, 0, 0};
+        if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
+        DownDgradArgs da{gd, b.raw + p.down[lin].w, b.G(o.src[0]), Hl, Wl, Hi, Wi};
+        down_dgrad_kernel<<<dim3(cdiv(Hi * Wi, 256), 1, n), 256, 0, st>>>(da);
+        break;
+      }
+      case OP_UP: {
+        const int lin = o.level + 1, Hs = c.ws->Hl[lin], Ws = c.ws->Wl[lin];
+        const float* gu = b.G(o.dst);
+        WgradArgs wa{gu, c.tensor_ptr(o.src[0]), nullptr, b.graw + p.up[lin].w, b.graw + p.up[lin].b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 1};
+        if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
+        if (int rc = dgrad3x3_enqueue(b, gu, b.raw + p.up[lin].w, 8, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
+        sum2x2_add_kernel<<<cdiv(n * 8 * Hs * Ws, 256), 256, 0, st>>>(DA, b.G(o.src[0]), n * 8, Hs, Ws);
+        break;
+      }
+      case OP_CONV_IN: {
+        const float* gh = b.G(o.dst);
+        WgradArgs wa{gh, cond, x_t, b.graw + p.conv_in.w, b.graw + p.conv_in.b, 8, 2, C, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
+        if (int rc = dgrad3x3_enqueue(b, gh, b.raw + p.conv_in.w, 8, C + 2, 0, 2, grad_cond, 2, 0, n, Hl, Wl)) return rc;
+        if (int rc = dgrad3x3_enqueue(b, gh, b.raw + p.conv_in.w, 8, C + 2, 2, C, grad_xt, C, 0, n, Hl, Wl)) return rc;
+        break;
+      }
+      case OP_ATTN:
+        return fail(GC_ERR_ARG, "gencomm_unet_bwd: AttnBlock backward is not implemented (attn_mask must be 0)");
+    }
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+}  // namespace gc

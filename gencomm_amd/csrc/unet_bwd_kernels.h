@@ -1,0 +1,258 @@
+// Backward kernels of the diffusion UNet (training branch: cond_diff.py:342-360 back-propagates through every UNet call,
+// SURVEY.md 8a / 8e).  Exact fp32, one launch per elementary gradient; the forward tensors come from re-running the HIP
+// forward with every intermediate kept (UNetPlan keep_all).  Input-gradient convolutions (dgrad) run on the general
+// implicit-GEMM kernel (conv_kernels.h) with transposed, tap-flipped weights; this file holds what has no forward twin:
+//   conv_wgrad_kernel      dW[oc][ic][ky][kx] += sum_{n,y,x} dY[oc](y,x) X[ic](y*s+ky-p, x*s+kx-p), dB[oc] += sum dY[oc]
+//                          (3x3 stride 1 / stride 2 / nearest-x2 input, 1x1; input = concat of up to two tensors)
+//   gn_silu_fwd_kernel     A = SiLU(GroupNorm(x)) materialised (the forward fuses it into its consumers' staging)
+//   gn_silu_bwd_*          GroupNorm(4 groups, eps 1e-6) + SiLU backward: per-(sample, channel) sums of dz and dz*xhat in
+//                          f64, then dx = rstd (gamma dz - mean_g(gamma dz) - xhat mean_g(gamma dz xhat)), d gamma, d beta
+//   down_dgrad_kernel      transposed stride-2 convolution of the Downsample layer (unet.py:71-75)
+//   sum2x2_add_kernel      nearest-x2 upsampling backward;  nin_dgrad_kernel  1x1 shortcut backward;  axpy_kernel
+// Gradient tensors are ACCUMULATED (+=): a forward tensor may have several consumers (skip connections, residuals).
+#pragma once
+#include "unet_kernels.h"
+
+namespace gc {
+
+// mean / rstd / scale of channel c from the f64 statistics, exactly as gn_coeff (unet_kernels.h) forms them
+__device__ __forceinline__ void gn_mean_rstd(const double* __restrict__ stat, int c, int gs, double inv_cnt, float* mean, float* rstd) {
+  const int g0 = c & ~(gs - 1);
+  double s = 0.0, q = 0.0;
+  for (int j = 0; j < gs; ++j) { s += stat[(g0 + j) * 2 + 0]; q += stat[(g0 + j) * 2 + 1]; }
+  const double m = s * inv_cnt;
+  const float var = fmaxf((float)(q * inv_cnt - m * m), 0.f);
+  *mean = (float)m;
+  *rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
+}
+
+struct GnArgs {
+  const float* x;        // [n][8][HW] one 8-channel source
+  const double* stat;    // [n][8][2]
+  const float* gamma;    // [8] of this source
+  const float* beta;
+  const float* da;       // [n][da_ctotal][HW]: gradient w.r.t. SiLU(GN(x)), this source's channels at da_coff (backward)
+  float* out;            // fwd: A [n][out_ctotal][HW] at channel offset out_coff;  bwd apply: G[x] [n][8][HW] (+=)
+  double* red;           // [n][8][2] f64: sum dz, sum dz*xhat (backward)
+  double inv_cnt;        // 1 / (gs * HW)
+  int gs, HW, out_ctotal, out_coff, da_ctotal, da_coff;
+};
+
+__global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const GnArgs a) {
+  const int n = blockIdx.z, c = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  float A, B;
+  gn_coeff(a.stat + (size_t)n * 16, c, a.gs, a.inv_cnt, a.gamma[c], a.beta[c], &A, &B);
+  if (p < a.HW) a.out[((size_t)n * a.out_ctotal + a.out_coff + c) * a.HW + p] = silu_f(fmaf(A, a.x[((size_t)n * 8 + c) * a.HW + p], B));
+}
+
+__device__ __forceinline__ float silu_grad_f(float z) {
+  const float s = sigmoid_f(z);
+  return s * fmaf(z, 1.0f - s, 1.0f);
+}
+
+__global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const GnArgs a) {
+  __shared__ double s_red[4][2];
+  const int n = blockIdx.z, c = blockIdx.y, tid = threadIdx.x;
+  float mean, rstd;
+  gn_mean_rstd(a.stat + (size_t)n * 16, c, a.gs, a.inv_cnt, &mean, &rstd);
+  const float g = a.gamma[c], b = a.beta[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = blockIdx.x * 256 + tid; p < a.HW; p += gridDim.x * 256) {
+    const float xh = (a.x[((size_t)n * 8 + c) * a.HW + p] - mean) * rstd;
+    const float dz = a.da[((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p] * silu_grad_f(fmaf(g, xh, b));
+    s1 += dz;
+    s2 += (double)dz * xh;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if ((tid & 63) == 0) { s_red[tid >> 6][0] = s1; s_red[tid >> 6][1] = s2; }
+  __syncthreads();
+  if (tid < 2) atomicAdd(&a.red[((size_t)n * 8 + c) * 2 + tid], s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]);
+}
+
+__global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const GnArgs a) {
+  const int n = blockIdx.z, c = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  float mean, rstd;
+  gn_mean_rstd(a.stat + (size_t)n * 16, c, a.gs, a.inv_cnt, &mean, &rstd);
+  const int g0 = c & ~(a.gs - 1);
+  double m1 = 0.0, m2 = 0.0;
+  for (int j = 0; j < a.gs; ++j) {
+    m1 += (double)a.gamma[g0 + j] * a.red[((size_t)n * 8 + g0 + j) * 2 + 0];
+    m2 += (double)a.gamma[g0 + j] * a.red[((size_t)n * 8 + g0 + j) * 2 + 1];
+  }
+  const float f1 = (float)(m1 * a.inv_cnt), f2 = (float)(m2 * a.inv_cnt);
+  if (p < a.HW) {
+    const size_t e = ((size_t)n * 8 + c) * a.HW + p;
+    const float g = a.gamma[c], xh = (a.x[e] - mean) * rstd;
+    const float dz = a.da[((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p] * silu_grad_f(fmaf(g, xh, a.beta[c]));
+    a.out[e] += rstd * (g * dz - f1 - xh * f2);
+  }
+}
+
+// d gamma[c] += sum_n red[n][c][1], d beta[c] += sum_n red[n][c][0]
+__global__ void gn_param_grad_kernel(const double* __restrict__ red, int n, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = threadIdx.x;
+  if (c >= 8) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < n; ++i) { s1 += red[((size_t)i * 8 + c) * 2 + 0]; s2 += red[((size_t)i * 8 + c) * 2 + 1]; }
+  dgamma[c] += (float)s2;
+  dbeta[c] += (float)s1;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dy;   // [n][Cout][Ho][Wo]
+  const float* x0;   // [n][c0][Hs][Ws]  (Hs = Hi, or Hi / 2 when up)
+  const float* x1;   // [n][c1][Hs][Ws] or null: the input is cat[x0, x1]
+  float* dw;         // [Cout][c0 + c1][K][K]  (+=)
+  float* db;         // [Cout] (+=) or null
+  int Cout, c0, c1, Ho, Wo, Hi, Wi, K, stride, pad, up;
+};
+
+template <int K, int STRIDE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int TP = 16, PH = (TP - 1) * STRIDE + K, PS = PH * PH, KK = K * K;
+  __shared__ float sdy[8][TP * TP + 1];
+  __shared__ float sx[8 * PS];
+  __shared__ float s_acc[4][64 * KK];
+  const int tid = threadIdx.x, n = blockIdx.z;
+  const int Cin = a.c0 + a.c1, icc = (Cin + 7) / 8;
+  const int occ = blockIdx.y / icc, ich = blockIdx.y - occ * icc;
+  const int tiles_x = (a.Wo + TP - 1) / TP;
+  const int oy0 = (blockIdx.x / tiles_x) * TP, ox0 = (blockIdx.x % tiles_x) * TP;
+  const int Hs = a.up ? a.Hi / 2 : a.Hi, Ws = a.up ? a.Wi / 2 : a.Wi;
+  for (int i = tid; i < 8 * TP * TP; i += 256) {
+    const int o = i / (TP * TP), r = i - o * (TP * TP), py = r / TP, px = r - py * TP;
+    const int oc = occ * 8 + o, oy = oy0 + py, ox = ox0 + px;
+    sdy[o][r] = (oc < a.Cout && oy < a.Ho && ox < a.Wo) ? a.dy[(((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox] : 0.f;
+  }
+  const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+  for (int i = tid; i < 8 * PS; i += 256) {
+    const int c = i / PS, r = i - c * PS, py = r / PH, px = r - py * PH;
+    const int ic = ich * 8 + c, iy = iy0 + py, ix = ix0 + px;
+    float v = 0.f;
+    if (ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+      const float* __restrict__ sp = ic < a.c0 ? a.x0 + ((size_t)n * a.c0 + ic) * Hs * Ws : a.x1 + ((size_t)n * a.c1 + (ic - a.c0)) * Hs * Ws;
+      v = a.up ? sp[(size_t)(iy >> 1) * Ws + (ix >> 1)] : sp[(size_t)iy * Ws + ix];
+    }
+    sx[i] = v;
+  }
+  __syncthreads();
+  const int pair = tid & 63, q = tid >> 6, ol = pair >> 3, il = pair & 7;
+  float acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+  for (int py = 4 * q; py < 4 * q + 4; ++py)
+    for (int px = 0; px < TP; ++px) {
+      const float d = sdy[ol][py * TP + px];
+      const float* __restrict__ xp = sx + il * PS + (py * STRIDE) * PH + px * STRIDE;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) acc[t] = fmaf(d, xp[(t / K) * PH + (t % K)], acc[t]);
+    }
+#pragma unroll
+  for (int t = 0; t < KK; ++t) s_acc[q][pair * KK + t] = acc[t];
+  __syncthreads();
+  for (int i = tid; i < 64 * KK; i += 256) {
+    const int pr = i / KK, t = i - pr * KK, oc = occ * 8 + (pr >> 3), ic = ich * 8 + (pr & 7);
+    if (oc < a.Cout && ic < Cin) atomicAdd(&a.dw[((size_t)oc * Cin + ic) * KK + t], s_acc[0][i] + s_acc[1][i] + s_acc[2][i] + s_acc[3][i]);
+  }
+  if (a.db != nullptr && ich == 0 && tid < 8 && occ * 8 + tid < a.Cout) {
+    float s = 0.f;
+    for (int r = 0; r < TP * TP; ++r) s += sdy[tid][r];
+    atomicAdd(&a.db[occ * 8 + tid], s);
+  }
+}
+
+inline int conv_wgrad_enqueue(const WgradArgs& a, int n, hipStream_t st) {
+  const int Cin = a.c0 + a.c1;
+  const dim3 grid(((a.Ho + 15) / 16) * ((a.Wo + 15) / 16), ((a.Cout + 7) / 8) * ((Cin + 7) / 8), n);
+  if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv_wgrad: too many channel chunks / samples");
+  if (a.K == 3 && a.stride == 1) conv_wgrad_kernel<3, 1><<<grid, 256, 0, st>>>(a);
+  else if (a.K == 3 && a.stride == 2) conv_wgrad_kernel<3, 2><<<grid, 256, 0, st>>>(a);
+  else if (a.K == 1 && a.stride == 1) conv_wgrad_kernel<1, 1><<<grid, 256, 0, st>>>(a);
+  else return fail(GC_ERR_ARG, "conv_wgrad: unsupported kernel size / stride");
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+// prepared weights (conv_kernels.h layout [(ci*9 + tap)][co]) of the INPUT-gradient convolution of a 3x3 stride-1 layer
+// with forward weights w [Cout][Cin][3][3]: dgrad input channels = forward oc, outputs = forward ic in [ic0, ic0 + nic),
+// taps flipped:  P[(oc*9 + (8 - tap))][ic - ic0] = w[oc][ic][tap]
+__global__ void prep_dgrad_w_kernel(const float* __restrict__ w, float* __restrict__ P, int Cout, int Cin, int ic0, int nic) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * nic * 9) return;
+  const int icl = i % nic, k = i / nic, oc = k / 9, tp = k - oc * 9;
+  P[i] = w[((size_t)oc * Cin + ic0 + icl) * 9 + (8 - tp)];
+}
+
+// Downsample backward (pad right/bottom by one, 3x3 stride 2, no padding): G[src][ic](iy, ix) += sum over oc and the taps
+// (ky, kx) with iy - ky = 2 oy, ix - kx = 2 ox inside the output
+struct DownDgradArgs {
+  const float* gd;  // [n][8][Ho][Wo]
+  const float* w;   // raw [8][8][3][3]
+  float* gs;        // [n][8][Hi][Wi] (+=)
+  int Ho, Wo, Hi, Wi;
+};
+__global__ __launch_bounds__(256) void down_dgrad_kernel(const DownDgradArgs a) {
+  const int n = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.Hi * a.Wi) return;
+  const int iy = i / a.Wi, ix = i - iy * a.Wi;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy - ky;
+    if (ty < 0 || (ty & 1) || (ty >> 1) >= a.Ho) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix - kx;
+      if (tx < 0 || (tx & 1) || (tx >> 1) >= a.Wo) continue;
+      for (int oc = 0; oc < 8; ++oc) {
+        const float g = a.gd[(((size_t)n * 8 + oc) * a.Ho + (ty >> 1)) * a.Wo + (tx >> 1)];
+#pragma unroll
+        for (int ic = 0; ic < 8; ++ic) acc[ic] = fmaf(as_const(a.w)[((oc * 8 + ic) * 3 + ky) * 3 + kx], g, acc[ic]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ic = 0; ic < 8; ++ic) a.gs[((size_t)n * 8 + ic) * a.Hi * a.Wi + i] += acc[ic];
+}
+
+// nearest x2 backward: gs[c](y, x) += sum of the 2x2 block of da
+__global__ __launch_bounds__(256) void sum2x2_add_kernel(const float* __restrict__ da, float* __restrict__ gs, int planes, int Hs, int Ws) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)planes * Hs * Ws) return;
+  const int x = (int)(i % Ws), y = (int)((i / Ws) % Hs);
+  const long long pl = i / ((long long)Hs * Ws);
+  const float* __restrict__ d = da + (pl * (2 * Hs) + 2 * y) * (2 * Ws) + 2 * x;
+  gs[i] += d[0] + d[1] + d[2 * Ws] + d[2 * Ws + 1];
+}
+
+// 1x1 nin_shortcut backward: g0[ic] += sum_oc w[oc][ic] go[oc], g1[ic] += sum_oc w[oc][8 + ic] go[oc]   (w raw [8][16])
+__global__ __launch_bounds__(256) void nin_dgrad_kernel(const float* __restrict__ go, const float* __restrict__ w, float* __restrict__ g0,
+                                                        float* __restrict__ g1, int HW) {
+  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float o[8];
+#pragma unroll
+  for (int oc = 0; oc < 8; ++oc) o[oc] = go[((size_t)n * 8 + oc) * HW + p];
+#pragma unroll
+  for (int ic = 0; ic < 8; ++ic) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int oc = 0; oc < 8; ++oc) { s0 = fmaf(as_const(w)[oc * 16 + ic], o[oc], s0); s1 = fmaf(as_const(w)[oc * 16 + 8 + ic], o[oc], s1); }
+    g0[((size_t)n * 8 + ic) * HW + p] += s0;
+    g1[((size_t)n * 8 + ic) * HW + p] += s1;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) y[i] = fmaf(alpha, x[i], y[i]);
+}
+__global__ void add_vec_kernel(float* __restrict__ y, const float* __restrict__ x, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) y[i] += x[i];
+}
+__global__ void fill_kernel(float* __restrict__ y, float v, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) y[i] = v;
+}
+
+}  // namespace gc

@@ -137,7 +137,8 @@ struct UNetPlan {
   }
 
   // Returns nullptr on success, else an error string.
-  const char* build(int C_, int L_, int R_, int attn_mask_, int T_) {
+  // keep_all: every intermediate gets a slot of its own (the backward pass reads all of them back)
+  const char* build(int C_, int L_, int R_, int attn_mask_, int T_, bool keep_all = false) {
     C = C_; L = L_; R = R_; T = T_; attn_mask = attn_mask_;
     if (attn_mask < 0 || attn_mask >= (1 << L_)) return "attn_mask has bits beyond the number of levels";
     if (C < 8 || C % 8 != 0) return "C must be a positive multiple of 8";
@@ -272,7 +273,7 @@ struct UNetPlan {
           // a tensor may appear twice in one op (src and res): release once
           bool dup = false;
           for (int k2 = 0; k2 < k; ++k2) dup |= ((k2 < 2 ? o.src[k2] : o.res[k2 - 2]) == id);
-          if (!dup) free_slots[tensors[id].level].push_back(tensors[id].slot);
+          if (!dup && !keep_all) free_slots[tensors[id].level].push_back(tensors[id].slot);
         }
       }
     }

@@ -21,130 +21,90 @@ def _cfg_get(cfg, key):
     return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
 
 
-def Normalize(in_channels: int) -> nn.GroupNorm:  # unet.py:36-37
-    return nn.GroupNorm(num_groups=4, num_channels=in_channels, eps=1e-6, affine=True)
+def _param_shape(name: str, numel: int, C: int):
+    """Shape of a parameter from its state_dict key (the library enumerates names, sizes and order; the layer kinds fix the
+    rest: 3x3 convs on 8-channel maps, Linear temb path, GroupNorm affines -- unet.py:81-118, :141-165, :222-233, :298-304)."""
+    leaf = name.rsplit(".", 1)[1]
+    owner = name.rsplit(".", 2)[-2]
+    if leaf == "bias" or owner.startswith("norm"):
+        return (numel,)
+    if name == "temb.dense.0.weight":
+        return (32, 8)
+    if name == "temb.dense.1.weight":
+        return (32, 32)
+    if owner == "temb_proj":
+        return (8, 32)
+    if owner in ("nin_shortcut", "q", "k", "v", "proj_out"):
+        return (8, numel // 8, 1, 1)
+    if name == "conv_out.weight":
+        return (C, 8, 3, 3)
+    return (8, numel // 72, 3, 3)  # conv_in, conv1, conv2, downsample.conv, upsample.conv
 
 
-class Upsample(nn.Module):  # unet.py:40-56
-    def __init__(self, in_channels, with_conv):
-        super().__init__()
-        self.with_conv = with_conv
-        if with_conv:
-            self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+def _materialise(tree: dict) -> nn.Module:
+    """Nested dict of the key paths -> module tree: all-numeric children become an nn.ModuleList in numeric order, named
+    children are registered in order of first appearance (the state_dict order of the reference's constructor)."""
+    if tree and all(k.isdigit() for k in tree):
+        return nn.ModuleList([_materialise(tree[k]) for k in sorted(tree, key=int)])
+    mod = nn.Module()
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            mod.add_module(k, _materialise(v))
+        else:
+            mod.register_parameter(k, nn.Parameter(torch.empty(v)))
+    return mod
 
 
-class Downsample(nn.Module):  # unet.py:59-78
-    def __init__(self, in_channels, with_conv):
-        super().__init__()
-        self.with_conv = with_conv
-        if with_conv:
-            self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
-
-
-class ResnetBlock(nn.Module):  # unet.py:81-138
-    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout, temb_channels=512):
-        super().__init__()
-        out_channels = in_channels if out_channels is None else out_channels
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.use_conv_shortcut = conv_shortcut
-        self.norm1 = Normalize(in_channels)
-        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
-        self.temb_proj = nn.Linear(temb_channels, out_channels)
-        self.norm2 = Normalize(out_channels)
-        self.dropout = nn.Dropout(dropout)
-        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
-        if in_channels != out_channels:
-            if conv_shortcut:
-                self.conv_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+def _default_init_(root: nn.Module) -> None:
+    """PyTorch's default initialisation of the layer kinds involved (Conv2d / Linear: kaiming_uniform(a=sqrt 5) weights,
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)) biases; GroupNorm: ones / zeros), in registration order."""
+    import math
+    for name, mod in root.named_modules():
+        w, b = getattr(mod, "weight", None), getattr(mod, "bias", None)
+        if not isinstance(w, nn.Parameter):
+            continue
+        with torch.no_grad():
+            if w.dim() == 1:
+                w.fill_(1.0)
+                b.zero_()
             else:
-                self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
-
-
-class AttnBlock(nn.Module):  # unet.py:141-193 (no shipped config instantiates it; runs as flash-style HIP attention)
-    def __init__(self, in_channels):
-        super().__init__()
-        self.in_channels = in_channels
-        self.norm = Normalize(in_channels)
-        self.q = nn.Conv2d(in_channels, in_channels, kernel_size=1)
-        self.k = nn.Conv2d(in_channels, in_channels, kernel_size=1)
-        self.v = nn.Conv2d(in_channels, in_channels, kernel_size=1)
-        self.proj_out = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+                nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                bound = 1.0 / math.sqrt(w[0].numel())
+                b.uniform_(-bound, bound)
 
 
 class DiffusionUNet(nn.Module):
-    """Constructor mirrors unet.py:198-305 (``config.model.*`` attribute access)."""
+    """Same constructor argument as unet.py:198 (``config.model.*``). The parameter tree is not written out here: it is built
+    from the library's own enumeration of the UNet's parameters (``gencomm_unet_param_info``: ``state_dict`` key, size and
+    execution order for this C / depth / res-block count / attention mask), so module and kernels cannot drift apart."""
 
     def __init__(self, config):
         super().__init__()
         m = _cfg_get(config, "model")
-        ch, out_ch, ch_mult = _cfg_get(m, "ch"), _cfg_get(m, "out_ch"), tuple(_cfg_get(m, "ch_mult"))
-        num_res_blocks = _cfg_get(m, "num_res_blocks")
-        attn_resolutions = _cfg_get(m, "attn_resolutions")
-        dropout = _cfg_get(m, "dropout")
-        in_channels = _cfg_get(m, "in_channels") + 2  # two message channels, unet.py:210
-        resolution = 128  # nominal, hard-coded in the reference (unet.py:211)
-        resamp_with_conv = _cfg_get(m, "resamp_with_conv")
-
         self.config = config
-        self.ch, self.temb_ch = ch, ch * 4
-        self.num_resolutions = len(ch_mult)
-        self.num_res_blocks = num_res_blocks
-        self.resolution = resolution
-        self.in_channels = in_channels
-        self.out_ch = out_ch
-        self.ch_mult = ch_mult
-        self.dropout_p = dropout
-        self.resamp_with_conv = resamp_with_conv
-
-        self.temb = nn.Module()
-        self.temb.dense = nn.ModuleList([nn.Linear(self.ch, self.temb_ch), nn.Linear(self.temb_ch, self.temb_ch)])
-        self.conv_in = nn.Conv2d(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
-
-        curr_res = resolution
-        in_ch_mult = (1,) + ch_mult
-        self.down = nn.ModuleList()
-        block_in = None
-        for i_level in range(self.num_resolutions):
-            block, attn = nn.ModuleList(), nn.ModuleList()
-            block_in = ch * in_ch_mult[i_level]
-            block_out = ch * ch_mult[i_level]
-            for _ in range(num_res_blocks):
-                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=self.temb_ch, dropout=dropout))
-                block_in = block_out
-                if curr_res in attn_resolutions:
-                    attn.append(AttnBlock(block_in))
-            down = nn.Module()
-            down.block, down.attn = block, attn
-            if i_level != self.num_resolutions - 1:
-                down.downsample = Downsample(block_in, resamp_with_conv)
-                curr_res = curr_res // 2
-            self.down.append(down)
-
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
-
-        self.up = nn.ModuleList()
-        for i_level in reversed(range(self.num_resolutions)):
-            block, attn = nn.ModuleList(), nn.ModuleList()
-            block_out = ch * ch_mult[i_level]
-            skip_in = ch * ch_mult[i_level]
-            for i_block in range(num_res_blocks + 1):
-                if i_block == num_res_blocks:
-                    skip_in = ch * in_ch_mult[i_level]
-                block.append(ResnetBlock(in_channels=block_in + skip_in, out_channels=block_out, temb_channels=self.temb_ch, dropout=dropout))
-                block_in = block_out
-                if curr_res in attn_resolutions:
-                    attn.append(AttnBlock(block_in))
-            up = nn.Module()
-            up.block, up.attn = block, attn
-            if i_level != 0:
-                up.upsample = Upsample(block_in, resamp_with_conv)
-                curr_res = curr_res * 2
-            self.up.insert(0, up)
-
-        self.norm_out = Normalize(block_in)
-        self.conv_out = nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+        self.ch, self.out_ch, self.ch_mult = _cfg_get(m, "ch"), _cfg_get(m, "out_ch"), tuple(_cfg_get(m, "ch_mult"))
+        self.temb_ch = self.ch * 4
+        self.num_resolutions = len(self.ch_mult)
+        self.num_res_blocks = _cfg_get(m, "num_res_blocks")
+        self.in_channels = _cfg_get(m, "in_channels") + 2  # two message channels, unet.py:210
+        self.dropout_p = _cfg_get(m, "dropout")
+        self.resamp_with_conv = _cfg_get(m, "resamp_with_conv")
+        self.resolution = 128  # nominal, hard-coded in the reference (unet.py:211); halved per level (:259)
+        attn_resolutions = list(_cfg_get(m, "attn_resolutions"))
+        self._attn_mask = sum(1 << l for l in range(self.num_resolutions) if (self.resolution >> l) in attn_resolutions)
+        self._check_supported()
+        table = _lib.unet_param_table(self.feature_channels, self.num_resolutions, self.num_res_blocks, self._attn_mask)
+        tree: dict = {}
+        for name, numel, _ in table:
+            node = tree
+            parts = name.split(".")
+            for part in parts[:-1]:
+                node = node.setdefault(part, {})
+            node[parts[-1]] = _param_shape(name, numel, self.feature_channels)
+        # reference registration order of the top level (unet.py:222-304): temb, conv_in, down, mid, up, norm_out, conv_out
+        for key in ("temb", "conv_in", "down", "mid", "up", "norm_out", "conv_out"):
+            self.add_module(key, _materialise(tree[key]))
+        _default_init_(self)
 
         self._packed = None
         self._prepared = None
@@ -170,8 +130,8 @@ class DiffusionUNet(nn.Module):
 
     @property
     def attn_mask(self) -> int:
-        """bit l = level l carries AttnBlocks (down and up paths agree by construction, unet.py:252,:286)."""
-        return sum(1 << l for l in range(self.num_resolutions) if len(self.down[l].attn) > 0)
+        """bit l = level l carries AttnBlocks (nominal resolution 128 >> l in attn_resolutions; unet.py:237,:252-253,:286)."""
+        return self._attn_mask
 
     def prepared_params(self, T: int, device: torch.device) -> torch.Tensor:
         """Device blob in kernel layout + the [block][t][8] timestep-bias tables for t < T."""
@@ -222,3 +182,21 @@ class DiffusionUNet(nn.Module):
                                                self.num_resolutions, self.num_res_blocks, self.attn_mask, T,
                                                ptr(ws), ws.numel(), stream_ptr(x.device)), "gencomm_unet_fwd")
         return out
+
+    # ------------------------------------------------------------------ HIP backward (training branch)
+    def backward_call(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, grad_x0: torch.Tensor, T: int):
+        """One UNet call backwards through ``gencomm_unet_bwd``: returns (grad_xt, grad_cond, grad_raw) where ``grad_raw`` is the
+        gradient of the packed parameter blob (``self._packed.table`` gives every parameter's offset)."""
+        n, C, H, W = x_t.shape
+        dev = x_t.device
+        l = _lib.lib()
+        prepared = self.prepared_params(T, dev)
+        raw = self._packed.flat
+        L, R, A = self.num_resolutions, self.num_res_blocks, self.attn_mask
+        ws = workspaces.get(dev, _lib.check_size(l.gencomm_unet_bwd_workspace_bytes(n, C, H, W, L, R, A), "gencomm_unet_bwd_workspace_bytes"), "unet_bwd")
+        gx = torch.empty_like(x_t)
+        gc = torch.empty_like(cond)
+        graw = torch.zeros_like(raw)
+        _lib.check(l.gencomm_unet_bwd(ptr(prepared), ptr(raw), ptr(x_t), ptr(cond), int(t_int), ptr(grad_x0), ptr(gx), ptr(gc), ptr(graw),
+                                      n, C, H, W, L, R, A, T, ptr(ws), ws.numel(), stream_ptr(dev)), "gencomm_unet_bwd")
+        return gx, gc, graw

@@ -105,6 +105,18 @@ long long gencomm_unet_prepared_floats(int C, int levels, int res_blocks, int at
 int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, int res_blocks, int attn_mask, int T,
                          void* stream);
 
+/* One DiffusionUNet call BACKWARDS (the training branch back-propagates through every call: cond_diff.py:342-360; what
+ * torch autograd does for unet.py:307-344 in the reference). Re-runs the forward with every intermediate kept, then:
+ * grad_xt [n][C][H][W] and grad_cond [n][2][H][W] are OVERWRITTEN with the gradients w.r.t. the two inputs; grad_raw
+ * (gencomm_unet_raw_floats floats, the raw blob's layout) is ACCUMULATED (+=) with the gradients of conv / norm / nin
+ * parameters. The timestep path enters the forward only through each ResnetBlock's conv1 bias, so its gradient is the one
+ * accumulated at `<block>.conv1.bias`; the caller chains it through temb_proj / temb.dense (32-vectors) on the host.
+ * `raw` = the parameter blob in the reference's layouts (what gencomm_unet_prepare consumed). attn_mask must be 0. */
+long long gencomm_unet_bwd_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask);
+int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
+                     float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
+                     int attn_mask, int T, void* workspace, long long workspace_bytes, void* stream);
+
 /* One 8 -> 8 channel 3x3 convolution (pad 1, bias) as the UNet's ResnetBlock / Upsample layers run it
  * (unet.py:52, :99-118), without norm or residual: dst[n,8,H,W] = conv(src[n,8,H,W], w[8,8,3,3]) + bias; dstat (nullable)
  * receives per-(sample, channel) {sum, sum of squares} of dst as [n][8][2] doubles. split != 0: fp16 hi/lo split

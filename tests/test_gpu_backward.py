@@ -1,0 +1,143 @@
+"""HIP backward of the GenComm training branch (gencomm_unet_bwd: conv dgrad / wgrad, GroupNorm+SiLU, nin, Downsample,
+Upsample backward kernels) against torch autograd through the CPU oracle's functional restatement (float64): EVERY parameter
+gradient, the gradient of the message channels and of the features, for one UNet call and for the T-step sampler chain the
+reference trains through (cond_diff.py:342-360); plus two DistributedDataParallel ranks (gloo, both on cuda:0) whose
+all-reduced gradients must equal the single-process gradients of the concatenated batch (train_ddp.py:121-125)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _close(name, got, want, rtol=2e-3):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert err <= rtol * scale + 1e-9, (name, err, scale)
+    return err / (scale + 1e-30)
+
+
+def _oracle_grads(cfg, gen, feat, cond, rl, n0, sn, single_t=None):
+    """float64 autograd through oracle/torch_port on the CPU: grads of mean(out^2) w.r.t. every parameter, feat, cond."""
+    from oracle import torch_port as O
+    sd = {k: v.detach().cpu().double().requires_grad_(v.is_floating_point() and "denoiser" in k) for k, v in gen.state_dict().items()}
+    f = feat.double().requires_grad_(True)
+    c = cond.double().requires_grad_(True)
+    if single_t is None:
+        out = O.gencomm_forward(sd, cfg, f, c, rl, n0.double(), sn.double())
+    else:
+        tt = torch.full((f.shape[0],), float(single_t), dtype=torch.float64)
+        out = O.unet_forward(sd, "denoiser", torch.cat([c, f], dim=1), tt, cfg["model"])
+    loss = (out ** 2).mean()
+    names = [k for k in sd if sd[k].requires_grad]
+    grads = torch.autograd.grad(loss, [sd[k] for k in names] + [f, c])
+    return out.detach(), float(loss), dict(zip(names, grads[:-2])), grads[-2], grads[-1]
+
+
+@pytest.mark.parametrize("C,H,W,n,levels,t", [(16, 16, 24, 2, 2, 1), (8, 24, 40, 1, 3, 0), (32, 20, 68, 3, 2, 2)])
+def test_unet_call_backward_all_gradients_vs_oracle_autograd(C, H, W, n, levels, t):
+    from gencomm_amd import GenComm, synth
+    from gencomm_amd.autograd import UNetFunction
+    T = 3
+    cfg = synth.default_gencomm_cfg(C, T)
+    cfg["model"]["ch_mult"] = [1] * levels
+    gen = GenComm(cfg).train()
+    synth.fill_params_(gen, 300 + C)
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(n, C, H, W, generator=g)
+    cond = torch.randn(n, 2, H, W, generator=g)
+    ref_out, _, pg, gx, gc = _oracle_grads(cfg, gen, x, cond, None, None, None, single_t=t)
+    gen = gen.to(DEV)
+    xd, cd = x.to(DEV).requires_grad_(True), cond.to(DEV).requires_grad_(True)
+    out = UNetFunction.apply(gen.denoiser, t, T, xd, cd, *list(gen.denoiser.parameters()))
+    _close("x0_hat", out, ref_out, 1e-4)
+    (out ** 2).mean().backward()
+    worst = max(_close("grad x_t", xd.grad, gx), _close("grad cond", cd.grad, gc))
+    for name, p in gen.denoiser.named_parameters():
+        assert p.grad is not None, name
+        worst = max(worst, _close("grad " + name, p.grad, pg["denoiser." + name]))
+    print(f"UNet call backward C={C} {H}x{W} n={n} levels={levels} t={t}: {len(pg)} parameter gradients, worst relative error {worst:.2e}")
+
+
+def test_sampler_chain_backward_vs_oracle_autograd():
+    from gencomm_amd import GenComm, synth
+    C, H, W, T, rl = 16, 16, 24, 3, [2, 1]
+    n = sum(rl)
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen = GenComm(cfg).train()
+    synth.fill_params_(gen, 77)
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(rl, C, H, W, 78).items()}
+    n0, sn = (torch.from_numpy(a) for a in synth.make_train_noise(79, n, C, H, W, T))
+    ref_out, ref_loss, pg, gf, gc = _oracle_grads(cfg, gen, inp["feat"], inp["cond"], inp["record_len"], n0, sn)
+    gen = gen.to(DEV)
+    feat, cond = inp["feat"].to(DEV).requires_grad_(True), inp["cond"].to(DEV).requires_grad_(True)
+    pred = gen(feat, cond, inp["record_len"], noise=(n0.to(DEV), sn.to(DEV)))["pred_feature"]
+    _close("pred_feature (train)", pred, ref_out, 1e-4)
+    loss = (pred ** 2).mean()
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss)
+    loss.backward()
+    worst = max(_close("grad feat", feat.grad, gf), _close("grad cond", cond.grad, gc))
+    assert float(feat.grad[1].abs().max()) == 0.0 and float(feat.grad[0].abs().max()) > 0  # only the ego rows feed x_start (cond_diff.py:332-337)
+    for name, p in gen.denoiser.named_parameters():
+        worst = max(worst, _close("grad " + name, p.grad, pg["denoiser." + name]))
+    print(f"sampler chain backward (T={T}): worst relative error {worst:.2e}")
+
+
+DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)   # before any GPU call
+from gencomm_amd import GenComm, synth
+C, H, W, T = 16, 16, 24, 3
+gen = GenComm(synth.default_gencomm_cfg(C, T)).train()
+synth.fill_params_(gen, 5)
+gen = gen.to("cuda:0")
+ddp = torch.nn.parallel.DistributedDataParallel(gen, find_unused_parameters=True)   # train_ddp.py:121-125 (gloo: CPU-side reduction of cuda grads)
+inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs([2], C, H, W, 100 + rank).items()}
+n0, sn = (torch.from_numpy(a).cuda() for a in synth.make_train_noise(200 + rank, 2, C, H, W, T))
+pred = ddp(inp["feat"].cuda(), inp["cond"].cuda(), inp["record_len"], noise=(n0, sn))["pred_feature"]
+(pred ** 2).mean().backward()
+torch.cuda.synchronize()
+if rank == 0:
+    torch.save({k: p.grad.cpu() for k, p in gen.named_parameters()}, out)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_ddp_gradient_sync_matches_single_process(tmp_path):
+    from gencomm_amd import GenComm, synth
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER)
+    out = tmp_path / "grads.pt"
+    port = str(29600 + os.getpid() % 300)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, str(r), "2", port, str(out)], env=env) for r in range(2)]
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs == [0, 0], rcs
+    ddp_grads = torch.load(out)
+    # single process: mean of the two ranks' losses == DDP's averaged gradients
+    C, H, W, T = 16, 16, 24, 3
+    gen = GenComm(synth.default_gencomm_cfg(C, T)).train()
+    synth.fill_params_(gen, 5)
+    gen = gen.to(DEV)
+    total = 0.0
+    for rank in range(2):
+        inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs([2], C, H, W, 100 + rank).items()}
+        n0, sn = (torch.from_numpy(a).to(DEV) for a in synth.make_train_noise(200 + rank, 2, C, H, W, T))
+        pred = gen(inp["feat"].to(DEV), inp["cond"].to(DEV), inp["record_len"], noise=(n0, sn))["pred_feature"]
+        total = total + 0.5 * (pred ** 2).mean()
+    total.backward()
+    worst = 0.0
+    for k, p in gen.named_parameters():
+        worst = max(worst, _close("ddp grad " + k, ddp_grads[k], p.grad, 1e-4))
+    print(f"2-rank DDP (gloo) averaged gradients vs single process: worst relative difference {worst:.2e}")

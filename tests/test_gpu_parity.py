@@ -149,7 +149,7 @@ def test_philox_noise_statistics_and_determinism():
 
 
 def test_training_gradients_match_reference():
-    """Training step: HIP forward + recompute-based autograd (gencomm_amd/autograd.py). Gradients of
+    """Training step: HIP forward + HIP backward (gencomm_unet_bwd through gencomm_amd/autograd.py UNetFunction). Gradients of
     mean(pred^2) w.r.t. three UNet parameters against the reference's own autograd (golden 'tiny')."""
     g = load_case("tiny")
     _, gen, _ = build_modules(g, DEV)
