@@ -279,7 +279,8 @@ def main():
             run_scene(i, 1000 + i)
         elapsed = timed_region(args.steps, 2000)
     timed = rank == 0 and not args.graph and not args.no_timer  # event pairs cannot be recorded into a replayed graph
-    split_default = lib.gencomm_get_mode(_lib.MODE_ARITH) == 0
+    arith_mode = lib.gencomm_get_mode(_lib.MODE_ARITH)
+    split_default = arith_mode == 0
     roofs = rooflines(family_pass(), "Arithmetic: see config.arithmetic.") if timed else {}
     # the same workload with the exact-fp32 MFMA kernels everywhere, the arithmetic that is identical to the reference's:
     # the full step count, timed the same way (rank 0), with its own family pass
@@ -306,7 +307,7 @@ def main():
         out = {
             "metric": "scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "total_scenes": total_scenes,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if arith_mode == 2 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
                                    f"T={T} x0-param ancestral steps, {B} scene(s)/step/GPU",
@@ -315,7 +316,11 @@ def main():
                        "arithmetic": ("fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
                                       "exact two-term fp16 splits of both operands (22-bit products: slightly narrower than an fp32 FMA, same parity "
                                       "tolerance; range-guarded, see DESIGN.md section 4); the arithmetic-identical-to-the-reference mode is "
-                                      "exact_fp32_mode") if split_default else "exact fp32 MFMA kernels (GENCOMM_MODE_ARITH = 1)",
+                                      "exact_fp32_mode") if split_default else
+                                     ("exact fp32 MFMA kernels (GENCOMM_MODE_ARITH = 1)" if arith_mode == 1 else
+                                      "bf16 denoise mode (GENCOMM_MODE_ARITH = 2): the UNet's 8-channel maps stored as bf16, single bf16 MFMA products, "
+                                      "fp32 accumulation, f64 GroupNorm statistics, fp32 sampler state; Enhancer / fusion as in the fp32 mode. "
+                                      "NOT the fp32 headline: accuracy of bf16 storage, see tests/test_gpu_bf16.py"),
                        "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph),
                        "modes": {k: lib.gencomm_get_mode(v) for k, v in mode_keys.items()},
                        "parallelism": f"replicas x{world} (scene-sharded, no collective)"},

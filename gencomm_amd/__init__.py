@@ -17,4 +17,18 @@ from .fusion import AttFusion, normalize_pairwise_tfm, regroup
 from .message_extractor import MessageExtractorv2
 from .unet import DiffusionUNet
 
-__all__ = ["GenComm", "DiffusionUNet", "Enhancer", "AttFusion", "MessageExtractorv2", "regroup", "normalize_pairwise_tfm"]
+
+
+def set_denoise_dtype(dtype) -> None:
+    """Arithmetic of the denoise loop, process-wide (``gencomm_set_mode(GENCOMM_MODE_ARITH, ...)``):
+    ``torch.float32`` (default: fp32 tensors, fp32-grade products on the f16 matrix pipe), ``"exact_fp32"`` (exact-fp32 MFMA
+    kernels) or ``torch.bfloat16`` (bf16 storage of the UNet's 8-channel maps and single bf16 products -- the analogue of the
+    reference's ``--half`` / autocast runs, ``train_ddp.py:139-141``; inference only)."""
+    import torch
+    from . import _lib
+    value = {torch.float32: 0, "float32": 0, "exact_fp32": 1, torch.bfloat16: 2, "bfloat16": 2, "bf16": 2}[dtype]
+    _lib.check(_lib.lib().gencomm_set_mode(_lib.MODE_ARITH, value), "gencomm_set_mode")
+
+
+__all__ = ["GenComm", "DiffusionUNet", "Enhancer", "AttFusion", "MessageExtractorv2", "regroup", "normalize_pairwise_tfm",
+           "set_denoise_dtype"]

@@ -45,7 +45,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // into a Modes snapshot that travels with the call -- never an environment variable, never re-read per launch.
 // ---------------------------------------------------------------------------------------------
 enum ModeKey : int {
-  MODE_ARITH = 0,        // 0: products on the f16 matrix pipe from exact fp16 hi/lo splits (default); 1: exact-fp32 kernels
+  MODE_ARITH = 0,        // 0: products on the f16 matrix pipe from exact fp16 hi/lo splits (default); 1: exact-fp32 kernels;
+                         // 2: bf16 denoise mode (bf16 storage of the UNet's 8-channel maps, single bf16 products: conv8b_kernels.h)
   MODE_SAMPLER = 1,      // 0: latent sampler structure (default); 1: literal conv_in .. conv_out + update per step
   MODE_TILE_WANT = 2,    // 0: automatic; > 0: minimum number of 64x16 workgroups before the 64x16-tile kernels are chosen
   MODE_ENH_FUSE = 3,     // 1: Enhancer Linear1 + depthwise stage fused at C = 64 (default); 0: separate launches
@@ -55,7 +56,8 @@ enum ModeKey : int {
 };
 struct Modes {
   long long v[MODE_COUNT];
-  bool split() const { return v[MODE_ARITH] == 0; }
+  bool split() const { return v[MODE_ARITH] != 1; }  // f16-pipe kernel family (fp16 split or bf16 mode)
+  bool bf16() const { return v[MODE_ARITH] == 2; }
   int xcd() const { return v[MODE_XCD_REMAP] != 0 ? 1 : 0; }
 };
 Modes modes_snapshot();  // defined in gencomm_abi.hip

@@ -47,7 +47,7 @@ const char* gencomm_last_error(void) { return last_error_buf(); }
 // ------------------------------------------------------------------------------------ modes
 int gencomm_set_mode(int key, long long value) {
   GC_CHECK_ARG(key >= 0 && key < MODE_COUNT, "unknown mode key");
-  GC_CHECK_ARG(key != MODE_ARITH || value == 0 || value == 1, "GENCOMM_MODE_ARITH: 0 (f16-pipe split) or 1 (exact fp32)");
+  GC_CHECK_ARG(key != MODE_ARITH || (value >= 0 && value <= 2), "GENCOMM_MODE_ARITH: 0 (f16-pipe split), 1 (exact fp32) or 2 (bf16 denoise)");
   GC_CHECK_ARG(key != MODE_SAMPLER || value == 0 || value == 1, "GENCOMM_MODE_SAMPLER: 0 (latent) or 1 (direct)");
   GC_CHECK_ARG(key != MODE_TILE_WANT || value >= 0, "GENCOMM_MODE_TILE_WANT: 0 (automatic) or a positive workgroup count");
   g_modes[key].store(value, std::memory_order_relaxed);
@@ -182,6 +182,14 @@ long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels
   return (long long)w.total;
 }
 
+// bf16 denoise mode: one kernel family (64x16 tiles, vector loads), no AttnBlock
+static int check_bf16_mode(const Modes& m, const UNetPlan& p, int W) {
+  if (!m.bf16()) return GC_OK;
+  GC_CHECK_ARG(p.attn_mask == 0, "bf16 denoise mode does not cover AttnBlocks");
+  GC_CHECK_ARG(W % (4 << (p.L - 1)) == 0, "bf16 denoise mode needs W divisible by 4 at every resolution level");
+  return GC_OK;
+}
+
 static int check_dims(int n, int C, int H, int W) {
   GC_CHECK_ARG(n >= 1 && n <= 65535, "n (agents) must be in 1..65535");
   GC_CHECK_ARG(H >= 1 && W >= 1 && (long long)H * W * (C + 8) < (1LL << 31), "C*H*W per agent must stay below 2^31 elements");
@@ -201,6 +209,7 @@ int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond,
   if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
   if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_denoise_workspace_bytes)");
   UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()};
+  if (int rc = check_bf16_mode(c.m, p, W)) return rc;
   GC_HIP(hipMemsetAsync(c.amax(), 0, 256, c.st));
   amax_kernel<<<256, 256, 0, c.st>>>(cond, (long long)n * 2 * H * W, c.amax());
   amax_kernel<<<1024, 256, 0, c.st>>>(x_t, (long long)n * C * H * W, c.amax() + 1);
@@ -232,6 +241,7 @@ int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, 
   const UNetBwdWs bw = unet_bwd_ws(p, w, n, H, W);
   if ((long long)bw.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_unet_bwd_workspace_bytes)");
   UNetBwdCall b{UNetCall{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()}, &bw, raw, grad_raw};
+  GC_CHECK_ARG(!b.c.m.bf16(), "gencomm_unet_bwd reads fp32 intermediates: not available in bf16 denoise mode (GENCOMM_MODE_ARITH = 2)");
   return unet_bwd_enqueue(b, x_t, cond, t, grad_x0, grad_xt, grad_cond);
 }
 
@@ -310,6 +320,7 @@ int gencomm_denoise_fwd_dseed(const float* prepared, const float* sched,
   const long long per_agent = (long long)C * H * W;
 
   UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, st, modes_snapshot()};
+  if (int rc = check_bf16_mode(c.m, p, W)) return rc;
   // range guard of conv_in on the f16 pipe: device bounds {max|cond|, max|x_T|} (common.h act_scale)
   GC_HIP(hipMemsetAsync(c.amax(), 0, 256, st));
   amax_kernel<<<256, 256, 0, st>>>(cond, (long long)n * 2 * H * W, c.amax());

@@ -91,6 +91,7 @@ struct LatentArgs {
   int C, H, W;
   const unsigned long long* seed_dev;  // optional device-resident Philox key
   int xcd;
+  int a_bf16;            // bf16 denoise mode: `a_src` is a bf16 map (latent_step_h_kernel only)
 };
 
 template <int TW, int TH, int NOISE>

@@ -8,6 +8,7 @@
 // conv8h's inner loop unchanged.  Per tile-wave: 192 + C/8 * 72 MFMAs of 16 cycles instead of 1600 + C/8 * 576 fp32
 // MFMAs of ~9 cycles, and they no longer compete with the Philox / Box-Muller VALU work for the issue port.
 #pragma once
+#include "conv8b_kernels.h"
 #include "conv8h_kernels.h"
 #include "latent_kernels.h"
 
@@ -335,9 +336,8 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
   const int nocb = (C + 15) / 16;
 
   TileRegs<TW, TH, NT, 8> R;
-  const float* __restrict__ sp = a.src + (size_t)n * 8 * plane;
-  stage_load<TW, TH, NT, 8, false>(R, sp, plane, W, H, W, x0, y0, tid);
-  const float2 hreg = halo_load_h<false>(sp, plane, W, H, W, x0, y0, tid);
+  float2 hreg;
+  stage_load_b<false>(R, hreg, a.src, !a.src_bf16, (size_t)n * 8 * plane, plane, W, H, W, x0, y0, tid);
   if (tid < 8) {
     float A, B;
     gn_coeff(a.sstat + (size_t)n * 16, tid, 2, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
@@ -453,21 +453,22 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
   const bool wave_live = y0 + 4 * wave < H;
 
   // ---------------- phase 1: A' = c1 * SiLU(GN(a)) with a 2-pixel halo -> LDS (fp16 hi / lo) ----------------
-  const float* __restrict__ ap = a.a_src + (size_t)n * 8 * plane;
+  const int af32 = !a.a_bf16;
+  const size_t abase = (size_t)n * 8 * plane;
   float4 qm[8], qr[2];
   float hh[2][2];
   const int r0 = tid >> 4, qx = tid & 15;
   const bool ok_m = (y0 - 2 + r0) >= 0 && (y0 - 2 + r0) < H && (x0 + 4 * qx) < W;
 #pragma unroll
   for (int c = 0; c < 8; ++c)
-    qm[c] = ok_m ? *reinterpret_cast<const float4*>(ap + ((unsigned)c * plane + (unsigned)(y0 - 2 + r0) * (unsigned)W + (unsigned)(x0 + 4 * qx)))
+    qm[c] = ok_m ? ld4(a.a_src, af32, abase + ((unsigned)c * plane + (unsigned)(y0 - 2 + r0) * (unsigned)W + (unsigned)(x0 + 4 * qx)))
                  : make_float4(0.f, 0.f, 0.f, 0.f);
   // rows 16..19: thread = (row 16 + (tid & 63) / 16, quad tid % 16, channel pair tid / 64)
   const int rrow = TH + ((tid & 63) >> 4), cpr = tid >> 6;
   const bool ok_r = (y0 - 2 + rrow) >= 0 && (y0 - 2 + rrow) < H && (x0 + 4 * qx) < W;
 #pragma unroll
   for (int k = 0; k < 2; ++k)
-    qr[k] = ok_r ? *reinterpret_cast<const float4*>(ap + ((unsigned)(2 * cpr + k) * plane + (unsigned)(y0 - 2 + rrow) * (unsigned)W + (unsigned)(x0 + 4 * qx)))
+    qr[k] = ok_r ? ld4(a.a_src, af32, abase + ((unsigned)(2 * cpr + k) * plane + (unsigned)(y0 - 2 + rrow) * (unsigned)W + (unsigned)(x0 + 4 * qx)))
                  : make_float4(0.f, 0.f, 0.f, 0.f);
   // halo columns x0-2, x0-1, x0+64, x0+65: item = (row idx / 16, column (idx / 4) & 3, channel pair idx & 3), 320 items
   bool ok_h[2];
@@ -479,8 +480,8 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
     ok_h[j] = idx < HL_LH5 * 16 && gy >= 0 && gy < H && gxh >= 0 && gxh < W;
     hh[j][0] = hh[j][1] = 0.f;
     if (ok_h[j]) {
-      hh[j][0] = ap[(unsigned)(2 * cp) * plane + (unsigned)gy * (unsigned)W + (unsigned)gxh];
-      hh[j][1] = ap[(unsigned)(2 * cp + 1) * plane + (unsigned)gy * (unsigned)W + (unsigned)gxh];
+      hh[j][0] = ld1(a.a_src, af32, abase + (unsigned)(2 * cp) * plane + (unsigned)gy * (unsigned)W + (unsigned)gxh);
+      hh[j][1] = ld1(a.a_src, af32, abase + (unsigned)(2 * cp + 1) * plane + (unsigned)gy * (unsigned)W + (unsigned)gxh);
     }
   }
   if (tid < 8) {

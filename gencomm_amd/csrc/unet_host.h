@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "attn_kernels.h"
+#include "conv8b_kernels.h"
 #include "conv8h_kernels.h"
 #include "latent_kernels.h"
 #include "latenth_kernels.h"
@@ -28,6 +29,7 @@ inline long long tile_want(const Modes& m) {
   return m.v[MODE_TILE_WANT] > 0 ? m.v[MODE_TILE_WANT] : (m.split() ? 160LL : 512LL);
 }
 inline TileCfg pick_tile(const Modes& m, int n, int H, int W, int zmul = 1) {
+  if (m.bf16()) return TILE_64x16;  // the bf16 mode has one kernel family
   const long long want = tile_want(m);
   if ((long long)cdiv(W, 64) * cdiv(H, 16) * n * zmul >= want) return TILE_64x16;
   if ((long long)cdiv(W, 32) * cdiv(H, 16) * n * zmul >= want) return TILE_32x16;
@@ -58,6 +60,14 @@ inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, h
   }
 }
 
+template <int NSRC, bool GN, bool UP, int RES>
+inline void launch_conv8b(const Conv8BArgs& a, int n, hipStream_t st) {
+  const double elt = 2.0;  // bf16 maps (the fp32 hs0 map appears in two launches per call: counted as bf16, a lower bound)
+  const double abytes = elt * n * ((double)NSRC * 8 * a.Hin * a.Win + (RES == 1 ? 8.0 : RES == 2 ? 16.0 : 0.0) * a.H * a.W + 8.0 * a.H * a.W);
+  TimedLaunch tl(UP ? KF_UP : (NSRC == 2 ? KF_CONV16 : (RES == 1 ? KF_CONV8_RES1 : RES == 2 ? KF_CONV8_RES2 : KF_CONV8)), st, abytes);
+  conv8b_kernel<NSRC, GN, UP, RES><<<dim3(cdiv(a.W, 64), cdiv(a.H, 16), n), 256, 0, st>>>(a);
+}
+
 struct UNetCall {
   const UNetPlan* plan;
   const UNetWorkspace* ws;
@@ -67,6 +77,8 @@ struct UNetCall {
   hipStream_t st;
   Modes m;
   float* amax() const { return reinterpret_cast<float*>(wsp + ws->amax_off); }  // {max|cond|, max|x_t|}, set by the caller
+  // bf16 denoise mode: every 8-channel map is bf16 except the sampler's carried state hs0 (tensor 0)
+  int is_f32(int id) const { return (!m.bf16() || id == plan->hs0_tensor) ? 1 : 0; }
 
   float* tensor_ptr(int id) const {
     const TensorPlan& t = plan->tensors[id];
@@ -109,6 +121,17 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
       }
       case OP_RES_CONV1: {
         const ResBlockPlan& b = p.blocks[o.blk];
+        if (c.m.bf16()) {
+          Conv8BArgs a{};
+          a.src[0] = c.tensor_ptr(o.src[0]); a.src_f32[0] = c.is_f32(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
+          if (o.src[1] >= 0) { a.src[1] = c.tensor_ptr(o.src[1]); a.src_f32[1] = c.is_f32(o.src[1]); a.sstat[1] = c.stat_ptr(o.src[1]); }
+          a.gamma = P + b.n1w; a.beta = P + b.n1b; a.wb = P + b.p_c1wb; a.bias = P + b.p_bias1 + (size_t)t * 8;
+          a.dst = c.tensor_ptr(o.dst); a.dst_f32 = c.is_f32(o.dst); a.dstat = c.stat_ptr(o.dst);
+          a.H = a.Hin = Hl; a.W = a.Win = Wl; a.inv_cnt = 1.0 / ((b.cin == 8 ? 2.0 : 4.0) * Hl * Wl); a.xcd = c.m.xcd();
+          if (b.cin == 8) launch_conv8b<1, true, false, 0>(a, c.n, c.st);
+          else launch_conv8b<2, true, false, 0>(a, c.n, c.st);
+          break;
+        }
         Conv8Args a{};
         a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
         if (o.src[1] >= 0) { a.src[1] = c.tensor_ptr(o.src[1]); a.sstat[1] = c.stat_ptr(o.src[1]); }
@@ -125,6 +148,18 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
       }
       case OP_RES_CONV2: {
         const ResBlockPlan& b = p.blocks[o.blk];
+        if (c.m.bf16()) {
+          Conv8BArgs a{};
+          a.src[0] = c.tensor_ptr(o.src[0]); a.src_f32[0] = c.is_f32(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
+          a.gamma = P + b.n2w; a.beta = P + b.n2b; a.wb = P + b.p_c2wb; a.bias = P + b.p_bias2;
+          a.res[0] = c.tensor_ptr(o.res[0]); a.res_f32[0] = c.is_f32(o.res[0]);
+          if (o.res[1] >= 0) { a.res[1] = c.tensor_ptr(o.res[1]); a.res_f32[1] = c.is_f32(o.res[1]); a.ninw = P + b.p_ninw; }
+          a.dst = c.tensor_ptr(o.dst); a.dst_f32 = c.is_f32(o.dst); a.dstat = c.stat_ptr(o.dst);
+          a.H = a.Hin = Hl; a.W = a.Win = Wl; a.inv_cnt = 1.0 / (2.0 * Hl * Wl); a.xcd = c.m.xcd();
+          if (b.cin == 8) launch_conv8b<1, true, false, 1>(a, c.n, c.st);
+          else launch_conv8b<1, true, false, 2>(a, c.n, c.st);
+          break;
+        }
         Conv8Args a{};
         a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
         a.gamma = P + b.n2w; a.beta = P + b.n2b;
@@ -143,7 +178,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
       case OP_DOWN: {
         const int lin = o.level - 1;
         DownArgs a{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst),
-                   c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin]};
+                   c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin], !c.is_f32(o.src[0]), !c.is_f32(o.dst)};
         TimedLaunch tl(KF_DOWN, c.st, 4.0 * c.n * 8.0 * ((double)a.Hin * a.Win + (double)Hl * Wl));
         if ((a.Win & 3) == 0) down8x2_kernel<<<dim3(cdiv(Hl * ((Wl + 1) / 2), 256), 1, c.n), 256, 0, c.st>>>(a);
         else down8_kernel<<<dim3(cdiv(Hl * Wl, 256), 1, c.n), 256, 0, c.st>>>(a);
@@ -151,6 +186,15 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
       }
       case OP_UP: {
         const int lin = o.level + 1;
+        if (c.m.bf16()) {
+          Conv8BArgs a{};
+          a.src[0] = c.tensor_ptr(o.src[0]); a.src_f32[0] = c.is_f32(o.src[0]);
+          a.wb = P + p.up[lin].p_wb; a.bias = P + p.up[lin].b;
+          a.dst = c.tensor_ptr(o.dst); a.dst_f32 = c.is_f32(o.dst); a.dstat = c.stat_ptr(o.dst);
+          a.H = Hl; a.W = Wl; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin]; a.xcd = c.m.xcd();
+          launch_conv8b<1, false, true, 0>(a, c.n, c.st);
+          break;
+        }
         Conv8Args a{};
         a.src[0] = c.tensor_ptr(o.src[0]);
         a.sstat[0] = c.stat_ptr(o.src[0]);  // raw input: range bound from its sum of squares (conv8h_kernel)
@@ -180,6 +224,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         co.inv_cnt = 1.0 / (2.0 * Hl * Wl);
         co.xcd = c.m.xcd();
         co.amax_out = post != 0 ? c.amax() + 1 : nullptr;  // literal sampler: x_{t-1} feeds the next step's conv_in
+        co.src_bf16 = !c.is_f32(o.src[0]);
         const int nocb = (p.C + 15) / 16;
         const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
         int tw, th;
@@ -247,6 +292,7 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   a.noise = noise; a.sched = sched_row; a.inv_cnt = 1.0 / (2.0 * c.H * c.W);
   a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id; a.C = p.C; a.H = c.H; a.W = c.W;
   a.xcd = c.m.xcd();
+  a.a_bf16 = !c.is_f32(p.last_body_tensor);
   // algorithmic bytes: last block's output (read), k map (read), hs0 (read + write): 4 eight-channel maps
   TimedLaunch tl(KF_LATENT_STEP, c.st, 4.0 * c.n * 32.0 * c.H * c.W);
   if (pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16 && c.m.split()) {
@@ -281,6 +327,7 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
     if (p.up[l].w >= 0) {
       conv_w(p.up[l].w, p.up[l].p_w, 8, 8, 8);
       prep_conv8h_kernel<<<1, 256, 0, st>>>(raw + p.up[l].w, prepared + p.up[l].p_wh, 8);
+      prep_conv8b_kernel<<<1, 256, 0, st>>>(raw + p.up[l].w, prepared + p.up[l].p_wb, 8);
     }
   }
   TembArgs ta{};
@@ -293,6 +340,8 @@ inline int unet_prepare_enqueue(const UNetPlan& p, const float* raw, float* prep
     conv_w(b.c2w, b.p_c2w, 8, 8, 8);
     prep_conv8h_kernel<<<1, 256, 0, st>>>(raw + b.c1w, prepared + b.p_c1wh, b.cin);
     prep_conv8h_kernel<<<1, 256, 0, st>>>(raw + b.c2w, prepared + b.p_c2wh, 8);
+    prep_conv8b_kernel<<<1, 256, 0, st>>>(raw + b.c1w, prepared + b.p_c1wb, b.cin);
+    prep_conv8b_kernel<<<1, 256, 0, st>>>(raw + b.c2w, prepared + b.p_c2wb, 8);
     if (b.cin != 8) prep_nin_w_kernel<<<1, 256, 0, st>>>(raw + b.ninw, prepared + b.p_ninw, 8, b.cin);
     prep_add_kernel<<<1, 64, 0, st>>>(raw + b.c2b, b.cin != 8 ? raw + b.ninb : nullptr, prepared + b.p_bias2, 8);
     ta.tpw[i] = b.tpw; ta.tpb[i] = b.tpb; ta.c1b[i] = b.c1b; ta.dst[i] = b.p_bias1;

@@ -470,6 +470,7 @@ struct DownArgs {
   float* dst;        // [n][8][H][W]
   double* dstat;
   int H, W, Hin, Win;
+  int src_bf16, dst_bf16;  // bf16 denoise mode (conv8b_kernels.h): the maps are bf16 (down8x2_kernel only)
 };
 
 __global__ __launch_bounds__(256) void down8_kernel(const DownArgs a) {
@@ -536,9 +537,17 @@ __global__ __launch_bounds__(256) void down8x2_kernel(const DownArgs a) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       float e = 0.f;
       if (ok && iy < a.Hin) {
-        const float* __restrict__ rp = sp + (size_t)ic * plane_in + (size_t)iy * a.Win + ix;
-        v = *reinterpret_cast<const float4*>(rp);  // ix + 3 < Win: Win % 4 == 0 and ix < Win
-        if (ix + 4 < a.Win) e = rp[4];
+        const size_t o = (size_t)ic * plane_in + (size_t)iy * a.Win + ix;
+        if (!a.src_bf16) {
+          const float* __restrict__ rp = sp + o;
+          v = *reinterpret_cast<const float4*>(rp);  // ix + 3 < Win: Win % 4 == 0 and ix < Win
+          if (ix + 4 < a.Win) e = rp[4];
+        } else {
+          const uint16_t* __restrict__ rp = reinterpret_cast<const uint16_t*>(a.src) + (size_t)n * 8 * plane_in + o;
+          const uint2 u = *reinterpret_cast<const uint2*>(rp);
+          v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+          if (ix + 4 < a.Win) e = __uint_as_float((uint32_t)rp[4] << 16);
+        }
       }
       in[dy][0] = v.x; in[dy][1] = v.y; in[dy][2] = v.z; in[dy][3] = v.w; in[dy][4] = e;
     }
@@ -556,8 +565,16 @@ __global__ __launch_bounds__(256) void down8x2_kernel(const DownArgs a) {
   const size_t total = (size_t)a.H * a.W;
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * total + (size_t)oy * a.W + ox;
-    if (ok1 && (a.W & 1) == 0) *reinterpret_cast<float2*>(dp) = make_float2(acc[0][o], acc[1][o]);
+    const size_t e = ((size_t)n * 8 + o) * total + (size_t)oy * a.W + ox;
+    float* __restrict__ dp = a.dst + e;
+    if (a.dst_bf16) {  // bf16 mode: rounded, W even (host-checked); the statistics describe the stored values
+      typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+      typedef float f2_t __attribute__((ext_vector_type(2)));
+      const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_t){acc[0][o], acc[1][o]}, b2_t));
+      if (ok1) reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(a.dst) + e)[0] = pk;
+      acc[0][o] = __uint_as_float(pk << 16);
+      acc[1][o] = __uint_as_float(pk & 0xffff0000u);
+    } else if (ok1 && (a.W & 1) == 0) *reinterpret_cast<float2*>(dp) = make_float2(acc[0][o], acc[1][o]);
     else {
       if (ok) dp[0] = acc[0][o];
       if (ok1) dp[1] = acc[1][o];
@@ -704,6 +721,7 @@ struct ConvOutArgs {
   const unsigned long long* seed_dev;  // optional: the Philox key is read from device memory (graph replay with a new seed)
   int xcd;
   float* amax_out;      // optional (POST != 0, f16-pipe kernel): max|out| is folded into it (bound for the next conv_in)
+  int src_bf16;         // bf16 denoise mode: `src` is a bf16 map (conv_out_h_kernel only)
 };
 
 template <int TW, int TH, int PPL, int POST>

@@ -25,6 +25,7 @@ struct ResBlockPlan {
   // prepared offsets
   long long p_c1w, p_c2w, p_ninw, p_bias1 /*[T][8]*/, p_bias2 /*[8]*/;
   long long p_c1wh, p_c2wh;  // fp16 hi/lo A-operand tables (conv8h_kernels.h): cin/8 * 1536 dwords + 64
+  long long p_c1wb, p_c2wb;  // bf16 A-operand tables (conv8b_kernels.h): cin/8 * 768 dwords
 };
 
 struct AttnPlan {  // AttnBlock parameters (raw offsets; 1x1 conv weights are used as stored, [oc][ic])
@@ -35,6 +36,7 @@ struct ConvPlan {  // plain 3x3 conv (conv_in, downsample, upsample, conv_out)
   long long w, b;  // raw
   long long p_w;   // prepared
   long long p_wh = -1;  // fp16 hi/lo table (upsample conv only)
+  long long p_wb = -1;  // bf16 table (upsample conv only)
 };
 
 enum OpKind { OP_CONV_IN, OP_RES_CONV1, OP_RES_CONV2, OP_DOWN, OP_UP, OP_CONV_OUT, OP_ATTN };
@@ -192,7 +194,7 @@ struct UNetPlan {
     conv_out.p_wh = padd((long long)((C + 15) / 16) * 1536 + 64);
     for (int l = 0; l < L; ++l) {
       if (down[l].w >= 0) down[l].p_w = padd(8 * 8 * 9);
-      if (up[l].w >= 0) { up[l].p_w = padd(8 * 8 * 9); up[l].p_wh = padd(1536 + 64); }
+      if (up[l].w >= 0) { up[l].p_w = padd(8 * 8 * 9); up[l].p_wh = padd(1536 + 64); up[l].p_wb = padd(768); }
     }
     p_wc5 = padd(1600); p_wc1 = padd(5184); p_bring = padd(72); p_bsum = padd(8);
     p_wc5h = padd(4096 + 64); p_wxh = padd((long long)(C / 8) * 1536); p_wch = padd(1536);
@@ -204,6 +206,8 @@ struct UNetPlan {
       b.p_bias2 = padd(8);
       b.p_c1wh = padd((long long)(b.cin / 8) * 1536 + 64);
       b.p_c2wh = padd(1536 + 64);
+      b.p_c1wb = padd((long long)(b.cin / 8) * 768);
+      b.p_c2wb = padd(768);
     }
 
     // ---- launch program (unet.py:307-344) ----

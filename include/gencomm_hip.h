@@ -58,7 +58,11 @@ const char* gencomm_build_info(void);
  * travel with the call from there on); the library reads no environment variable.  gencomm_set_mode returns 0 or 1
  * (unknown key / value out of range); gencomm_get_mode returns the value, -1 for an unknown key.
  *   GENCOMM_MODE_ARITH        0 (default): 3x3 / 5x5 / Linear products on the f16 matrix pipe from exact two-term fp16
- *                             splits of the fp32 operands (22-bit products, fp32 accumulation); 1: exact-fp32 kernels
+ *                             splits of the fp32 operands (22-bit products, fp32 accumulation); 1: exact-fp32 kernels;
+ *                             2: bf16 denoise mode (the reference's --half / autocast analogue, train_ddp.py:139-141): the
+ *                             UNet's 8-channel intermediates are stored as bf16 and multiplied by single bf16 MFMAs
+ *                             (fp32 accumulation, GroupNorm statistics in f64, the sampler's carried state in fp32);
+ *                             inference only, no AttnBlock, W divisible by 4 at every level
  *   GENCOMM_MODE_SAMPLER      0 (default): the loop is carried on conv_in's 8-channel output (one fused kernel per
  *                             step replaces conv_out + update + conv_in); 1: literal per-step structure of
  *                             cond_diff.py:321-329 (tests compare the two)
