@@ -66,6 +66,12 @@ _SIGNATURES = {
     "gencomm_conv2d_prepare": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_conv2d_fold": (_i, [_p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _p]),
     "gencomm_conv2d_fwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 13 + [_p]),
+    "gencomm_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "gencomm_ln_nchw_fwd": (_i, [_p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
+    "gencomm_ln_nchw_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
+    "gencomm_dwconv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_dwconv3x3_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_gelu_bwd": (_i, [_p, _p, _p, _ll, _p]),
     "gencomm_det_workspace_bytes": (C.c_longlong, [_i, _i, _i]),
     "gencomm_nms_workspace_bytes": (C.c_longlong, []),
     "gencomm_nms_max_candidates": (_i, []),
@@ -79,6 +85,7 @@ _SIGNATURES = {
     "gencomm_voxelize_workspace_bytes": (_ll, [_i]),
     "gencomm_voxelize_fwd": (_i, [_p, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p, _p, _p, _p, _p, _ll, _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_warp_attfuse_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_maxfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_attfuse_tok_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }

@@ -105,6 +105,8 @@ def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise
 
 # ----------------------------------------------------------------------------------------- Enhancer
 def enhancer_forward(enh, x):
+    """Differentiable torch restatement of Enhancer.forward (enhancer.py:367-383, :346-357, :222-250, :315-333) -- used by the
+    tests to check the HIP backward; the product path below does not call it."""
     b1, sa = enh.block_1, enh.split_attn
     B, C, H, W = x.shape
     tok = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
@@ -127,6 +129,11 @@ def enhancer_forward(enh, x):
 
 
 class EnhancerFunction(torch.autograd.Function):
+    """HIP forward (gencomm_enhancer_fwd, the fused inference kernels) and a backward composed of HIP primitives
+    (gencomm_amd/train_ops.py): the stage is recomputed layer by layer in NCHW with the exact-fp32 general convolution
+    (1x1 = Linear, 3x3 partial conv), LayerNorm and depthwise kernels, then walked backwards with their gradient kernels.
+    Elementwise products / sums and the channel gate's MLP on [n, C] vectors are plain torch tensor arithmetic."""
+
     @staticmethod
     def forward(ctx, enh, x, *params):
         with torch.no_grad():
@@ -137,21 +144,72 @@ class EnhancerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        from . import train_ops as T
         (x,) = ctx.saved_tensors
         enh = ctx.enh
-        params = [p for p in enh.parameters()]
+        b1, sa, m = enh.block_1, enh.split_attn, enh.block_1.mlp
+        n, C, H, W = x.shape
+        dc, hid, HW = C // 4, m.dwconv[0].weight.shape[0], H * W
+        with torch.no_grad():
+            # ---- forward recompute, every intermediate kept
+            y = T.ln_fwd(x, b1.norm1.weight, b1.norm1.bias, 1e-5, True)            # x + LN1(x)       enhancer.py:351-352
+            z = T.ln_fwd(y, b1.norm2.weight, b1.norm2.bias, 1e-5, False)           # LN2              :354
+            z1 = z[:, :dc].contiguous()
+            zi = torch.cat([T.conv2d(z1, m.partial_conv3.weight, None, 1), z[:, dc:]], dim=1)                    # :229-232
+            w1 = m.linear1[0].weight.detach()[:, :, None, None]
+            v = T.conv2d(zi, w1, m.linear1[0].bias, 0)                                # Linear1          :235
+            hdn = F.gelu(v)
+            h1, h2 = hdn[:, :hid].contiguous(), hdn[:, hid:].contiguous()
+            u = T.dwconv3x3(h1, m.dwconv[0].weight, m.dwconv[0].bias)                  # depthwise        :241-243
+            h1p = F.gelu(u)
+            g = h1p * h2
+            w2 = m.linear2[0].weight.detach()[:, :, None, None]
+            y2 = y + T.conv2d(g, w2, m.linear2[0].bias, 0)                             # Linear2 + residual :247, :354
+        # ---- channel gate on [n, C] vectors (split_attn, :315-333): torch autograd on a few hundred numbers
+        gate_params = [sa.fc1.weight, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight]
         with torch.enable_grad():
-            xi = x.detach().float().requires_grad_(ctx.needs_input_grad[1])
-            out = enhancer_forward(enh, xi)
-            wanted = ([xi] if xi.requires_grad else []) + [p for p in params if p.requires_grad]
-            grads = list(torch.autograd.grad(out, wanted, grad_out.float().contiguous(), allow_unused=True)) if wanted else []
-        gx = grads.pop(0) if xi.requires_grad else None
-        gp = [grads.pop(0) if p.requires_grad else None for p in params]
-        return (None, gx, *gp)
+            gap = y2.mean((2, 3)).requires_grad_(True)
+            local = [p.detach().requires_grad_(True) for p in gate_params]
+            a = torch.sigmoid(F.linear(F.relu(F.layer_norm(F.linear(gap, local[0]), (local[0].shape[0],), local[1], local[2], 1e-5)), local[3]))
+            go = grad_out.float()
+            da = (go * y2).sum((2, 3))
+            dgap, *dgate = torch.autograd.grad(a, [gap] + local, da)
+        with torch.no_grad():
+            a = a.detach()
+            dy2 = go * a[:, :, None, None] + dgap[:, :, None, None] / HW
+            # ---- Linear2
+            dg = T.conv2d(dy2, w2.transpose(0, 1).contiguous(), None, 0)
+            dW2, db2 = T.conv2d_wgrad(dy2, g, 1, 0, True)
+            dh1p, dh2 = dg * h2, dg * h1p
+            # ---- depthwise + GELU
+            du = T.gelu_bwd(u, dh1p)
+            dh1 = T.dwconv3x3(du, m.dwconv[0].weight, None, flip=True)
+            dWd, dbd = T.dwconv3x3_wgrad(h1, du)
+            # ---- Linear1 + GELU
+            dv = T.gelu_bwd(v, torch.cat([dh1, dh2], dim=1))
+            dzi = T.conv2d(dv, w1.transpose(0, 1).contiguous(), None, 0)
+            dW1, db1l = T.conv2d_wgrad(dv, zi, 1, 0, True)
+            # ---- partial conv
+            dzi1 = dzi[:, :dc].contiguous()
+            dz = torch.cat([T.conv2d_dgrad(dzi1, m.partial_conv3.weight, 1), dzi[:, dc:]], dim=1)
+            dWp, _ = T.conv2d_wgrad(dzi1, z1, 3, 1, False)
+            # ---- LayerNorms and residuals
+            dy_ln, dg2, db2n = T.ln_bwd(y, b1.norm2.weight, dz, 1e-5)
+            dy = dy2 + dy_ln
+            dx_ln, dg1, db1n = T.ln_bwd(x, b1.norm1.weight, dy, 1e-5)
+            dx = dy + dx_ln
+        grads = {id(b1.norm1.weight): dg1, id(b1.norm1.bias): db1n, id(b1.norm2.weight): dg2, id(b1.norm2.bias): db2n,
+                 id(m.partial_conv3.weight): dWp, id(m.linear1[0].weight): dW1[:, :, 0, 0], id(m.linear1[0].bias): db1l,
+                 id(m.dwconv[0].weight): dWd, id(m.dwconv[0].bias): dbd, id(m.linear2[0].weight): dW2[:, :, 0, 0], id(m.linear2[0].bias): db2}
+        grads.update({id(p): gr for p, gr in zip(gate_params, dgate)})
+        gp = [grads.get(id(p)) if p.requires_grad else None for p in enh.parameters()]
+        return (None, dx if ctx.needs_input_grad[1] else None, *gp)
 
 
 # ----------------------------------------------------------------------------------------- fusion
 def att_fusion_forward(xx, lens: List[int], affine_matrix):
+    """Differentiable torch restatement of warp + ego-row attention (fusion_in_one.py:131-151) -- used by the tests to check
+    the HIP backward; the product path below does not call it."""
     _, C, H, W = xx.shape
     out, o = [], 0
     for b, n in enumerate(lens):
@@ -166,19 +224,18 @@ def att_fusion_forward(xx, lens: List[int], affine_matrix):
 
 
 class AttFusionFunction(torch.autograd.Function):
+    """HIP forward (gencomm_warp_attfuse_fwd) and HIP backward (gencomm_warp_attfuse_bwd: softmax / dot-product backward
+    per pixel + the bilinear gather's adjoint with float atomics)."""
+
     @staticmethod
     def forward(ctx, fus, lens, affine_matrix, xx):
         with torch.no_grad():
             out = fus._forward_hip(xx, lens, affine_matrix)
-        ctx.lens, ctx.affine = list(lens), affine_matrix
+        ctx.fus, ctx.lens, ctx.affine = fus, list(lens), affine_matrix
         ctx.save_for_backward(xx)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (xx,) = ctx.saved_tensors
-        with torch.enable_grad():
-            xi = xx.detach().float().requires_grad_(True)
-            out = att_fusion_forward(xi, ctx.lens, ctx.affine)
-            (gx,) = torch.autograd.grad(out, [xi], grad_out.float().contiguous())
-        return None, None, None, gx
+        return None, None, None, ctx.fus._backward_hip(xx, ctx.lens, ctx.affine, grad_out.float().contiguous())

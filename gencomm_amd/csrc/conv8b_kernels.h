@@ -285,17 +285,19 @@ __global__ __launch_bounds__(HC_NT, RES == 2 ? 3 : 4) void conv8b_kernel(const C
 #pragma unroll
   for (int i = 0; i < 8; ++i) part[i] = 0.f;
   if (wave_live) {
-    float out[2][4][4];
+    // the epilogue works in place on the accumulators (acc[p][j][i] = row pair p, pixel j, channel i): no second copy
+    if (RES == 1) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[p][i][j] = RES == 1 ? acc[p][j][i] + resv[p][i][j] : acc[p][j][i];
-    if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block, one 8-channel source at a time
+          for (int j = 0; j < 4; ++j) acc[p][j][i] += resv[p][i][j];
+    }
+    if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
       auto nin_src = [&](int s, auto F) {
         constexpr bool F32 = decltype(F)::value;
-#pragma unroll 4
+#pragma unroll 8
         for (int c8 = 0; c8 < 8; ++c8) {
           const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + (8 * s + c8) * 8 + 4 * ch);
           const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(HC_NT, RES == 2 ? 3 : 4) void conv8b_kernel(const C
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) out[p][i][j] = fmaf(wv[i], r[j], out[p][i][j]);
+              for (int j = 0; j < 4; ++j) acc[p][j][i] = fmaf(wv[i], r[j], acc[p][j][i]);
           }
         }
       };
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(HC_NT, RES == 2 ? 3 : 4) void conv8b_kernel(const C
       for (int i = 0; i < 4; ++i) {
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = a.dst_f32 ? out[p][i][j] : round_bf16(out[p][i][j]);  // statistics of what is stored
+        for (int j = 0; j < 4; ++j) v[j] = a.dst_f32 ? acc[p][j][i] : round_bf16(acc[p][j][i]);  // statistics of what is stored
         st4(a.dst, a.dst_f32, ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx, v[0], v[1], v[2], v[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { part[i] += v[j]; part[4 + i] = fmaf(v[j], v[j], part[4 + i]); }

@@ -131,6 +131,135 @@ inline int warp_attfuse_enqueue(const float* x, const double* theta, const int* 
 
 
 // ---------------------------------------------------------------------------------------------
+// Backward of warp + ego-row attention (training: the detection loss back-propagates through AttFusion into the Enhancer
+// and GenComm).  One lane per OUTPUT pixel, same taps as the forward:
+//   w = softmax(s), s_j = <x_0, x_j> / sqrt(C), out = sum_j w_j x_j
+//   d w_j = <g, x_j>,  d s_j = w_j (d w_j - sum_k w_k d w_k) / sqrt(C)
+//   d x_j = w_j g + d s_j x_0  (j != 0),   d x_0 = w_0 g + sum_j d s_j x_j + d s_0 x_0
+// and the bilinear gather's adjoint: every tap of d x_j is added (float atomics) to the source pixel it was read from.
+// grad_x must be zero on entry.
+// ---------------------------------------------------------------------------------------------
+struct FuseBwdArgs {
+  const float* x;        // [n][C][H][W] forward input
+  const double* theta;   // [n][2][3]
+  const int* scene_off;  // [B+1]
+  const float* gout;     // [B][C][H][W]
+  float* gx;             // [n][C][H][W], zeroed by the caller
+  int C, H, W;
+};
+
+template <int N>
+__device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int off, int pix) {
+  const int H = a.H, W = a.W, HW = H * W;
+  const int h = pix / W, w = pix - h * W;
+  const double xb = (2.0 * w + 1.0) / (double)W - 1.0;
+  const double yb = (2.0 * h + 1.0) / (double)H - 1.0;
+  int idx[N][4];
+  float wt[N][4];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {  // identical to fuse_body's tap computation
+    const double* __restrict__ th = a.theta + (size_t)(off + j) * 6;
+    const float gx = (float)(th[0] * xb + th[1] * yb + th[2]);
+    const float gy = (float)(th[3] * xb + th[4] * yb + th[5]);
+    const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    const float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f);
+    const int y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+    const float tx = ix - fx, ty = iy - fy;
+    const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
+    const bool far = fx != (float)x0 || fy != (float)y0;
+    idx[j][0] = (xl && yt && !far) ? y0 * W + x0 : -1;
+    idx[j][1] = (xr && yt && !far) ? y0 * W + x0 + 1 : -1;
+    idx[j][2] = (xl && yb_ && !far) ? (y0 + 1) * W + x0 : -1;
+    idx[j][3] = (xr && yb_ && !far) ? (y0 + 1) * W + x0 + 1 : -1;
+    wt[j][0] = (1.f - tx) * (1.f - ty); wt[j][1] = tx * (1.f - ty); wt[j][2] = (1.f - tx) * ty; wt[j][3] = tx * ty;
+  }
+  auto sample = [&](int j, const float* __restrict__ plane) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v = fmaf(idx[j][k] >= 0 ? plane[idx[j][k]] : 0.f, wt[j][k], v);
+    return v;
+  };
+  const float* __restrict__ xs = a.x + (size_t)off * a.C * HW;
+  const float* __restrict__ gp = a.gout + (size_t)b * a.C * HW + pix;
+  float score[N], dw[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { score[j] = 0.f; dw[j] = 0.f; }
+  for (int c = 0; c < a.C; ++c) {
+    const float g = gp[(size_t)c * HW];
+    const float v0 = sample(0, xs + (size_t)c * HW);
+    score[0] = fmaf(v0, v0, score[0]);
+    dw[0] = fmaf(g, v0, dw[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) {
+      const float vj = sample(j, xs + ((size_t)j * a.C + c) * HW);
+      score[j] = fmaf(v0, vj, score[j]);
+      dw[j] = fmaf(g, vj, dw[j]);
+    }
+  }
+  const float inv = 1.0f / sqrtf((float)a.C);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { score[j] *= inv; mx = fmaxf(mx, score[j]); }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { score[j] = expf(score[j] - mx); den += score[j]; }
+  float sdot = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { score[j] /= den; sdot = fmaf(score[j], dw[j], sdot); }
+  float ds[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) ds[j] = score[j] * (dw[j] - sdot) * inv;
+  float* __restrict__ gxs = a.gx + (size_t)off * a.C * HW;
+  for (int c = 0; c < a.C; ++c) {
+    const float g = gp[(size_t)c * HW];
+    float v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = sample(j, xs + ((size_t)j * a.C + c) * HW);
+    float d0 = fmaf(score[0], g, ds[0] * v[0]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) d0 = fmaf(ds[j], v[j], d0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float dj = j == 0 ? d0 : fmaf(score[j], g, ds[j] * v[0]);
+      float* __restrict__ plane = gxs + ((size_t)j * a.C + c) * HW;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (idx[j][k] >= 0) atomicAdd(plane + idx[j][k], wt[j][k] * dj);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void warp_attfuse_bwd_kernel(const FuseBwdArgs a) {
+  const int b = blockIdx.y;
+  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= a.H * a.W) return;
+  switch (N) {
+    case 1: fuse_bwd_body<1>(a, b, off, pix); break;
+    case 2: fuse_bwd_body<2>(a, b, off, pix); break;
+    case 3: fuse_bwd_body<3>(a, b, off, pix); break;
+    case 4: fuse_bwd_body<4>(a, b, off, pix); break;
+    case 5: fuse_bwd_body<5>(a, b, off, pix); break;
+    case 6: fuse_bwd_body<6>(a, b, off, pix); break;
+    case 7: fuse_bwd_body<7>(a, b, off, pix); break;
+    case 8: fuse_bwd_body<8>(a, b, off, pix); break;
+    default: break;
+  }
+}
+
+inline int warp_attfuse_bwd_enqueue(const float* x, const double* theta, const int* scene_off, const float* gout, float* gx,
+                                    int B, int n, int C, int H, int W, hipStream_t st) {
+  GC_HIP(hipMemsetAsync(gx, 0, (size_t)n * C * H * W * sizeof(float), st));
+  FuseBwdArgs a{x, theta, scene_off, gout, gx, C, H, W};
+  warp_attfuse_bwd_kernel<<<dim3((H * W + 255) / 256, B), 256, 0, st>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Token-major fast path (ScenePipeline): reads the Enhancer's token-major result O [n][HW][C] and
 // its channel gate [n][C] straight from the Enhancer workspace (the NHWC->NCHW transpose launch is
 // skipped and the gate multiply happens here). QL lanes share one output pixel, each owning C/QL

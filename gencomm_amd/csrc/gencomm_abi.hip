@@ -8,6 +8,7 @@
 #include "fusion_kernels.h"
 #include "msgext_host.h"
 #include "pillar_kernels.h"
+#include "train_kernels.h"
 #include "unet_bwd_host.h"
 #include "unet_host.h"
 
@@ -496,6 +497,57 @@ int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale
   return conv2d_enqueue(a, N, KH, KW, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------------------------ training building blocks (NCHW fp32)
+int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
+                         int K, int stride, int pad, void* stream) {
+  GC_CHECK_ARG(dy && x && dw, "null pointer");
+  GC_CHECK_ARG(N >= 1 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && (K == 1 || K == 3) && (stride == 1 || stride == 2) && pad >= 0, "bad dims");
+  const int Ho = (Hi + 2 * pad - K) / stride + 1, Wo = (Wi + 2 * pad - K) / stride + 1;
+  GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
+  WgradArgs a{dy, x, nullptr, dw, db, Cout, Cin, 0, Ho, Wo, Hi, Wi, K, stride, pad, 0};
+  return conv_wgrad_enqueue(a, N, (hipStream_t)stream);
+}
+
+int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream) {
+  GC_CHECK_ARG(x && gamma && beta && out && n >= 1 && n <= 65535 && C >= 1 && HW >= 1, "bad arguments");
+  LnArgs a{x, gamma, beta, nullptr, out, nullptr, eps, C, HW, residual, 0};
+  ln_nchw_fwd_kernel<<<dim3((HW + 255) / 256, n), 256, 0, (hipStream_t)stream>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* scratch,
+                        float eps, int accumulate, int n, int C, int HW, void* stream) {
+  GC_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && scratch && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  LnArgs a{x, gamma, nullptr, dy, dx, scratch, eps, C, HW, 0, accumulate};
+  ln_nchw_bwd_kernel<<<dim3((HW + 255) / 256, n), 256, 0, st>>>(a);
+  ln_nchw_param_grad_kernel<<<C, 256, 0, st>>>(x, dy, scratch, dgamma, dbeta, n, C, HW);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream) {
+  GC_CHECK_ARG(x && w && y && n >= 1 && C >= 1 && (long long)n * C <= 65535 && H >= 1 && W >= 1, "bad arguments");
+  dwconv3x3_kernel<<<dim3((H * W + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(x && dy && dw && n >= 1 && C >= 1 && C <= 65535 && H >= 1 && W >= 1, "bad arguments");
+  dwconv3x3_wgrad_kernel<<<C, 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream) {
+  GC_CHECK_ARG(v && g && out && count >= 0 && (count + 255) / 256 < (1LL << 31), "bad arguments");
+  if (count > 0) gelu_bwd_kernel<<<(unsigned)((count + 255) / 256), 256, 0, (hipStream_t)stream>>>(v, g, out, count);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 // ------------------------------------------------------------------------------------ detection tail
 long long gencomm_det_workspace_bytes(int H, int W, int A) {
   if (H < 1 || W < 1 || A < 1) { fail(GC_ERR_ARG, "bad H/W/A"); return -1; }
@@ -548,6 +600,13 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
   GC_CHECK_ARG(x && theta && scene_off && out, "null pointer");
   GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && C >= 1 && H >= 1 && W >= 1, "bad B/n/C/H/W");
   return warp_attfuse_enqueue(x, theta, scene_off, out, B, n, C, H, W, (hipStream_t)stream);
+}
+
+int gencomm_warp_attfuse_bwd(const float* x, const double* theta, const int* scene_off, const float* grad_out, float* grad_x,
+                             int B, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(x && theta && scene_off && grad_out && grad_x, "null pointer");
+  GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && C >= 1 && H >= 1 && W >= 1, "bad B/n/C/H/W");
+  return warp_attfuse_bwd_enqueue(x, theta, scene_off, grad_out, grad_x, B, n, C, H, W, (hipStream_t)stream);
 }
 
 int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,

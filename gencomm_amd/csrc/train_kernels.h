@@ -1,0 +1,155 @@
+// Elementary backward (and the matching exact-fp32 forward-recompute) kernels of the Enhancer's training path, NCHW fp32:
+// LayerNorm over channels, depthwise 3x3 convolution, erf-GELU backward.  Together with the general convolution
+// (conv_kernels.h: 1x1 = Linear, 3x3 partial conv; transposed weights give the input gradients) and conv_wgrad_kernel
+// (unet_bwd_kernels.h: weight gradients) they let gencomm_amd/autograd.py run the backward of
+// Enhancer_block / FRFN (opencood/models/gencomm_modules/enhancer.py:346-357, :222-250) without a torch conv / norm call.
+// These are training-only, correctness-first kernels (one thread per pixel or element); the inference path never uses them.
+#pragma once
+#include "common.h"
+
+namespace gc {
+
+struct LnArgs {
+  const float* x;      // [n][C][HW]
+  const float* gamma;  // [C]
+  const float* beta;   // [C]
+  const float* dy;     // [n][C][HW] (backward)
+  float* out;          // fwd: y (= LN(x), or x + LN(x) when residual);  bwd: dx (+= when accumulate)
+  float* mean_rstd;    // [n][HW][2] written by both passes
+  float eps;
+  int C, HW, residual, accumulate;
+};
+
+// one thread per pixel; channel-strided accesses are coalesced across the threads of a wave
+__global__ __launch_bounds__(256) void ln_nchw_fwd_kernel(const LnArgs a) {
+  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.HW) return;
+  const float* __restrict__ xp = a.x + (size_t)n * a.C * a.HW + p;
+  float s = 0.f;
+  for (int c = 0; c < a.C; ++c) s += xp[(size_t)c * a.HW];
+  const float mean = s / (float)a.C;
+  float q = 0.f;
+  for (int c = 0; c < a.C; ++c) { const float d = xp[(size_t)c * a.HW] - mean; q = fmaf(d, d, q); }
+  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+  if (a.mean_rstd) { a.mean_rstd[((size_t)n * a.HW + p) * 2] = mean; a.mean_rstd[((size_t)n * a.HW + p) * 2 + 1] = rstd; }
+  float* __restrict__ op = a.out + (size_t)n * a.C * a.HW + p;
+  for (int c = 0; c < a.C; ++c) {
+    const float xv = xp[(size_t)c * a.HW];
+    const float y = fmaf((xv - mean) * rstd, a.gamma[c], a.beta[c]);
+    op[(size_t)c * a.HW] = a.residual ? xv + y : y;
+  }
+}
+
+// dx = rstd (gamma dy - mean_c(gamma dy) - xhat mean_c(gamma dy xhat))
+__global__ __launch_bounds__(256) void ln_nchw_bwd_kernel(const LnArgs a) {
+  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.HW) return;
+  const float* __restrict__ xp = a.x + (size_t)n * a.C * a.HW + p;
+  const float* __restrict__ gp = a.dy + (size_t)n * a.C * a.HW + p;
+  float s = 0.f;
+  for (int c = 0; c < a.C; ++c) s += xp[(size_t)c * a.HW];
+  const float mean = s / (float)a.C;
+  float q = 0.f;
+  for (int c = 0; c < a.C; ++c) { const float d = xp[(size_t)c * a.HW] - mean; q = fmaf(d, d, q); }
+  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+  a.mean_rstd[((size_t)n * a.HW + p) * 2] = mean;
+  a.mean_rstd[((size_t)n * a.HW + p) * 2 + 1] = rstd;
+  float m1 = 0.f, m2 = 0.f;
+  for (int c = 0; c < a.C; ++c) {
+    const float gd = a.gamma[c] * gp[(size_t)c * a.HW];
+    m1 += gd;
+    m2 = fmaf(gd, (xp[(size_t)c * a.HW] - mean) * rstd, m2);
+  }
+  m1 /= (float)a.C; m2 /= (float)a.C;
+  float* __restrict__ op = a.out + (size_t)n * a.C * a.HW + p;
+  for (int c = 0; c < a.C; ++c) {
+    const float xh = (xp[(size_t)c * a.HW] - mean) * rstd;
+    const float v = rstd * (a.gamma[c] * gp[(size_t)c * a.HW] - m1 - xh * m2);
+    op[(size_t)c * a.HW] = a.accumulate ? op[(size_t)c * a.HW] + v : v;
+  }
+}
+
+// d gamma[c] += sum dy xhat, d beta[c] += sum dy : one workgroup per channel
+__global__ __launch_bounds__(256) void ln_nchw_param_grad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean_rstd,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int C, int HW) {
+  __shared__ double s_red[4][2];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double sg = 0.0, sb = 0.0;
+  for (long long i = tid; i < (long long)n * HW; i += 256) {
+    const int s = (int)(i / HW), p = (int)(i - (long long)s * HW);
+    const size_t e = ((size_t)s * C + c) * HW + p;
+    const float d = dy[e];
+    sg += (double)d * ((x[e] - mean_rstd[i * 2]) * mean_rstd[i * 2 + 1]);
+    sb += d;
+  }
+  for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
+  if ((tid & 63) == 0) { s_red[tid >> 6][0] = sg; s_red[tid >> 6][1] = sb; }
+  __syncthreads();
+  if (tid == 0) {
+    dgamma[c] += (float)(s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0]);
+    dbeta[c] += (float)(s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1]);
+  }
+}
+
+// depthwise 3x3, padding 1: y[n][c] = conv(x[n][c], w[c][3][3]) + b[c].  flip = 1 computes the input gradient
+// (correlation with the flipped taps, no bias).
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* __restrict__ y, int C, int H, int W, int flip) {
+  const int nc = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int c = nc % C, h = p / W, x0 = p - h * W;
+  const float* __restrict__ xp = x + (size_t)nc * H * W;
+  float acc = (b != nullptr && !flip) ? b[c] : 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = h + ky - 1, xx = x0 + kx - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc = fmaf(w[c * 9 + (flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx)], xp[(size_t)yy * W + xx], acc);
+    }
+  y[(size_t)nc * H * W + p] = acc;
+}
+// dw[c][tap] += sum_{n,p} dy[n][c](p) x[n][c](p + tap), db[c] += sum dy: one workgroup per channel
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                              float* __restrict__ db, int n, int C, int H, int W) {
+  __shared__ float s_red[4][10];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  float acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+  for (long long i = tid; i < (long long)n * H * W; i += 256) {
+    const int s = (int)(i / (H * W)), p = (int)(i - (long long)s * H * W), h = p / W, x0 = p - h * W;
+    const size_t base = ((size_t)s * C + c) * H * W;
+    const float d = dy[base + p];
+    acc[9] += d;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = h + ky - 1, xx = x0 + kx - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[ky * 3 + kx] = fmaf(d, x[base + (size_t)yy * W + xx], acc[ky * 3 + kx]);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    float v = acc[t];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6][t] = v;
+  }
+  __syncthreads();
+  if (tid < 10) {
+    const float v = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    if (tid < 9) dw[c * 9 + tid] += v;
+    else if (db != nullptr) db[c] += v;
+  }
+}
+
+// out = g * d/dv GELU(v)   (erf form, nn.GELU default):  0.5 (1 + erf(v / sqrt 2)) + v exp(-v^2 / 2) / sqrt(2 pi)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ out, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float x = v[i];
+  out[i] = g[i] * (0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x));
+}
+
+}  // namespace gc

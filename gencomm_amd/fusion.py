@@ -63,7 +63,7 @@ class AttFusion(nn.Module):
             raise ValueError(f"each scene needs 1..{MAX_AGENTS_PER_SCENE} agents, got {lens}")
         xx = f32c(xx)
         if torch.is_grad_enabled() and xx.requires_grad:
-            from .autograd import AttFusionFunction  # HIP forward, recompute-based backward
+            from .autograd import AttFusionFunction  # HIP forward and HIP backward
             return AttFusionFunction.apply(self, lens, affine_matrix, xx)
         return self._forward_hip(xx, lens, affine_matrix)
 
@@ -81,6 +81,20 @@ class AttFusion(nn.Module):
         _lib.check(getattr(_lib.lib(), self._entry)(ptr(xx), ptr(theta), ptr(scene_off), ptr(out), B, n, C, H, W,
                                                     stream_ptr(xx.device)), self._entry)
         return out
+
+
+    def _backward_hip(self, xx, lens, affine_matrix, grad_out):
+        n, C, H, W = xx.shape
+        B = affine_matrix.shape[0]
+        theta = gather_ego_thetas(affine_matrix, lens).to(xx.device)
+        off = [0]
+        for k in lens:
+            off.append(off[-1] + k)
+        scene_off = torch.tensor(off, dtype=torch.int32, device=xx.device)
+        gx = torch.empty_like(xx)
+        _lib.check(_lib.lib().gencomm_warp_attfuse_bwd(ptr(xx), ptr(theta), ptr(scene_off), ptr(grad_out), ptr(gx), B, n, C, H, W,
+                                                       stream_ptr(xx.device)), "gencomm_warp_attfuse_bwd")
+        return gx
 
 
 class MaxFusion(AttFusion):

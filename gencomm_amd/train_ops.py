@@ -1,0 +1,98 @@
+"""Training building blocks on the HIP kernels (NCHW fp32): the forward-recompute and backward primitives the Enhancer's
+backward is composed of in ``autograd.py`` -- general convolution (3x3 / 1x1 = Linear) with its input and weight gradients,
+LayerNorm over channels, depthwise 3x3 convolution, erf-GELU backward. Thin wrappers over the C ABI
+(``gencomm_conv2d_{prepare,fold,fwd,wgrad}``, ``gencomm_ln_nchw_{fwd,bwd}``, ``gencomm_dwconv3x3_{fwd,wgrad}``,
+``gencomm_gelu_bwd``); no torch convolution / normalisation call anywhere."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .runtime import ptr, stream_ptr
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float().contiguous()
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad: int, stride: int = 1) -> torch.Tensor:
+    """y = conv(x, w [Cout, Cin, K, K]) + b, K in {1, 3} (exact-fp32 implicit GEMM, csrc/conv_kernels.h)."""
+    x, w = _c(x), _c(w)
+    n, cin, H, W = x.shape
+    cout, _, kh, kw = w.shape
+    l, st, dev = _lib.lib(), stream_ptr(x.device), x.device
+    prepared = torch.empty(w.numel(), dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cin, cout, kh, kw, 0, st), "gencomm_conv2d_prepare")
+    ss = torch.empty(2, cout, dtype=torch.float32, device=dev)
+    bb = _c(b) if b is not None else None
+    _lib.check(l.gencomm_conv2d_fold(None, None, None, None, ptr(bb), 0.0, cout, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = torch.empty(n, cout, Ho, Wo, dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_conv2d_fwd(ptr(x), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(y), n, cin, H, W, cout, kh, kw, stride, pad, 0, 1,
+                                    cout, 0, st), "gencomm_conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(dy: torch.Tensor, w: torch.Tensor, pad: int) -> torch.Tensor:
+    """Input gradient of a stride-1 convolution: the same kernel with the transposed, tap-flipped weight."""
+    k = w.shape[2]
+    return conv2d(dy, w.detach().flip(2, 3).transpose(0, 1).contiguous(), None, k - 1 - pad)
+
+
+def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, k: int, pad: int, bias: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    dy, x = _c(dy), _c(x)
+    n, cout = dy.shape[:2]
+    cin, H, W = x.shape[1:]
+    dw = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=x.device)
+    db = torch.zeros(cout, dtype=torch.float32, device=x.device) if bias else None
+    _lib.check(_lib.lib().gencomm_conv2d_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), n, cin, H, W, cout, k, 1, pad, stream_ptr(x.device)),
+               "gencomm_conv2d_wgrad")
+    return dw, db
+
+
+def ln_fwd(x: torch.Tensor, gamma, beta, eps: float, residual: bool) -> torch.Tensor:
+    x = _c(x)
+    n, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().gencomm_ln_nchw_fwd(ptr(x), ptr(_c(gamma)), ptr(_c(beta)), ptr(out), float(eps), int(residual), n, C, H * W,
+                                              stream_ptr(x.device)), "gencomm_ln_nchw_fwd")
+    return out
+
+
+def ln_bwd(x: torch.Tensor, gamma, dy: torch.Tensor, eps: float):
+    x, dy = _c(x), _c(dy)
+    n, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.zeros(C, dtype=torch.float32, device=x.device)
+    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(n * H * W * 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gencomm_ln_nchw_bwd(ptr(x), ptr(_c(gamma)), ptr(dy), ptr(dx), ptr(dg), ptr(db), ptr(scratch), float(eps), 0,
+                                              n, C, H * W, stream_ptr(x.device)), "gencomm_ln_nchw_bwd")
+    return dx, dg, db
+
+
+def dwconv3x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], flip: bool = False) -> torch.Tensor:
+    x = _c(x)
+    n, C, H, W = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().gencomm_dwconv3x3_fwd(ptr(x), ptr(_c(w)), ptr(_c(b)) if b is not None else None, ptr(y), n, C, H, W, int(flip),
+                                                stream_ptr(x.device)), "gencomm_dwconv3x3_fwd")
+    return y
+
+
+def dwconv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor):
+    x, dy = _c(x), _c(dy)
+    n, C, H, W = x.shape
+    dw = torch.zeros(C, 1, 3, 3, dtype=torch.float32, device=x.device)
+    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gencomm_dwconv3x3_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(db), n, C, H, W, stream_ptr(x.device)), "gencomm_dwconv3x3_wgrad")
+    return dw, db
+
+
+def gelu_bwd(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    v, g = _c(v), _c(g)
+    out = torch.empty_like(v)
+    _lib.check(_lib.lib().gencomm_gelu_bwd(ptr(v), ptr(g), ptr(out), v.numel(), stream_ptr(v.device)), "gencomm_gelu_bwd")
+    return out

@@ -263,6 +263,11 @@ int gencomm_bbox_overlaps_fwd(const float* boxes, const float* query_boxes, floa
 
 /* MaxFusion.forward (opencood/models/fuse_modules/fusion_in_one.py:87-124): same warp, element-wise max over the
  * agents of a scene instead of the attention; arguments as gencomm_warp_attfuse_fwd. */
+/* Backward of gencomm_warp_attfuse_fwd (what autograd does for fusion_in_one.py:131-151 + F.grid_sample in the reference's
+ * training runs): grad_x [n][C][H][W] is OVERWRITTEN with the gradient w.r.t. x given grad_out [B][C][H][W]; the bilinear
+ * gather's adjoint uses float atomics (summation order varies in the last bits). */
+int gencomm_warp_attfuse_bwd(const float* x, const double* theta, const int* scene_off, const float* grad_out, float* grad_x,
+                             int B, int n, int C, int H, int W, void* stream);
 int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
                              int B, int n, int C, int H, int W, void* stream);
 
@@ -272,6 +277,27 @@ int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* sce
  * workspace pointer and (n, C, H, W). Same maths as gencomm_warp_attfuse_fwd(enhancer output). C in {64,128,256}. */
 int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* theta, const int* scene_off, float* out,
                                  int B, int n, int C, int H, int W, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Training building blocks (NCHW fp32, correctness-first; the inference path never calls them): what torch autograd's
+ * conv / layer_norm / gelu backward functions do in the reference's training runs for the Enhancer
+ * (opencood/models/gencomm_modules/enhancer.py:346-357, :222-250) and the dense conv stacks.
+ *   gencomm_conv2d_wgrad     dw[Cout][Cin][K][K] += sum dy (x) x, db[Cout] += sum dy (db may be NULL); K = 1 or 3, stride 1 or 2
+ *                            (input gradients: gencomm_conv2d_fwd with the transposed, tap-flipped weight)
+ *   gencomm_ln_nchw_fwd      LayerNorm over the channel axis of every pixel; residual != 0: out = x + LN(x)
+ *   gencomm_ln_nchw_bwd      dx (= or +=), dgamma +=, dbeta +=; scratch: n * HW * 2 floats
+ *   gencomm_dwconv3x3_fwd    depthwise 3x3 pad 1 (+ bias); flip != 0: correlation with the flipped taps = input gradient
+ *   gencomm_dwconv3x3_wgrad  dw[C][3][3] +=, db[C] += (db may be NULL)
+ *   gencomm_gelu_bwd         out = g * GELU'(v), erf form
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
+                         int K, int stride, int pad, void* stream);
+int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream);
+int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* scratch,
+                        float eps, int accumulate, int n, int C, int HW, void* stream);
+int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream);
+int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream);
+int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * iou3d_nms with the reference extension's own semantics (opencood/pcdet_utils/iou3d_nms: src/iou3d_nms_kernel.cu:104-372,

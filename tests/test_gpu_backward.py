@@ -141,3 +141,51 @@ def test_two_rank_ddp_gradient_sync_matches_single_process(tmp_path):
     for k, p in gen.named_parameters():
         worst = max(worst, _close("ddp grad " + k, ddp_grads[k], p.grad, 1e-4))
     print(f"2-rank DDP (gloo) averaged gradients vs single process: worst relative difference {worst:.2e}")
+
+
+@pytest.mark.parametrize("C,H,W,rl", [(16, 12, 20, [2, 1]), (64, 24, 40, [3]), (128, 16, 16, [1, 2])])
+def test_enhancer_backward_hip_vs_torch_autograd(C, H, W, rl):
+    """EnhancerFunction.backward (LayerNorm / conv / depthwise / GELU gradient kernels, gencomm_amd/train_ops.py) against
+    torch autograd through the differentiable restatement of the stage: input gradient and every live parameter gradient."""
+    from gencomm_amd import Enhancer, normalize_pairwise_tfm, synth
+    from gencomm_amd.autograd import enhancer_forward
+    enh = Enhancer(C, [8, 8], 4).to(DEV)
+    synth.fill_params_(enh, 3 + C)
+    inp = synth.make_inputs(rl, C, H, W, 4)
+    x = torch.from_numpy(inp["feat"]).to(DEV).requires_grad_(True)
+    g = torch.Generator(device=DEV).manual_seed(C)
+    wgt = torch.randn(sum(rl), C, H, W, generator=g, device=DEV)
+    y = enh(x, None, rl)
+    (y * wgt).sum().backward()
+    got = {"x": x.grad.clone(), **{k: p.grad.clone() for k, p in enh.named_parameters() if p.grad is not None}}
+    for p in enh.parameters():
+        p.grad = None
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = enhancer_forward(enh, x2)
+    _close("enhancer forward", y, y2, 1e-4)
+    (y2 * wgt).sum().backward()
+    want = {"x": x2.grad, **{k: p.grad for k, p in enh.named_parameters() if p.grad is not None}}
+    assert set(got) == set(want) and len(got) >= 16, (sorted(got), sorted(want))
+    worst = max(_close("enhancer grad " + k, got[k], want[k]) for k in want)
+    print(f"Enhancer backward C={C} {H}x{W}: {len(want) - 1} parameter gradients + input, worst relative error {worst:.2e}")
+
+
+@pytest.mark.parametrize("C,H,W,rl,shift", [(16, 12, 20, [2, 1], 3.0), (64, 40, 72, [5], 30.0), (32, 30, 50, [1, 4, 2], 12.0)])
+def test_fusion_backward_hip_vs_torch_autograd(C, H, W, rl, shift):
+    """gencomm_warp_attfuse_bwd (softmax / dot-product backward + the bilinear gather's adjoint) against torch autograd through
+    affine_grid + grid_sample + softmax attention, with agents partly and wholly out of range."""
+    from gencomm_amd import AttFusion, normalize_pairwise_tfm, synth
+    from gencomm_amd.autograd import att_fusion_forward
+    inp = synth.make_inputs(rl, C, H, W, 9, max_shift=shift)
+    affine = normalize_pairwise_tfm(torch.from_numpy(inp["pairwise_t_matrix"]), H * 0.8, W * 0.8, 1)
+    x = torch.from_numpy(inp["feat"]).to(DEV).requires_grad_(True)
+    g = torch.Generator(device=DEV).manual_seed(C + 1)
+    wgt = torch.randn(len(rl), C, H, W, generator=g, device=DEV)
+    y = AttFusion(C)(x, rl, affine)
+    (y * wgt).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = att_fusion_forward(x2, rl, affine)
+    _close("fusion forward", y, y2, 1e-4)
+    (y2 * wgt).sum().backward()
+    worst = _close("fusion grad x", x.grad, x2.grad)
+    print(f"fusion backward C={C} {H}x{W} scenes {rl}: worst relative error {worst:.2e}")

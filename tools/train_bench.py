@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Training-step timing of the hot path (HIP forward + HIP backward): GenComm (training branch) -> Enhancer -> AttFusion,
+loss = mean(fused^2), at the shipped shape (2 agents, C=128, 64x128, T=3) and at the metric geometry's per-scene size with
+T=3. Prints scenes/s for forward+backward."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, synth
+
+DEV = "cuda:0"
+for name, (N, C, H, W, T) in {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128, 64, 128, 3),
+                               "4 agents, C=64, 200x704, T=3": (4, 64, 200, 704, 3)}.items():
+    gen, enh, fus = GenComm(synth.default_gencomm_cfg(C, T)).train().to(DEV), Enhancer(C, [8, 8], 4).train().to(DEV), AttFusion(C)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    feat = torch.randn(N, C, H, W, generator=g, device=DEV).clamp_(min=0)
+    cond = torch.randn(N, 2, H, W, generator=g, device=DEV).requires_grad_(True)
+    ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N], 5, 7, 10.0))
+    affine = normalize_pairwise_tfm(ptm, H * 0.4, W * 0.4, 1)
+    def step():
+        for p in list(gen.parameters()) + list(enh.parameters()):
+            p.grad = None
+        pred = gen(feat, cond, [N], seed=3)["pred_feature"]
+        if pred.dim() == 3:
+            pred = pred.unsqueeze(0)
+        out = fus(enh(pred, affine, [N]), [N], affine)
+        out.square().mean().backward()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 5
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    print(f"train step [{name}]: {1e3 * dt:.1f} ms per scene (forward + backward) = {1.0 / dt:.2f} scenes/s", flush=True)
