@@ -78,6 +78,9 @@ _SIGNATURES = {
     "gencomm_det_decode_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, _p, _p, _i, _p, C.c_longlong, _p]),
     "gencomm_nms_rotated_fwd": (_i, [_p, _p, _p, C.c_float, _i, _p, _p, _p, _p, _p, _p, C.c_longlong, _p]),
     "gencomm_bbox_overlaps_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
+    "gencomm_warp_affine_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_hgt_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_win_attn_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "gencomm_iou3d_pairwise_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p]),
     "gencomm_iou3d_max_boxes": (_i, []),
     "gencomm_iou3d_nms_workspace_bytes": (_ll, [_i]),

@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "iou3d_kernels.h"
+#include "v2xvit_kernels.h"
 #include "voxel_kernels.h"
 
 using namespace gc;
@@ -76,6 +77,43 @@ int gencomm_voxelize_fwd(const float* points, int n, int nfeat, const float* vox
   GC_CHECK_ARG(voxels && coords_zyx && num_points && count && workspace && (n == 0 || points), "null pointer");
   if ((long long)voxel_ws(n).total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (gencomm_voxelize_workspace_bytes)");
   return voxelize_enqueue(a, voxels, coords_zyx, num_points, count, (char*)workspace, (hipStream_t)stream);
+}
+
+int gencomm_warp_affine_fwd(const float* x, const double* theta, float* out, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(x && theta && out && n >= 1 && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad arguments");
+  WarpArgs a{x, theta, out, C, H, W};
+  warp_affine_kernel<<<dim3((H * W + 255) / 256, n), 256, 0, (hipStream_t)stream>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int B, int heads, int dim_head, int HW, void* stream) {
+  GC_CHECK_ARG(qkv && scene_off && out && B >= 1 && B <= 65535 && heads >= 1 && heads <= 65535 && HW >= 1, "bad arguments");
+  HgtArgs a{qkv, scene_off, out, heads, HW, 1.0f / sqrtf((float)dim_head)};
+  const dim3 grid((HW + 255) / 256, heads, B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dim_head == 32) hgt_attn_kernel<32><<<grid, 256, 0, st>>>(a);
+  else if (dim_head == 64) hgt_attn_kernel<64><<<grid, 256, 0, st>>>(a);
+  else if (dim_head == 16) hgt_attn_kernel<16><<<grid, 256, 0, st>>>(a);
+  else return fail(GC_ERR_ARG, "hgt attention: dim_head must be 16, 32 or 64");
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* out, int n, int heads, int dim_head, int window, int H, int W,
+                         void* stream) {
+  GC_CHECK_ARG(qkv && pos_embedding && out && n >= 1 && n <= 65535 && heads >= 1 && heads <= 65535, "bad arguments");
+  GC_CHECK_ARG(H >= window && W >= window && H % window == 0 && W % window == 0, "H and W must be multiples of the window size");
+  WinArgs a{qkv, pos_embedding, out, heads, H, W, 1.0f / sqrtf((float)dim_head)};
+  hipStream_t st = (hipStream_t)stream;
+  if (window == 4 && dim_head == 16) return win_attn_launch<16, 4>(a, n, st);
+  if (window == 8 && dim_head == 32) return win_attn_launch<32, 8>(a, n, st);
+  if (window == 16 && dim_head == 64) return win_attn_launch<64, 16>(a, n, st);
+  if (window == 4 && dim_head == 32) return win_attn_launch<32, 4>(a, n, st);
+  if (window == 8 && dim_head == 16) return win_attn_launch<16, 8>(a, n, st);
+  if (window == 8 && dim_head == 64) return win_attn_launch<64, 8>(a, n, st);
+  if (window == 16 && dim_head == 32) return win_attn_launch<32, 16>(a, n, st);
+  return fail(GC_ERR_ARG, "window attention: supported (window, dim_head) pairs are (4,16) (4,32) (8,16) (8,32) (8,64) (16,32) (16,64)");
 }
 
 }  // extern "C"

@@ -1,0 +1,176 @@
+// V2X-ViT fusion (reference: opencood/models/fuse_modules/fusion_in_one.py:355-407 +
+// sub_modules/{v2xvit_basic, hmsa, mswin, split_attn, base_transformer}.py) -- the kernels that have no counterpart elsewhere
+// in the library.  Activations are NCHW fp32 per agent, [sumN][C][H][W]; the Linear layers run as 1x1 convolutions on the
+// general implicit-GEMM kernel (conv_kernels.h), LayerNorm on ln_nchw_fwd_kernel (train_kernels.h).
+//   warp_affine_kernel   warp_affine_simple (torch_transformation_utils.py:323-332): every agent into the ego frame
+//   hgt_attn_kernel      HGTCavAttention's core (hmsa.py:117-150): per pixel and head, attention ACROSS the agents of a scene.
+//                        GenComm passes an all-zero prior encoding, so every agent has type 0 and a single relation: the host
+//                        folds relation_att into the key projection and relation_msg into the value projection, which leaves a
+//                        plain masked softmax attention over at most 8 agents here.
+//   win_attn_kernel      BaseWindowAttention's core (mswin.py:47-83): per agent, head and window, softmax(q k^T scale +
+//                        relative position bias) v with the keys / values of the window staged in LDS.
+// fp32 throughout; softmax with the running maximum; one lane per query.
+#pragma once
+#include "common.h"
+
+namespace gc {
+
+struct WarpArgs {
+  const float* x;        // [n][C][H][W]
+  const double* theta;   // [n][2][3] (ego <- agent, normalised: output of normalize_pairwise_tfm)
+  float* out;            // [n][C][H][W]
+  int C, H, W;
+};
+__global__ __launch_bounds__(256) void warp_affine_kernel(const WarpArgs a) {
+  const int n = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+  const int H = a.H, W = a.W, HW = H * W;
+  if (pix >= HW) return;
+  const int h = pix / W, w = pix - h * W;
+  const double xb = (2.0 * w + 1.0) / (double)W - 1.0, yb = (2.0 * h + 1.0) / (double)H - 1.0;  // affine_grid, align_corners=False, float64
+  const double* __restrict__ th = a.theta + (size_t)n * 6;
+  const float gx = (float)(th[0] * xb + th[1] * yb + th[2]);
+  const float gy = (float)(th[3] * xb + th[4] * yb + th[5]);
+  const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+  const float tx = ix - fx, ty = iy - fy;
+  const bool far = fx != (float)x0 || fy != (float)y0;
+  const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W, yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
+  const int i0 = (xl && yt && !far) ? y0 * W + x0 : -1, i1 = (xr && yt && !far) ? y0 * W + x0 + 1 : -1;
+  const int i2 = (xl && yb_ && !far) ? (y0 + 1) * W + x0 : -1, i3 = (xr && yb_ && !far) ? (y0 + 1) * W + x0 + 1 : -1;
+  const float w0 = (1.f - tx) * (1.f - ty), w1 = tx * (1.f - ty), w2 = (1.f - tx) * ty, w3 = tx * ty;
+  const float* __restrict__ xp = a.x + (size_t)n * a.C * HW;
+  float* __restrict__ op = a.out + (size_t)n * a.C * HW + pix;
+  for (int c = 0; c < a.C; ++c) {
+    const float* __restrict__ pl = xp + (size_t)c * HW;
+    float v = 0.f;
+    v = fmaf(i0 >= 0 ? pl[i0] : 0.f, w0, v);
+    v = fmaf(i1 >= 0 ? pl[i1] : 0.f, w1, v);
+    v = fmaf(i2 >= 0 ? pl[i2] : 0.f, w2, v);
+    v = fmaf(i3 >= 0 ? pl[i3] : 0.f, w3, v);
+    op[(size_t)c * HW] = v;
+  }
+}
+
+// qkv [n][3*inner][HW] (q | k' | v' blocks of `inner` = heads * DH channels, head-major) -> out [n][inner][HW]
+struct HgtArgs {
+  const float* qkv;
+  const int* scene_off;  // [B+1]
+  float* out;
+  int heads, HW;
+  float scale;
+};
+template <int DH>
+__global__ __launch_bounds__(256) void hgt_attn_kernel(const HgtArgs a) {
+  constexpr int MAXN = 8;
+  const int b = blockIdx.z, m = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
+  if (p >= a.HW || N < 1 || N > MAXN) return;
+  const int inner = a.heads * DH;
+  const size_t agent = (size_t)3 * inner * a.HW;
+  const float* __restrict__ base = a.qkv + (size_t)off * agent + p;
+  for (int i = 0; i < N; ++i) {
+    float q[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) q[c] = base[i * agent + (size_t)(m * DH + c) * a.HW];
+    float s[MAXN];
+    float mx = -INFINITY;
+    for (int j = 0; j < N; ++j) {
+      const float* __restrict__ kp = base + j * agent + (size_t)(inner + m * DH) * a.HW;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) d = fmaf(q[c], kp[(size_t)c * a.HW], d);
+      s[j] = d * a.scale;
+      mx = fmaxf(mx, s[j]);
+    }
+    float den = 0.f;
+    for (int j = 0; j < N; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+    const float rden = 1.0f / den;
+    float o[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) o[c] = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float* __restrict__ vp = base + j * agent + (size_t)(2 * inner + m * DH) * a.HW;
+      const float wj = s[j] * rden;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) o[c] = fmaf(wj, vp[(size_t)c * a.HW], o[c]);
+    }
+    float* __restrict__ op = a.out + ((size_t)(off + i) * inner + m * DH) * a.HW + p;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) op[(size_t)c * a.HW] = o[c];
+  }
+}
+
+// qkv [n][3*inner][H][W] (q | k | v, head-major inside each) -> out [n][inner][H][W]; one workgroup = 256 query tokens of
+// one (agent, head): 256 / WS^2 horizontally adjacent windows.  pos [2 WS - 1][2 WS - 1].
+struct WinArgs {
+  const float* qkv;
+  const float* pos;
+  float* out;
+  int heads, H, W;
+  float scale;
+};
+template <int DH, int WS>
+__global__ __launch_bounds__(256) void win_attn_kernel(const WinArgs a) {
+  constexpr int T = WS * WS, WPB = 256 / T;  // tokens per window, windows per block
+  extern __shared__ float wa_smem[];         // K [WPB][T][DH], V [WPB][T][DH], pos [(2WS-1)^2]
+  float* sK = wa_smem;
+  float* sV = wa_smem + WPB * T * DH;
+  float* sP = sV + WPB * T * DH;
+  const int n = blockIdx.z, m = blockIdx.y, tid = threadIdx.x;
+  const int nw = a.W / WS, nwin = (a.H / WS) * nw;
+  const int win0 = blockIdx.x * WPB;
+  const int inner = a.heads * DH, HW = a.H * a.W;
+  const float* __restrict__ base = a.qkv + (size_t)n * 3 * inner * HW;
+  const int wl = tid / T, tok = tid - wl * T, win = win0 + wl;
+  const bool live = win < nwin;
+  const int wy = live ? win / nw : 0, wx = live ? win - wy * nw : 0;
+  const int ty = tok / WS, tx = tok - ty * WS;
+  const int pix = (wy * WS + ty) * a.W + wx * WS + tx;
+  for (int i = tid; i < (2 * WS - 1) * (2 * WS - 1); i += 256) sP[i] = a.pos[i];
+  float q[DH];
+#pragma unroll
+  for (int c = 0; c < DH; ++c) {
+    const float kq = live ? base[(size_t)(m * DH + c) * HW + pix] : 0.f;
+    q[c] = kq * a.scale;
+    sK[(wl * T + tok) * DH + c] = live ? base[(size_t)(inner + m * DH + c) * HW + pix] : 0.f;
+    sV[(wl * T + tok) * DH + c] = live ? base[(size_t)(2 * inner + m * DH + c) * HW + pix] : 0.f;
+  }
+  __syncthreads();
+  if (!live) return;
+  float mx = -INFINITY, den = 0.f;
+  float o[DH];
+#pragma unroll
+  for (int c = 0; c < DH; ++c) o[c] = 0.f;
+  const float* __restrict__ kw = sK + wl * T * DH;
+  const float* __restrict__ vw = sV + wl * T * DH;
+  for (int j = 0; j < T; ++j) {
+    const int jy = j / WS, jx = j - jy * WS;
+    float d = sP[(jy - ty + WS - 1) * (2 * WS - 1) + (jx - tx + WS - 1)];  // relative_indices[i][j] = idx[j] - idx[i] + WS - 1 (mswin.py:12-16, :34-35)
+#pragma unroll
+    for (int c = 0; c < DH; ++c) d = fmaf(q[c], kw[j * DH + c], d);
+    const float nm = fmaxf(mx, d);
+    const float corr = expf(mx - nm), e = expf(d - nm);
+    den = den * corr + e;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) o[c] = fmaf(e, vw[j * DH + c], o[c] * corr);
+    mx = nm;
+  }
+  const float rden = 1.0f / den;
+  float* __restrict__ op = a.out + ((size_t)n * inner + m * DH) * HW + pix;
+#pragma unroll
+  for (int c = 0; c < DH; ++c) op[(size_t)c * HW] = o[c] * rden;
+}
+
+template <int DH, int WS>
+inline int win_attn_launch(const WinArgs& a, int n, hipStream_t st) {
+  constexpr int T = WS * WS, WPB = 256 / T;
+  const size_t sh = ((size_t)2 * WPB * T * DH + (2 * WS - 1) * (2 * WS - 1)) * sizeof(float);
+  if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)win_attn_kernel<DH, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  const int nwin = (a.H / WS) * (a.W / WS);
+  win_attn_kernel<DH, WS><<<dim3((nwin + WPB - 1) / WPB, a.heads, n), 256, sh, st>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+}  // namespace gc

@@ -99,8 +99,11 @@ class HeterModelBaselineWGenComm(nn.Module):
             self.fusion_net = AttFusion(args["att"]["feat_dim"])
         elif method == "max":
             self.fusion_net = MaxFusion()
+        elif method == "v2xvit":
+            from .v2xvit import V2XViTFusion
+            self.fusion_net = V2XViTFusion(args["v2xvit"])  # stage1.py:122-123
         elif method in _OTHER_FUSIONS:
-            raise NotImplementedError(f"fusion_method '{method}' is outside this build ('att' and 'max' are implemented)")
+            raise NotImplementedError(f"fusion_method '{method}' is outside this build ('att', 'max' and 'v2xvit' are implemented)")
         else:
             raise ValueError(f"unknown fusion_method '{method}'")
 

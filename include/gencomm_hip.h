@@ -329,6 +329,22 @@ int gencomm_voxelize_fwd(const float* points, int n, int nfeat, const float* vox
                          int max_voxels, float* voxels, int* coords_zyx, int* num_points, int* count,
                          void* workspace, long long workspace_bytes, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * V2X-ViT fusion building blocks (opencood/models/fuse_modules/fusion_in_one.py:355-407, sub_modules/hmsa.py:117-150,
+ * sub_modules/mswin.py:47-83); NCHW fp32 per agent. The Linear layers around them run through gencomm_conv2d_fwd (1x1),
+ * the LayerNorms through gencomm_ln_nchw_fwd; gencomm_amd/v2xvit.py is the module with the reference's state_dict keys.
+ *   gencomm_warp_affine_fwd  warp_affine_simple: out[i] = bilinear sample of x[i] on the float64 affine grid theta[i] [2][3]
+ *   gencomm_hgt_attn_fwd     qkv [n][3 heads dim_head][HW] (q | k | v blocks) -> out [n][heads dim_head][HW]: per pixel and head,
+ *                            softmax attention across the agents of each scene (scene_off [B+1]); relation matrices folded into
+ *                            the k / v projections by the caller (all agents have type 0 in GenComm's use)
+ *   gencomm_win_attn_fwd     per agent, head and window x window tile: softmax(q k^T / sqrt(dim_head) + pos[dy][dx]) v,
+ *                            pos_embedding [2 window - 1][2 window - 1]
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_warp_affine_fwd(const float* x, const double* theta, float* out, int n, int C, int H, int W, void* stream);
+int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int B, int heads, int dim_head, int HW, void* stream);
+int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* out, int n, int heads, int dim_head, int window, int H, int W,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

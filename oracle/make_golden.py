@@ -500,6 +500,41 @@ def run_eval_case() -> None:
           "per-frame order", [round(float(rec[f'ap_{t}_0']), 4) for t in (0.3, 0.5, 0.7)])
 
 
+V2XVIT_ARGS = {"transformer": {"encoder": {
+    "num_blocks": 1, "depth": 3, "use_roi_mask": True, "use_RTE": False, "RTE_ratio": 0,
+    "cav_att_config": {"dim": 128, "use_hetero": True, "use_RTE": False, "RTE_ratio": 0, "heads": 8, "dim_head": 32, "dropout": 0.3},
+    "pwindow_att_config": {"dim": 128, "heads": [16, 8, 4], "dim_head": [16, 32, 64], "dropout": 0.3, "window_size": [4, 8, 16],
+                           "relative_pos_embedding": True, "fusion_method": "split_attn128"},
+    "feed_forward": {"mlp_dim": 128, "dropout": 0.3},
+    "sttf": {"voxel_size": [0.4, 0.4, 4], "downsample_rate": 4}}}}  # opv2v/GenComm_yamls/gencomm/stage1/m1_v2xvit.yaml:137-171
+
+
+def run_v2xvit_case() -> None:
+    """V2XViTFusion (fusion_in_one.py:355-407 + sub_modules/v2xvit_basic.py, hmsa.py, mswin.py, split_attn.py,
+    base_transformer.py) with the shipped m1_v2xvit.yaml transformer block, eval mode, the reference's own modules."""
+    import json
+    from opencood.models.fuse_modules.fusion_in_one import V2XViTFusion
+    from opencood.utils.transformation_utils import normalize_pairwise_tfm
+    C, H, W, rl, L = 128, 16, 32, [3, 1, 2], 5
+    net = V2XViTFusion(json.loads(json.dumps(V2XVIT_ARGS))).eval()
+    seed_w, seed_d = WEIGHT_SEED + 70, DATA_SEED + 70
+    synth.fill_params_(net, seed_w)
+    inp = synth.make_inputs(rl, C, H, W, seed_d, max_shift=4.0)
+    x = torch.from_numpy(inp["feat"])
+    record_len = torch.from_numpy(inp["record_len"])
+    ptm = torch.from_numpy(inp["pairwise_t_matrix"])
+    affine = normalize_pairwise_tfm(ptm, H * 0.8, W * 0.8, 1)
+    with torch.no_grad():
+        out = net(x, record_len, affine)
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(OUT, "v2xvit_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+    np.savez_compressed(os.path.join(OUT, "v2xvit.npz"), C=C, H=H, W=W, record_len=np.array(rl), max_cav=L, weight_seed=seed_w, data_seed=seed_d,
+                        max_shift=4.0, stride=3, fused=sub(out.numpy(), 3), fused_shape=np.array(out.shape), args=json.dumps(V2XVIT_ARGS))
+    print(f"v2xvit: {len(keys)} state_dict tensors, {sum(int(np.prod(v)) for v in keys.values())} values, out {tuple(out.shape)} "
+          f"mean |out| {float(out.abs().mean()):.4f} finite {bool(torch.isfinite(out).all())}")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -527,7 +562,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()
