@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Forward latency of V2XViTFusion (HIP path) with the shipped m1_v2xvit.yaml transformer block at the shipped map size
+(C=128, 64x128) for 2 and 5 agents, and at 100x352 (the 200x704 grid after the backbone's stride 2) for 4 agents."""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+from gencomm_amd import normalize_pairwise_tfm, synth
+from gencomm_amd.v2xvit import V2XViTFusion
+
+args = json.loads(str(np.load(os.path.join(REPO, "tests", "golden", "v2xvit.npz"))["args"]))
+net = V2XViTFusion(args).eval()
+synth.fill_params_(net, 5)
+net = net.cuda()
+for (H, W, rl) in ((64, 128, [2]), (64, 128, [5]), (96, 352, [4])):
+    inp = synth.make_inputs(rl, 128, H, W, 9, max_shift=10.0)
+    aff = normalize_pairwise_tfm(torch.from_numpy(inp["pairwise_t_matrix"]), H * 0.8, W * 0.8, 1)
+    x = torch.from_numpy(inp["feat"]).cuda()
+    with torch.no_grad():
+        for _ in range(3):
+            net(x, rl, aff)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = 10
+        for _ in range(K):
+            net(x, rl, aff)
+        torch.cuda.synchronize()
+    print(f"v2xvit forward: {sum(rl)} agents, C=128, {H}x{W}: {1e3 * (time.perf_counter() - t0) / K:.2f} ms per scene", flush=True)
