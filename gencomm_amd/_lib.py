@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP = range(6)
 
 _lock = threading.Lock()
@@ -85,6 +85,17 @@ _SIGNATURES = {
     "gencomm_iou3d_max_boxes": (_i, []),
     "gencomm_iou3d_nms_workspace_bytes": (_ll, [_i]),
     "gencomm_iou3d_nms_fwd": (_i, [_p, _i, C.c_float, _i, _p, _p, _p, _ll, _p]),
+    "gencomm_sp_out_dims": (_i, [_p, _p, _p, _p, _p]),
+    "gencomm_sp_index_workspace_bytes": (_ll, [_i]),
+    "gencomm_sp_index_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _ll, _p]),
+    "gencomm_sp_sites_workspace_bytes": (_ll, [_i, _p]),
+    "gencomm_sp_sites_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
+    "gencomm_sp_rules_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "gencomm_sp_prepared_floats": (_ll, [_i, _i, _i]),
+    "gencomm_sp_prepare": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_sp_conv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_sp_dense_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "gencomm_mean_vfe_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "gencomm_voxelize_workspace_bytes": (_ll, [_i]),
     "gencomm_voxelize_fwd": (_i, [_p, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p, _p, _p, _p, _p, _ll, _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

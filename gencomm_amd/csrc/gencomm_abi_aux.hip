@@ -1,4 +1,5 @@
-// Second translation unit of libgencomm_hip.so: iou3d_nms (reference extension semantics) and the point-cloud voxeliser.
+// Second translation unit of libgencomm_hip.so: iou3d_nms (reference extension semantics), the point-cloud voxeliser,
+// the V2X-ViT attention kernels and the sparse 3-D convolutions of the SECOND encoder.
 // Kept apart from gencomm_abi.hip so that the rocPRIM templates do not lengthen the hot path's compile.
 #include "../../include/gencomm_hip.h"
 
@@ -6,6 +7,7 @@
 
 #include "common.h"
 #include "iou3d_kernels.h"
+#include "sparse_kernels.h"
 #include "v2xvit_kernels.h"
 #include "voxel_kernels.h"
 
@@ -114,6 +116,150 @@ int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* ou
   if (window == 8 && dim_head == 64) return win_attn_launch<64, 8>(a, n, st);
   if (window == 16 && dim_head == 32) return win_attn_launch<32, 16>(a, n, st);
   return fail(GC_ERR_ARG, "window attention: supported (window, dim_head) pairs are (4,16) (4,32) (8,16) (8,32) (8,64) (16,32) (16,64)");
+}
+
+// ---- sparse 3-D convolution (SECOND encoder) -------------------------------------------------------------------------
+static int sp_grid(SpGrid& g, int B, const int* dims3, const char* what) {
+  GC_CHECK_ARG(dims3 != nullptr && B >= 1 && dims3[0] >= 1 && dims3[1] >= 1 && dims3[2] >= 1, what);
+  g.B = B; g.D = dims3[0]; g.H = dims3[1]; g.W = dims3[2];
+  return GC_OK;
+}
+static int sp_geom(SpConvGeom& g, int B, const int* in_dims3, const int* kernel3, const int* stride3, const int* pad3) {
+  if (int rc = sp_grid(g.in, B, in_dims3, "bad input grid")) return rc;
+  GC_CHECK_ARG(kernel3 && stride3 && pad3, "null pointer");
+  g.out.B = B;
+  int od[3];
+  for (int j = 0; j < 3; ++j) {
+    GC_CHECK_ARG(kernel3[j] >= 1 && kernel3[j] <= 7 && stride3[j] >= 1 && pad3[j] >= 0, "bad kernel / stride / padding");
+    g.k[j] = kernel3[j]; g.stride[j] = stride3[j]; g.pad[j] = pad3[j];
+    const int num = in_dims3[j] + 2 * pad3[j] - kernel3[j];
+    GC_CHECK_ARG(num >= 0, "kernel larger than the padded grid");
+    od[j] = num / stride3[j] + 1;
+  }
+  g.out.D = od[0]; g.out.H = od[1]; g.out.W = od[2];
+  return GC_OK;
+}
+
+int gencomm_sp_out_dims(const int* in_dims3, const int* kernel3, const int* stride3, const int* pad3, int* out_dims3) {
+  SpConvGeom g{};
+  if (int rc = sp_geom(g, 1, in_dims3, kernel3, stride3, pad3)) return rc;
+  GC_CHECK_ARG(out_dims3 != nullptr, "null pointer");
+  out_dims3[0] = g.out.D; out_dims3[1] = g.out.H; out_dims3[2] = g.out.W;
+  return GC_OK;
+}
+
+long long gencomm_sp_index_workspace_bytes(int n) {
+  if (n < 0) { fail(GC_ERR_ARG, "n must be non-negative"); return -1; }
+  return (long long)sp_sort_ws(n).total;
+}
+int gencomm_sp_index_fwd(const int* coords_bzyx, int n, int B, const int* dims3, long long* keys, int* perm, void* workspace, long long workspace_bytes,
+                         void* stream) {
+  SpGrid g{};
+  if (int rc = sp_grid(g, B, dims3, "bad grid")) return rc;
+  GC_CHECK_ARG(n >= 0, "n must be non-negative");
+  if (n == 0) return GC_OK;
+  GC_CHECK_ARG(coords_bzyx && keys && perm && workspace, "null pointer");
+  const SpSortWs w = sp_sort_ws(n);
+  if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (gencomm_sp_index_workspace_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  char* wsp = (char*)workspace;
+  long long* key = reinterpret_cast<long long*>(wsp + w.key);
+  int* val = reinterpret_cast<int*>(wsp + w.val);
+  sp_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(coords_bzyx, n, g, key, val);
+  size_t tb = w.temp_bytes;
+  GC_HIP(rocprim::radix_sort_pairs(wsp + w.temp, tb, key, keys, val, perm, (size_t)n, 0, 64, st));
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_sp_rules_fwd(const long long* out_keys, int n_out, const long long* in_keys, int n_in, int B, const int* in_dims3, const int* kernel3,
+                         const int* stride3, const int* pad3, int* nbr, void* stream) {
+  SpConvGeom g{};
+  if (int rc = sp_geom(g, B, in_dims3, kernel3, stride3, pad3)) return rc;
+  GC_CHECK_ARG(n_out >= 0 && n_in >= 0, "negative count");
+  if (n_out == 0) return GC_OK;
+  GC_CHECK_ARG(out_keys && nbr && (n_in == 0 || in_keys), "null pointer");
+  const int K = g.k[0] * g.k[1] * g.k[2];
+  sp_rules_kernel<<<dim3((n_out + 255) / 256, K), 256, 0, (hipStream_t)stream>>>(out_keys, n_out, in_keys, n_in, g, nbr);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+long long gencomm_sp_sites_workspace_bytes(int n_in, const int* kernel3) {
+  if (n_in < 0 || kernel3 == nullptr) { fail(GC_ERR_ARG, "bad arguments"); return -1; }
+  return (long long)sp_sites_ws((long long)n_in * kernel3[0] * kernel3[1] * kernel3[2]).total;
+}
+// out_keys must hold n_in * K entries (the upper bound); *n_out (device) receives the number of output sites
+int gencomm_sp_sites_fwd(const long long* in_keys, int n_in, int B, const int* in_dims3, const int* kernel3, const int* stride3, const int* pad3,
+                         long long* out_keys, int* n_out, void* workspace, long long workspace_bytes, void* stream) {
+  SpConvGeom g{};
+  if (int rc = sp_geom(g, B, in_dims3, kernel3, stride3, pad3)) return rc;
+  GC_CHECK_ARG(n_in >= 0 && n_out != nullptr, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_in == 0) {
+    GC_HIP(hipMemsetAsync(n_out, 0, sizeof(int), st));
+    return GC_OK;
+  }
+  GC_CHECK_ARG(in_keys && out_keys && workspace, "null pointer");
+  const int K = g.k[0] * g.k[1] * g.k[2];
+  const long long nc = (long long)n_in * K;
+  GC_CHECK_ARG(nc < (1LL << 31), "too many candidate sites");
+  const SpSitesWs w = sp_sites_ws(nc);
+  if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (gencomm_sp_sites_workspace_bytes)");
+  char* wsp = (char*)workspace;
+  long long* cand = reinterpret_cast<long long*>(wsp + w.cand);
+  long long* sorted = reinterpret_cast<long long*>(wsp + w.sorted);
+  sp_candidates_kernel<<<dim3((n_in + 255) / 256, K), 256, 0, st>>>(in_keys, n_in, g, cand);
+  size_t tb = w.temp_bytes;
+  GC_HIP(rocprim::radix_sort_keys(wsp + w.temp, tb, cand, sorted, (size_t)nc, 0, 64, st));
+  tb = w.temp_bytes;
+  GC_HIP(rocprim::unique(wsp + w.temp, tb, sorted, out_keys, n_out, (size_t)nc, rocprim::equal_to<long long>(), st));
+  sp_fix_count_kernel<<<1, 64, 0, st>>>(out_keys, n_out);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+long long gencomm_sp_prepared_floats(int K, int Cin, int Cout) {
+  if (K < 1 || Cin < 1 || Cin > 64 || Cout < 1) { fail(GC_ERR_ARG, "sparse conv: 1 <= Cin <= 64"); return -1; }
+  return (long long)K * sp_cin_padded(Cin) * (long long)align_up((size_t)Cout, 32);
+}
+int gencomm_sp_prepare(const float* w, float* prepared, int K, int Cin, int Cout, int layout, void* stream) {
+  GC_CHECK_ARG(w && prepared && (layout == 0 || layout == 1), "bad arguments");
+  const long long total = gencomm_sp_prepared_floats(K, Cin, Cout);
+  if (total < 0) return GC_ERR_ARG;
+  sp_prep_w_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, prepared, K, Cin, Cout, sp_cin_padded(Cin), (int)align_up((size_t)Cout, 32), layout);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_sp_conv_fwd(const float* x, const int* nbr, const float* prepared, const float* scale, const float* shift, float* y, int n_out, int K, int Cin,
+                        int Cout, int relu, void* stream) {
+  GC_CHECK_ARG(n_out >= 0 && K >= 1 && Cin >= 1 && Cin <= 64 && Cout >= 1, "bad arguments");
+  if (n_out == 0) return GC_OK;
+  GC_CHECK_ARG(x && nbr && prepared && scale && shift && y, "null pointer");
+  SpConvArgs a{x, nbr, prepared, scale, shift, y, n_out, K, Cin, Cout, (int)align_up((size_t)Cout, 32), relu};
+  return sp_conv_enqueue(a, (hipStream_t)stream);
+}
+int gencomm_sp_dense_fwd(const float* feat, const long long* keys, int n, int C, int B, const int* dims3, float* out, void* stream) {
+  SpGrid g{};
+  if (int rc = sp_grid(g, B, dims3, "bad grid")) return rc;
+  GC_CHECK_ARG(n >= 0 && C >= 1 && out, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  GC_HIP(hipMemsetAsync(out, 0, (size_t)B * C * g.D * g.H * g.W * sizeof(float), st));
+  if (n == 0) return GC_OK;
+  GC_CHECK_ARG(feat && keys, "null pointer");
+  const long long total = (long long)n * C;
+  sp_dense_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(feat, keys, n, C, g, out);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_mean_vfe_fwd(const float* voxels, const int* num_points, const int* perm, float* out, int n, int max_points, int nfeat, void* stream) {
+  GC_CHECK_ARG(n >= 0 && max_points >= 1 && nfeat >= 1, "bad arguments");
+  if (n == 0) return GC_OK;
+  GC_CHECK_ARG(voxels && num_points && out, "null pointer");
+  const long long total = (long long)n * nfeat;
+  mean_vfe_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(voxels, num_points, perm, out, n, max_points, nfeat);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
 }
 
 }  // extern "C"

@@ -5,8 +5,8 @@ names (= checkpoint keys: ``encoder_m1, backbone_m1, shrinker_m1, message_extrac
 fusion_net, shrink_conv, cls_head, reg_head, dir_head``), same forward order and output dict keys. Every tensor op
 of the forward runs in the HIP library.
 
-Scope: lidar modalities encoded by ``point_pillar``; fusion ``att`` or ``max``. SECOND / camera
-encoders and the other fusion nets are outside this build and raise ``NotImplementedError`` at
+Scope: lidar modalities encoded by ``point_pillar`` or ``second``; fusion ``att``, ``max`` or ``v2xvit``.
+Camera encoders and the other fusion nets are outside this build and raise ``NotImplementedError`` at
 construction with the yaml key that asked for them.
 
 Reference defects absorbed at this boundary: the resolver wants a class whose lower-cased name
@@ -28,8 +28,9 @@ from .enhancer import Enhancer
 from .fusion import AttFusion, MaxFusion, normalize_pairwise_tfm
 from .message_extractor import MessageExtractorv2
 from .point_pillar import PointPillar
+from .second import SECOND
 
-_ENCODERS = {"pointpillar": PointPillar}
+_ENCODERS = {"pointpillar": PointPillar, "second": SECOND}  # heter_encoders.py (resolved by lower-cased class name, stage1.py:54-61)
 _OTHER_FUSIONS = ("disconet", "v2vnet", "v2xvit", "cobevt", "where2comm", "who2com")
 
 
@@ -62,7 +63,7 @@ class HeterModelBaselineWGenComm(nn.Module):
             enc_name = setting["core_method"].replace("_", "").lower()
             if enc_name not in _ENCODERS or setting["sensor_type"] != "lidar":
                 raise NotImplementedError(f"{modality_name}: encoder '{setting['core_method']}' / sensor '{setting['sensor_type']}' "
-                                          "is outside this build (lidar + point_pillar only, SURVEY.md 8f rank 4)")
+                                          "is outside this build (lidar with point_pillar or second, SURVEY.md 8f rank 4)")
             setattr(self, f"encoder_{modality_name}", _ENCODERS[enc_name](setting["encoder_args"]))
             setattr(self, f"depth_supervision_{modality_name}", False)
             if setting["backbone_args"] == "identity":

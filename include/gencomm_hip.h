@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 3
+#define GENCOMM_ABI_VERSION 4
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -343,6 +343,40 @@ int gencomm_voxelize_fwd(const float* points, int n, int nfeat, const float* vox
 int gencomm_warp_affine_fwd(const float* x, const double* theta, float* out, int n, int C, int H, int W, void* stream);
 int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int B, int heads, int dim_head, int HW, void* stream);
 int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* out, int n, int heads, int dim_head, int window, int H, int W,
+                         void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Sparse 3-D convolutions of the SECOND encoder without spconv (opencood/models/heter_encoders.py:52-81,
+ * sub_modules/sparse_backbone_3d.py:33-152, mean_vfe.py:14-33, height_compression.py:10-30). A sparse tensor is
+ * (keys int64 [n] ascending, features fp32 [n][C]); key = ((b D + z) H + y) W + x. dims3 = (D, H, W); kernel3 / stride3 /
+ * pad3 = (z, y, x). spconv's arithmetic is not part of the reference checkout: parity unpinned, semantics as published
+ * (SubMConv3d: output sites = input sites; SparseConv3d: every site whose receptive field holds an active input).
+ *   gencomm_sp_index_fwd    coords [n][4] int32 (b, z, y, x) -> keys (sorted) and perm (sorted row -> input row)
+ *   gencomm_sp_sites_fwd    output sites of a strided SparseConv3d: out_keys (capacity n_in * K, ascending), *n_out (device int)
+ *   gencomm_sp_rules_fwd    rulebook nbr [K][n_out] int32: input row of out_coord * stride - pad + offset, -1 if inactive
+ *                           (SubMConv3d: out_keys = in_keys, stride 1, pad = k / 2)
+ *   gencomm_sp_prepare      weights -> kernel layout; layout 0 = spconv 2.x [Cout][kD][kH][kW][Cin], 1 = spconv 1.x
+ *                           [kD][kH][kW][Cin][Cout]
+ *   gencomm_sp_conv_fwd     y[j][co] = act(scale[co] * sum_o sum_ci w[o][ci][co] x[nbr[o][j]][ci] + shift[co]): gather-GEMM on
+ *                           v_mfma_f32_32x32x2_f32; scale / shift = folded BatchNorm1d (gencomm_conv2d_fold)
+ *   gencomm_sp_dense_fwd    SparseConvTensor.dense(): out [B][C][D][H][W] (zeroed here)
+ *   gencomm_mean_vfe_fwd    MeanVFE: out[j] = sum over all point slots of voxel perm[j] / max(num_points, 1)
+ * -------------------------------------------------------------------------------------------- */
+int gencomm_sp_out_dims(const int* in_dims3, const int* kernel3, const int* stride3, const int* pad3, int* out_dims3);
+long long gencomm_sp_index_workspace_bytes(int n);
+int gencomm_sp_index_fwd(const int* coords_bzyx, int n, int B, const int* dims3, long long* keys, int* perm,
+                         void* workspace, long long workspace_bytes, void* stream);
+long long gencomm_sp_sites_workspace_bytes(int n_in, const int* kernel3);
+int gencomm_sp_sites_fwd(const long long* in_keys, int n_in, int B, const int* in_dims3, const int* kernel3, const int* stride3,
+                         const int* pad3, long long* out_keys, int* n_out, void* workspace, long long workspace_bytes, void* stream);
+int gencomm_sp_rules_fwd(const long long* out_keys, int n_out, const long long* in_keys, int n_in, int B, const int* in_dims3,
+                         const int* kernel3, const int* stride3, const int* pad3, int* nbr, void* stream);
+long long gencomm_sp_prepared_floats(int K, int Cin, int Cout);
+int gencomm_sp_prepare(const float* w, float* prepared, int K, int Cin, int Cout, int layout, void* stream);
+int gencomm_sp_conv_fwd(const float* x, const int* nbr, const float* prepared, const float* scale, const float* shift, float* y,
+                        int n_out, int K, int Cin, int Cout, int relu, void* stream);
+int gencomm_sp_dense_fwd(const float* feat, const long long* keys, int n, int C, int B, const int* dims3, float* out, void* stream);
+int gencomm_mean_vfe_fwd(const float* voxels, const int* num_points, const int* perm, float* out, int n, int max_points, int nfeat,
                          void* stream);
 
 #ifdef __cplusplus

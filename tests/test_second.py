@@ -1,0 +1,199 @@
+"""SECOND encoder without spconv (heter_encoders.py:52-81, sparse_backbone_3d.py:33-152).
+spconv is not part of the reference checkout: PARITY UNPINNED. CPU: known answers of the dense-volume oracle
+(oracle/second_port.py) for the published SubMConv3d / SparseConv3d semantics, the product module's state_dict keys and
+shapes as the reference's constructor code implies them, spconv-1.x checkpoint layout. GPU: the HIP sparse path against
+the oracle, stage by stage and end to end."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+from helpers import assert_close
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _args(nx, ny, nz=40, cout=64):
+    vs = [0.1, 0.1, 0.1]
+    return {"voxel_size": vs, "lidar_range": [0.0, 0.0, -3.0, nx * 0.1, ny * 0.1, -3.0 + nz * 0.1],
+            "mean_vfe": {"num_point_features": 4}, "spconv": {"num_features_in": 4, "num_features_out": cout},
+            "map2bev": {"feature_num": cout * 2}}
+
+
+def _module(args, seed):
+    from gencomm_amd.second import SECOND
+    net = SECOND(args).eval()
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in sorted(net.named_parameters()):
+            if p.dim() == 5:   # sparse conv: activations stay O(1-4) through the 13 layers (the tolerance is defined for O(1) data)
+                fan = p.shape[4] * 16
+                p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * np.sqrt(2.0 / fan)))
+            elif name.endswith("weight"):
+                p.copy_(torch.from_numpy((1.0 + 0.2 * rng.standard_normal(p.shape)).astype(np.float32)))
+            else:
+                p.copy_(torch.from_numpy((0.1 * rng.standard_normal(p.shape)).astype(np.float32)))
+        for name, b in sorted(net.named_buffers()):
+            if name.endswith("running_mean"):
+                b.copy_(torch.from_numpy((0.1 * rng.standard_normal(b.shape)).astype(np.float32)))
+            elif name.endswith("running_var"):
+                b.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, b.shape).astype(np.float32)))
+    return net
+
+
+def _voxels(rng, batch_counts, nx, ny, nz, P=5, clustered=True):
+    """Unique random voxels per batch element: coords [M, 4] (b, z, y, x) in 'first appearance' (random) order."""
+    coords, feats, nums = [], [], []
+    for b, m in enumerate(batch_counts):
+        if clustered:   # a few blobs: neighbours exist, as in a lidar sweep
+            centres = rng.randint(0, [nz + 1, ny, nx], size=(max(m // 40, 1), 3))
+            c = centres[rng.randint(0, len(centres), size=4 * m)] + np.round(rng.standard_normal((4 * m, 3)) * [1.5, 3, 3]).astype(np.int64)
+        else:
+            c = rng.randint(0, [nz + 1, ny, nx], size=(4 * m, 3))
+        ok = (c >= 0).all(1) & (c[:, 0] <= nz) & (c[:, 1] < ny) & (c[:, 2] < nx)
+        c = c[ok]
+        _, first = np.unique(c[:, 0] * 10 ** 8 + c[:, 1] * 10 ** 4 + c[:, 2], return_index=True)
+        c = c[np.sort(first)][:m]
+        coords.append(np.concatenate([np.full((len(c), 1), b), c], 1))
+        k = rng.randint(1, P + 1, size=len(c))
+        f = rng.standard_normal((len(c), P, 4)).astype(np.float32)
+        f[np.arange(P)[None, :] >= k[:, None]] = 0.0
+        feats.append(f)
+        nums.append(k)
+    return (torch.from_numpy(np.concatenate(feats)), torch.from_numpy(np.concatenate(coords)).int(), torch.from_numpy(np.concatenate(nums)).int())
+
+
+# ------------------------------------------------------------------------------------------ CPU: oracle + boundary
+def test_oracle_known_answers_submanifold_and_strided_site_sets():
+    import second_port as S
+    # one active voxel: SubM output = centre tap only; inactive sites stay zero even though BatchNorm has a shift
+    sd = {"c.weight": torch.arange(2 * 27 * 3, dtype=torch.float32).reshape(2, 3, 3, 3, 3) / 100.0,
+          "b.weight": torch.tensor([1.0, 2.0]), "b.bias": torch.tensor([0.5, -0.25]),
+          "b.running_mean": torch.zeros(2), "b.running_var": torch.ones(2) - S.BN_EPS}
+    f = torch.tensor([[1.0, 2.0, 3.0]])
+    x, m = S.to_dense(f, torch.tensor([[0, 4, 4, 4]]), 1, [9, 9, 9])
+    y = S.subm_block(sd, "c", "b", x, m)
+    centre = sd["c.weight"][:, 1, 1, 1, :] @ f[0]
+    want = torch.relu(centre * sd["b.weight"] + sd["b.bias"])
+    assert torch.allclose(y[0, :, 4, 4, 4], want, atol=1e-6)
+    assert float(y.abs().sum() - y[0, :, 4, 4, 4].abs().sum()) == 0.0
+    # strided SparseConv3d (k 3, stride 2, pad 1): an even coordinate lies in ONE receptive field per axis, an odd one in TWO
+    _, m_even = S.spconv_block(sd, "c", "b", x, m, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    assert int(m_even.sum()) == 1 and float(m_even[0, 0, 2, 2, 2]) == 1.0
+    x2, m2 = S.to_dense(f, torch.tensor([[0, 5, 5, 5]]), 1, [9, 9, 9])
+    y2, m_odd = S.spconv_block(sd, "c", "b", x2, m2, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    assert int(m_odd.sum()) == 8 and tuple(m_odd.shape[2:]) == (5, 5, 5)
+    # output (3,3,3) covers inputs 5..7: the voxel at 5 is its tap 0 in every axis
+    tap0 = torch.relu((sd["c.weight"][:, 0, 0, 0, :] @ f[0]) * sd["b.weight"] + sd["b.bias"])
+    assert torch.allclose(y2[0, :, 3, 3, 3], tap0, atol=1e-6)
+    # MeanVFE divides the sum over ALL slots by max(num_points, 1)
+    v = torch.tensor([[[1.0, 2.0], [3.0, 4.0], [0.0, 0.0]], [[5.0, 6.0], [0.0, 0.0], [0.0, 0.0]]])
+    assert torch.equal(S.mean_vfe(v, torch.tensor([2, 0])), torch.tensor([[2.0, 3.0], [5.0, 6.0]]))
+
+
+def test_state_dict_keys_follow_the_reference_constructor():
+    """Keys as sparse_backbone_3d.py:48-93 registers them (SparseSequential children "0", "1", "2"; post_act_block nests one
+    level deeper), BatchNorm1d buffers included; spconv 2.x weight layout [Cout, kD, kH, kW, Cin]."""
+    from gencomm_amd.second import SECOND
+    net = SECOND(_args(48, 32))
+    want = {}
+
+    def layer(prefix, cin, cout, k=(3, 3, 3)):
+        want[prefix + ".0.weight"] = [cout, *k, cin]
+        for leaf, shape in (("weight", [cout]), ("bias", [cout]), ("running_mean", [cout]), ("running_var", [cout]), ("num_batches_tracked", [])):
+            want[f"{prefix}.1.{leaf}"] = shape
+    layer("spconv_block.conv_input", 4, 16)
+    layer("spconv_block.conv1.0", 16, 16)
+    for lvl, (cin, cout) in ((2, (16, 32)), (3, (32, 64)), (4, (64, 64))):
+        layer(f"spconv_block.conv{lvl}.0", cin, cout)
+        layer(f"spconv_block.conv{lvl}.1", cout, cout)
+        layer(f"spconv_block.conv{lvl}.2", cout, cout)
+    layer("spconv_block.conv_out", 64, 64, (3, 1, 1))
+    got = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert got == want
+    assert net.spconv_block.sparse_shape == [41, 32, 48]           # grid_size[::-1] + [1, 0, 0]
+
+
+def test_spconv1_checkpoint_layout_is_recognised_on_load():
+    from gencomm_amd.second import SECOND
+    a, b = SECOND(_args(48, 32)), SECOND(_args(48, 32))
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    old = {k: (v.permute(1, 2, 3, 4, 0).contiguous() if v.dim() == 5 else v) for k, v in sd.items()}   # [kD, kH, kW, Cin, Cout]
+    b.load_state_dict(old)
+    for k, v in b.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_training_mode_is_refused():
+    from gencomm_amd.second import SECOND
+    net = SECOND(_args(48, 32)).train()
+    with pytest.raises(NotImplementedError):
+        net({"inputs_m3": {"voxel_features": torch.zeros(1, 5, 4), "voxel_coords": torch.zeros(1, 4, dtype=torch.int32),
+                           "voxel_num_points": torch.ones(1, dtype=torch.int32)}}, "m3")
+
+
+# ------------------------------------------------------------------------------------------ GPU: HIP path vs oracle
+def _dense_of(sp):
+    return sp.dense().cpu()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,counts,clustered,cout", [(48, 32, [300, 40, 1], True, 64), (40, 24, [500], False, 128),
+                                                          (256, 128, [6000, 9000], True, 64)],
+                         ids=["3_scenes_clustered", "uniform_cout128", "2_scenes_15k_voxels"])
+def test_hip_second_vs_oracle_stage_by_stage(nx, ny, counts, clustered, cout):
+    import second_port as S
+    args = _args(nx, ny, cout=cout)
+    net = _module(args, 5)
+    rng = np.random.RandomState(7)
+    vf, vc, vn = _voxels(rng, counts, nx, ny, 40, clustered=clustered)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = S.second_forward(sd, "", vf, vc, vn, [nx, ny, 40])
+    feats = S.mean_vfe(vf, vn)
+    _, _, stages = S.voxel_backbone_8x(sd, "spconv_block", feats, vc, len(counts), [41, ny, nx])
+    net = net.cuda()
+    with torch.no_grad():
+        bd = {"inputs_m3": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}}
+        out = net(bd, "m3")
+        # the stages again through the same modules (multi_scale_3d_features of the reference's batch_dict)
+        from gencomm_amd.second import SparseTensor, index_voxels
+        keys, perm = index_voxels(vc.cuda(), len(counts), net.spconv_block.sparse_shape)
+        b2 = net.vfe({"voxel_features": vf.cuda(), "voxel_num_points": vn.cuda(), "_sorted_perm": perm})
+        b2["_sparse_input"] = SparseTensor(keys, b2["voxel_features"], len(counts), net.spconv_block.sparse_shape)
+        b2 = net.spconv_block(b2)
+    assert list(out.shape) == list(ref.shape) == [len(counts), cout * 2, ny // 8, nx // 8]
+    for name, (want, mask) in stages.items():
+        sp = b2["multi_scale_3d_features"][name]
+        assert sp.n == int(mask.sum()), (name, sp.n, int(mask.sum()))         # the active-site sets agree exactly
+        assert_close(_dense_of(sp).numpy(), want.numpy(), RTOL, ATOL, f"SECOND {name}")
+    assert_close(out.cpu().numpy(), ref.numpy(), RTOL, ATOL, "SECOND spatial_features")
+    assert float(ref.abs().max()) > 0.05
+    print(f"SECOND HIP vs oracle, {sum(counts)} voxels: output {tuple(out.shape)}, max |ref| {float(ref.abs().max()):.3f}, "
+          f"sites per stage {[b2['multi_scale_3d_features'][k].n for k in stages]} -> {b2['encoded_spconv_tensor'].n}")
+
+
+@pytest.mark.gpu
+def test_hip_second_is_deterministic_and_order_independent():
+    """The same voxels presented in a different row order give bit-identical output (sorted keys, no atomics)."""
+    args = _args(64, 48)
+    net = _module(args, 9).cuda()
+    vf, vc, vn = _voxels(np.random.RandomState(3), [700, 300], 64, 48, 40)
+    p = torch.from_numpy(np.random.RandomState(4).permutation(len(vc)))
+    with torch.no_grad():
+        a = net({"inputs_m3": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}}, "m3")
+        b = net({"inputs_m3": {"voxel_features": vf[p].cuda(), "voxel_coords": vc[p].cuda(), "voxel_num_points": vn[p].cuda()}}, "m3")
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_hip_second_refuses_cpu_tensors():
+    from gencomm_amd._lib import GenCommHipError
+    net = _module(_args(48, 32), 1)
+    vf, vc, vn = _voxels(np.random.RandomState(1), [20], 48, 32, 40)
+    with pytest.raises(GenCommHipError):
+        net({"inputs_m3": {"voxel_features": vf, "voxel_coords": vc, "voxel_num_points": vn}}, "m3")
