@@ -88,7 +88,8 @@ _SIGNATURES = {
     "gencomm_sp_out_dims": (_i, [_p, _p, _p, _p, _p]),
     "gencomm_sp_index_workspace_bytes": (_ll, [_i]),
     "gencomm_sp_index_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _ll, _p]),
-    "gencomm_sp_sites_workspace_bytes": (_ll, [_i, _p]),
+    "gencomm_sp_sites_capacity": (_ll, [_i, _p, _p]),
+    "gencomm_sp_sites_workspace_bytes": (_ll, [_i, _p, _p]),
     "gencomm_sp_sites_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
     "gencomm_sp_rules_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "gencomm_sp_prepared_floats": (_ll, [_i, _i, _i]),

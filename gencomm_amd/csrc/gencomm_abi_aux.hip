@@ -167,7 +167,7 @@ int gencomm_sp_index_fwd(const int* coords_bzyx, int n, int B, const int* dims3,
   int* val = reinterpret_cast<int*>(wsp + w.val);
   sp_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(coords_bzyx, n, g, key, val);
   size_t tb = w.temp_bytes;
-  GC_HIP(rocprim::radix_sort_pairs(wsp + w.temp, tb, key, keys, val, perm, (size_t)n, 0, 64, st));
+  GC_HIP(rocprim::radix_sort_pairs(wsp + w.temp, tb, key, keys, val, perm, (size_t)n, 0, 63, st));   // keys are non-negative; out-of-grid rows carry kSpNoKey
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -185,11 +185,21 @@ int gencomm_sp_rules_fwd(const long long* out_keys, int n_out, const long long* 
   return GC_OK;
 }
 
-long long gencomm_sp_sites_workspace_bytes(int n_in, const int* kernel3) {
-  if (n_in < 0 || kernel3 == nullptr) { fail(GC_ERR_ARG, "bad arguments"); return -1; }
-  return (long long)sp_sites_ws((long long)n_in * kernel3[0] * kernel3[1] * kernel3[2]).total;
+static long long sp_slots(const int* kernel3, const int* stride3) {
+  long long s = 1;
+  for (int j = 0; j < 3; ++j) s *= (kernel3[j] + stride3[j] - 1) / stride3[j];
+  return s;
 }
-// out_keys must hold n_in * K entries (the upper bound); *n_out (device) receives the number of output sites
+long long gencomm_sp_sites_capacity(int n_in, const int* kernel3, const int* stride3) {
+  if (n_in < 0 || !kernel3 || !stride3 || stride3[0] < 1 || stride3[1] < 1 || stride3[2] < 1) { fail(GC_ERR_ARG, "bad arguments"); return -1; }
+  return (long long)n_in * sp_slots(kernel3, stride3);
+}
+long long gencomm_sp_sites_workspace_bytes(int n_in, const int* kernel3, const int* stride3) {
+  const long long cap = gencomm_sp_sites_capacity(n_in, kernel3, stride3);
+  if (cap < 0) return -1;
+  return (long long)sp_sites_ws(cap).total;
+}
+// out_keys must hold gencomm_sp_sites_capacity entries (the upper bound); *n_out (device) receives the number of output sites
 int gencomm_sp_sites_fwd(const long long* in_keys, int n_in, int B, const int* in_dims3, const int* kernel3, const int* stride3, const int* pad3,
                          long long* out_keys, int* n_out, void* workspace, long long workspace_bytes, void* stream) {
   SpConvGeom g{};
@@ -201,20 +211,25 @@ int gencomm_sp_sites_fwd(const long long* in_keys, int n_in, int B, const int* i
     return GC_OK;
   }
   GC_CHECK_ARG(in_keys && out_keys && workspace, "null pointer");
-  const int K = g.k[0] * g.k[1] * g.k[2];
-  const long long nc = (long long)n_in * K;
+  SpSlots sl{};
+  for (int j = 0; j < 3; ++j) sl.n[j] = sp_slot_count(g, j);
+  const int slots = sl.n[0] * sl.n[1] * sl.n[2];
+  const long long nc = (long long)n_in * slots;
   GC_CHECK_ARG(nc < (1LL << 31), "too many candidate sites");
   const SpSitesWs w = sp_sites_ws(nc);
   if ((long long)w.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (gencomm_sp_sites_workspace_bytes)");
+  const long long nokey = (long long)B * g.out.D * g.out.H * g.out.W;   // one past the largest key
+  int bits = 1;
+  while ((1LL << bits) <= nokey) ++bits;                                // radix passes over the bits in use only
   char* wsp = (char*)workspace;
   long long* cand = reinterpret_cast<long long*>(wsp + w.cand);
   long long* sorted = reinterpret_cast<long long*>(wsp + w.sorted);
-  sp_candidates_kernel<<<dim3((n_in + 255) / 256, K), 256, 0, st>>>(in_keys, n_in, g, cand);
+  sp_candidates_kernel<<<dim3((n_in + 255) / 256, slots), 256, 0, st>>>(in_keys, n_in, g, sl, nokey, cand);
   size_t tb = w.temp_bytes;
-  GC_HIP(rocprim::radix_sort_keys(wsp + w.temp, tb, cand, sorted, (size_t)nc, 0, 64, st));
+  GC_HIP(rocprim::radix_sort_keys(wsp + w.temp, tb, cand, sorted, (size_t)nc, 0, bits, st));
   tb = w.temp_bytes;
   GC_HIP(rocprim::unique(wsp + w.temp, tb, sorted, out_keys, n_out, (size_t)nc, rocprim::equal_to<long long>(), st));
-  sp_fix_count_kernel<<<1, 64, 0, st>>>(out_keys, n_out);
+  sp_fix_count_kernel<<<1, 64, 0, st>>>(out_keys, nokey, n_out);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

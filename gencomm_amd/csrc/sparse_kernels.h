@@ -81,30 +81,39 @@ __global__ __launch_bounds__(256) void sp_rules_kernel(const long long* __restri
   nbr[(size_t)o * n_out + j] = res;
 }
 
-// candidate output sites of a strided SparseConv3d: one per (input site, kernel offset)
-__global__ __launch_bounds__(256) void sp_candidates_kernel(const long long* __restrict__ in_keys, int n_in, const SpConvGeom g, long long* __restrict__ cand) {
+// candidate output sites of a strided SparseConv3d.  Along an axis only the kernel offsets congruent to (coord + pad)
+// modulo the stride reach an output position: ceil(k / stride) slots per axis instead of k (8 instead of 27 for k 3,
+// stride 2).  Invalid slots get `nokey` = number of cells of the output grid (sorts last, needs no extra key bits).
+struct SpSlots {
+  int n[3];   // slots per axis
+};
+__host__ __device__ inline int sp_slot_count(const SpConvGeom& g, int j) { return (g.k[j] + g.stride[j] - 1) / g.stride[j]; }
+__global__ __launch_bounds__(256) void sp_candidates_kernel(const long long* __restrict__ in_keys, int n_in, const SpConvGeom g, const SpSlots sl,
+                                                            long long nokey, long long* __restrict__ cand) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int o = blockIdx.y;
+  const int slot = blockIdx.y;
   if (i >= n_in) return;
   const long long key = in_keys[i];
-  long long res = kSpNoKey;
+  long long res = nokey;
   if (key != kSpNoKey) {
     int b, z, y, x;
     sp_decode(g.in, key, b, z, y, x);
-    const int kx = o % g.k[2], ky = (o / g.k[2]) % g.k[1], kz = o / (g.k[2] * g.k[1]);
-    const int tz = z + g.pad[0] - kz, ty = y + g.pad[1] - ky, tx = x + g.pad[2] - kx;
-    if (tz >= 0 && ty >= 0 && tx >= 0 && tz % g.stride[0] == 0 && ty % g.stride[1] == 0 && tx % g.stride[2] == 0) {
+    const int sx = slot % sl.n[2], sy = (slot / sl.n[2]) % sl.n[1], sz = slot / (sl.n[2] * sl.n[1]);
+    const int kz = (z + g.pad[0]) % g.stride[0] + sz * g.stride[0], ky = (y + g.pad[1]) % g.stride[1] + sy * g.stride[1],
+              kx = (x + g.pad[2]) % g.stride[2] + sx * g.stride[2];
+    const int tz = z + g.pad[0] - kz, ty = y + g.pad[1] - ky, tx = x + g.pad[2] - kx;   // multiples of the stride by construction
+    if (kz < g.k[0] && ky < g.k[1] && kx < g.k[2] && tz >= 0 && ty >= 0 && tx >= 0) {
       const int oz = tz / g.stride[0], oy = ty / g.stride[1], ox = tx / g.stride[2];
       if (oz < g.out.D && oy < g.out.H && ox < g.out.W) res = sp_encode(g.out, b, oz, oy, ox);
     }
   }
-  cand[(size_t)o * n_in + i] = res;
+  cand[(size_t)slot * n_in + i] = res;
 }
 // the unique pass keeps the "no key" value as one last entry: drop it from the count
-__global__ void sp_fix_count_kernel(const long long* __restrict__ keys, int* __restrict__ count) {
+__global__ void sp_fix_count_kernel(const long long* __restrict__ keys, long long nokey, int* __restrict__ count) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int c = *count;
-    if (c > 0 && keys[c - 1] == kSpNoKey) *count = c - 1;
+    if (c > 0 && keys[c - 1] >= nokey) *count = c - 1;
   }
 }
 
@@ -186,25 +195,39 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvArgs a) {
   constexpr int EPT = CIN / 4;                 // floats per thread and staging pass
   __shared__ float As[(CIN / 2) * 64 * 2];     // [cpair][site][2]
   __shared__ float Bs[(CIN / 2) * 64 * 2];     // [cpair][co][2]
+  __shared__ unsigned int s_mask;
   const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
   const int site0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
   const int sh = wv >> 1, ch = wv & 1;
   const bool co_live = co0 + ch * 32 < a.CoutP;   // wave-uniform
-  const int s_site = tid >> 2, s_q = tid & 3;     // staging: 4 threads per site row
-  const int gsite = site0 + s_site;
+  // staging: lane = site (consecutive lanes -> consecutive LDS words), wave = channel quarter
+  const int gsite = site0 + l;
+  const int c0 = wv * EPT;
+
+  // kernel offsets at which at least one site of this tile has a neighbour (K <= 32)
+  if (tid == 0) s_mask = 0u;
+  __syncthreads();
+  {
+    unsigned int m = 0u;
+    if (gsite < a.n_out)
+      for (int o = wv; o < a.K; o += 4) m |= (a.nbr[(size_t)o * a.n_out + gsite] >= 0) ? (1u << o) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d);
+    if (l == 0 && m) atomicOr(&s_mask, m);
+  }
+  __syncthreads();
+  unsigned int mask = s_mask;
 
   f32x16s acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  for (int o = 0; o < a.K; ++o) {
+  float va[EPT], vb[EPT];
+  auto fetch = [&](int o) {
     const int idx = gsite < a.n_out ? a.nbr[(size_t)o * a.n_out + gsite] : -1;
-    if (!__syncthreads_or(idx >= 0)) continue;   // nobody in this tile has a neighbour at this offset (also: previous MFMAs are done with LDS)
-    float va[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) va[e] = 0.f;
     if (idx >= 0) {
-      const float* __restrict__ src = a.x + (size_t)idx * a.Cin + s_q * EPT;
+      const float* __restrict__ src = a.x + (size_t)idx * a.Cin + c0;
       if constexpr (EPT % 4 == 0) {
         if (a.Cin == CIN) {
 #pragma unroll
@@ -214,35 +237,50 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvArgs a) {
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) if (s_q * EPT + e < a.Cin) va[e] = src[e];
+          for (int e = 0; e < EPT; ++e) if (c0 + e < a.Cin) va[e] = src[e];
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) if (s_q * EPT + e < a.Cin) va[e] = src[e];
+        for (int e = 0; e < EPT; ++e) if (c0 + e < a.Cin) va[e] = src[e];
       }
     }
+    // weight slab of this offset: (CIN / 2) rows of 128 floats (64 co x 2 k-lanes), consecutive threads = consecutive words
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const int c = s_q * EPT + e;
-      As[((c >> 1) * 64 + s_site) * 2 + (c & 1)] = va[e];
-    }
-    // weight slab of this offset: (CIN / 2) rows of 128 floats (64 co x 2 lanes)
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int i = tid * EPT + e;
+      const int i = e * 256 + tid;
       const int cp = i >> 7, rem = i & 127;
-      float v = 0.f;
-      if (co0 + (rem >> 1) < a.CoutP) v = a.w[(((size_t)o * (CIN / 2) + cp) * a.CoutP + co0) * 2 + rem];
-      Bs[i] = v;
+      vb[e] = (co0 + (rem >> 1) < a.CoutP) ? a.w[(((size_t)o * (CIN / 2) + cp) * a.CoutP + co0) * 2 + rem] : 0.f;
     }
-    __syncthreads();
-    if (co_live) {
+  };
+  auto commit = [&]() {
+    if constexpr (EPT >= 2) {
 #pragma unroll
-      for (int cp = 0; cp < CIN / 2; ++cp) {
-        const float av = As[(cp * 64 + sh * 32 + r) * 2 + h];
-        const float bv = Bs[(cp * 64 + ch * 32 + r) * 2 + h];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      for (int e = 0; e < EPT; e += 2)
+        *reinterpret_cast<float2*>(&As[(((c0 + e) >> 1) * 64 + l) * 2]) = make_float2(va[e], va[e + 1]);
+    } else {
+      As[((c0 >> 1) * 64 + l) * 2 + (c0 & 1)] = va[0];
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) Bs[e * 256 + tid] = vb[e];
+  };
+
+  if (mask != 0u) {
+    fetch(__builtin_ctz(mask));
+    while (true) {
+      __syncthreads();   // every wave is done with the previous offset's tiles
+      commit();
+      __syncthreads();
+      mask &= mask - 1u;
+      if (mask != 0u) fetch(__builtin_ctz(mask));   // next offset's rows and weights travel while the matrix cores run
+      if (co_live) {
+#pragma unroll
+        for (int cp = 0; cp < CIN / 2; ++cp) {
+          const float av = As[(cp * 64 + sh * 32 + r) * 2 + h];
+          const float bv = Bs[(cp * 64 + ch * 32 + r) * 2 + h];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
       }
+      if (mask == 0u) break;
     }
   }
   if (!co_live) return;
@@ -260,6 +298,7 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvArgs a) {
 }
 
 inline int sp_conv_enqueue(const SpConvArgs& a, hipStream_t st) {
+  if (a.K > 32) return fail(GC_ERR_ARG, "sparse conv: at most 32 kernel offsets (3 x 3 x 3)");
   const dim3 grid((a.n_out + 63) / 64, (a.CoutP + 63) / 64);
   if (a.Cin <= 4) sp_conv_kernel<4><<<grid, 256, 0, st>>>(a);
   else if (a.Cin <= 16) sp_conv_kernel<16><<<grid, 256, 0, st>>>(a);

@@ -23,6 +23,9 @@ from . import _lib
 from .runtime import f32c, ptr, require_gpu, stream_ptr, workspaces
 
 
+TRACE = None  # tools/second_bench.py sets a list here to collect (Cin, Cout, rulebook) per layer for the FLOP count
+
+
 def _i3(v: Sequence[int]):
     return (C.c_int * 3)(*[int(x) for x in v])
 
@@ -144,10 +147,11 @@ def sparse_conv_bn_relu(x: SparseTensor, conv: _SparseConvBase, bn: nn.BatchNorm
     else:
         od = (C.c_int * 3)()
         _lib.check(l.gencomm_sp_out_dims(_i3(x.shape), _i3(conv.kernel_size), _i3(conv.stride), _i3(conv.padding), od), "gencomm_sp_out_dims")
-        cap = max(x.n * K, 1)
+        cap = max(_lib.check_size(l.gencomm_sp_sites_capacity(x.n, _i3(conv.kernel_size), _i3(conv.stride)), "gencomm_sp_sites_capacity"), 1)
         keys = torch.empty(cap, dtype=torch.int64, device=dev)
-        count = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws = workspaces.get(dev, _lib.check_size(l.gencomm_sp_sites_workspace_bytes(x.n, _i3(conv.kernel_size)), "gencomm_sp_sites_workspace_bytes"), "sp_sites")
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = workspaces.get(dev, _lib.check_size(l.gencomm_sp_sites_workspace_bytes(x.n, _i3(conv.kernel_size), _i3(conv.stride)),
+                                                 "gencomm_sp_sites_workspace_bytes"), "sp_sites")
         _lib.check(l.gencomm_sp_sites_fwd(ptr(x.keys), x.n, x.batch, _i3(x.shape), _i3(conv.kernel_size), _i3(conv.stride), _i3(conv.padding),
                                           ptr(keys), ptr(count), ptr(ws), ws.numel(), st), "gencomm_sp_sites_fwd")
         n_out = int(count.item())                 # one host read per strided layer (spconv's indice generation does the same)
@@ -155,6 +159,8 @@ def sparse_conv_bn_relu(x: SparseTensor, conv: _SparseConvBase, bn: nn.BatchNorm
         nbr = _rules(keys, n_out, x, conv.kernel_size, conv.stride, conv.padding)
         out = SparseTensor(keys, None, x.batch, list(od))
     prep, ss = conv.prepared(bn, dev)
+    if TRACE is not None:
+        TRACE.append((conv.in_channels, conv.out_channels, nbr))
     y = torch.empty(out.n, conv.out_channels, dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_sp_conv_fwd(ptr(x.features), ptr(nbr), ptr(prep), ptr(ss[0]), ptr(ss[1]), ptr(y), out.n, K, conv.in_channels,
                                      conv.out_channels, int(relu), st), "gencomm_sp_conv_fwd")

@@ -352,7 +352,8 @@ int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* ou
  * pad3 = (z, y, x). spconv's arithmetic is not part of the reference checkout: parity unpinned, semantics as published
  * (SubMConv3d: output sites = input sites; SparseConv3d: every site whose receptive field holds an active input).
  *   gencomm_sp_index_fwd    coords [n][4] int32 (b, z, y, x) -> keys (sorted) and perm (sorted row -> input row)
- *   gencomm_sp_sites_fwd    output sites of a strided SparseConv3d: out_keys (capacity n_in * K, ascending), *n_out (device int)
+ *   gencomm_sp_sites_fwd    output sites of a strided SparseConv3d: out_keys (capacity gencomm_sp_sites_capacity, ascending),
+ *                           *n_out (device int)
  *   gencomm_sp_rules_fwd    rulebook nbr [K][n_out] int32: input row of out_coord * stride - pad + offset, -1 if inactive
  *                           (SubMConv3d: out_keys = in_keys, stride 1, pad = k / 2)
  *   gencomm_sp_prepare      weights -> kernel layout; layout 0 = spconv 2.x [Cout][kD][kH][kW][Cin], 1 = spconv 1.x
@@ -366,7 +367,8 @@ int gencomm_sp_out_dims(const int* in_dims3, const int* kernel3, const int* stri
 long long gencomm_sp_index_workspace_bytes(int n);
 int gencomm_sp_index_fwd(const int* coords_bzyx, int n, int B, const int* dims3, long long* keys, int* perm,
                          void* workspace, long long workspace_bytes, void* stream);
-long long gencomm_sp_sites_workspace_bytes(int n_in, const int* kernel3);
+long long gencomm_sp_sites_capacity(int n_in, const int* kernel3, const int* stride3);   /* entries out_keys must hold */
+long long gencomm_sp_sites_workspace_bytes(int n_in, const int* kernel3, const int* stride3);
 int gencomm_sp_sites_fwd(const long long* in_keys, int n_in, int B, const int* in_dims3, const int* kernel3, const int* stride3,
                          const int* pad3, long long* out_keys, int* n_out, void* workspace, long long workspace_bytes, void* stream);
 int gencomm_sp_rules_fwd(const long long* out_keys, int n_out, const long long* in_keys, int n_in, int B, const int* in_dims3,

@@ -65,7 +65,7 @@ def test_unsupported_blocks_fail_loudly():
     bad = copy.deepcopy(args); bad["fusion_method"] = "v2vnet"
     with pytest.raises(NotImplementedError):
         cls(bad)
-    bad = copy.deepcopy(args); bad["m1"]["core_method"] = "second"
+    bad = copy.deepcopy(args); bad["m1"]["core_method"] = "lift_splat_shoot"; bad["m1"]["sensor_type"] = "camera"
     with pytest.raises(NotImplementedError):
         cls(bad)
     with_comp = copy.deepcopy(args); with_comp["compressor"] = {"input_dim": 128, "compress_ratio": 2}
@@ -154,3 +154,59 @@ def test_v2xvit_shell_forward_runs_on_the_hip_path():
     sd = {k[len("fusion_net."):] if False else k: v.detach().cpu() for k, v in model.fusion_net.state_dict().items()}
     ref = V.v2xvit_fusion(sd, args["v2xvit"], seen["x"], rl, seen["aff"].cpu())
     assert_close(seen["out"].numpy(), ref.numpy(), 1e-4, 1e-5, "V2X-ViT fused map inside the shell")
+
+
+def _second_shell_args():
+    """m3 of opv2v/GenComm_yamls/gencomm/stage1/m3_att.yaml:101-133 (SECOND encoder, 0.1 m voxels, stride-1 first backbone block)
+    on the golden shell's lidar range."""
+    args = copy.deepcopy(_spec()["args"])
+    rng_ = args["lidar_range"]
+    args["m1"] = {"core_method": "second", "sensor_type": "lidar",
+                  "encoder_args": {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": rng_, "mean_vfe": {"num_point_features": 4},
+                                   "spconv": {"num_features_in": 4, "num_features_out": 64}, "map2bev": {"feature_num": 128}},
+                  "backbone_args": {"layer_nums": [3, 5, 8], "layer_strides": [1, 2, 2], "num_filters": [64, 128, 256],
+                                    "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128], "inplanes": 128},
+                  "shrink_header": {"kernal_size": [3], "stride": [2], "padding": [1], "dim": [128], "input_dim": 384}}
+    return args
+
+
+def test_second_shell_constructs_with_encoder_keys():
+    m = _resolve("heter_model_baseline_w_gencomm_stage1")(_second_shell_args())
+    keys = [k for k in m.state_dict() if k.startswith("encoder_m1.")]
+    assert "encoder_m1.spconv_block.conv_input.0.weight" in keys and "encoder_m1.spconv_block.conv_out.1.running_var" in keys
+    assert list(m.state_dict()["encoder_m1.spconv_block.conv4.0.0.weight"].shape) == [64, 3, 3, 3, 64]
+    assert list(m.state_dict()["backbone_m1.blocks.0.1.weight"].shape)[:2] == [64, 128]      # inplanes 128 = 64 channels x 2 height slices
+
+
+@pytest.mark.gpu
+def test_second_shell_forward_runs_on_the_hip_path():
+    """Stage-1 shell with the SECOND encoder end to end on the GPU (voxels -> sparse 3-D backbone -> BEV backbone -> GenComm ->
+    Enhancer -> AttFusion -> heads); the encoder's output inside the shell must equal the dense-volume oracle's."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import second_port as S
+    from test_second import _voxels
+    g = load_case("shell")
+    dev = "cuda:0"
+    args = _second_shell_args()
+    model = _resolve("heter_model_baseline_w_gencomm_stage1")(args).eval()
+    synth.fill_params_(model, int(g["weight_seed"]))
+    synth.fill_bn_stats_(model, int(g["bn_seed"]))
+    rl = [2, 1]
+    vf, vc, vn = _voxels(np.random.RandomState(11), [4000, 2500, 3000], 512, 256, 40)
+    enc_sd = {k[len("encoder_m1."):]: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("encoder_m1.")}
+    ref = S.second_forward(enc_sd, "", vf, vc, vn, [512, 256, 40])
+    model = model.to(dev)
+    ptm = synth.make_pairwise_t_matrix(rl, 5, int(g["pose_seed"]), max_shift=float(g["max_shift"]))
+    data = {"agent_modality_list": ["m1"] * sum(rl), "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(dev),
+            "inputs_m1": {"voxel_features": vf.to(dev), "voxel_coords": vc.to(dev), "voxel_num_points": vn.to(dev)}}
+    seen = {}
+    hook = model.encoder_m1.register_forward_hook(lambda mod, inp, out: seen.update(out=out.detach().cpu()))
+    with torch.no_grad(), shell_noise(model.gencomm, int(g["noise_seed"]), sum(rl), 128, 16, 32, dev):
+        out = model(data)
+    hook.remove()
+    assert list(seen["out"].shape) == [3, 128, 32, 64]
+    assert_close(seen["out"].numpy(), ref.numpy(), 1e-4, 1e-5, "SECOND output inside the shell")
+    assert list(out["cls_preds"].shape) == [2, 2, 16, 32] and list(out["pred_feature"].shape) == [3, 128, 16, 32]
+    for k in ("cls_preds", "reg_preds", "dir_preds", "pred_feature", "message"):
+        assert torch.isfinite(out[k]).all(), k
