@@ -4,7 +4,7 @@ GenComm (the T-step chain of UNet calls the reference's training branch back-pro
 HIP forward AND HIP backward -- ``UNetFunction`` wraps one UNet call (``gencomm_unet_fwd`` / ``gencomm_unet_bwd``: conv dgrad
 and wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample backward; only the call's inputs are saved, the backward
 re-runs the HIP forward with every intermediate kept), the sampler's affine updates between the calls are elementwise torch
-ops that autograd composes. The one piece of the UNet's backward that is not a HIP kernel is the timestep MLP on 32-vectors.
+ops that autograd composes.
 Gradients reach what the reference's do (training-branch row): the UNet weights, every row of ``conditions``
 and -- through the ego repeat -- the ego rows of ``spatial_features``.
 
@@ -44,11 +44,14 @@ def _resblocks_in_execution_order(unet):
 
 class UNetFunction(torch.autograd.Function):
     """x0_hat = DiffusionUNet(cat[cond, x_t], t): HIP forward (gencomm_unet_fwd) and HIP backward (gencomm_unet_bwd: conv
-    dgrad / wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample backward kernels, csrc/unet_bwd_kernels.h). Only the
-    inputs are saved; the backward pass re-runs the HIP forward with every intermediate kept."""
+    dgrad / wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample backward, timestep MLP backward; csrc/unet_bwd_kernels.h).
+    Only the inputs are saved; the backward pass re-runs the HIP forward with every intermediate kept.
+    `flat` is the UNet's parameters as ONE differentiable vector in the library's blob order (`DiffusionUNet.flat_params()`):
+    the backward returns one gradient blob per call, autograd sums T blobs and splits the sum once (instead of 146 small
+    accumulations per call)."""
 
     @staticmethod
-    def forward(ctx, unet, t_int, T, x_t, cond, *params):
+    def forward(ctx, unet, t_int, T, x_t, cond, flat):
         with torch.no_grad():
             out = unet(torch.cat([cond, x_t], dim=1), torch.full((x_t.shape[0],), float(t_int), device=x_t.device), T=T)
         ctx.unet, ctx.t_int, ctx.T = unet, int(t_int), int(T)
@@ -58,33 +61,10 @@ class UNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x_t, cond = ctx.saved_tensors
-        unet = ctx.unet
-        gx, gc, graw = unet.backward_call(x_t.detach().float().contiguous(), cond.detach().float().contiguous(), ctx.t_int,
-                                          grad_out.float().contiguous(), ctx.T)
-        named = dict(unet.named_parameters())
-        off = {name: (o, numel) for name, numel, o in unet._packed.table}
-        grads = {name: graw[o:o + numel].view_as(named[name]) for name, (o, numel) in off.items()}
-        # timestep path: d conv1.bias of every block is also the gradient of temb_proj(SiLU(temb)) (same for every sample)
-        blocks = _resblocks_in_execution_order(unet)
-        with torch.enable_grad():
-            leaves = [unet.temb.dense[0].weight, unet.temb.dense[0].bias, unet.temb.dense[1].weight, unet.temb.dense[1].bias]
-            leaves += [p for _, blk in blocks for p in (blk.temb_proj.weight, blk.temb_proj.bias)]
-            local = [p.detach().requires_grad_(True) for p in leaves]
-            half = unet.ch // 2
-            freq = torch.exp(torch.arange(half, dtype=torch.float32, device=x_t.device) * -(math.log(10000) / (half - 1)))
-            ang = float(ctx.t_int) * freq
-            temb = torch.cat([torch.sin(ang), torch.cos(ang)])
-            temb = F.linear(temb, local[0], local[1])
-            temb = _silu(F.linear(_silu(temb), local[2], local[3]))
-            outs = [F.linear(temb, local[4 + 2 * i], local[5 + 2 * i]) for i in range(len(blocks))]
-            gouts = [grads[f"{key}.conv1.bias"] for key, _ in blocks]
-            tg = torch.autograd.grad(outs, local, gouts)
-        tnames = ["temb.dense.0.weight", "temb.dense.0.bias", "temb.dense.1.weight", "temb.dense.1.bias"]
-        tnames += [f"{key}.temb_proj.{w}" for key, _ in blocks for w in ("weight", "bias")]
-        for name, g in zip(tnames, tg):
-            grads[name] = g
-        gp = [grads[name] if p.requires_grad else None for name, p in unet.named_parameters()]
-        return (None, None, None, gx if ctx.needs_input_grad[3] else None, gc if ctx.needs_input_grad[4] else None, *gp)
+        gx, gc, graw = ctx.unet.backward_call(x_t.detach().float().contiguous(), cond.detach().float().contiguous(), ctx.t_int,
+                                              grad_out.float().contiguous(), ctx.T)
+        return (None, None, None, gx if ctx.needs_input_grad[3] else None, gc if ctx.needs_input_grad[4] else None,
+                graw if ctx.needs_input_grad[5] else None)
 
 
 def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise):
@@ -92,10 +72,10 @@ def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise
     elementwise torch ops; autograd composes the T steps. `step_noise[i]` is the noise of the i-th loop iteration."""
     T = gen.num_timesteps
     idx = torch.as_tensor(list(src_rows), dtype=torch.long, device=feat.device)
-    params = list(gen.denoiser.parameters())
+    flat = gen.denoiser.flat_params()
     x = gen.sqrt_alphas_cumprod[T - 1] * feat.index_select(0, idx) + gen.sqrt_one_minus_alphas_cumprod[T - 1] * noise0
     for i, t in enumerate(reversed(range(T))):
-        x0 = UNetFunction.apply(gen.denoiser, t, T, x, cond, *params)
+        x0 = UNetFunction.apply(gen.denoiser, t, T, x, cond, flat)
         if t == 0:
             return x0
         x = gen.posterior_mean_coef1[t] * x0 + gen.posterior_mean_coef2[t] * x \

@@ -241,7 +241,9 @@ int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, 
   if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
   const UNetBwdWs bw = unet_bwd_ws(p, w, n, H, W);
   if ((long long)bw.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_unet_bwd_workspace_bytes)");
+  const std::vector<DgradEntry> dg = dgrad_entries(p);
   UNetBwdCall b{UNetCall{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()}, &bw, raw, grad_raw};
+  b.dg = &dg;
   GC_CHECK_ARG(!b.c.m.bf16(), "gencomm_unet_bwd reads fp32 intermediates: not available in bf16 denoise mode (GENCOMM_MODE_ARITH = 2)");
   return unet_bwd_enqueue(b, x_t, cond, t, grad_x0, grad_xt, grad_cond);
 }

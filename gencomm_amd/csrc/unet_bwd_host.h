@@ -8,6 +8,34 @@
 
 namespace gc {
 
+// dgrad weight table of one UNet call: every 3x3 stride-1 layer's input-gradient weights, in the order the backward walk uses
+// them (conv_out, then per op from the last to the first; conv_in contributes two entries: cond channels, x channels)
+struct DgradEntry { long long w_off; int cout, cin, ic0, nic; long long p_off; };
+inline std::vector<DgradEntry> dgrad_entries(const UNetPlan& p) {
+  std::vector<DgradEntry> e;
+  long long off = 0;
+  auto add = [&](long long w, int cout, int cin, int ic0, int nic) {
+    e.push_back(DgradEntry{w, cout, cin, ic0, nic, off});
+    off += (long long)align_up((size_t)cout * nic * 9, 64);
+  };
+  for (int oi = (int)p.ops.size() - 1; oi >= 0; --oi) {
+    const Op& o = p.ops[oi];
+    switch (o.kind) {
+      case OP_CONV_OUT: add(p.conv_out.w, p.C, 8, 0, 8); break;
+      case OP_RES_CONV2: add(p.blocks[o.blk].c2w, 8, 8, 0, 8); break;
+      case OP_RES_CONV1: add(p.blocks[o.blk].c1w, 8, p.blocks[o.blk].cin, 0, p.blocks[o.blk].cin); break;
+      case OP_UP: add(p.up[o.level + 1].w, 8, 8, 0, 8); break;
+      case OP_CONV_IN: add(p.conv_in.w, 8, p.C + 2, 0, 2); add(p.conv_in.w, 8, p.C + 2, 2, p.C); break;
+      default: break;
+    }
+  }
+  return e;
+}
+inline size_t dgrad_table_floats(const UNetPlan& p) {
+  const std::vector<DgradEntry> e = dgrad_entries(p);
+  return e.empty() ? 64 : (size_t)(e.back().p_off + (long long)align_up((size_t)e.back().cout * e.back().nic * 9, 64));
+}
+
 struct UNetBwdWs {
   size_t fwd_total, g_base, A, DA, red, wtmp, ones, zeros, total;
   std::vector<size_t> g_level_base;
@@ -26,8 +54,8 @@ inline UNetBwdWs unet_bwd_ws(const UNetPlan& p, const UNetWorkspace& w, int n, i
   const size_t map16 = (size_t)n * 16 * H * W * sizeof(float);
   b.A = take(map16);
   b.DA = take(map16);
-  b.red = take((size_t)n * 16 * 2 * sizeof(double));
-  b.wtmp = take((size_t)(p.C + 16) * 9 * 16 * sizeof(float));
+  b.red = take((size_t)kMaxGnUses * n * 16 * sizeof(double));
+  b.wtmp = take(dgrad_table_floats(p) * sizeof(float));
   b.ones = take((size_t)(p.C + 16) * sizeof(float));
   b.zeros = take((size_t)(p.C + 16) * sizeof(float));
   b.total = off;
@@ -44,17 +72,21 @@ struct UNetBwdCall {
     return reinterpret_cast<float*>(c.wsp + bw->g_level_base[t.level] + c.ws->slot_bytes[t.level] * t.slot);
   }
   float* F(size_t off) const { return reinterpret_cast<float*>(c.wsp + off); }
+  // walk state: next entry of the dgrad weight table, GroupNorm uses recorded for the batched parameter-gradient kernel
+  const std::vector<DgradEntry>* dg = nullptr;
+  mutable size_t dg_next = 0;
+  mutable GnParamArgs gp{};
 };
 
 // out[n][Cout][H][W] = 3x3 stride-1 pad-1 convolution of dy[n][Cin_d][H][W] with the input-gradient weights of a forward
 // layer w [Cout_f = Cin_d][Cin_f][3][3], restricted to forward input channels [ic0, ic0 + nic)
 inline int dgrad3x3_enqueue(const UNetBwdCall& b, const float* dy, const float* w_fwd, int Cout_f, int Cin_f, int ic0, int nic,
                             float* out, int out_ctotal, int out_coff, int n, int H, int W) {
-  hipStream_t st = b.c.st;
-  float* P = b.F(b.bw->wtmp);
-  prep_dgrad_w_kernel<<<cdiv(Cout_f * nic * 9, 256), 256, 0, st>>>(w_fwd, P, Cout_f, Cin_f, ic0, nic);
-  Conv2dArgs a{dy, P, b.F(b.bw->ones), b.F(b.bw->zeros), out, Cout_f, H, W, nic, H, W, 1, 1, 0, 1, out_ctotal, out_coff};
-  return conv2d_enqueue(a, n, 3, 3, st);
+  const DgradEntry& e = (*b.dg)[b.dg_next++];
+  if (b.raw + e.w_off != w_fwd || e.cout != Cout_f || e.cin != Cin_f || e.ic0 != ic0 || e.nic != nic)
+    return fail(GC_ERR_ARG, "gencomm_unet_bwd: dgrad weight table out of step with the backward walk");
+  Conv2dArgs a{dy, b.F(b.bw->wtmp) + e.p_off, b.F(b.bw->ones), b.F(b.bw->zeros), out, Cout_f, H, W, nic, H, W, 1, 1, 0, 1, out_ctotal, out_coff};
+  return conv2d_enqueue(a, n, 3, 3, b.c.st);
 }
 
 // SiLU(GN(x)) of one 8-channel source into A at channel offset coff (ctotal channels)
@@ -66,16 +98,17 @@ inline void gn_fwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma,
 }
 // G[src] += backward of SiLU(GN(src)) given dA (channels coff.. of a ctotal-channel tensor); d gamma / d beta accumulated
 inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, const float* beta, int gs, int HW, const float* dA, int ctotal,
-                          int coff, float* dgamma, float* dbeta) {
+                          int coff, long long dgamma_off, long long dbeta_off) {
   hipStream_t st = b.c.st;
-  double* red = reinterpret_cast<double*>(b.c.wsp + b.bw->red);
-  GC_HIP(hipMemsetAsync(red, 0, (size_t)b.c.n * 16 * sizeof(double), st));
+  const int u = b.gp.uses;
+  if (u >= kMaxGnUses) return fail(GC_ERR_ARG, "gencomm_unet_bwd: too many GroupNorm uses");
+  double* red = reinterpret_cast<double*>(b.c.wsp + b.bw->red) + (size_t)u * b.c.n * 16;   // zeroed once per call
+  b.gp.dgamma[u] = (int)dgamma_off; b.gp.dbeta[u] = (int)dbeta_off; b.gp.uses = u + 1;
   GnArgs g{};
   g.x = b.c.tensor_ptr(src_id); g.stat = b.c.stat_ptr(src_id); g.gamma = gamma; g.beta = beta; g.da = dA; g.out = b.G(src_id); g.red = red;
   g.inv_cnt = 1.0 / ((double)gs * HW); g.gs = gs; g.HW = HW; g.da_ctotal = ctotal; g.da_coff = coff;
   gn_silu_bwd_reduce_kernel<<<dim3(std::min(cdiv(HW, 256), 64), 8, b.c.n), 256, 0, st>>>(g);
   gn_silu_bwd_apply_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, st>>>(g);
-  gn_param_grad_kernel<<<1, 64, 0, st>>>(red, b.c.n, dgamma, dbeta);
   return GC_OK;
 }
 
@@ -96,6 +129,23 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
   size_t gbytes = 0;
   for (int l = 0; l < p.L; ++l) gbytes += c.ws->slot_bytes[l] * p.slots_per_level[l];
   GC_HIP(hipMemsetAsync(c.wsp + b.bw->g_base, 0, gbytes, st));
+  GC_HIP(hipMemsetAsync(c.wsp + b.bw->red, 0, (size_t)kMaxGnUses * n * 16 * sizeof(double), st));
+  {
+    const std::vector<DgradEntry>& e = *b.dg;
+    if ((int)e.size() > kMaxDgradLayers) return fail(GC_ERR_ARG, "gencomm_unet_bwd: too many layers");
+    PrepDgradArgs pa{};
+    pa.raw = b.raw; pa.P = b.F(b.bw->wtmp); pa.layers = (int)e.size();
+    int most = 0;
+    for (size_t i = 0; i < e.size(); ++i) {
+      pa.w_off[i] = (int)e[i].w_off; pa.p_off[i] = (int)e[i].p_off;
+      pa.cout[i] = (short)e[i].cout; pa.cin[i] = (short)e[i].cin; pa.ic0[i] = (short)e[i].ic0; pa.nic[i] = (short)e[i].nic;
+      most = std::max(most, e[i].cout * e[i].nic * 9);
+    }
+    prep_dgrad_all_kernel<<<dim3(std::min(cdiv(most, 256), 8), (unsigned)e.size()), 256, 0, st>>>(pa);
+  }
+  b.dg_next = 0;
+  b.gp = GnParamArgs{};
+  b.gp.red = reinterpret_cast<const double*>(c.wsp + b.bw->red); b.gp.graw = b.graw; b.gp.n = n;
   fill_kernel<<<cdiv(C + 16, 256), 256, 0, st>>>(b.F(b.bw->ones), 1.0f, C + 16);
   GC_HIP(hipMemsetAsync(b.F(b.bw->zeros), 0, (size_t)(C + 16) * sizeof(float), st));
   float* A = b.F(b.bw->A);
@@ -111,7 +161,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         WgradArgs wa{grad_x0, A, nullptr, b.graw + p.conv_out.w, b.graw + p.conv_out.b, C, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad3x3_enqueue(b, grad_x0, b.raw + p.conv_out.w, C, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
-        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, DA, 8, 0, b.graw + p.nout_w, b.graw + p.nout_b)) return rc;
+        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, DA, 8, 0, p.nout_w, p.nout_b)) return rc;
         break;
       }
       case OP_RES_CONV2: {
@@ -122,7 +172,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         WgradArgs wa{go, A, nullptr, b.graw + rb.c2w, b.graw + rb.c2b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad3x3_enqueue(b, go, b.raw + rb.c2w, 8, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
-        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, b.graw + rb.n2w, b.graw + rb.n2b)) return rc;
+        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, rb.n2w, rb.n2b)) return rc;
         if (rb.cin == 8) {
           axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
         } else {
@@ -143,7 +193,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         if (int rc = dgrad3x3_enqueue(b, gt, b.raw + rb.c1w, 8, rb.cin, 0, rb.cin, DA, rb.cin, 0, n, Hl, Wl)) return rc;
         for (int s = 0; s < nsrc; ++s)
           if (int rc = gn_bwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, DA, rb.cin, 8 * s,
-                                      b.graw + rb.n1w + 8 * s, b.graw + rb.n1b + 8 * s)) return rc;
+                                      rb.n1w + 8 * s, rb.n1b + 8 * s)) return rc;
         break;
       }
       case OP_DOWN: {
@@ -175,6 +225,15 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
       case OP_ATTN:
         return fail(GC_ERR_ARG, "gencomm_unet_bwd: AttnBlock backward is not implemented (attn_mask must be 0)");
     }
+  }
+  if (b.gp.uses > 0) gn_param_grad_all_kernel<<<b.gp.uses, 64, 0, st>>>(b.gp);
+  {
+    // timestep MLP: needs every block's d conv1.bias (the wgrad launches above), adds the temb.dense / temb_proj gradients
+    TembBwdArgs ta{};
+    ta.raw = b.raw; ta.graw = b.graw; ta.d0w = p.d0w; ta.d0b = p.d0b; ta.d1w = p.d1w; ta.d1b = p.d1b;
+    ta.nblocks = (int)p.blocks.size(); ta.t = t;
+    for (size_t i = 0; i < p.blocks.size(); ++i) { ta.tpw[i] = p.blocks[i].tpw; ta.tpb[i] = p.blocks[i].tpb; ta.c1b[i] = p.blocks[i].c1b; }
+    temb_bwd_kernel<<<1, 64, 0, st>>>(ta);
   }
   GC_HIP(hipGetLastError());
   return GC_OK;

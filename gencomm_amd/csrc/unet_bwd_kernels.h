@@ -88,14 +88,87 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const GnArgs a) 
   }
 }
 
-// d gamma[c] += sum_n red[n][c][1], d beta[c] += sum_n red[n][c][0]
-__global__ void gn_param_grad_kernel(const double* __restrict__ red, int n, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = threadIdx.x;
+// d gamma[c] += sum_n red[n][c][1], d beta[c] += sum_n red[n][c][0] for EVERY GroupNorm use of a UNet call at once: the
+// backward walk gives each use its own slot of the reduction table and this kernel runs after the walk (one launch
+// instead of one per GroupNorm).  blockIdx.x = use.
+constexpr int kMaxGnUses = 192;
+struct GnParamArgs {
+  const double* red;   // [uses][n][8][2]
+  float* graw;
+  int n, uses;
+  int dgamma[kMaxGnUses], dbeta[kMaxGnUses];   // float offsets into graw
+};
+__global__ __launch_bounds__(64) void gn_param_grad_all_kernel(const GnParamArgs a) {
+  const int u = blockIdx.x, c = threadIdx.x;
   if (c >= 8) return;
+  const double* __restrict__ red = a.red + (size_t)u * a.n * 16;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < n; ++i) { s1 += red[((size_t)i * 8 + c) * 2 + 0]; s2 += red[((size_t)i * 8 + c) * 2 + 1]; }
-  dgamma[c] += (float)s2;
-  dbeta[c] += (float)s1;
+  for (int i = 0; i < a.n; ++i) { s1 += red[((size_t)i * 8 + c) * 2 + 0]; s2 += red[((size_t)i * 8 + c) * 2 + 1]; }
+  atomicAdd(&a.graw[a.dgamma[u] + c], (float)s2);   // two uses never share a parameter, but the blob is "+=" by contract
+  atomicAdd(&a.graw[a.dbeta[u] + c], (float)s1);
+}
+
+// Timestep path backwards (unet.py:309-312, :124): the timestep term only shifts conv1's bias, so d conv1.bias of block b
+// (already in graw, summed over the samples: every sample has the same t) is the gradient of temb_proj_b(SiLU(temb)).
+//   emb -> h0 = W0 emb + b0 -> a0 = SiLU(h0) -> h1 = W1 a0 + b1 -> a1 = SiLU(h1) -> proj_b = Wp_b a1 + bp_b
+// One workgroup; gradients are ADDED to graw at the parameters' raw offsets.
+struct TembBwdArgs {
+  const float* raw;
+  float* graw;
+  long long d0w, d0b, d1w, d1b;
+  long long tpw[kMaxResBlocks], tpb[kMaxResBlocks], c1b[kMaxResBlocks];
+  int nblocks, t;
+};
+__global__ __launch_bounds__(64) void temb_bwd_kernel(const TembBwdArgs a) {
+  __shared__ float e[8], h0[32], a0[32], h1[32], a1[32], da1[32], dh1[32], da0[32];
+  const int j = threadIdx.x;
+  if (j < 8) {
+    const int k = j & 3;
+    const float f = expf((float)k * -(9.210340371976184f / 3.0f));
+    const float ang = (float)a.t * f;
+    e[j] = j < 4 ? sinf(ang) : cosf(ang);
+  }
+  __syncthreads();
+  if (j < 32) {
+    float s = a.raw[a.d0b + j];
+    for (int k = 0; k < 8; ++k) s = fmaf(a.raw[a.d0w + j * 8 + k], e[k], s);
+    h0[j] = s; a0[j] = s / (1.0f + expf(-s));
+  }
+  __syncthreads();
+  if (j < 32) {
+    float s = a.raw[a.d1b + j];
+    for (int k = 0; k < 32; ++k) s = fmaf(a.raw[a.d1w + j * 32 + k], a0[k], s);
+    h1[j] = s; a1[j] = s / (1.0f + expf(-s));
+  }
+  __syncthreads();
+  // temb_proj of every block: d bias = g, d W[o][k] = g[o] a1[k], d a1[k] = sum_b sum_o W_b[o][k] g_b[o]
+  if (j < 32) {
+    float acc = 0.f;
+    for (int b = 0; b < a.nblocks; ++b)
+      for (int o = 0; o < 8; ++o) acc = fmaf(a.raw[a.tpw[b] + o * 32 + j], a.graw[a.c1b[b] + o], acc);
+    da1[j] = acc;
+  }
+  for (int i = j; i < a.nblocks * 8; i += 64) {
+    const int b = i >> 3, o = i & 7;
+    const float g = a.graw[a.c1b[b] + o];
+    a.graw[a.tpb[b] + o] += g;
+    for (int k = 0; k < 32; ++k) a.graw[a.tpw[b] + o * 32 + k] += g * a1[k];
+  }
+  __syncthreads();
+  auto dsilu = [](float z) { const float s = 1.0f / (1.0f + expf(-z)); return s * fmaf(z, 1.0f - s, 1.0f); };
+  if (j < 32) {
+    dh1[j] = da1[j] * dsilu(h1[j]);
+    a.graw[a.d1b + j] += dh1[j];
+    for (int k = 0; k < 32; ++k) a.graw[a.d1w + j * 32 + k] += dh1[j] * a0[k];
+  }
+  __syncthreads();
+  if (j < 32) {
+    float acc = 0.f;
+    for (int i = 0; i < 32; ++i) acc = fmaf(a.raw[a.d1w + i * 32 + j], dh1[i], acc);
+    da0[j] = acc * dsilu(h0[j]);   // = d h0
+    a.graw[a.d0b + j] += da0[j];
+    for (int k = 0; k < 8; ++k) a.graw[a.d0w + j * 8 + k] += da0[j] * e[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -176,12 +249,24 @@ inline int conv_wgrad_enqueue(const WgradArgs& a, int n, hipStream_t st) {
 
 // prepared weights (conv_kernels.h layout [(ci*9 + tap)][co]) of the INPUT-gradient convolution of a 3x3 stride-1 layer
 // with forward weights w [Cout][Cin][3][3]: dgrad input channels = forward oc, outputs = forward ic in [ic0, ic0 + nic),
-// taps flipped:  P[(oc*9 + (8 - tap))][ic - ic0] = w[oc][ic][tap]
-__global__ void prep_dgrad_w_kernel(const float* __restrict__ w, float* __restrict__ P, int Cout, int Cin, int ic0, int nic) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Cout * nic * 9) return;
-  const int icl = i % nic, k = i / nic, oc = k / 9, tp = k - oc * 9;
-  P[i] = w[((size_t)oc * Cin + ic0 + icl) * 9 + (8 - tp)];
+// taps flipped:  P[(oc*9 + (8 - tap))][ic - ic0] = w[oc][ic][tap].  Every layer of a UNet call in ONE launch (blockIdx.y = layer).
+constexpr int kMaxDgradLayers = 192;
+struct PrepDgradArgs {
+  const float* raw;
+  float* P;                      // base of the table
+  int layers;
+  int w_off[kMaxDgradLayers], p_off[kMaxDgradLayers];
+  short cout[kMaxDgradLayers], cin[kMaxDgradLayers], ic0[kMaxDgradLayers], nic[kMaxDgradLayers];
+};
+__global__ __launch_bounds__(256) void prep_dgrad_all_kernel(const PrepDgradArgs a) {
+  const int L = blockIdx.y;
+  const int Cin = a.cin[L], ic0 = a.ic0[L], nic = a.nic[L], total = a.cout[L] * nic * 9;
+  const float* __restrict__ w = a.raw + a.w_off[L];
+  float* __restrict__ P = a.P + a.p_off[L];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int icl = i % nic, k = i / nic, oc = k / 9, tp = k - oc * 9;
+    P[i] = w[((size_t)oc * Cin + ic0 + icl) * 9 + (8 - tp)];
+  }
 }
 
 // Downsample backward (pad right/bottom by one, 3x3 stride 2, no padding): G[src][ic](iy, ix) += sum over oc and the taps

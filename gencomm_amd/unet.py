@@ -133,14 +133,18 @@ class DiffusionUNet(nn.Module):
         """bit l = level l carries AttnBlocks (nominal resolution 128 >> l in attn_resolutions; unet.py:237,:252-253,:286)."""
         return self._attn_mask
 
+    def _ensure_packed(self) -> None:
+        if self._packed is None:
+            C, L, R, A = self.feature_channels, self.num_resolutions, self.num_res_blocks, self.attn_mask
+            table = _lib.unet_param_table(C, L, R, A)
+            self._packed = PackedParams(table, _lib.check_size(_lib.lib().gencomm_unet_raw_floats(C, L, R, A), "gencomm_unet_raw_floats"))
+
     def prepared_params(self, T: int, device: torch.device) -> torch.Tensor:
         """Device blob in kernel layout + the [block][t][8] timestep-bias tables for t < T."""
         self._check_supported()
         l = _lib.lib()
         C, L, R, A = self.feature_channels, self.num_resolutions, self.num_res_blocks, self.attn_mask
-        if self._packed is None:
-            table = _lib.unet_param_table(C, L, R, A)
-            self._packed = PackedParams(table, _lib.check_size(l.gencomm_unet_raw_floats(C, L, R, A), "gencomm_unet_raw_floats"))
+        self._ensure_packed()
         named = dict(self.named_parameters())
         for p in named.values():
             require_gpu(p, "DiffusionUNet parameters")
@@ -184,6 +188,15 @@ class DiffusionUNet(nn.Module):
         return out
 
     # ------------------------------------------------------------------ HIP backward (training branch)
+    def flat_params(self) -> torch.Tensor:
+        """Every parameter as one differentiable float32 vector in the order / layout of the library's raw blob
+        (``gencomm_unet_param_info``): the parameter input of ``autograd.UNetFunction``."""
+        self._ensure_packed()
+        named = dict(self.named_parameters())
+        flat = torch.cat([named[name].reshape(-1).float() for name, _, _ in self._packed.table])
+        assert flat.numel() == self._packed.total
+        return flat
+
     def backward_call(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, grad_x0: torch.Tensor, T: int):
         """One UNet call backwards through ``gencomm_unet_bwd``: returns (grad_xt, grad_cond, grad_raw) where ``grad_raw`` is the
         gradient of the packed parameter blob (``self._packed.table`` gives every parameter's offset)."""

@@ -112,9 +112,9 @@ int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, i
 /* One DiffusionUNet call BACKWARDS (the training branch back-propagates through every call: cond_diff.py:342-360; what
  * torch autograd does for unet.py:307-344 in the reference). Re-runs the forward with every intermediate kept, then:
  * grad_xt [n][C][H][W] and grad_cond [n][2][H][W] are OVERWRITTEN with the gradients w.r.t. the two inputs; grad_raw
- * (gencomm_unet_raw_floats floats, the raw blob's layout) is ACCUMULATED (+=) with the gradients of conv / norm / nin
- * parameters. The timestep path enters the forward only through each ResnetBlock's conv1 bias, so its gradient is the one
- * accumulated at `<block>.conv1.bias`; the caller chains it through temb_proj / temb.dense (32-vectors) on the host.
+ * (gencomm_unet_raw_floats floats, the raw blob's layout) must be ZERO on entry and holds the gradient of EVERY parameter
+ * on return: conv / norm / nin parameters, and the timestep path (temb.dense.{0,1}, every <block>.temb_proj), which enters
+ * the forward only through each ResnetBlock's conv1 bias and is chained from this call's d conv1.bias by one small kernel.
  * `raw` = the parameter blob in the reference's layouts (what gencomm_unet_prepare consumed). attn_mask must be 0. */
 long long gencomm_unet_bwd_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask);
 int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,

@@ -56,7 +56,7 @@ def test_unet_call_backward_all_gradients_vs_oracle_autograd(C, H, W, n, levels,
     ref_out, _, pg, gx, gc = _oracle_grads(cfg, gen, x, cond, None, None, None, single_t=t)
     gen = gen.to(DEV)
     xd, cd = x.to(DEV).requires_grad_(True), cond.to(DEV).requires_grad_(True)
-    out = UNetFunction.apply(gen.denoiser, t, T, xd, cd, *list(gen.denoiser.parameters()))
+    out = UNetFunction.apply(gen.denoiser, t, T, xd, cd, gen.denoiser.flat_params())
     _close("x0_hat", out, ref_out, 1e-4)
     (out ** 2).mean().backward()
     worst = max(_close("grad x_t", xd.grad, gx), _close("grad cond", cd.grad, gc))
