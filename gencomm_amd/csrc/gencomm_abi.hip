@@ -506,6 +506,8 @@ int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, 
   GC_CHECK_ARG(N >= 1 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && (K == 1 || K == 3) && (stride == 1 || stride == 2) && pad >= 0, "bad dims");
   const int Ho = (Hi + 2 * pad - K) / stride + 1, Wo = (Wi + 2 * pad - K) / stride + 1;
   GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
+  if (K == 1 && stride == 1 && pad == 0 && Cin >= 32 && Cout >= 32)   // Linear layers: split-K GEMM on the matrix cores
+    return wgrad1x1_enqueue(dy, x, dw, db, N, Cin, Cout, Hi * Wi, (hipStream_t)stream);
   WgradArgs a{dy, x, nullptr, dw, db, Cout, Cin, 0, Ho, Wo, Hi, Wi, K, stride, pad, 0};
   return conv_wgrad_enqueue(a, N, (hipStream_t)stream);
 }
@@ -524,7 +526,7 @@ int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, flo
   hipStream_t st = (hipStream_t)stream;
   LnArgs a{x, gamma, nullptr, dy, dx, scratch, eps, C, HW, 0, accumulate};
   ln_nchw_bwd_kernel<<<dim3((HW + 255) / 256, n), 256, 0, st>>>(a);
-  ln_nchw_param_grad_kernel<<<C, 256, 0, st>>>(x, dy, scratch, dgamma, dbeta, n, C, HW);
+  ln_nchw_param_grad_kernel<<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 128)), 256, 0, st>>>(x, dy, scratch, dgamma, dbeta, n, C, HW);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -538,7 +540,7 @@ int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float*
 
 int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream) {
   GC_CHECK_ARG(x && dy && dw && n >= 1 && C >= 1 && C <= 65535 && H >= 1 && W >= 1, "bad arguments");
-  dwconv3x3_wgrad_kernel<<<C, 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
+  dwconv3x3_wgrad_kernel<<<dim3(C, (unsigned)std::min<long long>(((long long)n * H * W + 4095) / 4096, 128)), 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

@@ -69,13 +69,14 @@ __global__ __launch_bounds__(256) void ln_nchw_bwd_kernel(const LnArgs a) {
   }
 }
 
-// d gamma[c] += sum dy xhat, d beta[c] += sum dy : one workgroup per channel
+// d gamma[c] += sum dy xhat, d beta[c] += sum dy : grid (channel, pixel chunk); a chunk's partial sums (f64) are committed
+// with one f32 atomic per output
 __global__ __launch_bounds__(256) void ln_nchw_param_grad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean_rstd,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int C, int HW) {
   __shared__ double s_red[4][2];
   const int c = blockIdx.x, tid = threadIdx.x;
   double sg = 0.0, sb = 0.0;
-  for (long long i = tid; i < (long long)n * HW; i += 256) {
+  for (long long i = (long long)blockIdx.y * 256 + tid; i < (long long)n * HW; i += (long long)gridDim.y * 256) {
     const int s = (int)(i / HW), p = (int)(i - (long long)s * HW);
     const size_t e = ((size_t)s * C + c) * HW + p;
     const float d = dy[e];
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(256) void ln_nchw_param_grad_kernel(const float* __
   if ((tid & 63) == 0) { s_red[tid >> 6][0] = sg; s_red[tid >> 6][1] = sb; }
   __syncthreads();
   if (tid == 0) {
-    dgamma[c] += (float)(s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0]);
-    dbeta[c] += (float)(s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1]);
+    atomicAdd(&dgamma[c], (float)(s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0]));
+    atomicAdd(&dbeta[c], (float)(s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1]));
   }
 }
 
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
     }
   y[(size_t)nc * H * W + p] = acc;
 }
-// dw[c][tap] += sum_{n,p} dy[n][c](p) x[n][c](p + tap), db[c] += sum dy: one workgroup per channel
+// dw[c][tap] += sum_{n,p} dy[n][c](p) x[n][c](p + tap), db[c] += sum dy: grid (channel, pixel chunk), one f32 atomic per
+// output and workgroup
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                                               float* __restrict__ db, int n, int C, int H, int W) {
   __shared__ float s_red[4][10];
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
   float acc[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = 0.f;
-  for (long long i = tid; i < (long long)n * H * W; i += 256) {
+  for (long long i = (long long)blockIdx.y * 256 + tid; i < (long long)n * H * W; i += (long long)gridDim.y * 256) {
     const int s = (int)(i / (H * W)), p = (int)(i - (long long)s * H * W), h = p / W, x0 = p - h * W;
     const size_t base = ((size_t)s * C + c) * H * W;
     const float d = dy[base + p];
@@ -139,9 +141,105 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
   __syncthreads();
   if (tid < 10) {
     const float v = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-    if (tid < 9) dw[c * 9 + tid] += v;
-    else if (db != nullptr) db[c] += v;
+    if (tid < 9) atomicAdd(&dw[c * 9 + tid], v);
+    else if (db != nullptr) atomicAdd(&db[c], v);
   }
+}
+
+// Weight gradient of a 1x1 convolution (= Linear over NCHW pixels) as a split-K GEMM on the matrix cores (exact fp32):
+//   dW[co][ci] += sum_{n,p} dY[n][co][p] X[n][ci][p],  dB[co] += sum dY.
+// M = 64 output channels x N = 64 input channels per workgroup (wave = one 32 x 32 block of v_mfma_f32_32x32x2_f32), K = a
+// chunk of pixels of one sample, walked in 64-pixel tiles staged through LDS (rows padded to 66 words: the MFMA operand
+// reads of 32 rows land in distinct banks); the chunk's 64 x 64 partial product is committed with f32 atomics.
+// grid = (pixel chunks x samples, Cout / 64, Cin / 64).
+struct Wgrad1x1Args {
+  const float* dy;   // [n][Cout][HW]
+  const float* x;    // [n][Cin][HW]
+  float* dw;         // [Cout][Cin] (+=)
+  float* db;         // [Cout] (+=) or null
+  int Cout, Cin, HW, chunk, chunks;
+};
+__global__ __launch_bounds__(256) void wgrad1x1_mfma_kernel(const Wgrad1x1Args a) {
+  constexpr int LD = 66;
+  __shared__ float sA[64 * LD];   // dY tile [co][px]
+  __shared__ float sB[64 * LD];   // X tile  [ci][px]
+  using f32x16t = __attribute__((ext_vector_type(16))) float;
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int n = blockIdx.x / a.chunks, ck = blockIdx.x - n * a.chunks;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int p_begin = ck * a.chunk, p_end = min(p_begin + a.chunk, a.HW);
+  const float* __restrict__ dyn = a.dy + (size_t)n * a.Cout * a.HW;
+  const float* __restrict__ xn = a.x + (size_t)n * a.Cin * a.HW;
+  const int mh = wv & 1, nh = wv >> 1;
+  f32x16t acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float bsum = 0.f;   // threads 0..63: bias gradient of row tid
+  // staging: thread -> (row = tid / 4 + 64 j? no: 16 floats per thread) rows of 64 pixels: 4 threads per row, 16 px each
+  const int srow = tid >> 2, sq = (tid & 3) * 16;
+  for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+    float va[16], vb[16];
+    const bool full = p0 + 64 <= p_end && (a.HW & 3) == 0;
+    {
+      const int co = co0 + srow, ci = ci0 + srow;
+      const float* __restrict__ pa = dyn + (size_t)co * a.HW + p0 + sq;
+      const float* __restrict__ pb = xn + (size_t)ci * a.HW + p0 + sq;
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+          const float4 u = co < a.Cout ? *reinterpret_cast<const float4*>(pa + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 w = ci < a.Cin ? *reinterpret_cast<const float4*>(pb + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+          va[e] = u.x; va[e + 1] = u.y; va[e + 2] = u.z; va[e + 3] = u.w;
+          vb[e] = w.x; vb[e + 1] = w.y; vb[e + 2] = w.z; vb[e + 3] = w.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool ok = p0 + sq + e < p_end;
+          va[e] = (ok && co < a.Cout) ? pa[e] : 0.f;
+          vb[e] = (ok && ci < a.Cin) ? pb[e] : 0.f;
+        }
+      }
+    }
+    __syncthreads();   // previous tile's MFMAs are done
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      *reinterpret_cast<float2*>(&sA[srow * LD + sq + e]) = make_float2(va[e], va[e + 1]);
+      *reinterpret_cast<float2*>(&sB[srow * LD + sq + e]) = make_float2(vb[e], vb[e + 1]);
+    }
+    __syncthreads();
+    if (a.db != nullptr && blockIdx.z == 0 && tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) s += sA[tid * LD + k];
+      bsum += s;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float av = sA[(mh * 32 + r) * LD + 2 * k + h];
+      const float bv = sB[(nh * 32 + r) * LD + 2 * k + h];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  // acc[reg]: row (co) = (reg & 3) + 8 (reg >> 2) + 4 h, column (ci) = r
+  const int ci = ci0 + nh * 32 + r;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int co = co0 + mh * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (co < a.Cout && ci < a.Cin) atomicAdd(&a.dw[(size_t)co * a.Cin + ci], acc[reg]);
+  }
+  if (a.db != nullptr && blockIdx.z == 0 && tid < 64 && co0 + tid < a.Cout) atomicAdd(&a.db[co0 + tid], bsum);
+}
+inline int wgrad1x1_enqueue(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Cout, int HW, hipStream_t st) {
+  Wgrad1x1Args a{dy, x, dw, db, Cout, Cin, HW, 0, 0};
+  a.chunk = 2048;
+  while (a.chunk > 256 && (long long)N * ((HW + a.chunk - 1) / a.chunk) < 256) a.chunk >>= 1;   // enough workgroups on small maps
+  a.chunks = (HW + a.chunk - 1) / a.chunk;
+  const dim3 grid((unsigned)(N * a.chunks), (Cout + 63) / 64, (Cin + 63) / 64);
+  if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "wgrad 1x1: too many channel blocks");
+  wgrad1x1_mfma_kernel<<<grid, 256, 0, st>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
 }
 
 // out = g * d/dv GELU(v)   (erf form, nn.GELU default):  0.5 (1 + erf(v / sqrt 2)) + v exp(-v^2 / 2) / sqrt(2 pi)

@@ -23,7 +23,7 @@ inline std::vector<DgradEntry> dgrad_entries(const UNetPlan& p) {
     switch (o.kind) {
       case OP_CONV_OUT: add(p.conv_out.w, p.C, 8, 0, 8); break;
       case OP_RES_CONV2: add(p.blocks[o.blk].c2w, 8, 8, 0, 8); break;
-      case OP_RES_CONV1: add(p.blocks[o.blk].c1w, 8, p.blocks[o.blk].cin, 0, p.blocks[o.blk].cin); break;
+      case OP_RES_CONV1: for (int s0 = 0; s0 < p.blocks[o.blk].cin; s0 += 8) add(p.blocks[o.blk].c1w, 8, p.blocks[o.blk].cin, s0, 8); break;
       case OP_UP: add(p.up[o.level + 1].w, 8, 8, 0, 8); break;
       case OP_CONV_IN: add(p.conv_in.w, 8, p.C + 2, 0, 2); add(p.conv_in.w, 8, p.C + 2, 2, p.C); break;
       default: break;
@@ -87,6 +87,23 @@ inline int dgrad3x3_enqueue(const UNetBwdCall& b, const float* dy, const float* 
     return fail(GC_ERR_ARG, "gencomm_unet_bwd: dgrad weight table out of step with the backward walk");
   Conv2dArgs a{dy, b.F(b.bw->wtmp) + e.p_off, b.F(b.bw->ones), b.F(b.bw->zeros), out, Cout_f, H, W, nic, H, W, 1, 1, 0, 1, out_ctotal, out_coff};
   return conv2d_enqueue(a, n, 3, 3, b.c.st);
+}
+
+// The same for an 8 -> 8 channel layer (forward output channels 8, forward input channels [ic0, ic0 + 8)) through the UNet's
+// own exact-fp32 8-channel kernel (conv8_kernel on v_mfma_f32_4x4x1, unet_kernels.h): the table entry for nic = 8,
+// [(oc * 9 + flipped tap)][8], IS that kernel's weight layout [ic][tap][oc].  out = [n][8][H][W].
+inline int dgrad8_enqueue(const UNetBwdCall& b, const float* dy, const float* w_fwd, int Cin_f, int ic0, float* out, int n, int H, int W) {
+  const DgradEntry& e = (*b.dg)[b.dg_next++];
+  if (b.raw + e.w_off != w_fwd || e.cout != 8 || e.cin != Cin_f || e.ic0 != ic0 || e.nic != 8)
+    return fail(GC_ERR_ARG, "gencomm_unet_bwd: dgrad weight table out of step with the backward walk");
+  Conv8Args a{};
+  a.src[0] = dy; a.w = b.F(b.bw->wtmp) + e.p_off; a.wh = nullptr; a.bias = b.F(b.bw->zeros); a.dst = out; a.dstat = nullptr;
+  a.H = a.Hin = H; a.W = a.Win = W;
+  a.xcd = b.c.m.xcd();
+  Modes mf = b.c.m;
+  mf.v[MODE_ARITH] = 1;   // exact fp32: gradients span many orders of magnitude
+  launch_conv8<1, false, false, 0>(mf, pick_tile(mf, n, H, W), a, n, b.c.st);
+  return GC_OK;
 }
 
 // SiLU(GN(x)) of one 8-channel source into A at channel offset coff (ctotal channels)
@@ -171,7 +188,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         gn_fwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, A, 8, 0);
         WgradArgs wa{go, A, nullptr, b.graw + rb.c2w, b.graw + rb.c2b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        if (int rc = dgrad3x3_enqueue(b, go, b.raw + rb.c2w, 8, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
+        if (int rc = dgrad8_enqueue(b, go, b.raw + rb.c2w, 8, 0, DA, n, Hl, Wl)) return rc;
         if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, rb.n2w, rb.n2b)) return rc;
         if (rb.cin == 8) {
           axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
@@ -190,9 +207,10 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         for (int s = 0; s < nsrc; ++s) gn_fwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, A, rb.cin, 8 * s);
         WgradArgs wa{gt, A, nullptr, b.graw + rb.c1w, b.graw + rb.c1b, 8, rb.cin, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        if (int rc = dgrad3x3_enqueue(b, gt, b.raw + rb.c1w, 8, rb.cin, 0, rb.cin, DA, rb.cin, 0, n, Hl, Wl)) return rc;
+        for (int s = 0; s < nsrc; ++s)   // one 8-channel input gradient per source, DA = [source][n][8][HW]
+          if (int rc = dgrad8_enqueue(b, gt, b.raw + rb.c1w, rb.cin, 8 * s, DA + (size_t)s * n * 8 * HW, n, Hl, Wl)) return rc;
         for (int s = 0; s < nsrc; ++s)
-          if (int rc = gn_bwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, DA, rb.cin, 8 * s,
+          if (int rc = gn_bwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, DA + (size_t)s * n * 8 * HW, 8, 0,
                                       rb.n1w + 8 * s, rb.n1b + 8 * s)) return rc;
         break;
       }
@@ -210,7 +228,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         const float* gu = b.G(o.dst);
         WgradArgs wa{gu, c.tensor_ptr(o.src[0]), nullptr, b.graw + p.up[lin].w, b.graw + p.up[lin].b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 1};
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        if (int rc = dgrad3x3_enqueue(b, gu, b.raw + p.up[lin].w, 8, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
+        if (int rc = dgrad8_enqueue(b, gu, b.raw + p.up[lin].w, 8, 0, DA, n, Hl, Wl)) return rc;
         sum2x2_add_kernel<<<cdiv(n * 8 * Hs * Ws, 256), 256, 0, st>>>(DA, b.G(o.src[0]), n * 8, Hs, Ws);
         break;
       }
