@@ -2,8 +2,8 @@
 
 GenComm (the T-step chain of UNet calls the reference's training branch back-propagates through, cond_diff.py:342-360):
 HIP forward AND HIP backward -- ``UNetFunction`` wraps one UNet call (``gencomm_unet_fwd`` / ``gencomm_unet_bwd``: conv dgrad
-and wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample backward; only the call's inputs are saved, the backward
-re-runs the HIP forward with every intermediate kept), the sampler's affine updates between the calls are elementwise torch
+and wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample / timestep-MLP backward; the forward keeps the call's
+intermediates in a workspace of its own, nothing is recomputed), the sampler's affine updates between the calls are elementwise torch
 ops that autograd composes.
 Gradients reach what the reference's do (training-branch row): the UNet weights, every row of ``conditions``
 and -- through the ego repeat -- the ego rows of ``spatial_features``.
@@ -45,7 +45,8 @@ def _resblocks_in_execution_order(unet):
 class UNetFunction(torch.autograd.Function):
     """x0_hat = DiffusionUNet(cat[cond, x_t], t): HIP forward (gencomm_unet_fwd) and HIP backward (gencomm_unet_bwd: conv
     dgrad / wgrad, GroupNorm+SiLU backward, nin / Downsample / Upsample backward, timestep MLP backward; csrc/unet_bwd_kernels.h).
-    Only the inputs are saved; the backward pass re-runs the HIP forward with every intermediate kept.
+    The forward keeps every intermediate of the call in a workspace of its own (288 GB of HBM: 0.5 GB per call at 4 x 64 x 200 x 704);
+    the backward reads them -- nothing is recomputed.
     `flat` is the UNet's parameters as ONE differentiable vector in the library's blob order (`DiffusionUNet.flat_params()`):
     the backward returns one gradient blob per call, autograd sums T blobs and splits the sum once (instead of 146 small
     accumulations per call)."""
@@ -53,16 +54,17 @@ class UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, unet, t_int, T, x_t, cond, flat):
         with torch.no_grad():
-            out = unet(torch.cat([cond, x_t], dim=1), torch.full((x_t.shape[0],), float(t_int), device=x_t.device), T=T)
-        ctx.unet, ctx.t_int, ctx.T = unet, int(t_int), int(T)
-        ctx.save_for_backward(x_t, cond)
+            xt, cd = x_t.detach().float().contiguous(), cond.detach().float().contiguous()
+            out, ws = unet.forward_train(xt, cd, int(t_int), int(T))
+        ctx.unet, ctx.t_int, ctx.T, ctx.ws = unet, int(t_int), int(T), ws   # the call's intermediates: no recomputation in backward
+        ctx.save_for_backward(xt, cd)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         x_t, cond = ctx.saved_tensors
-        gx, gc, graw = ctx.unet.backward_call(x_t.detach().float().contiguous(), cond.detach().float().contiguous(), ctx.t_int,
-                                              grad_out.float().contiguous(), ctx.T)
+        gx, gc, graw = ctx.unet.backward_call(x_t, cond, ctx.t_int, grad_out.float().contiguous(), ctx.T, ws=ctx.ws)
+        ctx.ws = None
         return (None, None, None, gx if ctx.needs_input_grad[3] else None, gc if ctx.needs_input_grad[4] else None,
                 graw if ctx.needs_input_grad[5] else None)
 

@@ -228,9 +228,34 @@ long long gencomm_unet_bwd_workspace_bytes(int n, int C, int H, int W, int level
   return (long long)unet_bwd_ws(p, w, n, H, W).total;
 }
 
+// The forward of a call that WILL be differentiated: every intermediate and its GroupNorm statistics are kept in `workspace`
+// (gencomm_unet_bwd_workspace_bytes), which the caller hands to gencomm_unet_bwd(forward_done = 1) later -- no recomputation.
+int gencomm_unet_fwd_train(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,
+                           int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
+                           void* workspace, long long workspace_bytes, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, T, true)) return fail(GC_ERR_ARG, e);
+  if (int rc = check_dims(n, C, H, W)) return rc;
+  GC_CHECK_ARG(attn_mask == 0, "gencomm_unet_fwd_train: AttnBlock backward is not implemented (attn_mask must be 0)");
+  GC_CHECK_ARG(prepared && x_t && cond && x0_out && workspace, "null pointer");
+  GC_CHECK_ARG(t >= 0 && t < T, "timestep out of range");
+  UNetWorkspace w;
+  if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
+  const UNetBwdWs bw = unet_bwd_ws(p, w, n, H, W);
+  if ((long long)bw.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_unet_bwd_workspace_bytes)");
+  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()};
+  GC_CHECK_ARG(!c.m.bf16(), "gencomm_unet_fwd_train keeps fp32 intermediates: not available in bf16 denoise mode (GENCOMM_MODE_ARITH = 2)");
+  GC_HIP(hipMemsetAsync(c.amax(), 0, 256, c.st));
+  amax_kernel<<<256, 256, 0, c.st>>>(cond, (long long)n * 2 * H * W, c.amax());
+  amax_kernel<<<1024, 256, 0, c.st>>>(x_t, (long long)n * C * H * W, c.amax() + 1);
+  ConvOutArgs co{};
+  co.out = x0_out;
+  return unet_enqueue(c, x_t, cond, t, 0, co);
+}
+
 int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
                      float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
-                     int attn_mask, int T, void* workspace, long long workspace_bytes, void* stream) {
+                     int attn_mask, int T, int forward_done, void* workspace, long long workspace_bytes, void* stream) {
   UNetPlan p;
   if (const char* e = p.build(C, levels, res_blocks, attn_mask, T, true)) return fail(GC_ERR_ARG, e);
   if (int rc = check_dims(n, C, H, W)) return rc;
@@ -245,7 +270,7 @@ int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, 
   UNetBwdCall b{UNetCall{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()}, &bw, raw, grad_raw};
   b.dg = &dg;
   GC_CHECK_ARG(!b.c.m.bf16(), "gencomm_unet_bwd reads fp32 intermediates: not available in bf16 denoise mode (GENCOMM_MODE_ARITH = 2)");
-  return unet_bwd_enqueue(b, x_t, cond, t, grad_x0, grad_xt, grad_cond);
+  return unet_bwd_enqueue(b, x_t, cond, t, grad_x0, grad_xt, grad_cond, forward_done != 0);
 }
 
 // One plain 8 -> 8 channel 3x3 convolution (stride 1, zero padding 1, bias, no norm, no residual) through the same

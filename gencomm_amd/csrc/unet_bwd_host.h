@@ -106,6 +106,14 @@ inline int dgrad8_enqueue(const UNetBwdCall& b, const float* dy, const float* w_
   return GC_OK;
 }
 
+// weight gradient whose input is SiLU(GroupNorm(.)) of one or two 8-channel forward tensors, applied in the staging
+inline void wgrad_gn_sources(const UNetBwdCall& b, WgradArgs& wa, int src0, int src1, const float* gamma, const float* beta, int gs, int HW) {
+  wa.x0 = b.c.tensor_ptr(src0);
+  wa.gn_stat[0] = b.c.stat_ptr(src0);
+  if (src1 >= 0) { wa.x1 = b.c.tensor_ptr(src1); wa.gn_stat[1] = b.c.stat_ptr(src1); }
+  wa.gn_gamma = gamma; wa.gn_beta = beta; wa.gn_gs = gs; wa.gn_inv_cnt = 1.0 / ((double)gs * HW);
+}
+
 // SiLU(GN(x)) of one 8-channel source into A at channel offset coff (ctotal channels)
 inline void gn_fwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, const float* beta, int gs, int HW, float* A, int ctotal, int coff) {
   GnArgs g{};
@@ -130,18 +138,20 @@ inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, 
 }
 
 inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float* cond, int t, const float* grad_x0,
-                            float* grad_xt, float* grad_cond) {
+                            float* grad_xt, float* grad_cond, bool forward_done) {
   const UNetCall& c = b.c;
   const UNetPlan& p = *c.plan;
   hipStream_t st = c.st;
   const int n = c.n, C = p.C;
   // ---- forward with every intermediate kept (x0_hat itself is not needed: it lands in grad_xt, overwritten below)
-  GC_HIP(hipMemsetAsync(c.amax(), 0, 256, st));
-  amax_kernel<<<256, 256, 0, st>>>(cond, (long long)n * 2 * c.H * c.W, c.amax());
-  amax_kernel<<<1024, 256, 0, st>>>(x_t, (long long)n * C * c.H * c.W, c.amax() + 1);
-  ConvOutArgs co{};
-  co.out = grad_xt;
-  if (int rc = unet_enqueue(c, x_t, cond, t, 0, co)) return rc;
+  if (!forward_done) {   // otherwise gencomm_unet_fwd_train left them in this workspace
+    GC_HIP(hipMemsetAsync(c.amax(), 0, 256, st));
+    amax_kernel<<<256, 256, 0, st>>>(cond, (long long)n * 2 * c.H * c.W, c.amax());
+    amax_kernel<<<1024, 256, 0, st>>>(x_t, (long long)n * C * c.H * c.W, c.amax() + 1);
+    ConvOutArgs co{};
+    co.out = grad_xt;
+    if (int rc = unet_enqueue(c, x_t, cond, t, 0, co)) return rc;
+  }
   // ---- gradient buffers, constants
   size_t gbytes = 0;
   for (int l = 0; l < p.L; ++l) gbytes += c.ws->slot_bytes[l] * p.slots_per_level[l];
@@ -165,7 +175,6 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
   b.gp.red = reinterpret_cast<const double*>(c.wsp + b.bw->red); b.gp.graw = b.graw; b.gp.n = n;
   fill_kernel<<<cdiv(C + 16, 256), 256, 0, st>>>(b.F(b.bw->ones), 1.0f, C + 16);
   GC_HIP(hipMemsetAsync(b.F(b.bw->zeros), 0, (size_t)(C + 16) * sizeof(float), st));
-  float* A = b.F(b.bw->A);
   float* DA = b.F(b.bw->DA);
 
   for (int oi = (int)p.ops.size() - 1; oi >= 0; --oi) {
@@ -174,8 +183,8 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
     switch (o.kind) {
       case OP_CONV_OUT: {
         // y = conv_out(SiLU(GN_out(h))) + b
-        gn_fwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, A, 8, 0);
-        WgradArgs wa{grad_x0, A, nullptr, b.graw + p.conv_out.w, b.graw + p.conv_out.b, C, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        WgradArgs wa{grad_x0, nullptr, nullptr, b.graw + p.conv_out.w, b.graw + p.conv_out.b, C, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        wgrad_gn_sources(b, wa, o.src[0], -1, b.raw + p.nout_w, b.raw + p.nout_b, 2, HW);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad3x3_enqueue(b, grad_x0, b.raw + p.conv_out.w, C, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
         if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, DA, 8, 0, p.nout_w, p.nout_b)) return rc;
@@ -185,8 +194,8 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         // out = shortcut(in) + conv2(SiLU(GN2(tmp))) + b2 (+ nin bias)
         const ResBlockPlan& rb = p.blocks[o.blk];
         const float* go = b.G(o.dst);
-        gn_fwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, A, 8, 0);
-        WgradArgs wa{go, A, nullptr, b.graw + rb.c2w, b.graw + rb.c2b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        WgradArgs wa{go, nullptr, nullptr, b.graw + rb.c2w, b.graw + rb.c2b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        wgrad_gn_sources(b, wa, o.src[0], -1, b.raw + rb.n2w, b.raw + rb.n2b, 2, HW);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad8_enqueue(b, go, b.raw + rb.c2w, 8, 0, DA, n, Hl, Wl)) return rc;
         if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, rb.n2w, rb.n2b)) return rc;
@@ -204,8 +213,8 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         const ResBlockPlan& rb = p.blocks[o.blk];
         const float* gt = b.G(o.dst);
         const int nsrc = rb.cin / 8, gs = rb.cin == 8 ? 2 : 4;
-        for (int s = 0; s < nsrc; ++s) gn_fwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, A, rb.cin, 8 * s);
-        WgradArgs wa{gt, A, nullptr, b.graw + rb.c1w, b.graw + rb.c1b, 8, rb.cin, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        WgradArgs wa{gt, nullptr, nullptr, b.graw + rb.c1w, b.graw + rb.c1b, 8, 8, nsrc == 2 ? 8 : 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        wgrad_gn_sources(b, wa, o.src[0], nsrc == 2 ? o.src[1] : -1, b.raw + rb.n1w, b.raw + rb.n1b, gs, HW);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         for (int s = 0; s < nsrc; ++s)   // one 8-channel input gradient per source, DA = [source][n][8][HW]
           if (int rc = dgrad8_enqueue(b, gt, b.raw + rb.c1w, rb.cin, 8 * s, DA + (size_t)s * n * 8 * HW, n, Hl, Wl)) return rc;

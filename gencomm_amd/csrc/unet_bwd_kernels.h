@@ -179,6 +179,13 @@ struct WgradArgs {
   float* dw;         // [Cout][c0 + c1][K][K]  (+=)
   float* db;         // [Cout] (+=) or null
   int Cout, c0, c1, Ho, Wo, Hi, Wi, K, stride, pad, up;
+  // optional: the input is SiLU(GroupNorm(x)) of 8-channel sources (x0 = first source, x1 = second), applied while the tile is
+  // staged -- the forward never materialises that tensor and neither does the backward
+  const double* gn_stat[2] = {nullptr, nullptr};   // [n][8][2] per source
+  const float* gn_gamma = nullptr;                 // [c0 + c1]
+  const float* gn_beta = nullptr;
+  double gn_inv_cnt = 0.0;
+  int gn_gs = 0;
 };
 
 template <int K, int STRIDE>
@@ -199,6 +206,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     sdy[o][r] = (oc < a.Cout && oy < a.Ho && ox < a.Wo) ? a.dy[(((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox] : 0.f;
   }
   const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+  __shared__ float s_gn[8][2];
+  const bool gn = a.gn_stat[0] != nullptr;   // 8-channel sources: chunk ich is source ich
+  if (gn) {
+    if (tid < 8) {
+      const int ic = ich * 8 + tid;
+      float A = 0.f, B = 0.f;
+      if (ic < Cin) gn_coeff(a.gn_stat[ic < a.c0 ? 0 : 1] + (size_t)n * 16, tid, a.gn_gs, a.gn_inv_cnt, a.gn_gamma[ic], a.gn_beta[ic], &A, &B);
+      s_gn[tid][0] = A; s_gn[tid][1] = B;
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < 8 * PS; i += 256) {
     const int c = i / PS, r = i - c * PS, py = r / PH, px = r - py * PH;
     const int ic = ich * 8 + c, iy = iy0 + py, ix = ix0 + px;
@@ -206,6 +224,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     if (ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
       const float* __restrict__ sp = ic < a.c0 ? a.x0 + ((size_t)n * a.c0 + ic) * Hs * Ws : a.x1 + ((size_t)n * a.c1 + (ic - a.c0)) * Hs * Ws;
       v = a.up ? sp[(size_t)(iy >> 1) * Ws + (ix >> 1)] : sp[(size_t)iy * Ws + ix];
+      if (gn) v = silu_f(fmaf(s_gn[c][0], v, s_gn[c][1]));   // zero padding stays zero: only inside the image
     }
     sx[i] = v;
   }

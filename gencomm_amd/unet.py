@@ -197,19 +197,37 @@ class DiffusionUNet(nn.Module):
         assert flat.numel() == self._packed.total
         return flat
 
-    def backward_call(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, grad_x0: torch.Tensor, T: int):
+    def forward_train(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, T: int):
+        """x0_hat of a call that will be differentiated, through ``gencomm_unet_fwd_train``: returns (x0_hat, workspace) where
+        the workspace (a tensor of its own, not the shared scratch) holds every intermediate for ``backward_call``."""
+        n, C, H, W = x_t.shape
+        dev = x_t.device
+        l = _lib.lib()
+        prepared = self.prepared_params(T, dev)
+        L, R, A = self.num_resolutions, self.num_res_blocks, self.attn_mask
+        ws = torch.empty(_lib.check_size(l.gencomm_unet_bwd_workspace_bytes(n, C, H, W, L, R, A), "gencomm_unet_bwd_workspace_bytes"),
+                         dtype=torch.uint8, device=dev)
+        out = torch.empty((n, C, H, W), dtype=torch.float32, device=dev)
+        _lib.check(l.gencomm_unet_fwd_train(ptr(prepared), ptr(x_t), ptr(cond), ptr(out), int(t_int), n, C, H, W, L, R, A, T,
+                                            ptr(ws), ws.numel(), stream_ptr(dev)), "gencomm_unet_fwd_train")
+        return out, ws
+
+    def backward_call(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, grad_x0: torch.Tensor, T: int, ws: torch.Tensor = None):
         """One UNet call backwards through ``gencomm_unet_bwd``: returns (grad_xt, grad_cond, grad_raw) where ``grad_raw`` is the
-        gradient of the packed parameter blob (``self._packed.table`` gives every parameter's offset)."""
+        gradient of the packed parameter blob (``self._packed.table`` gives every parameter's offset). ``ws``: the workspace
+        ``forward_train`` filled (no recomputation); without it the library re-runs the forward."""
         n, C, H, W = x_t.shape
         dev = x_t.device
         l = _lib.lib()
         prepared = self.prepared_params(T, dev)
         raw = self._packed.flat
         L, R, A = self.num_resolutions, self.num_res_blocks, self.attn_mask
-        ws = workspaces.get(dev, _lib.check_size(l.gencomm_unet_bwd_workspace_bytes(n, C, H, W, L, R, A), "gencomm_unet_bwd_workspace_bytes"), "unet_bwd")
+        done = ws is not None
+        if ws is None:
+            ws = workspaces.get(dev, _lib.check_size(l.gencomm_unet_bwd_workspace_bytes(n, C, H, W, L, R, A), "gencomm_unet_bwd_workspace_bytes"), "unet_bwd")
         gx = torch.empty_like(x_t)
         gc = torch.empty_like(cond)
         graw = torch.zeros_like(raw)
         _lib.check(l.gencomm_unet_bwd(ptr(prepared), ptr(raw), ptr(x_t), ptr(cond), int(t_int), ptr(grad_x0), ptr(gx), ptr(gc), ptr(graw),
-                                      n, C, H, W, L, R, A, T, ptr(ws), ws.numel(), stream_ptr(dev)), "gencomm_unet_bwd")
+                                      n, C, H, W, L, R, A, T, int(done), ptr(ws), ws.numel(), stream_ptr(dev)), "gencomm_unet_bwd")
         return gx, gc, graw

@@ -117,9 +117,15 @@ int gencomm_unet_prepare(const float* raw, float* prepared, int C, int levels, i
  * the forward only through each ResnetBlock's conv1 bias and is chained from this call's d conv1.bias by one small kernel.
  * `raw` = the parameter blob in the reference's layouts (what gencomm_unet_prepare consumed). attn_mask must be 0. */
 long long gencomm_unet_bwd_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask);
+/* Forward of a call that will be differentiated: as gencomm_unet_fwd, but every intermediate (and its GroupNorm statistics)
+ * stays in `workspace` (gencomm_unet_bwd_workspace_bytes; one workspace per call in flight -- MI355X has the HBM for it),
+ * to be handed to gencomm_unet_bwd with forward_done = 1. With forward_done = 0 gencomm_unet_bwd re-runs that forward itself. */
+int gencomm_unet_fwd_train(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,
+                           int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
+                           void* workspace, long long workspace_bytes, void* stream);
 int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
                      float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
-                     int attn_mask, int T, void* workspace, long long workspace_bytes, void* stream);
+                     int attn_mask, int T, int forward_done, void* workspace, long long workspace_bytes, void* stream);
 
 /* One 8 -> 8 channel 3x3 convolution (pad 1, bias) as the UNet's ResnetBlock / Upsample layers run it
  * (unet.py:52, :99-118), without norm or residual: dst[n,8,H,W] = conv(src[n,8,H,W], w[8,8,3,3]) + bias; dstat (nullable)
