@@ -9,6 +9,7 @@ import torch
 from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, synth
 
 DEV = "cuda:0"
+OPTIMIZER = "--no-optimizer" not in sys.argv
 for name, (N, C, H, W, T) in {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128, 64, 128, 3),
                                "4 agents, C=64, 200x704, T=3": (4, 64, 200, 704, 3)}.items():
     gen, enh, fus = GenComm(synth.default_gencomm_cfg(C, T)).train().to(DEV), Enhancer(C, [8, 8], 4).train().to(DEV), AttFusion(C)
@@ -17,14 +18,19 @@ for name, (N, C, H, W, T) in {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128,
     cond = torch.randn(N, 2, H, W, generator=g, device=DEV).requires_grad_(True)
     ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N], 5, 7, 10.0))
     affine = normalize_pairwise_tfm(ptm, H * 0.4, W * 0.4, 1)
+    params = [p for p in list(gen.parameters()) + list(enh.parameters()) if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-5, fused=True) if OPTIMIZER else None   # train.py uses Adam (hypes_yaml optimizer block)
+
     def step():
-        for p in list(gen.parameters()) + list(enh.parameters()):
+        for p in params:
             p.grad = None
         pred = gen(feat, cond, [N], seed=3)["pred_feature"]
         if pred.dim() == 3:
             pred = pred.unsqueeze(0)
         out = fus(enh(pred, affine, [N]), [N], affine)
         out.square().mean().backward()
+        if opt is not None:
+            opt.step()          # the weights change: the next forward re-packs and re-prepares them (gencomm_unet_prepare)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -34,4 +40,4 @@ for name, (N, C, H, W, T) in {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128,
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
-    print(f"train step [{name}]: {1e3 * dt:.1f} ms per scene (forward + backward) = {1.0 / dt:.2f} scenes/s", flush=True)
+    print(f"train step [{name}]: {1e3 * dt:.1f} ms per scene (forward + backward{' + Adam step' if OPTIMIZER else ''}) = {1.0 / dt:.2f} scenes/s", flush=True)
