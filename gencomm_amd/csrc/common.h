@@ -205,6 +205,21 @@ __device__ __forceinline__ void wave_amax_commit(float v, float* __restrict__ ds
     if (bits > __builtin_nontemporal_load(p)) atomicMax(p, bits);
   }
 }
+// the same with ONE atomic per workgroup (256 threads): kernels whose workgroups all start together would otherwise all read
+// the initial 0 and queue one atomic per wave on the same address (8 200 of them took 150 us in q_sample_kernel on small maps)
+__device__ __forceinline__ void block_amax_commit(float v, float* __restrict__ dst) {
+  __shared__ float s_amax[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+    unsigned int* __restrict__ p = reinterpret_cast<unsigned int*>(dst);
+    const unsigned int bits = __float_as_uint(m);
+    if (bits > __builtin_nontemporal_load(p)) atomicMax(p, bits);
+  }
+}
 static __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long count, float* __restrict__ dst) {
   float m = 0.f;
   const long long nvec = (count & 3) ? 0 : (count >> 2);
@@ -213,7 +228,7 @@ static __global__ __launch_bounds__(256) void amax_kernel(const float* __restric
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   for (long long i = (nvec << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-  wave_amax_commit(m, dst);
+  block_amax_commit(m, dst);
 }
 
 // Butterfly sum, result in every lane (ds_bpermute based).

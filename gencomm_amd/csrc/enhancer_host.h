@@ -88,7 +88,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   }
   if (m.split() && (p.dc == 16 || p.dc == 32) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
     const int nslice = (9 * p.dc + 31) / 32;
-    enh_prep_pconv_h_kernel<<<1, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, nslice);
+    enh_prep_pconv_h_kernel<<<(p.dc / 16) * nslice * 2, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, nslice);   // 256 table entries per workgroup
     TimedLaunch tl(KF_ENH_PCONV, st);
     EnhPconvHArgs a{F(w.Zc), F(w.wT), F(w.Z), C, p.dc, H, W, nslice};
     const size_t sh = (size_t)2 * 18 * 34 * p.dc * 2;

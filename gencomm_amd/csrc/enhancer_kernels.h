@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void enh_prep_pconv_h_kernel(const float* __re
   const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
   const int nob = dc / 16, total = nob * nslice * 512;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
-  for (int i = tid; i < total; i += 256) {
+  for (int i = blockIdx.x * 256 + tid; i < total; i += gridDim.x * 256) {   // every workgroup derives the same scale
     const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, sl = (i >> 9) % nslice, ob = (i >> 9) / nslice;
     const int mrow = l & 15, kg = l >> 4, oc = 16 * ob + mrow;
     uint16_t v[2];
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void enh_prep_pconv_h_kernel(const float* __re
     }
     out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
   }
-  if (tid < 64) tab[total + tid] = (tid & 1) ? scale : 1.0f / scale;
+  if (blockIdx.x == 0 && tid < 64) tab[total + tid] = (tid & 1) ? scale : 1.0f / scale;
 }
 
 __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a) {

@@ -303,7 +303,8 @@ int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, 
 
 static void launch_q_sample(const QSampleArgs& q, int n, bool philox, hipStream_t st) {
   TimedLaunch tl(KF_Q_SAMPLE, st);
-  const dim3 qgrid((unsigned)std::min<long long>((q.per_agent / 4 + 255) / 256 + 1, 2048), n);
+  // 8 octets (64 elements) per thread: few enough workgroups that the max|x| commit (one atomic each) stays cheap on small maps
+  const dim3 qgrid((unsigned)std::max<long long>(1, std::min<long long>((q.per_agent / 64 + 255) / 256, 2048)), n);
   if (philox) q_sample_kernel<true><<<qgrid, 256, 0, st>>>(q);
   else q_sample_kernel<false><<<qgrid, 256, 0, st>>>(q);
 }

@@ -295,7 +295,10 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   a.a_bf16 = !c.is_f32(p.last_body_tensor);
   // algorithmic bytes: last block's output (read), k map (read), hs0 (read + write): 4 eight-channel maps
   TimedLaunch tl(KF_LATENT_STEP, c.st, 4.0 * c.n * 32.0 * c.H * c.W);
-  if (pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16 && c.m.split()) {
+  // small maps too: per pixel this kernel is 1600 + 72 C MACs, and a 64 x 128 map gives the fp32 kernel only 32 workgroups of
+  // two waves (122 us per launch at C = 128 against 40 us for the f16-pipe kernel on 16 workgroups of four waves)
+  const bool small_h = c.m.split() && (c.W & 3) == 0 && c.W >= 64 && c.H >= 16 && c.m.v[MODE_TILE_WANT] == 0;
+  if ((pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16 || small_h) && c.m.split()) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
     if (noise) latent_step_h_kernel<1><<<grid, 256, 0, c.st>>>(a);
     else latent_step_h_kernel<2><<<grid, 256, 0, c.st>>>(a);

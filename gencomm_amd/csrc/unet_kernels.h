@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const QSampleArgs a) {
     op[i] = fmaf(sa, fp[i], sb * z);
     amax = fmaxf(amax, fabsf(op[i]));
   }
-  if (a.amax != nullptr) wave_amax_commit(amax, a.amax);
+  if (a.amax != nullptr) block_amax_commit(amax, a.amax);   // wave-uniform condition: every thread reaches the barrier inside
 }
 
 // ---------------------------------------------------------------------------------------------
