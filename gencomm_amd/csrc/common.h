@@ -47,7 +47,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum ModeKey : int {
   MODE_ARITH = 0,        // 0: products on the f16 matrix pipe from exact fp16 hi/lo splits (default); 1: exact-fp32 kernels;
                          // 2: bf16 denoise mode (bf16 storage of the UNet's 8-channel maps, single bf16 products: conv8b_kernels.h)
-  MODE_SAMPLER = 1,      // 0: latent sampler structure (default); 1: literal conv_in .. conv_out + update per step
+  MODE_SAMPLER = 1,      // 0: automatic (latent structure on large maps, literal on small); 1: literal conv_in .. conv_out + update per step; 2: latent
   MODE_TILE_WANT = 2,    // 0: automatic; > 0: minimum number of 64x16 workgroups before the 64x16-tile kernels are chosen
   MODE_ENH_FUSE = 3,     // 1: Enhancer Linear1 + depthwise stage fused at C = 64 (default); 0: separate launches
   MODE_CONV8H_MASK = 4,  // diagnostic: bit mask of conv8h variants allowed on the f16 pipe (-1: all)

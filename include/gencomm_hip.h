@@ -63,9 +63,10 @@ const char* gencomm_build_info(void);
  *                             UNet's 8-channel intermediates are stored as bf16 and multiplied by single bf16 MFMAs
  *                             (fp32 accumulation, GroupNorm statistics in f64, the sampler's carried state in fp32);
  *                             inference only, no AttnBlock, W divisible by 4 at every level
- *   GENCOMM_MODE_SAMPLER      0 (default): the loop is carried on conv_in's 8-channel output (one fused kernel per
- *                             step replaces conv_out + update + conv_in); 1: literal per-step structure of
- *                             cond_diff.py:321-329 (tests compare the two)
+ *   GENCOMM_MODE_SAMPLER      2: the loop is carried on conv_in's 8-channel output (one fused kernel per step replaces
+ *                             conv_out + update + conv_in); 1: literal per-step structure of cond_diff.py:321-329 (tests
+ *                             compare the two); 0 (default): automatic -- 2 on maps large enough for the 64x16-tile
+ *                             kernels (x_t stays out of HBM), 1 on small, cache-resident maps (shorter dependent chain)
  *   GENCOMM_MODE_TILE_WANT    0 (default): automatic tile choice; > 0: minimum number of 64x16 workgroups before the
  *                             64x16-tile kernels are used (1 forces them onto small maps: tests)
  *   GENCOMM_MODE_ENH_FUSE     1 (default): Enhancer Linear1 + depthwise stage fused at C = 64; 0: separate launches
