@@ -29,7 +29,8 @@ struct Conv2dArgs {
   const float* shift;  // [Cout]
   float* y;            // [N][out_ctotal][Ho*ups][Wo*ups], this layer writes channels [out_coff, out_coff + Cout)
   int Cin, H, W, CoutP, Ho, Wo;
-  int stride, pad, relu, ups, out_ctotal, out_coff;
+  int stride, pad, relu /* 0 none, 1 ReLU, 2 erf-GELU */, ups, out_ctotal, out_coff;
+  const float* res = nullptr;  // optional residual, same layout as y, added after the activation
 };
 
 template <int KH, int KW, int CC, int STRIDE>
@@ -125,8 +126,11 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(const Conv2dArgs a) {
     if (gco >= a.CoutP) continue;
     const int co = gco / s2, sub = gco - co * s2, dy = sub / s, dx = sub - dy * s;
     float v = fmaf(acc[reg], a.scale[co], a.shift[co]);
-    if (a.relu) v = fmaxf(v, 0.f);
-    yn[(size_t)co * oplane + (size_t)(oy * s + dy) * (a.Wo * s) + (ox * s + dx)] = v;
+    if (a.relu == 1) v = fmaxf(v, 0.f);
+    else if (a.relu == 2) v = gelu_erf_f(v);
+    const size_t oi = (size_t)co * oplane + (size_t)(oy * s + dy) * (a.Wo * s) + (ox * s + dx);
+    if (a.res != nullptr) v += a.res[((size_t)n * a.out_ctotal + a.out_coff) * oplane + oi];
+    yn[oi] = v;
   }
 }
 

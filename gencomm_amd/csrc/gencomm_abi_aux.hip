@@ -118,6 +118,23 @@ int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* ou
   return fail(GC_ERR_ARG, "window attention: supported (window, dim_head) pairs are (4,16) (4,32) (8,16) (8,32) (8,64) (16,32) (16,64)");
 }
 
+// radix-3 split attention over three branch maps [n][C][HW] (+ residual): gap -> fc1 -> LayerNorm -> ReLU -> fc2 -> softmax over the
+// branches -> weighted sum (sub_modules/split_attn.py:31-62 with radix 3); scratch >= 4 n C floats
+int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, const float* fc1_w, const float* ln_w, const float* ln_b,
+                            const float* fc2_w, const float* residual, float* out, float* scratch, int n, int C, int HW, void* stream) {
+  GC_CHECK_ARG(a && b && c && fc1_w && ln_w && ln_b && fc2_w && out && scratch, "null pointer");
+  GC_CHECK_ARG(n >= 1 && n <= 65535 && C >= 1 && C <= 256 && HW >= 1, "split attention: 1 <= C <= 256");
+  hipStream_t st = (hipStream_t)stream;
+  float* gap = scratch;
+  float* gate = scratch + (size_t)n * C;
+  split3_gap_kernel<<<dim3(C, n), 256, 0, st>>>(a, b, c, gap, C, HW);
+  Split3GateArgs ga{gap, fc1_w, ln_w, ln_b, fc2_w, gate, C};
+  split3_gate_kernel<<<n, 256, 0, st>>>(ga);
+  split3_apply_kernel<<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(a, b, c, gate, residual, out, C, HW);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 // ---- sparse 3-D convolution (SECOND encoder) -------------------------------------------------------------------------
 static int sp_grid(SpGrid& g, int B, const int* dims3, const char* what) {
   GC_CHECK_ARG(dims3 != nullptr && B >= 1 && dims3[0] >= 1 && dims3[1] >= 1 && dims3[2] >= 1, what);

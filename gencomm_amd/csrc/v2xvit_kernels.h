@@ -173,4 +173,69 @@ inline int win_attn_launch(const WinArgs& a, int n, hipStream_t st) {
   return GC_OK;
 }
 
+// ---- radix-3 split attention (sub_modules/split_attn.py:31-62) over the three window branches -------------------------
+// gap[n][c] = mean over HW of (a + b + c): one workgroup per (channel, agent)
+__global__ __launch_bounds__(256) void split3_gap_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                         float* __restrict__ gap, int C, int HW) {
+  __shared__ float s_red[4];
+  const int ch = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const size_t base = ((size_t)n * C + ch) * HW;
+  float s = 0.f;
+  for (int p = tid; p < HW; p += 256) s += a[base + p] + b[base + p] + c[base + p];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) gap[(size_t)n * C + ch] = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)HW;
+}
+// gate[n][r][c] = softmax over r of fc2(ReLU(LayerNorm(fc1(gap[n])))) [r * C + c]: fc1 [C][C], fc2 [3C][C], no biases;
+// one workgroup per agent, C <= 256
+struct Split3GateArgs {
+  const float* gap; const float* fc1; const float* lnw; const float* lnb; const float* fc2;
+  float* gate;   // [n][3][C]
+  int C;
+};
+__global__ __launch_bounds__(256) void split3_gate_kernel(const Split3GateArgs a) {
+  __shared__ float s_in[256], s_h[256], s_stat[2];
+  const int n = blockIdx.x, tid = threadIdx.x, C = a.C;
+  if (tid < C) s_in[tid] = a.gap[(size_t)n * C + tid];
+  __syncthreads();
+  float h = 0.f;
+  if (tid < C) for (int k = 0; k < C; ++k) h = fmaf(a.fc1[(size_t)tid * C + k], s_in[k], h);
+  s_h[tid] = tid < C ? h : 0.f;
+  __syncthreads();
+  if (tid == 0) {
+    float m = 0.f, v = 0.f;
+    for (int k = 0; k < C; ++k) m += s_h[k];
+    m /= (float)C;
+    for (int k = 0; k < C; ++k) v += (s_h[k] - m) * (s_h[k] - m);
+    s_stat[0] = m; s_stat[1] = rsqrtf(v / (float)C + 1e-5f);
+  }
+  __syncthreads();
+  if (tid < C) s_in[tid] = fmaxf((s_h[tid] - s_stat[0]) * s_stat[1] * a.lnw[tid] + a.lnb[tid], 0.f);
+  __syncthreads();
+  if (tid < C) {
+    float z[3];
+    for (int r = 0; r < 3; ++r) {
+      float acc = 0.f;
+      for (int k = 0; k < C; ++k) acc = fmaf(a.fc2[((size_t)r * C + tid) * C + k], s_in[k], acc);
+      z[r] = acc;
+    }
+    const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+    const float e0 = expf(z[0] - mx), e1 = expf(z[1] - mx), e2 = expf(z[2] - mx), inv = 1.0f / (e0 + e1 + e2);
+    a.gate[((size_t)n * 3 + 0) * C + tid] = e0 * inv;
+    a.gate[((size_t)n * 3 + 1) * C + tid] = e1 * inv;
+    a.gate[((size_t)n * 3 + 2) * C + tid] = e2 * inv;
+  }
+}
+// out = a g0 + b g1 + c g2 + res   (per agent and channel gates)
+__global__ __launch_bounds__(256) void split3_apply_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                           const float* __restrict__ gate, const float* __restrict__ res, float* __restrict__ out,
+                                                           int C, int HW) {
+  const int ch = blockIdx.y, n = blockIdx.z, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float g0 = gate[((size_t)n * 3 + 0) * C + ch], g1 = gate[((size_t)n * 3 + 1) * C + ch], g2 = gate[((size_t)n * 3 + 2) * C + ch];
+  const size_t e = ((size_t)n * C + ch) * HW + p;
+  out[e] = fmaf(a[e], g0, fmaf(b[e], g1, fmaf(c[e], g2, res != nullptr ? res[e] : 0.f)));
+}
+
 }  // namespace gc

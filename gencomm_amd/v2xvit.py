@@ -141,10 +141,6 @@ class V2XTransformer(nn.Module):  # v2xvit_basic.py:181-192
 
 
 # ----------------------------------------------------------------------------------------- HIP forward
-def _conv1x1(x, weight, bias):
-    return T.conv2d(x, weight.detach()[:, :, None, None], bias, 0)
-
-
 def _hgt_weights(att: HGTCavAttention):
     """q / k / v projections of agent type 0 with relation 0 folded in: k' = relation_att . k, v' = relation_msg^T . v
     (hmsa.py:131-141 with every type index 0), concatenated for one 1x1 convolution."""
@@ -158,46 +154,89 @@ def _hgt_weights(att: HGTCavAttention):
     return torch.cat([wq, wk2, wv2], 0).contiguous(), torch.cat([bq, bk2, bv2], 0).contiguous()
 
 
+class _LinearCache:
+    """Kernel-layout weights + folded bias of the 1x1 convolutions (= Linear layers), rebuilt only when a source parameter changed."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def get(self, key, sources, make, device):
+        """`sources`: the parameters the weight derives from; `make()` -> (weight [Cout, Cin], bias [Cout] or None)."""
+        ver = tuple((t.data_ptr(), t._version) for t in sources) + (str(device),)
+        hit = self._entries.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1:]
+        w, b = make()
+        w = f32c(w.detach())
+        cout, cin = w.shape
+        l, st = _lib.lib(), stream_ptr(device)
+        prepared = torch.empty(w.numel(), dtype=torch.float32, device=device)
+        _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cin, cout, 1, 1, 0, st), "gencomm_conv2d_prepare")
+        ss = torch.empty(2, cout, dtype=torch.float32, device=device)
+        bb = f32c(b.detach()) if b is not None else None
+        _lib.check(l.gencomm_conv2d_fold(None, None, None, None, ptr(bb), 0.0, cout, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
+        self._entries[key] = (ver, prepared, ss, cin, cout)
+        return prepared, ss, cin, cout
+
+
+def _linear(x, entry, act: int = 0, residual=None):
+    """1x1 convolution over NCHW pixels with a cached weight; act 2 = erf-GELU; optional residual added in the epilogue."""
+    prepared, ss, cin, cout = entry
+    n, c, H, W = x.shape
+    assert c == cin, (c, cin)
+    y = torch.empty(n, cout, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gencomm_conv2d_act_res_fwd(ptr(x), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(residual) if residual is not None else None,
+                                                     ptr(y), n, cin, H, W, cout, 1, 1, 1, 0, int(act), stream_ptr(x.device)), "gencomm_conv2d_act_res_fwd")
+    return y
+
+
 class V2XViTFusion(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.fusion_net = V2XTransformer(args["transformer"])
+        self._linears = _LinearCache()
 
-    # ---- one agent-wise attention layer: x [n, C, H, W] -> [n, C, H, W]
-    def _cav_attention(self, att, xn, scene_off, B):
+    # ---- one agent-wise attention layer (+ residual): x [n, C, H, W] -> [n, C, H, W]
+    def _cav_attention(self, key, att, xn, scene_off, B, residual):
         n, _, H, W = xn.shape
-        l = _lib.lib()
+        l, dev, cache = _lib.lib(), xn.device, self._linears
         if isinstance(att, HGTCavAttention):
-            w, b = _hgt_weights(att)
-            qkv = T.conv2d(xn, w[:, :, None, None], b, 0)
-            to_out_w, to_out_b = att.a_linears[0].weight, att.a_linears[0].bias
+            src = [att.q_linears[0].weight, att.q_linears[0].bias, att.k_linears[0].weight, att.k_linears[0].bias, att.v_linears[0].weight,
+                   att.v_linears[0].bias, att.relation_att, att.relation_msg]
+            qkv = _linear(xn, cache.get((key, "qkv"), src, lambda: _hgt_weights(att), dev))
+            out_lin = att.a_linears[0]
         else:
-            qkv = _conv1x1(xn, att.to_qkv.weight, None)
-            to_out_w, to_out_b = att.to_out[0].weight, att.to_out[0].bias
+            qkv = _linear(xn, cache.get((key, "qkv"), [att.to_qkv.weight], lambda: (att.to_qkv.weight, None), dev))
+            out_lin = att.to_out[0]
         inner = att.heads * att.dim_head
-        out = torch.empty(n, inner, H, W, dtype=torch.float32, device=xn.device)
-        _lib.check(l.gencomm_hgt_attn_fwd(ptr(qkv), ptr(scene_off), ptr(out), B, att.heads, att.dim_head, H * W, stream_ptr(xn.device)),
+        out = torch.empty(n, inner, H, W, dtype=torch.float32, device=dev)
+        _lib.check(l.gencomm_hgt_attn_fwd(ptr(qkv), ptr(scene_off), ptr(out), B, att.heads, att.dim_head, H * W, stream_ptr(dev)),
                    "gencomm_hgt_attn_fwd")
-        return _conv1x1(out, to_out_w, to_out_b)
+        return _linear(out, cache.get((key, "out"), [out_lin.weight, out_lin.bias], lambda: (out_lin.weight, out_lin.bias), dev), 0, residual)
 
-    def _window_attention(self, wa: BaseWindowAttention, xn):
+    def _window_attention(self, key, wa: BaseWindowAttention, xn):
         n, _, H, W = xn.shape
-        qkv = _conv1x1(xn, wa.to_qkv.weight, None)
+        dev, cache = xn.device, self._linears
+        qkv = _linear(xn, cache.get((key, "qkv"), [wa.to_qkv.weight], lambda: (wa.to_qkv.weight, None), dev))
         inner = wa.heads * wa.dim_head
-        out = torch.empty(n, inner, H, W, dtype=torch.float32, device=xn.device)
+        out = torch.empty(n, inner, H, W, dtype=torch.float32, device=dev)
         pos = f32c(wa.pos_embedding.detach())
         _lib.check(_lib.lib().gencomm_win_attn_fwd(ptr(qkv), ptr(pos), ptr(out), n, wa.heads, wa.dim_head, wa.window_size, H, W,
-                                                   stream_ptr(xn.device)), "gencomm_win_attn_fwd")
-        return _conv1x1(out, wa.to_out[0].weight, wa.to_out[0].bias)
+                                                   stream_ptr(dev)), "gencomm_win_attn_fwd")
+        o = wa.to_out[0]
+        return _linear(out, cache.get((key, "out"), [o.weight, o.bias], lambda: (o.weight, o.bias), dev))
 
     @staticmethod
-    def _split_attn(sa: SplitAttn3, wl: List[torch.Tensor]):
+    def _split_attn(sa: SplitAttn3, wl: List[torch.Tensor], residual):
+        """Radix-3 split attention over the three window branches + the block's residual, on the HIP kernels (split_attn.py:31-62)."""
         sw, mw, bw = wl
-        C = sw.shape[1]
-        gap = (sw + mw + bw).mean((2, 3))                                              # [n, C]   split_attn.py:50-53
-        g = F.relu(F.layer_norm(F.linear(gap, sa.fc1.weight), (C,), sa.bn1.weight, sa.bn1.bias, 1e-5))
-        a = F.linear(g, sa.fc2.weight).view(-1, 3, C).softmax(dim=1)                    # radix softmax, split_attn.py:13-25
-        return sw * a[:, 0, :, None, None] + mw * a[:, 1, :, None, None] + bw * a[:, 2, :, None, None]
+        n, C, H, W = sw.shape
+        out = torch.empty_like(sw)
+        scratch = torch.empty(4 * n * C, dtype=torch.float32, device=sw.device)
+        _lib.check(_lib.lib().gencomm_split3_attn_fwd(ptr(sw), ptr(mw), ptr(bw), ptr(f32c(sa.fc1.weight.detach())), ptr(f32c(sa.bn1.weight.detach())),
+                                                      ptr(f32c(sa.bn1.bias.detach())), ptr(f32c(sa.fc2.weight.detach())), ptr(residual), ptr(out),
+                                                      ptr(scratch), n, C, H * W, stream_ptr(sw.device)), "gencomm_split3_attn_fwd")
+        return out
 
     def forward(self, x, record_len, affine_matrix):
         """x [sumN, C, H, W], record_len [B], affine_matrix [B, L, L, 2, 3] -> [B, C, H, W]."""
@@ -223,13 +262,15 @@ class V2XViTFusion(nn.Module):
             scene_off = torch.tensor(off, dtype=torch.int32, device=dev)
             h = torch.empty_like(x)
             _lib.check(_lib.lib().gencomm_warp_affine_fwd(ptr(x), ptr(theta), ptr(h), n, C, H, W, stream_ptr(dev)), "gencomm_warp_affine_fwd")
-            for block, ff in enc.layers:
-                for cav, pwin in block.layers:
-                    h = self._cav_attention(cav.fn, T.ln_fwd(h, cav.norm.weight, cav.norm.bias, 1e-5, False), scene_off, B) + h
+            cache = self._linears
+            for bi, (block, ff) in enumerate(enc.layers):
+                for li, (cav, pwin) in enumerate(block.layers):
+                    h = self._cav_attention((bi, li, "cav"), cav.fn, T.ln_fwd(h, cav.norm.weight, cav.norm.bias, 1e-5, False), scene_off, B, h)
                     hn = T.ln_fwd(h, pwin.norm.weight, pwin.norm.bias, 1e-5, False)
-                    wl = [self._window_attention(wa, hn) for wa in pwin.fn.pwmsa]
-                    h = self._split_attn(pwin.fn.split_attn, wl) + h
+                    wl = [self._window_attention((bi, li, "win", wi), wa, hn) for wi, wa in enumerate(pwin.fn.pwmsa)]
+                    h = self._split_attn(pwin.fn.split_attn, wl, h)
                 hn = T.ln_fwd(h, ff.norm.weight, ff.norm.bias, 1e-5, False)
-                mid = F.gelu(_conv1x1(hn, ff.fn.net[0].weight, ff.fn.net[0].bias))
-                h = _conv1x1(mid, ff.fn.net[3].weight, ff.fn.net[3].bias) + h
+                l0, l3 = ff.fn.net[0], ff.fn.net[3]
+                mid = _linear(hn, cache.get((bi, "ff0"), [l0.weight, l0.bias], lambda: (l0.weight, l0.bias), dev), 2)       # Linear + GELU
+                h = _linear(mid, cache.get((bi, "ff3"), [l3.weight, l3.bias], lambda: (l3.weight, l3.bias), dev), 0, h)     # Linear + residual
             return h[scene_off[:-1].long()].contiguous()

@@ -239,6 +239,11 @@ int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const floa
 int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale, const float* shift, float* y,
                        int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
                        int ups, int out_ctotal, int out_coff, void* stream);
+/* the same (no transposed-conv mode, whole-tensor output) with act in {0 none, 1 ReLU, 2 erf-GELU (nn.GELU)} and an optional
+ * residual [N][Cout][Ho][Wo] added after the activation: Linear + GELU and Linear + skip connection in one launch */
+int gencomm_conv2d_act_res_fwd(const float* x, const float* prepared, const float* scale, const float* shift, const float* residual,
+                               float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int act,
+                               void* stream);
 
 /* ---- Detection tail ---------------------------------------------------------------
  * Replaces, for one agent's head outputs (batch 1), the torch/numpy/shapely chain of
@@ -351,6 +356,10 @@ int gencomm_warp_affine_fwd(const float* x, const double* theta, float* out, int
 int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int B, int heads, int dim_head, int HW, void* stream);
 int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* out, int n, int heads, int dim_head, int window, int H, int W,
                          void* stream);
+/* radix-3 split attention over the three window branches (sub_modules/split_attn.py:31-62): out = sum_r softmax_r(fc2(ReLU(LN(fc1(
+ * mean_HW(a + b + c))))))[r] * branch_r (+ residual); fc1 [C][C], fc2 [3 C][C] without biases; scratch >= 4 n C floats; C <= 256 */
+int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, const float* fc1_w, const float* ln_w, const float* ln_b,
+                            const float* fc2_w, const float* residual, float* out, float* scratch, int n, int C, int HW, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Sparse 3-D convolutions of the SECOND encoder without spconv (opencood/models/heter_encoders.py:52-81,
