@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 2, GPU call 11: the round's reference measurements -- full GPU suite, default bench line, 1-stream kernel trace,
+# round 2, the round's reference measurements (run again after every batch of changes) -- full GPU suite, default bench line, 1-stream kernel trace,
 # PMC traffic passes, bf16 / shipped / cfg2 lines, train step, V2X-ViT latency
 set -o pipefail
 mkdir -p gpurun_out
@@ -26,3 +26,7 @@ timeout -k 10 300 python tools/train_bench.py > gpurun_out/r2c11_train.log 2>&1 
 cat gpurun_out/r2c11_train.log
 timeout -k 10 300 python tools/v2xvit_bench.py > gpurun_out/r2c11_v2xvit.log 2>&1 || { tail gpurun_out/r2c11_v2xvit.log; exit 1; }
 cat gpurun_out/r2c11_v2xvit.log
+timeout -k 10 300 python tools/second_bench.py > gpurun_out/r2c11_second.log 2>&1 || { tail gpurun_out/r2c11_second.log; exit 1; }
+cat gpurun_out/r2c11_second.log
+timeout -k 10 300 python bench.py --workload shipped --batch 1 --streams 1 --steps 50 --warmup 5 --no-cpu-baseline --no-exact --no-timer > gpurun_out/r2c11_bench_shipped_1x1.json 2> gpurun_out/r2c11_bench_shipped_1x1.err || exit 1
+cut -c1-200 gpurun_out/r2c11_bench_shipped_1x1.json
