@@ -71,8 +71,11 @@ class PointPillar(nn.Module):
                 and self.scatter.num_bev_features == 64):
             raise NotImplementedError("gencomm_amd.PointPillar: the HIP kernel covers the shipped configuration "
                                       "(use_norm, use_absolute_xyz, no distance feature, num_filters [64])")
-        if self.training:
-            raise NotImplementedError("gencomm_amd.PointPillar: training-mode BatchNorm (batch statistics) is not implemented; use .eval()")
+        pfn = v.pfn_layers[0]
+        if pfn.norm.training:
+            # a frozen encoder inside a model in train mode (stage 2: fix_bn keeps its BatchNorm in eval mode) is fine
+            raise NotImplementedError("gencomm_amd.PointPillar: training-mode BatchNorm (batch statistics) is not implemented; use .eval() "
+                                      "(or freeze the encoder as stage 2 does)")
 
     def forward(self, data_dict, modality_name):
         inp = data_dict[f"inputs_{modality_name}"]

@@ -280,8 +280,10 @@ class SECOND(nn.Module):  # heter_encoders.py:52-81
     def forward(self, data_dict, modality_name):
         inp = data_dict[f'inputs_{modality_name}']
         voxel_features, voxel_coords, voxel_num_points = inp['voxel_features'], inp['voxel_coords'], inp['voxel_num_points']
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("SECOND on the HIP path is inference-only; call .eval() / torch.no_grad()")
+        # a frozen encoder inside a model in train mode (stage 2: fix_bn keeps its BatchNorm in eval mode) is fine
+        if any(isinstance(m, nn.BatchNorm1d) and m.training for m in self.modules()):
+            raise NotImplementedError("SECOND on the HIP path is inference-only (BatchNorm1d batch statistics / sparse backward are not "
+                                      "implemented); call .eval() or freeze the encoder as stage 2 does")
         batch_size = int(voxel_coords[:, 0].max()) + 1          # heter_encoders.py:70 (one host read, as in the reference)
         keys, perm = index_voxels(voxel_coords, batch_size, self.spconv_block.sparse_shape)
         batch_dict = {'voxel_features': voxel_features, 'voxel_coords': voxel_coords, 'voxel_num_points': voxel_num_points,

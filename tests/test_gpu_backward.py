@@ -189,3 +189,82 @@ def test_fusion_backward_hip_vs_torch_autograd(C, H, W, rl, shift):
     (y2 * wgt).sum().backward()
     worst = _close("fusion grad x", x.grad, x2.grad)
     print(f"fusion backward C={C} {H}x{W} scenes {rl}: worst relative error {worst:.2e}")
+
+
+@pytest.mark.parametrize("C,H,W,n", [(16, 12, 20, 2), (128, 32, 48, 1)])
+def test_message_extractor_backward_vs_oracle_autograd(C, H, W, n):
+    """MessageExtractorv2 is THE module stage 2 trains (stage2.py:99-101): HIP forward, gradients of all 12 parameters and of
+    the input against float64 autograd through the oracle (offsets scaled so that the sampling positions cross pixels)."""
+    from gencomm_amd import MessageExtractorv2, synth
+    from oracle import torch_port as O
+    me = MessageExtractorv2(C, 2).train()
+    synth.fill_params_(me, 41)
+    with torch.no_grad():
+        me.bev_extractor.offset1.weight.mul_(5.0)
+        me.bev_extractor.offset1.bias.mul_(5.0)
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n, C, H, W, generator=g)
+    sd = {k: v.detach().double().requires_grad_(True) for k, v in me.state_dict().items()}
+    xd = x.double().requires_grad_(True)
+    ref = O.message_extractor_forward(sd, xd)
+    names = list(sd)
+    rg = torch.autograd.grad((ref ** 2).mean(), [sd[k] for k in names] + [xd])
+    me = me.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = me(xg)
+    _close("message", out, ref, 1e-4)
+    (out ** 2).mean().backward()
+    worst = _close("grad input", xg.grad, rg[-1])
+    got = dict(me.named_parameters())
+    for k, r in zip(names, rg[:-1]):
+        assert got[k].grad is not None, k
+        worst = max(worst, _close("grad " + k, got[k].grad, r))
+    print(f"MessageExtractorv2 backward C={C} {H}x{W}: {len(names)} parameter gradients + input, worst relative error {worst:.2e}")
+
+
+def test_stage2_training_step_reaches_only_the_new_agents_message_extractor():
+    """Stage 2 (heter_model_baseline_w_gencomm_stage2.py:99-101, :180-185): every module is frozen except the message
+    extractor of the new (non-ego) modality. One training step through the stage-2 shell on the HIP path: loss.backward()
+    must leave finite, non-zero gradients on message_extractor_m2 and on nothing else."""
+    import copy, json, os
+    from gencomm_amd import synth
+    from gencomm_amd.heter_model_baseline_w_gencomm_stage2 import HeterModelBaselineWDiffCommStage2
+    with open(os.path.join(REPO, "tests", "golden", "shell_state_dict_keys.json")) as f:
+        args = copy.deepcopy(json.load(f)["args"])
+    args["m2"] = copy.deepcopy(args["m1"])            # the new agent type: its own encoder / backbone / shrinker / extractor
+    model = HeterModelBaselineWDiffCommStage2(args)
+    synth.fill_params_(model, 3)
+    synth.fill_bn_stats_(model, 4)
+    model = model.to(DEV).train()
+    model.model_train_init_stage2()                   # train.py:136-139 calls the model's train-init each epoch
+    trainable = sorted({n.split(".")[0] for n, p in model.named_parameters() if p.requires_grad})
+    assert trainable == ["message_extractor_m2"], trainable
+    rl = [2, 1]
+    pil = synth.make_pillars(600, 3, 128, 64, 9, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
+    ptm = synth.make_pairwise_t_matrix(rl, 5, 10, max_shift=4.0)
+    coords = torch.from_numpy(pil["voxel_coords"])
+    inputs = {k: torch.from_numpy(pil[k]) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
+    # agents 0 and 2 are ego-type (m1), agent 1 is the new type (m2): split the pillars by agent, re-number the batch index
+    def pick(agents):
+        sel = torch.zeros(len(coords), dtype=torch.bool)
+        out_c = coords.clone()
+        for new_i, a in enumerate(agents):
+            m = coords[:, 0] == a
+            sel |= m
+            out_c[m, 0] = new_i
+        return {"voxel_features": inputs["voxel_features"][sel].to(DEV), "voxel_coords": out_c[sel].to(DEV),
+                "voxel_num_points": inputs["voxel_num_points"][sel].to(DEV)}
+    data = {"agent_modality_list": ["m1", "m2", "m1"], "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(DEV),
+            "inputs_m1": pick([0, 2]), "inputs_m2": pick([1])}
+    out = model(data)
+    loss = out["cls_preds"].square().mean() + out["reg_preds"].square().mean() + (out["pred_feature"] - out["gt_feature"]).square().mean()
+    loss.backward()
+    with_grad = sorted({n.split(".")[0] for n, p in model.named_parameters() if p.grad is not None})
+    assert with_grad == ["message_extractor_m2"], with_grad
+    tot = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+            tot += float(p.grad.abs().sum())
+    assert tot > 0.0
+    print(f"stage-2 training step: loss {float(loss):.4f}, sum |grad| over message_extractor_m2 {tot:.3e}")
