@@ -553,6 +553,21 @@ int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, 
   return conv_wgrad_enqueue(a, N, (hipStream_t)stream);
 }
 
+// deformable 3x3 convolution split into sampling + GEMM for the training path of MessageExtractorv2 (train_kernels.h)
+int gencomm_dcn_sample_fwd(const float* x, const float* offset, float* col, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(x && offset && col && n >= 1 && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad arguments");
+  dcn_sample_kernel<<<dim3((H * W + 255) / 256, 9, n), 256, 0, (hipStream_t)stream>>>(x, offset, col, C, H, W);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int n, int C, int H, int W,
+                            void* stream) {
+  GC_CHECK_ARG(x && offset && dcol && dx && doffset && n >= 1 && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad arguments");
+  dcn_scatter_bwd_kernel<<<dim3((H * W + 255) / 256, 9, n), 256, 0, (hipStream_t)stream>>>(x, offset, dcol, dx, doffset, C, H, W);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream) {
   GC_CHECK_ARG(x && gamma && beta && out && n >= 1 && n <= 65535 && C >= 1 && HW >= 1, "bad arguments");
   LnArgs a{x, gamma, beta, nullptr, out, nullptr, eps, C, HW, residual, 0};

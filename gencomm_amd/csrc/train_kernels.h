@@ -250,4 +250,72 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   out[i] = g[i] * (0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x));
 }
 
+// ---- deformable 3x3 convolution (DCNv1, one offset group, padding 1) for the training path of MessageExtractorv2 ------------
+// (message_extractor_v2.py:78,:108; sampling arithmetic as in dcn_kernel, msgext_kernels.h).  The convolution is split
+// into its sampling half and its GEMM half so that the backward is GEMMs on the general kernels plus one scatter kernel:
+//   col[n][c * 9 + k][p] = bilinear sample of x[n][c] at (y - 1 + ky + off[2k], x - 1 + kx + off[2k + 1])
+//   b1 = W[64][9 C] col + bias        (1x1 convolution over 9 C channels)
+// dcn_scatter_bwd: given dcol, dx[n][c][corner] += w_corner dcol (atomics), d off[2k] = sum_c dcol d val / d py, d off[2k+1] likewise.
+struct DcnTap {
+  float hy, ly, hx, lx;          // bilinear fractions
+  int j00, j01, j10, j11;        // corner indices (0 where the corner is outside the map)
+  bool c00, c01, c10, c11;       // corner inside the map (and the sample position inside (-1, H) x (-1, W))
+};
+__device__ __forceinline__ DcnTap dcn_tap(const float* __restrict__ off, int n, int k, int pix, int y, int x, int H, int W) {
+  const int HW = H * W;
+  const float py = (float)(y - 1 + k / 3) + off[((size_t)n * 18 + 2 * k) * HW + pix];
+  const float px = (float)(x - 1 + k % 3) + off[((size_t)n * 18 + 2 * k + 1) * HW + pix];
+  DcnTap t;
+  const bool inside = py > -1.f && py < (float)H && px > -1.f && px < (float)W;
+  const float fy = floorf(py), fx = floorf(px);
+  const int iy = (int)fy, ix = (int)fx;
+  t.ly = py - fy; t.lx = px - fx; t.hy = 1.f - t.ly; t.hx = 1.f - t.lx;
+  const bool y0 = inside && iy >= 0, y1 = inside && iy + 1 <= H - 1, x0 = ix >= 0, x1 = ix + 1 <= W - 1;
+  const int i00 = iy * W + ix;
+  t.c00 = y0 && x0; t.c01 = y0 && x1; t.c10 = y1 && x0; t.c11 = y1 && x1;
+  t.j00 = t.c00 ? i00 : 0; t.j01 = t.c01 ? i00 + 1 : 0; t.j10 = t.c10 ? i00 + W : 0; t.j11 = t.c11 ? i00 + W + 1 : 0;
+  return t;
+}
+__global__ __launch_bounds__(256) void dcn_sample_kernel(const float* __restrict__ x, const float* __restrict__ off, float* __restrict__ col,
+                                                         int C, int H, int W) {
+  const int n = blockIdx.z, k = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x, HW = H * W;
+  if (pix >= HW) return;
+  const int y = pix / W, xx = pix - y * W;
+  const DcnTap t = dcn_tap(off, n, k, pix, y, xx, H, W);
+  const float w00 = t.c00 ? t.hy * t.hx : 0.f, w01 = t.c01 ? t.hy * t.lx : 0.f, w10 = t.c10 ? t.ly * t.hx : 0.f, w11 = t.c11 ? t.ly * t.lx : 0.f;
+  const float* __restrict__ xn = x + (size_t)n * C * HW;
+  float* __restrict__ cn = col + (size_t)n * C * 9 * HW;
+  for (int c = 0; c < C; ++c) {
+    const float* __restrict__ pl = xn + (size_t)c * HW;
+    cn[((size_t)c * 9 + k) * HW + pix] = w00 * pl[t.j00] + w01 * pl[t.j01] + w10 * pl[t.j10] + w11 * pl[t.j11];
+  }
+}
+__global__ __launch_bounds__(256) void dcn_scatter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ dcol,
+                                                              float* __restrict__ dx, float* __restrict__ doff, int C, int H, int W) {
+  const int n = blockIdx.z, k = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x, HW = H * W;
+  if (pix >= HW) return;
+  const int y = pix / W, xx = pix - y * W;
+  const DcnTap t = dcn_tap(off, n, k, pix, y, xx, H, W);
+  const float w00 = t.c00 ? t.hy * t.hx : 0.f, w01 = t.c01 ? t.hy * t.lx : 0.f, w10 = t.c10 ? t.ly * t.hx : 0.f, w11 = t.c11 ? t.ly * t.lx : 0.f;
+  const float* __restrict__ xn = x + (size_t)n * C * HW;
+  float* __restrict__ dxn = dx + (size_t)n * C * HW;
+  const float* __restrict__ dn = dcol + (size_t)n * C * 9 * HW;
+  float gy = 0.f, gx = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float dv = dn[((size_t)c * 9 + k) * HW + pix];
+    const float* __restrict__ pl = xn + (size_t)c * HW;
+    float* __restrict__ dpl = dxn + (size_t)c * HW;
+    const float v00 = t.c00 ? pl[t.j00] : 0.f, v01 = t.c01 ? pl[t.j01] : 0.f, v10 = t.c10 ? pl[t.j10] : 0.f, v11 = t.c11 ? pl[t.j11] : 0.f;
+    // val = hy hx v00 + hy lx v01 + ly hx v10 + ly lx v11;  d ly / d py = 1, d hy / d py = -1 (floor is constant almost everywhere)
+    gy = fmaf(dv, t.hx * (v10 - v00) + t.lx * (v11 - v01), gy);
+    gx = fmaf(dv, t.hy * (v01 - v00) + t.ly * (v11 - v10), gx);
+    if (t.c00) atomicAdd(&dpl[t.j00], w00 * dv);
+    if (t.c01) atomicAdd(&dpl[t.j01], w01 * dv);
+    if (t.c10) atomicAdd(&dpl[t.j10], w10 * dv);
+    if (t.c11) atomicAdd(&dpl[t.j11], w11 * dv);
+  }
+  doff[((size_t)n * 18 + 2 * k) * HW + pix] = gy;
+  doff[((size_t)n * 18 + 2 * k + 1) * HW + pix] = gx;
+}
+
 }  // namespace gc

@@ -51,7 +51,8 @@ class BEVDeformableExtractor(nn.Module):
 def _deform_conv3x3_torch(x, offset, weight, bias):
     """Differentiable restatement of the 3x3 / padding-1 deformable convolution (DCNv1 as torchvision defines it: offset
     channel 2k / 2k+1 = vertical / horizontal displacement of tap k, bilinear sampling, zero outside the map) with torch
-    gathers -- used ONLY to differentiate: the forward value always comes from the HIP kernel."""
+    gathers. DIAGNOSTIC ONLY (tools/diag_msgext_bwd.py checks the HIP backward pieces against its autograd): neither the
+    forward nor the backward of the module calls it."""
     n, C, H, W = x.shape
     O = weight.shape[0]
     ys = torch.arange(H, dtype=x.dtype, device=x.device).view(1, H, 1)
@@ -75,7 +76,7 @@ def _deform_conv3x3_torch(x, offset, weight, bias):
 
 
 def _extractor_torch(x, ow, ob, dw, db, f0w, f0b, f2w, f2b, a1w, a1b, a3w, a3b):
-    """BEVDeformableExtractor.forward (message_extractor_v2.py:103-118) in differentiable torch ops (backward only)."""
+    """BEVDeformableExtractor.forward (message_extractor_v2.py:103-118) in differentiable torch ops (diagnostic only)."""
     import torch.nn.functional as F
     off = F.conv2d(x, ow, ob, padding=1)
     b1 = _deform_conv3x3_torch(x, off, dw, db)
@@ -86,29 +87,71 @@ def _extractor_torch(x, ow, ob, dw, db, f0w, f0b, f2w, f2b, a1w, a1b, a3w, a3b):
 
 
 class _MsgExtFn(torch.autograd.Function):
-    """HIP forward (gencomm_msgext_fwd); the backward re-evaluates the extractor with differentiable torch ops on the GPU from
-    the saved input (activation-checkpoint style) -- stage 2 of the reference trains exactly this module (stage2.py:99-101),
-    with every other module frozen, so its gradients must exist; dedicated HIP backward kernels are the next step."""
+    """HIP forward (gencomm_msgext_fwd, the fused inference kernels) and a backward composed of HIP primitives
+    (gencomm_amd/train_ops.py) -- stage 2 of the reference trains exactly this module (stage2.py:99-101) with every other
+    module frozen. The deformable convolution is split into its sampling half (gencomm_dcn_sample_fwd) and its GEMM half, so
+    its backward is two GEMMs on the general kernels (d weight on the split-K MFMA kernel, d columns) plus one scatter kernel
+    (gencomm_dcn_scatter_bwd: d input by atomics, d offsets); the offset convolution and the two 1x1 layers use the general
+    convolution's dgrad / wgrad. Elementwise products / sums and the squeeze-excitation gate's MLP on [n, 64] vectors are plain
+    torch tensor arithmetic, as in EnhancerFunction."""
 
     @staticmethod
     def forward(ctx, mod, x, *params):
         ctx.mod = mod
-        ctx.save_for_backward(x, *params)
+        ctx.save_for_backward(x)
         with torch.no_grad():
             return mod._forward_hip(x)
 
     @staticmethod
     def backward(ctx, gy):
-        x, *params = ctx.saved_tensors
+        import torch.nn.functional as F
+        from . import train_ops as T
+        (x,) = ctx.saved_tensors
+        e_ = ctx.mod.bev_extractor
+        ow, ob, dw, db = e_.offset1.weight, e_.offset1.bias, e_.dcn1.weight, e_.dcn1.bias
+        f0, f2, a1, a3 = e_.fuse[0], e_.fuse[2], e_.attn[1], e_.attn[3]
+        n, C, H, W = x.shape
+        HW = H * W
+        with torch.no_grad():
+            x = x.detach().float().contiguous()
+            # ---- forward recompute with every intermediate kept (message_extractor_v2.py:103-118)
+            off = T.conv2d(x, ow, ob, 1)
+            col = T.dcn_sample(x, off)                                               # [n, 9 C, H, W]
+            wd2 = dw.detach().reshape(64, C * 9)[:, :, None, None]
+            b1 = T.conv2d(col, wd2, db, 0)                                           # deformable conv = 1x1 GEMM over the samples
+            w0 = f0.weight.detach()
+            w2 = f2.weight.detach()
+        # ---- squeeze-excitation gate on [n, 64] vectors: torch autograd on a few hundred numbers
+        gate_params = [a1.weight, a1.bias, a3.weight, a3.bias]
         with torch.enable_grad():
-            xd = x.detach().float().requires_grad_(ctx.needs_input_grad[1])
-            pd = [p.detach().float().requires_grad_(need) for p, need in zip(params, ctx.needs_input_grad[2:])]
-            y = _extractor_torch(xd, *pd)
-            wanted = ([xd] if ctx.needs_input_grad[1] else []) + [p for p in pd if p.requires_grad]
-            grads = list(torch.autograd.grad(y, wanted, gy.contiguous().float(), allow_unused=True))
-        gx = grads.pop(0) if ctx.needs_input_grad[1] else None
-        gp = [grads.pop(0) if need else None for need in ctx.needs_input_grad[2:]]
-        return (None, gx, *gp)
+            mean = b1.mean((2, 3), keepdim=True).requires_grad_(True)
+            local = [p.detach().requires_grad_(True) for p in gate_params]
+            gate = torch.sigmoid(F.conv2d(F.relu(F.conv2d(mean, local[0], local[1])), local[2], local[3]))
+        with torch.no_grad():
+            g = gate.detach()
+            e = b1 * g
+            hpre = T.conv2d(e, w0, f0.bias, 0)
+            h = torch.relu(hpre)
+            go = gy.float().contiguous()
+            # ---- fuse: 1x1 64 -> 2, ReLU, 1x1 64 -> 64
+            dW2, db2 = T.conv2d_wgrad(go, h, 1, 0, True)
+            dh = T.conv2d(go, w2.transpose(0, 1).contiguous(), None, 0) * (hpre > 0)
+            dW0, db0 = T.conv2d_wgrad(dh, e, 1, 0, True)
+            de = T.conv2d(dh, w0.transpose(0, 1).contiguous(), None, 0)
+            dgate = (de * b1).sum((2, 3), keepdim=True)
+        dmean, *dgp = torch.autograd.grad(gate, [mean] + local, dgate)
+        with torch.no_grad():
+            db1 = de * g + dmean / HW
+            # ---- deformable convolution: GEMM half, then the sampling half
+            dWd, dbd = T.conv2d_wgrad(db1, col, 1, 0, True)                          # [64, 9 C, 1, 1]
+            dcol = T.conv2d(db1, wd2.transpose(0, 1).contiguous(), None, 0)          # [n, 9 C, H, W]
+            dx, doff = T.dcn_scatter_bwd(x, off, dcol)
+            # ---- offset convolution
+            dWo, dbo = T.conv2d_wgrad(doff, x, 3, 1, True)
+            dx = dx + T.conv2d_dgrad(doff, ow, 1)
+        grads = [dWo, dbo, dWd.reshape(64, C, 3, 3), dbd, dW0, db0, dW2, db2] + list(dgp)
+        gp = [gr if need else None for gr, need in zip(grads, ctx.needs_input_grad[2:])]
+        return (None, dx if ctx.needs_input_grad[1] else None, *gp)
 
 
 class MessageExtractorv2(nn.Module):

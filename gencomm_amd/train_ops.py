@@ -1,6 +1,7 @@
 """Training building blocks on the HIP kernels (NCHW fp32): the forward-recompute and backward primitives the Enhancer's
 backward is composed of in ``autograd.py`` -- general convolution (3x3 / 1x1 = Linear) with its input and weight gradients,
-LayerNorm over channels, depthwise 3x3 convolution, erf-GELU backward. Thin wrappers over the C ABI
+LayerNorm over channels, depthwise 3x3 convolution, erf-GELU backward, and the sampling / scatter halves of the message extractor's
+deformable convolution. Thin wrappers over the C ABI
 (``gencomm_conv2d_{prepare,fold,fwd,wgrad}``, ``gencomm_ln_nchw_{fwd,bwd}``, ``gencomm_dwconv3x3_{fwd,wgrad}``,
 ``gencomm_gelu_bwd``); no torch convolution / normalisation call anywhere."""
 from __future__ import annotations
@@ -96,3 +97,23 @@ def gelu_bwd(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(v)
     _lib.check(_lib.lib().gencomm_gelu_bwd(ptr(v), ptr(g), ptr(out), v.numel(), stream_ptr(v.device)), "gencomm_gelu_bwd")
     return out
+
+
+def dcn_sample(x: torch.Tensor, offset: torch.Tensor) -> torch.Tensor:
+    """col [n, 9 C, H, W]: the bilinear samples the 3x3 deformable convolution multiplies its weights with (channel c * 9 + tap)."""
+    x, offset = _c(x), _c(offset)
+    n, C, H, W = x.shape
+    col = torch.empty(n, C * 9, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gencomm_dcn_sample_fwd(ptr(x), ptr(offset), ptr(col), n, C, H, W, stream_ptr(x.device)), "gencomm_dcn_sample_fwd")
+    return col
+
+
+def dcn_scatter_bwd(x: torch.Tensor, offset: torch.Tensor, dcol: torch.Tensor):
+    """(dx [n, C, H, W], doffset [n, 18, H, W]) from the gradient of the sampled columns."""
+    x, offset, dcol = _c(x), _c(offset), _c(dcol)
+    n, C, H, W = x.shape
+    dx = torch.zeros_like(x)
+    doff = torch.empty(n, 18, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gencomm_dcn_scatter_bwd(ptr(x), ptr(offset), ptr(dcol), ptr(dx), ptr(doff), n, C, H, W, stream_ptr(x.device)),
+               "gencomm_dcn_scatter_bwd")
+    return dx, doff

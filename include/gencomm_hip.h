@@ -361,6 +361,16 @@ int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* ou
 int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, const float* fc1_w, const float* ln_w, const float* ln_b,
                             const float* fc2_w, const float* residual, float* out, float* scratch, int n, int C, int HW, void* stream);
 
+/* Training path of MessageExtractorv2's deformable 3x3 convolution (message_extractor_v2.py:78,:108; DCNv1, padding 1, one offset
+ * group), split into its sampling half and its GEMM half so that the backward is GEMMs on the general kernels + one scatter:
+ *   gencomm_dcn_sample_fwd   col[n][c * 9 + k][p] = bilinear sample of x[n][c] at tap k's displaced position (zero outside)
+ *                            -- the deformable convolution is then gencomm_conv2d_fwd(col, W [64][9 C], 1x1)
+ *   gencomm_dcn_scatter_bwd  given dcol: dx += scatter of the bilinear weights (atomics; dx zeroed or pre-filled by the caller),
+ *                            doffset [n][18][H][W] = d loss / d offset (overwritten) */
+int gencomm_dcn_sample_fwd(const float* x, const float* offset, float* col, int n, int C, int H, int W, void* stream);
+int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int n, int C, int H, int W,
+                            void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Sparse 3-D convolutions of the SECOND encoder without spconv (opencood/models/heter_encoders.py:52-81,
  * sub_modules/sparse_backbone_3d.py:33-152, mean_vfe.py:14-33, height_compression.py:10-30). A sparse tensor is

@@ -191,10 +191,14 @@ def test_fusion_backward_hip_vs_torch_autograd(C, H, W, rl, shift):
     print(f"fusion backward C={C} {H}x{W} scenes {rl}: worst relative error {worst:.2e}")
 
 
-@pytest.mark.parametrize("C,H,W,n", [(16, 12, 20, 2), (128, 32, 48, 1)])
+@pytest.mark.parametrize("C,H,W,n", [(16, 12, 20, 2), (128, 16, 24, 1)])
 def test_message_extractor_backward_vs_oracle_autograd(C, H, W, n):
-    """MessageExtractorv2 is THE module stage 2 trains (stage2.py:99-101): HIP forward, gradients of all 12 parameters and of
-    the input against float64 autograd through the oracle (offsets scaled so that the sampling positions cross pixels)."""
+    """MessageExtractorv2 is THE module stage 2 trains (stage2.py:99-101): HIP forward, HIP-composed backward; gradients of all
+    12 parameters and of the input against float64 autograd through the oracle (offsets scaled so that the sampling positions
+    cross pixels). The gradient of bilinear sampling is DISCONTINUOUS where a sampling position crosses an integer, and the HIP
+    path's float32 offsets differ from the float64 ones by ~2e-5: the input is drawn (by seed) so that no position lies within
+    1e-4 of an integer -- otherwise a handful of pixels legitimately land in the neighbouring cell (tools/diag_msgext_bwd.py)."""
+    import torch.nn.functional as F
     from gencomm_amd import MessageExtractorv2, synth
     from oracle import torch_port as O
     me = MessageExtractorv2(C, 2).train()
@@ -202,8 +206,13 @@ def test_message_extractor_backward_vs_oracle_autograd(C, H, W, n):
     with torch.no_grad():
         me.bev_extractor.offset1.weight.mul_(5.0)
         me.bev_extractor.offset1.bias.mul_(5.0)
-    g = torch.Generator().manual_seed(C)
-    x = torch.randn(n, C, H, W, generator=g)
+    for seed in range(200):
+        x = torch.randn(n, C, H, W, generator=torch.Generator().manual_seed(1000 * C + seed))
+        off = F.conv2d(x.double(), me.bev_extractor.offset1.weight.double(), me.bev_extractor.offset1.bias.double(), padding=1)
+        if float((off - off.round()).abs().min()) > 1e-4:
+            break
+    else:
+        pytest.skip("no seed keeps every sampling position away from the integers")
     sd = {k: v.detach().double().requires_grad_(True) for k, v in me.state_dict().items()}
     xd = x.double().requires_grad_(True)
     ref = O.message_extractor_forward(sd, xd)
