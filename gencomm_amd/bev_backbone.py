@@ -40,21 +40,57 @@ def _torch_expr(x, conv, bn, relu, pad):
     return F.relu(y) if relu else y
 
 
+def _hip_backward(x, y, gy, conv, bn, relu, pad, need_x):
+    """Backward of act(BN_eval(conv(x))) on the HIP primitives (train_ops) for what they cover: nn.Conv2d, 1x1 or 3x3, stride 1.
+    Returns (dx, {parameter: gradient}) or None when the layer needs the torch fallback (stride 2, ConvTranspose2d)."""
+    from . import train_ops as T
+    if isinstance(conv, nn.ConvTranspose2d) or conv.stride != (1, 1) or conv.kernel_size not in ((1, 1), (3, 3)):
+        return None
+    k = conv.kernel_size[0]
+    p = conv.padding[0] if pad is None else pad
+    g = gy.float().contiguous()
+    if relu:
+        g = g * (y > 0)
+    grads = {}
+    if bn is not None:   # eval-mode BatchNorm: y = scale (conv + bias - mean) + beta
+        rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        scale = bn.weight.detach().float() * rstd
+        if bn.weight.requires_grad or bn.bias.requires_grad:
+            pre = T.conv2d(x, conv.weight, conv.bias, p)                       # the convolution's own output, unfused
+            grads[bn.weight] = (g * (pre - bn.running_mean.float().view(1, -1, 1, 1))).sum((0, 2, 3)) * rstd
+            grads[bn.bias] = g.sum((0, 2, 3))
+        g = g * scale.view(1, -1, 1, 1)
+    if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+        dw, db = T.conv2d_wgrad(g, x, k, p, conv.bias is not None)
+        grads[conv.weight] = dw
+        if conv.bias is not None:
+            grads[conv.bias] = db
+    dx = T.conv2d_dgrad(g, conv.weight, p) if need_x else None
+    return dx, grads
+
+
 class _Conv2dHipFn(torch.autograd.Function):
-    """HIP forward; backward re-evaluates the layer with differentiable torch ops from the saved input (the recompute
-    scheme of gencomm_amd/autograd.py), so gradients reach the input and the conv / BatchNorm-affine parameters."""
+    """HIP forward. Backward: stride-1 1x1 / 3x3 layers (the detection heads, the backbone's inner layers) on the HIP dgrad /
+    wgrad kernels; stride-2 convolutions and ConvTranspose2d re-evaluate the layer with differentiable torch ops from the saved
+    input. Either way gradients reach the input and the conv / BatchNorm-affine parameters: the graph is never cut."""
 
     @staticmethod
     def forward(ctx, x, conv, bn, relu, pad, *params):
         ctx.conv, ctx.bn, ctx.relu, ctx.pad = conv, bn, relu, pad
-        ctx.save_for_backward(x)
         with torch.no_grad():
-            return conv2d_hip(x, conv, bn, relu=relu, pad=pad)
+            y = conv2d_hip(x, conv, bn, relu=relu, pad=pad)
+        ctx.save_for_backward(x, y)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        (x,) = ctx.saved_tensors
+        x, y = ctx.saved_tensors
         params = [p for p in (ctx.conv.weight, ctx.conv.bias) + ((ctx.bn.weight, ctx.bn.bias) if ctx.bn is not None else ()) if p is not None]
+        with torch.no_grad():
+            hip = _hip_backward(x.detach().float().contiguous(), y, gy, ctx.conv, ctx.bn, ctx.relu, ctx.pad, ctx.needs_input_grad[0])
+        if hip is not None:
+            dx, grads = hip
+            return (dx, None, None, None, None, *[grads.get(p) if p.requires_grad else None for p in params])
         with torch.enable_grad():
             xd = x.detach().requires_grad_(True)
             y = _torch_expr(xd, ctx.conv, ctx.bn, ctx.relu, ctx.pad)
