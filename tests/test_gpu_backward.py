@@ -231,16 +231,24 @@ def test_message_extractor_backward_vs_oracle_autograd(C, H, W, n):
     print(f"MessageExtractorv2 backward C={C} {H}x{W}: {len(names)} parameter gradients + input, worst relative error {worst:.2e}")
 
 
-def test_stage2_training_step_reaches_only_the_new_agents_message_extractor():
+@pytest.mark.parametrize("new_agent", ["point_pillar", "second"])
+def test_stage2_training_step_reaches_only_the_new_agents_message_extractor(new_agent):
     """Stage 2 (heter_model_baseline_w_gencomm_stage2.py:99-101, :180-185): every module is frozen except the message
     extractor of the new (non-ego) modality. One training step through the stage-2 shell on the HIP path: loss.backward()
-    must leave finite, non-zero gradients on message_extractor_m2 and on nothing else."""
+    must leave finite, non-zero gradients on message_extractor_m2 and on nothing else. The new agent is a second PointPillars
+    model (m1m1-style) or a SECOND model (the shipped stage2/m1m3_att.yaml pairing: sparse 3-D encoder, stride-1 first backbone block)."""
     import copy, json, os
     from gencomm_amd import synth
     from gencomm_amd.heter_model_baseline_w_gencomm_stage2 import HeterModelBaselineWDiffCommStage2
     with open(os.path.join(REPO, "tests", "golden", "shell_state_dict_keys.json")) as f:
         args = copy.deepcopy(json.load(f)["args"])
     args["m2"] = copy.deepcopy(args["m1"])            # the new agent type: its own encoder / backbone / shrinker / extractor
+    if new_agent == "second":
+        args["m2"].update({"core_method": "second",
+                           "encoder_args": {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": args["lidar_range"], "mean_vfe": {"num_point_features": 4},
+                                            "spconv": {"num_features_in": 4, "num_features_out": 64}, "map2bev": {"feature_num": 128}},
+                           "backbone_args": {"layer_nums": [3, 5, 8], "layer_strides": [1, 2, 2], "num_filters": [64, 128, 256],
+                                             "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128], "inplanes": 128}})
     model = HeterModelBaselineWDiffCommStage2(args)
     synth.fill_params_(model, 3)
     synth.fill_bn_stats_(model, 4)
@@ -265,6 +273,11 @@ def test_stage2_training_step_reaches_only_the_new_agents_message_extractor():
                 "voxel_num_points": inputs["voxel_num_points"][sel].to(DEV)}
     data = {"agent_modality_list": ["m1", "m2", "m1"], "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(DEV),
             "inputs_m1": pick([0, 2]), "inputs_m2": pick([1])}
+    if new_agent == "second":
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from test_second import _voxels
+        vf, vc, vn = _voxels(np.random.RandomState(5), [3000], 512, 256, 40)
+        data["inputs_m2"] = {"voxel_features": vf.to(DEV), "voxel_coords": vc.to(DEV), "voxel_num_points": vn.to(DEV)}
     out = model(data)
     loss = out["cls_preds"].square().mean() + out["reg_preds"].square().mean() + (out["pred_feature"] - out["gt_feature"]).square().mean()
     loss.backward()
