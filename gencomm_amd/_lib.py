@@ -69,6 +69,10 @@ _SIGNATURES = {
     "gencomm_conv2d_fwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 13 + [_p]),
     "gencomm_conv2d_act_res_fwd": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "gencomm_split3_attn_fwd": (_i, [_p] * 10 + [_i, _i, _i, _p]),
+    "gencomm_warp_affine_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_hgt_attn_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_win_attn_bwd_scratch_floats": (_ll, [_i, _i, _i, _i, _i]),
+    "gencomm_win_attn_bwd": (_i, [_p] * 7 + [_i] * 6 + [_p]),
     "gencomm_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gencomm_ln_nchw_fwd": (_i, [_p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
     "gencomm_ln_nchw_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),

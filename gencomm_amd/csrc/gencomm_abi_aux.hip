@@ -118,6 +118,50 @@ int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* ou
   return fail(GC_ERR_ARG, "window attention: supported (window, dim_head) pairs are (4,16) (4,32) (8,16) (8,32) (8,64) (16,32) (16,64)");
 }
 
+// ---- V2X-ViT backward building blocks (v2xvit_kernels.h) ----------------------------------------------------------------
+int gencomm_warp_affine_bwd(const double* theta, const float* dout, float* dx, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(theta && dout && dx && n >= 1 && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  GC_HIP(hipMemsetAsync(dx, 0, (size_t)n * C * H * W * sizeof(float), st));
+  WarpArgs a{nullptr, theta, dx, C, H, W};
+  warp_affine_bwd_kernel<<<dim3((H * W + 255) / 256, n), 256, 0, st>>>(a, dout);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_hgt_attn_bwd(const float* qkv, const int* scene_off, const float* dout, float* dqkv, int B, int heads, int dim_head, int HW, void* stream) {
+  GC_CHECK_ARG(qkv && scene_off && dout && dqkv && B >= 1 && B <= 65535 && heads >= 1 && heads <= 65535 && HW >= 1, "bad arguments");
+  HgtBwdArgs a{qkv, scene_off, dout, dqkv, heads, HW, 1.0f / sqrtf((float)dim_head)};
+  const dim3 grid((HW + 255) / 256, heads, B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dim_head == 32) hgt_attn_bwd_kernel<32><<<grid, 256, 0, st>>>(a);
+  else if (dim_head == 64) hgt_attn_bwd_kernel<64><<<grid, 256, 0, st>>>(a);
+  else if (dim_head == 16) hgt_attn_bwd_kernel<16><<<grid, 256, 0, st>>>(a);
+  else return fail(GC_ERR_ARG, "hgt attention: dim_head must be 16, 32 or 64");
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+long long gencomm_win_attn_bwd_scratch_floats(int n, int heads, int window, int H, int W) {
+  if (n < 1 || heads < 1 || window < 1 || H < window || W < window || H % window || W % window) { fail(GC_ERR_ARG, "bad arguments"); return -1; }
+  const long long T = (long long)window * window, nwin = (long long)(H / window) * (W / window);
+  return (long long)n * heads * nwin * 2 * T * T;
+}
+// dqkv [n][3 inner][H][W] is overwritten; dpos [(2 window - 1)^2] is ACCUMULATED (+=); `out` = the forward's output
+int gencomm_win_attn_bwd(const float* qkv, const float* pos_embedding, const float* out, const float* dout, float* dqkv, float* dpos,
+                         float* scratch, int n, int heads, int dim_head, int window, int H, int W, void* stream) {
+  GC_CHECK_ARG(qkv && pos_embedding && out && dout && dqkv && dpos && scratch && n >= 1 && n <= 65535 && heads >= 1 && heads <= 65535, "bad arguments");
+  GC_CHECK_ARG(H >= window && W >= window && H % window == 0 && W % window == 0, "H and W must be multiples of the window size");
+  WinBwdArgs a{qkv, pos_embedding, out, dout, dqkv, dpos, scratch, heads, H, W, 1.0f / sqrtf((float)dim_head)};
+  hipStream_t st = (hipStream_t)stream;
+  if (window == 4 && dim_head == 16) return win_attn_bwd_launch<16, 4>(a, n, st);
+  if (window == 8 && dim_head == 32) return win_attn_bwd_launch<32, 8>(a, n, st);
+  if (window == 16 && dim_head == 64) return win_attn_bwd_launch<64, 16>(a, n, st);
+  if (window == 4 && dim_head == 32) return win_attn_bwd_launch<32, 4>(a, n, st);
+  if (window == 8 && dim_head == 16) return win_attn_bwd_launch<16, 8>(a, n, st);
+  if (window == 8 && dim_head == 64) return win_attn_bwd_launch<64, 8>(a, n, st);
+  if (window == 16 && dim_head == 32) return win_attn_bwd_launch<32, 16>(a, n, st);
+  return fail(GC_ERR_ARG, "window attention: supported (window, dim_head) pairs are (4,16) (4,32) (8,16) (8,32) (8,64) (16,32) (16,64)");
+}
+
 // radix-3 split attention over three branch maps [n][C][HW] (+ residual): gap -> fc1 -> LayerNorm -> ReLU -> fc2 -> softmax over the
 // branches -> weighted sum (sub_modules/split_attn.py:31-62 with radix 3); scratch >= 4 n C floats
 int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, const float* fc1_w, const float* ln_w, const float* ln_b,

@@ -238,4 +238,213 @@ __global__ __launch_bounds__(256) void split3_apply_kernel(const float* __restri
   out[e] = fmaf(a[e], g0, fmaf(b[e], g1, fmaf(c[e], g2, res != nullptr ? res[e] : 0.f)));
 }
 
+// =====================================================================================================================
+// Backward kernels (training with fusion_method v2xvit; first-correct, one lane per query / key, fp32).
+// =====================================================================================================================
+// warp_affine backward: dx[i][c][corner] += bilinear weight * dout[i][c][pixel]  (the sampling grid does not depend on x)
+__global__ __launch_bounds__(256) void warp_affine_bwd_kernel(const WarpArgs a /* x unused; out = dx (zeroed by the caller) */, const float* __restrict__ dout) {
+  const int n = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+  const int H = a.H, W = a.W, HW = H * W;
+  if (pix >= HW) return;
+  const int h = pix / W, w = pix - h * W;
+  const double xb = (2.0 * w + 1.0) / (double)W - 1.0, yb = (2.0 * h + 1.0) / (double)H - 1.0;
+  const double* __restrict__ th = a.theta + (size_t)n * 6;
+  const float gx = (float)(th[0] * xb + th[1] * yb + th[2]);
+  const float gy = (float)(th[3] * xb + th[4] * yb + th[5]);
+  const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  if (!(fx >= -1.f && fx <= (float)W && fy >= -1.f && fy <= (float)H)) return;   // all four corners outside
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = ix - fx, ty = iy - fy;
+  const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W, yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
+  const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+  for (int c = 0; c < a.C; ++c) {
+    const float g = dout[((size_t)n * a.C + c) * HW + pix];
+    float* __restrict__ d = a.out + ((size_t)n * a.C + c) * HW;
+    if (xl && yt) atomicAdd(&d[y0 * W + x0], w00 * g);
+    if (xr && yt) atomicAdd(&d[y0 * W + x0 + 1], w01 * g);
+    if (xl && yb_) atomicAdd(&d[(y0 + 1) * W + x0], w10 * g);
+    if (xr && yb_) atomicAdd(&d[(y0 + 1) * W + x0 + 1], w11 * g);
+  }
+}
+
+// agent-wise attention backward: dqkv [n][3 inner][HW] from dout [n][inner][HW]; one lane per (pixel, head), all agents of the scene
+struct HgtBwdArgs {
+  const float* qkv; const int* scene_off; const float* dout; float* dqkv;
+  int heads, HW; float scale;
+};
+template <int DH>
+__global__ __launch_bounds__(256) void hgt_attn_bwd_kernel(const HgtBwdArgs a) {
+  constexpr int MAXN = 8;
+  const int b = blockIdx.z, m = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
+  if (p >= a.HW || N < 1 || N > MAXN) return;
+  const int inner = a.heads * DH;
+  const size_t agent = (size_t)3 * inner * a.HW, HWs = (size_t)a.HW;
+  const float* __restrict__ base = a.qkv + (size_t)off * agent + p;
+  float* __restrict__ dbase = a.dqkv + (size_t)off * agent + p;
+  const float* __restrict__ dob = a.dout + ((size_t)off * inner + m * DH) * HWs + p;
+  auto Q = [&](int i, int c) { return base[i * agent + (size_t)(m * DH + c) * HWs]; };
+  auto K = [&](int j, int c) { return base[j * agent + (size_t)(inner + m * DH + c) * HWs]; };
+  auto V = [&](int j, int c) { return base[j * agent + (size_t)(2 * inner + m * DH + c) * HWs]; };
+  auto DO = [&](int i, int c) { return dob[(size_t)i * inner * HWs + (size_t)c * HWs]; };
+  // probabilities P[i][j] and dS[i][j] = P (dO_i . v_j - D_i), D_i = sum_j P_ij dO_i . v_j
+  float P[MAXN][MAXN], dS[MAXN][MAXN];
+  for (int i = 0; i < N; ++i) {
+    float s[MAXN], t[MAXN], mx = -INFINITY;
+    for (int j = 0; j < N; ++j) {
+      float d = 0.f, e = 0.f;
+      for (int c = 0; c < DH; ++c) { d = fmaf(Q(i, c), K(j, c), d); e = fmaf(DO(i, c), V(j, c), e); }
+      s[j] = d * a.scale; t[j] = e; mx = fmaxf(mx, s[j]);
+    }
+    float den = 0.f;
+    for (int j = 0; j < N; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+    float D = 0.f;
+    for (int j = 0; j < N; ++j) { P[i][j] = s[j] / den; D = fmaf(P[i][j], t[j], D); }
+    for (int j = 0; j < N; ++j) dS[i][j] = P[i][j] * (t[j] - D);
+  }
+  for (int c = 0; c < DH; ++c) {
+    for (int i = 0; i < N; ++i) {   // dQ_i = scale sum_j dS_ij k_j
+      float g = 0.f;
+      for (int j = 0; j < N; ++j) g = fmaf(dS[i][j], K(j, c), g);
+      dbase[i * agent + (size_t)(m * DH + c) * HWs] = g * a.scale;
+    }
+    for (int j = 0; j < N; ++j) {   // dK_j = scale sum_i dS_ij q_i,  dV_j = sum_i P_ij dO_i
+      float gk = 0.f, gv = 0.f;
+      for (int i = 0; i < N; ++i) { gk = fmaf(dS[i][j], Q(i, c), gk); gv = fmaf(P[i][j], DO(i, c), gv); }
+      dbase[j * agent + (size_t)(inner + m * DH + c) * HWs] = gk * a.scale;
+      dbase[j * agent + (size_t)(2 * inner + m * DH + c) * HWs] = gv;
+    }
+  }
+}
+
+// window attention backward, phase A (lane = query): dQ, the probability / dS matrices of every window to scratch
+// (PS [n][heads][nwin][T][T] x 2), d pos (LDS table, then atomics).  Phase B (lane = key): dK, dV from the columns of PS.
+struct WinBwdArgs {
+  const float* qkv; const float* pos; const float* out; const float* dout;
+  float* dqkv; float* dpos; float* PS;
+  int heads, H, W; float scale;
+};
+template <int DH, int WS>
+__global__ __launch_bounds__(256) void win_attn_bwd_a_kernel(const WinBwdArgs a) {
+  constexpr int T = WS * WS, WPB = 256 / T, NP = (2 * WS - 1) * (2 * WS - 1);
+  extern __shared__ float wb_smem[];  // K [WPB][T][DH], V [WPB][T][DH], pos [NP], dpos [NP]
+  float* sK = wb_smem;
+  float* sV = wb_smem + WPB * T * DH;
+  float* sP = sV + WPB * T * DH;
+  float* sD = sP + NP;
+  const int n = blockIdx.z, m = blockIdx.y, tid = threadIdx.x;
+  const int nw = a.W / WS, nwin = (a.H / WS) * nw;
+  const int win0 = blockIdx.x * WPB;
+  const int inner = a.heads * DH, HW = a.H * a.W;
+  const float* __restrict__ base = a.qkv + (size_t)n * 3 * inner * HW;
+  const int wl = tid / T, tok = tid - wl * T, win = win0 + wl;
+  const bool live = win < nwin;
+  const int wy = live ? win / nw : 0, wx = live ? win - wy * nw : 0;
+  const int ty = tok / WS, tx = tok - ty * WS;
+  const int pix = (wy * WS + ty) * a.W + wx * WS + tx;
+  for (int i = tid; i < NP; i += 256) { sP[i] = a.pos[i]; sD[i] = 0.f; }
+  float q[DH], go[DH];
+  float D = 0.f;
+#pragma unroll
+  for (int c = 0; c < DH; ++c) {
+    q[c] = live ? base[(size_t)(m * DH + c) * HW + pix] * a.scale : 0.f;
+    go[c] = live ? a.dout[((size_t)n * inner + m * DH + c) * HW + pix] : 0.f;
+    D = fmaf(go[c], live ? a.out[((size_t)n * inner + m * DH + c) * HW + pix] : 0.f, D);   // sum_j P_ij dO_i . v_j = dO_i . O_i
+    sK[(wl * T + tok) * DH + c] = live ? base[(size_t)(inner + m * DH + c) * HW + pix] : 0.f;
+    sV[(wl * T + tok) * DH + c] = live ? base[(size_t)(2 * inner + m * DH + c) * HW + pix] : 0.f;
+  }
+  __syncthreads();
+  if (live) {
+    const float* __restrict__ kw = sK + wl * T * DH;
+    const float* __restrict__ vw = sV + wl * T * DH;
+    float mx = -INFINITY, den = 0.f;
+    for (int j = 0; j < T; ++j) {
+      const int jy = j / WS, jx = j - jy * WS;
+      float d = sP[(jy - ty + WS - 1) * (2 * WS - 1) + (jx - tx + WS - 1)];
+#pragma unroll
+      for (int c = 0; c < DH; ++c) d = fmaf(q[c], kw[j * DH + c], d);
+      const float nm = fmaxf(mx, d);
+      den = den * expf(mx - nm) + expf(d - nm);
+      mx = nm;
+    }
+    const float rden = 1.0f / den;
+    float dq[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) dq[c] = 0.f;
+    float* __restrict__ prow = a.PS + ((((size_t)n * a.heads + m) * nwin + win) * 2 * T + tok) * T;   // P row, then dS row at + T * T
+    for (int j = 0; j < T; ++j) {
+      const int jy = j / WS, jx = j - jy * WS;
+      const int pi = (jy - ty + WS - 1) * (2 * WS - 1) + (jx - tx + WS - 1);
+      float d = sP[pi], t = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) { d = fmaf(q[c], kw[j * DH + c], d); t = fmaf(go[c], vw[j * DH + c], t); }
+      const float pij = expf(d - mx) * rden;
+      const float ds = pij * (t - D);
+      prow[j] = pij;
+      prow[(size_t)T * T + j] = ds;
+      atomicAdd(&sD[pi], ds);
+#pragma unroll
+      for (int c = 0; c < DH; ++c) dq[c] = fmaf(ds, kw[j * DH + c], dq[c]);
+    }
+    float* __restrict__ dqp = a.dqkv + (size_t)n * 3 * inner * HW + (size_t)(m * DH) * HW + pix;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) dqp[(size_t)c * HW] = dq[c] * a.scale;
+  }
+  __syncthreads();
+  for (int i = tid; i < NP; i += 256) if (sD[i] != 0.f) atomicAdd(&a.dpos[i], sD[i]);
+}
+template <int DH, int WS>
+__global__ __launch_bounds__(256) void win_attn_bwd_b_kernel(const WinBwdArgs a) {
+  constexpr int T = WS * WS, WPB = 256 / T;
+  extern __shared__ float wb_smem[];  // Q [WPB][T][DH] (scaled), dO [WPB][T][DH]
+  float* sQ = wb_smem;
+  float* sG = wb_smem + WPB * T * DH;
+  const int n = blockIdx.z, m = blockIdx.y, tid = threadIdx.x;
+  const int nw = a.W / WS, nwin = (a.H / WS) * nw;
+  const int win0 = blockIdx.x * WPB;
+  const int inner = a.heads * DH, HW = a.H * a.W;
+  const float* __restrict__ base = a.qkv + (size_t)n * 3 * inner * HW;
+  const int wl = tid / T, tok = tid - wl * T, win = win0 + wl;
+  const bool live = win < nwin;
+  const int wy = live ? win / nw : 0, wx = live ? win - wy * nw : 0;
+  const int ty = tok / WS, tx = tok - ty * WS;
+  const int pix = (wy * WS + ty) * a.W + wx * WS + tx;
+#pragma unroll
+  for (int c = 0; c < DH; ++c) {
+    sQ[(wl * T + tok) * DH + c] = live ? base[(size_t)(m * DH + c) * HW + pix] * a.scale : 0.f;
+    sG[(wl * T + tok) * DH + c] = live ? a.dout[((size_t)n * inner + m * DH + c) * HW + pix] : 0.f;
+  }
+  __syncthreads();
+  if (!live) return;
+  float dk[DH], dv[DH];
+#pragma unroll
+  for (int c = 0; c < DH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+  const float* __restrict__ qw = sQ + wl * T * DH;
+  const float* __restrict__ gw = sG + wl * T * DH;
+  const float* __restrict__ pcol = a.PS + (((size_t)n * a.heads + m) * nwin + win) * 2 * T * T + tok;   // column `tok` of P (then of dS)
+  for (int i = 0; i < T; ++i) {
+    const float pij = pcol[(size_t)i * T], ds = pcol[(size_t)T * T + (size_t)i * T];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) { dv[c] = fmaf(pij, gw[i * DH + c], dv[c]); dk[c] = fmaf(ds, qw[i * DH + c], dk[c]); }   // qw is q * scale already
+  }
+  float* __restrict__ dkp = a.dqkv + (size_t)n * 3 * inner * HW + (size_t)(inner + m * DH) * HW + pix;
+  float* __restrict__ dvp = a.dqkv + (size_t)n * 3 * inner * HW + (size_t)(2 * inner + m * DH) * HW + pix;
+#pragma unroll
+  for (int c = 0; c < DH; ++c) { dkp[(size_t)c * HW] = dk[c]; dvp[(size_t)c * HW] = dv[c]; }
+}
+template <int DH, int WS>
+inline int win_attn_bwd_launch(const WinBwdArgs& a, int n, hipStream_t st) {
+  constexpr int T = WS * WS, WPB = 256 / T, NP = (2 * WS - 1) * (2 * WS - 1);
+  const size_t sha = ((size_t)2 * WPB * T * DH + 2 * NP) * sizeof(float), shb = (size_t)2 * WPB * T * DH * sizeof(float);
+  if (sha > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)win_attn_bwd_a_kernel<DH, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sha));
+  if (shb > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)win_attn_bwd_b_kernel<DH, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+  const int nwin = (a.H / WS) * (a.W / WS);
+  const dim3 grid((nwin + WPB - 1) / WPB, a.heads, n);
+  win_attn_bwd_a_kernel<DH, WS><<<grid, 256, sha, st>>>(a);
+  win_attn_bwd_b_kernel<DH, WS><<<grid, 256, shb, st>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 }  // namespace gc

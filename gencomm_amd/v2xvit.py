@@ -61,6 +61,7 @@ class HGTCavAttention(nn.Module):  # hmsa.py:7-36
             self.q_linears.append(nn.Linear(dim, inner))
             self.v_linears.append(nn.Linear(dim, inner))
             self.a_linears.append(nn.Linear(inner, dim))
+        self.drop_out = nn.Dropout(dropout)   # hmsa.py:36 (applied to the output projection, :148)
         self.relation_att = nn.Parameter(torch.empty(num_relations, heads, dim_head, dim_head))
         self.relation_msg = nn.Parameter(torch.empty(num_relations, heads, dim_head, dim_head))
         nn.init.xavier_uniform_(self.relation_att)
@@ -141,14 +142,16 @@ class V2XTransformer(nn.Module):  # v2xvit_basic.py:181-192
 
 
 # ----------------------------------------------------------------------------------------- HIP forward
-def _hgt_weights(att: HGTCavAttention):
+def _hgt_weights(att: HGTCavAttention, detach: bool = True):
     """q / k / v projections of agent type 0 with relation 0 folded in: k' = relation_att . k, v' = relation_msg^T . v
-    (hmsa.py:131-141 with every type index 0), concatenated for one 1x1 convolution."""
+    (hmsa.py:131-141 with every type index 0), concatenated for one 1x1 convolution. `detach=False` keeps the expression
+    differentiable (the backward unfolds the gradient of the folded weights through it)."""
     m, dh = att.heads, att.dim_head
-    wq, bq = att.q_linears[0].weight.detach(), att.q_linears[0].bias.detach()
-    wk, bk = att.k_linears[0].weight.detach().view(m, dh, -1), att.k_linears[0].bias.detach().view(m, dh)
-    wv, bv = att.v_linears[0].weight.detach().view(m, dh, -1), att.v_linears[0].bias.detach().view(m, dh)
-    ra, rm = att.relation_att.detach()[0], att.relation_msg.detach()[0]
+    d = (lambda t: t.detach()) if detach else (lambda t: t)
+    wq, bq = d(att.q_linears[0].weight), d(att.q_linears[0].bias)
+    wk, bk = d(att.k_linears[0].weight).view(m, dh, -1), d(att.k_linears[0].bias).view(m, dh)
+    wv, bv = d(att.v_linears[0].weight).view(m, dh, -1), d(att.v_linears[0].bias).view(m, dh)
+    ra, rm = d(att.relation_att)[0], d(att.relation_msg)[0]
     wk2, bk2 = torch.einsum("mpq,mqc->mpc", ra, wk).reshape(m * dh, -1), torch.einsum("mpq,mq->mp", ra, bk).reshape(-1)
     wv2, bv2 = torch.einsum("mpc,mpk->mck", rm, wv).reshape(m * dh, -1), torch.einsum("mpc,mp->mc", rm, bv).reshape(-1)
     return torch.cat([wq, wk2, wv2], 0).contiguous(), torch.cat([bq, bk2, bv2], 0).contiguous()
@@ -241,8 +244,6 @@ class V2XViTFusion(nn.Module):
     def forward(self, x, record_len, affine_matrix):
         """x [sumN, C, H, W], record_len [B], affine_matrix [B, L, L, 2, 3] -> [B, C, H, W]."""
         require_gpu(x, "V2XViTFusion.forward")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
-            raise NotImplementedError("V2XViTFusion: the HIP path is forward-only; run it in eval mode / under torch.no_grad()")
         lens = record_len_list(record_len)
         n, C, H, W = x.shape
         B = affine_matrix.shape[0]
@@ -253,13 +254,27 @@ class V2XViTFusion(nn.Module):
         if H % ws_max or W % ws_max:
             raise ValueError(f"V2XViTFusion: H and W must be multiples of the largest window ({ws_max}), got {H}x{W}")
         dev = x.device
+        theta = gather_ego_thetas(affine_matrix, lens).to(dev)
+        off = [0]
+        for k in lens:
+            off.append(off[-1] + k)
+        scene_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .v2xvit_bwd import V2XViTFunction
+            return V2XViTFunction.apply(self, x, theta, scene_off, B, *self.parameters())
+        if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.modules()):
+            from .v2xvit_bwd import _Masks, run_layers   # train mode without gradients: the dropouts are still active, as in the reference
+            with torch.no_grad():
+                h, _ = run_layers(self, x, theta, scene_off, B, _Masks(True))
+                return h[scene_off[:-1].long()].contiguous()
+        return self._forward_hip(x, theta, scene_off, B)
+
+    def _forward_hip(self, x, theta, scene_off, B):
+        enc = self.fusion_net.encoder
+        n, C, H, W = x.shape
+        dev = x.device
         with torch.no_grad():
             x = f32c(x)
-            theta = gather_ego_thetas(affine_matrix, lens).to(dev)
-            off = [0]
-            for k in lens:
-                off.append(off[-1] + k)
-            scene_off = torch.tensor(off, dtype=torch.int32, device=dev)
             h = torch.empty_like(x)
             _lib.check(_lib.lib().gencomm_warp_affine_fwd(ptr(x), ptr(theta), ptr(h), n, C, H, W, stream_ptr(dev)), "gencomm_warp_affine_fwd")
             cache = self._linears

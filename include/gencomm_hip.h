@@ -356,6 +356,15 @@ int gencomm_warp_affine_fwd(const float* x, const double* theta, float* out, int
 int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int B, int heads, int dim_head, int HW, void* stream);
 int gencomm_win_attn_fwd(const float* qkv, const float* pos_embedding, float* out, int n, int heads, int dim_head, int window, int H, int W,
                          void* stream);
+/* Backward of the three blocks above (training with fusion_method v2xvit): gencomm_warp_affine_bwd zeroes dx and scatters dout
+ * through the bilinear weights; gencomm_hgt_attn_bwd overwrites dqkv; gencomm_win_attn_bwd overwrites dqkv, ACCUMULATES dpos
+ * [(2 window - 1)^2] and needs the forward's output `out` and gencomm_win_attn_bwd_scratch_floats floats of scratch. */
+int gencomm_warp_affine_bwd(const double* theta, const float* dout, float* dx, int n, int C, int H, int W, void* stream);
+int gencomm_hgt_attn_bwd(const float* qkv, const int* scene_off, const float* dout, float* dqkv, int B, int heads, int dim_head, int HW,
+                         void* stream);
+long long gencomm_win_attn_bwd_scratch_floats(int n, int heads, int window, int H, int W);
+int gencomm_win_attn_bwd(const float* qkv, const float* pos_embedding, const float* out, const float* dout, float* dqkv, float* dpos,
+                         float* scratch, int n, int heads, int dim_head, int window, int H, int W, void* stream);
 /* radix-3 split attention over the three window branches (sub_modules/split_attn.py:31-62): out = sum_r softmax_r(fc2(ReLU(LN(fc1(
  * mean_HW(a + b + c))))))[r] * branch_r (+ residual); fc1 [C][C], fc2 [3 C][C] without biases; scratch >= 4 n C floats; C <= 256 */
 int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, const float* fc1_w, const float* ln_w, const float* ln_b,

@@ -98,9 +98,8 @@ def v2xvit_fusion(sd: SD, args: dict, x: torch.Tensor, record_len, affine_matrix
     lens = [int(v) for v in (record_len.tolist() if hasattr(record_len, "tolist") else record_len)]
     _, C, H, W = x.shape
     out, o = [], 0
-    with torch.no_grad():
-        for b, n in enumerate(lens):
-            xb = warp_affine_simple(x[o:o + n], affine_matrix[b, 0, :n], (H, W))          # fusion_in_one.py:393-395
-            out.append(encoder_scene(sd, "fusion_net.encoder", xb.permute(0, 2, 3, 1), enc).permute(2, 0, 1))
-            o += n
+    for b, n in enumerate(lens):   # differentiable: the backward tests take float64 autograd through this function
+        xb = warp_affine_simple(x[o:o + n], affine_matrix[b, 0, :n], (H, W))          # fusion_in_one.py:393-395
+        out.append(encoder_scene(sd, "fusion_net.encoder", xb.permute(0, 2, 3, 1), enc).permute(2, 0, 1))
+        o += n
     return torch.stack(out)

@@ -231,18 +231,23 @@ def test_message_extractor_backward_vs_oracle_autograd(C, H, W, n):
     print(f"MessageExtractorv2 backward C={C} {H}x{W}: {len(names)} parameter gradients + input, worst relative error {worst:.2e}")
 
 
-@pytest.mark.parametrize("new_agent", ["point_pillar", "second"])
-def test_stage2_training_step_reaches_only_the_new_agents_message_extractor(new_agent):
+@pytest.mark.parametrize("new_agent,fusion", [("point_pillar", "att"), ("second", "att"), ("second", "v2xvit")])
+def test_stage2_training_step_reaches_only_the_new_agents_message_extractor(new_agent, fusion):
     """Stage 2 (heter_model_baseline_w_gencomm_stage2.py:99-101, :180-185): every module is frozen except the message
     extractor of the new (non-ego) modality. One training step through the stage-2 shell on the HIP path: loss.backward()
     must leave finite, non-zero gradients on message_extractor_m2 and on nothing else. The new agent is a second PointPillars
-    model (m1m1-style) or a SECOND model (the shipped stage2/m1m3_att.yaml pairing: sparse 3-D encoder, stride-1 first backbone block)."""
+    model (m1m1-style) or a SECOND model (the shipped stage2/m1m3_att.yaml / m1m3_v2xvit.yaml pairings: sparse 3-D encoder, stride-1 first
+    backbone block; AttFusion or the frozen V2X-ViT transformer as the fusion net)."""
     import copy, json, os
     from gencomm_amd import synth
     from gencomm_amd.heter_model_baseline_w_gencomm_stage2 import HeterModelBaselineWDiffCommStage2
     with open(os.path.join(REPO, "tests", "golden", "shell_state_dict_keys.json")) as f:
         args = copy.deepcopy(json.load(f)["args"])
     args["m2"] = copy.deepcopy(args["m1"])            # the new agent type: its own encoder / backbone / shrinker / extractor
+    if fusion == "v2xvit":                            # stage2/m1m3_v2xvit.yaml: the frozen V2X-ViT (dropouts active) passes the gradient back
+        from helpers import load_case
+        args["fusion_method"] = "v2xvit"
+        args["v2xvit"] = json.loads(str(load_case("v2xvit")["args"]))
     if new_agent == "second":
         args["m2"].update({"core_method": "second",
                            "encoder_args": {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": args["lidar_range"], "mean_vfe": {"num_point_features": 4},

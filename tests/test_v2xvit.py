@@ -90,3 +90,84 @@ def test_hip_v2xvit_vs_oracle(H, W, rl, hetero):
     assert torch.isfinite(out).all() and list(out.shape) == [len(rl), C, H, W]
     if hetero:
         assert_close(out.numpy(), ref.numpy(), 1e-4, 1e-5, "v2xvit HIP vs oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,rl,hetero", [(16, 16, [2, 1], True), (16, 32, [3], True)])
+def test_hip_v2xvit_backward_vs_oracle_autograd(H, W, rl, hetero):
+    """Gradients of every parameter the forward uses and of the input against float64 autograd through the oracle (eval mode:
+    no dropout). Parameters of agent types / relations GenComm never selects get no gradient on either side."""
+    import v2xvit_port as V
+    from torch_port import normalize_pairwise_tfm as npt_oracle
+    from gencomm_amd import normalize_pairwise_tfm
+    g = load_case("v2xvit")
+    args = json.loads(str(g["args"]))
+    args["transformer"]["encoder"]["cav_att_config"]["use_hetero"] = hetero
+    args["transformer"]["encoder"]["depth"] = 2
+    C = 128
+    net = _module(args, 31)
+    inp = synth.make_inputs(rl, C, H, W, 32, max_shift=3.0)
+    ptm = torch.from_numpy(inp["pairwise_t_matrix"])
+    sd = {k: v.detach().double().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    xd = torch.from_numpy(inp["feat"]).double().requires_grad_(True)
+    ref = V.v2xvit_fusion(sd, args, xd, rl, npt_oracle(ptm, H * 0.8, W * 0.8, 1.0))
+    names = [k for k in sd if sd[k].requires_grad]
+    rg = torch.autograd.grad((ref ** 2).mean(), [sd[k] for k in names] + [xd], allow_unused=True)
+    net = net.cuda()
+    x = torch.from_numpy(inp["feat"]).cuda().requires_grad_(True)
+    out = net(x, rl, normalize_pairwise_tfm(ptm, H * 0.8, W * 0.8, 1))
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), 1e-4, 1e-5, "v2xvit forward (grad mode)")
+    (out ** 2).mean().backward()
+
+    def close(name, got, want):
+        scale = float(want.abs().max())
+        err = float((got.detach().cpu().double() - want).abs().max())
+        assert err <= 2e-3 * scale + 1e-9, (name, err, scale)
+        return err / (scale + 1e-30)
+    worst = close("grad input", x.grad, rg[-1])
+    got = dict(net.named_parameters())
+    used = 0
+    for k, r in zip(names, rg[:-1]):
+        if r is None or float(r.abs().max()) == 0.0:
+            assert got[k].grad is None or float(got[k].grad.abs().max()) == 0.0, k
+            continue
+        assert got[k].grad is not None, k
+        rel = close("grad " + k, got[k].grad, r)
+        if float(r.abs().max()) > 1e-9:      # gradients that are zero analytically (e.g. the key bias under softmax) are noise on both sides
+            worst = max(worst, rel)
+        used += 1
+    print(f"V2X-ViT backward {H}x{W} scenes {rl} hetero={hetero}: {used} parameter gradients + input, worst relative error {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_hip_v2xvit_train_mode_dropout_is_consistent():
+    """Train mode: the reference's dropouts (p = 0.3 after the attention projections and inside the FeedForward) are active -- also
+    for a frozen fusion net in stage 2. Same torch seed -> same masks -> identical output; the input gradient agrees with a central
+    finite difference of the loss along a random direction (masks replayed through the seed)."""
+    from gencomm_amd import normalize_pairwise_tfm
+    g = load_case("v2xvit")
+    args = json.loads(str(g["args"]))
+    args["transformer"]["encoder"]["depth"] = 1
+    H, W, rl, C = 16, 16, [2], 128
+    net = _module(args, 5).cuda().train()
+    inp = synth.make_inputs(rl, C, H, W, 6, max_shift=2.0)
+    aff = normalize_pairwise_tfm(torch.from_numpy(inp["pairwise_t_matrix"]), H * 0.8, W * 0.8, 1)
+    x = torch.from_numpy(inp["feat"]).cuda()
+
+    def loss_of(xx):
+        torch.manual_seed(1234)
+        return (net(xx, rl, aff) ** 2).mean()
+    xg = x.clone().requires_grad_(True)
+    l0 = loss_of(xg)
+    l0.backward()
+    with torch.no_grad():
+        assert float((loss_of(xg.detach().requires_grad_(True)) - l0).abs()) == 0.0          # same seed, same masks
+        net.eval()
+        l_eval = (net(x, rl, aff) ** 2).mean()
+        net.train()
+    assert abs(float(l_eval) - float(l0)) > 1e-4 * abs(float(l0))                               # dropout does something
+    d = xg.grad / xg.grad.norm() * x.norm() * 0.05          # along the gradient: the largest, best-conditioned directional derivative
+    fd = (float(loss_of((x + d).requires_grad_(True))) - float(loss_of((x - d).requires_grad_(True)))) / 2
+    an = float((xg.grad * d).sum())
+    print(f"V2X-ViT train-mode dropout: directional derivative analytic {an:.6e}, finite difference {fd:.6e}")
+    assert abs(an - fd) <= 3e-2 * abs(fd) + 1e-7
