@@ -9,8 +9,8 @@ The modules own their parameters in the reference's ``nn.Sequential`` layout, so
 identical (``blocks.0.1.weight``, ``blocks.0.2.running_mean``, ``deblocks.1.0.weight``,
 ``layers.0.double_conv.2.bias`` ...). ``forward`` never calls the torch layers: every conv (+ folded
 eval-mode BatchNorm + ReLU) is one launch of the implicit-GEMM HIP kernel through the C ABI; deblocks write
-straight into their channel slice of the concatenated output. BatchNorm in training mode (batch statistics)
-is not implemented on this path and raises.
+straight into their channel slice of the concatenated output. In training mode BatchNorm uses batch statistics
+(HIP statistics / normalisation kernels, running statistics updated as nn.BatchNorm2d does) and every layer has a HIP backward.
 """
 from __future__ import annotations
 
@@ -40,14 +40,43 @@ def _torch_expr(x, conv, bn, relu, pad):
     return F.relu(y) if relu else y
 
 
-def _hip_backward(x, y, gy, conv, bn, relu, pad, need_x):
-    """Backward of act(BN_eval(conv(x))) on the HIP primitives (train_ops) for what they cover: nn.Conv2d, 1x1 or 3x3, stride 1.
-    Returns (dx, {parameter: gradient}) or None when the layer needs the torch fallback (stride 2, ConvTranspose2d)."""
+def _conv_backward(x, g, conv, pad, need_x):
+    """(dx, {parameter: gradient}) of the bare convolution given d(conv output) on the HIP primitives: nn.Conv2d 1x1 / 3x3 with stride
+    1 or 2 (stride 2: dy spread onto the stride-1 grid, then the stride-1 input-gradient kernel), nn.ConvTranspose2d with kernel ==
+    stride (pixel-unshuffled dy, 1x1 GEMMs). None when the layer is outside that set."""
+    import torch.nn.functional as F
     from . import train_ops as T
-    if isinstance(conv, nn.ConvTranspose2d) or conv.stride != (1, 1) or conv.kernel_size not in ((1, 1), (3, 3)):
+    grads = {}
+    if isinstance(conv, nn.ConvTranspose2d):
+        s = conv.stride[0]
+        if conv.kernel_size != (s, s) or conv.stride != (s, s) or conv.padding != (0, 0):
+            return None
+        cin, cout = conv.weight.shape[:2]
+        gu = F.pixel_unshuffle(g, s).contiguous()                                    # [n, cout s^2, H, W], channel = co s^2 + dy s + dx
+        wm = conv.weight.detach().reshape(cin, cout * s * s)
+        if conv.weight.requires_grad:
+            dwt, _ = T.conv2d_wgrad(gu, x, 1, 0, False)                              # [cout s^2, cin, 1, 1]
+            grads[conv.weight] = dwt[:, :, 0, 0].t().reshape(cin, cout, s, s)
+        if conv.bias is not None and conv.bias.requires_grad:
+            grads[conv.bias] = g.sum((0, 2, 3))
+        dx = T.conv2d(gu, wm[:, :, None, None], None, 0) if need_x else None          # dx[ci] = sum_j W[ci][j] gu[j]
+        return dx, grads
+    if conv.kernel_size not in ((1, 1), (3, 3)) or conv.stride not in ((1, 1), (2, 2)) or conv.groups != 1 or conv.dilation != (1, 1):
         return None
-    k = conv.kernel_size[0]
+    k, st = conv.kernel_size[0], conv.stride[0]
     p = conv.padding[0] if pad is None else pad
+    if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+        dw, db = T.conv2d_wgrad(g, x, k, p, conv.bias is not None, st)
+        grads[conv.weight] = dw
+        if conv.bias is not None:
+            grads[conv.bias] = db
+    dx = T.conv2d_dgrad_strided(g, conv.weight, p, st, (x.shape[2], x.shape[3])) if need_x else None
+    return dx, grads
+
+
+def _hip_backward(x, y, gy, conv, bn, relu, pad, need_x):
+    """Backward of act(BN_eval(conv(x))) on the HIP primitives; None when the convolution is outside what `_conv_backward` covers."""
+    from . import train_ops as T
     g = gy.float().contiguous()
     if relu:
         g = g * (y > 0)
@@ -56,23 +85,59 @@ def _hip_backward(x, y, gy, conv, bn, relu, pad, need_x):
         rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
         scale = bn.weight.detach().float() * rstd
         if bn.weight.requires_grad or bn.bias.requires_grad:
-            pre = T.conv2d(x, conv.weight, conv.bias, p)                       # the convolution's own output, unfused
+            pre = conv2d_hip_raw(x, conv, pad)                                  # the convolution's own output, unfused
             grads[bn.weight] = (g * (pre - bn.running_mean.float().view(1, -1, 1, 1))).sum((0, 2, 3)) * rstd
             grads[bn.bias] = g.sum((0, 2, 3))
         g = g * scale.view(1, -1, 1, 1)
-    if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
-        dw, db = T.conv2d_wgrad(g, x, k, p, conv.bias is not None)
-        grads[conv.weight] = dw
-        if conv.bias is not None:
-            grads[conv.bias] = db
-    dx = T.conv2d_dgrad(g, conv.weight, p) if need_x else None
+    r = _conv_backward(x, g, conv, pad, need_x)
+    if r is None:
+        return None
+    dx, cg = r
+    grads.update(cg)
     return dx, grads
 
 
+def conv2d_hip_raw(x, conv, pad):
+    """The bare convolution (bias included, no norm, no activation) on the HIP kernel, without touching autograd."""
+    with torch.no_grad():
+        return conv2d_hip(x.detach(), conv, None, relu=False, pad=pad)
+
+
+class _ConvBnTrainFn(torch.autograd.Function):
+    """act(BatchNorm2d_batch(conv(x))) in TRAINING mode (stage 1 trains the backbone: base_bev_backbone.py:40-92): HIP convolution,
+    HIP batch statistics / normalisation (running statistics updated as nn.BatchNorm2d does), HIP backward (BatchNorm backward
+    kernels, then the convolution's dgrad / wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, conv, bn, relu, pad, *params):
+        from . import train_ops as T
+        ctx.conv, ctx.bn, ctx.relu, ctx.pad = conv, bn, relu, pad
+        pre = conv2d_hip_raw(x, conv, pad)
+        with torch.no_grad():
+            y, save = T.bn2d_train_fwd(pre, bn, relu)
+        ctx.save_for_backward(x, pre, y, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import train_ops as T
+        x, pre, y, save = ctx.saved_tensors
+        conv, bn = ctx.conv, ctx.bn
+        params = [p for p in (conv.weight, conv.bias, bn.weight, bn.bias) if p is not None]
+        with torch.no_grad():
+            dpre, dg, db = T.bn2d_train_bwd(pre, y, gy.float().contiguous(), save, bn.weight, ctx.relu)
+            r = _conv_backward(x.detach().float().contiguous(), dpre, conv, ctx.pad, ctx.needs_input_grad[0])
+        if r is None:
+            raise NotImplementedError("training this convolution shape on the HIP path is not implemented")
+        dx, grads = r
+        grads[bn.weight], grads[bn.bias] = dg, db
+        return (dx, None, None, None, None, *[grads.get(p) if p.requires_grad else None for p in params])
+
+
 class _Conv2dHipFn(torch.autograd.Function):
-    """HIP forward. Backward: stride-1 1x1 / 3x3 layers (the detection heads, the backbone's inner layers) on the HIP dgrad /
-    wgrad kernels; stride-2 convolutions and ConvTranspose2d re-evaluate the layer with differentiable torch ops from the saved
-    input. Either way gradients reach the input and the conv / BatchNorm-affine parameters: the graph is never cut."""
+    """act(BN_eval(conv(x))) with gradients: HIP forward; HIP backward (dgrad / wgrad kernels; stride-2 and transposed convolutions
+    included) -- the differentiable torch expression of the layer is only the fallback for shapes `_conv_backward` does not cover.
+    Gradients reach the input and the conv / BatchNorm-affine parameters: the graph is never cut."""
 
     @staticmethod
     def forward(ctx, x, conv, bn, relu, pad, *params):
@@ -93,9 +158,9 @@ class _Conv2dHipFn(torch.autograd.Function):
             return (dx, None, None, None, None, *[grads.get(p) if p.requires_grad else None for p in params])
         with torch.enable_grad():
             xd = x.detach().requires_grad_(True)
-            y = _torch_expr(xd, ctx.conv, ctx.bn, ctx.relu, ctx.pad)
+            yy = _torch_expr(xd, ctx.conv, ctx.bn, ctx.relu, ctx.pad)
             wanted = [xd] + [p for p in params if p.requires_grad]
-            grads = torch.autograd.grad(y, wanted, gy.contiguous(), allow_unused=True)
+            grads = torch.autograd.grad(yy, wanted, gy.contiguous(), allow_unused=True)
         gx = grads[0] if ctx.needs_input_grad[0] else None
         it = iter(grads[1:])
         gp = [next(it) if p.requires_grad else None for p in params]
@@ -108,14 +173,14 @@ def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = 
     ``nn.ConvTranspose2d`` whose kernel equals its stride; ``pad`` overrides ``conv.padding`` (ZeroPad2d(1)
     in front of a padding-0 conv). ``out``/``out_coff``: write into a channel slice of a larger tensor.
     With gradients enabled and anything differentiable among the input and the layer's parameters the call goes
-    through ``_Conv2dHipFn`` (HIP forward, recompute backward): the graph is never cut silently."""
+    through ``_Conv2dHipFn`` (eval-mode BatchNorm) or ``_ConvBnTrainFn`` (batch statistics), HIP forward and HIP backward: the graph
+    is never cut silently."""
     require_gpu(x, "conv2d_hip")
     if torch.is_grad_enabled():
         params = [p for p in (conv.weight, conv.bias) + ((bn.weight, bn.bias) if bn is not None else ()) if p is not None]
         if x.requires_grad or any(p.requires_grad for p in params):
-            if bn is not None and bn.training:
-                raise NotImplementedError("BatchNorm2d in training mode (batch statistics) is not implemented on the HIP path; call .eval()")
-            y = _Conv2dHipFn.apply(x, conv, bn, relu, pad, *params)
+            fn = _ConvBnTrainFn if (bn is not None and bn.training) else _Conv2dHipFn
+            y = fn.apply(x, conv, bn, relu, pad, *params)
             if out is None:
                 return y
             out[:, out_coff:out_coff + y.shape[1]] = y  # differentiable slice assignment (training only)
@@ -135,8 +200,13 @@ def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = 
             raise NotImplementedError("grouped / dilated / anisotropic Conv2d is not supported")
         stride, ups, gkh, gkw = conv.stride[0], 1, kh, kw
         p = conv.padding[0] if pad is None else pad
-    if bn is not None and bn.training:
-        raise NotImplementedError("BatchNorm2d in training mode (batch statistics) is not implemented on the HIP path; call .eval()")
+    if bn is not None and bn.training:   # batch statistics without gradients (e.g. a training-mode forward under no_grad)
+        from . import train_ops as T
+        y, _ = T.bn2d_train_fwd(conv2d_hip(x, conv, None, relu=False, pad=pad), bn, relu)
+        if out is None:
+            return y
+        out[:, out_coff:out_coff + y.shape[1]] = y
+        return out
     n, c, H, W = x.shape
     if c != cin:
         raise ValueError(f"expected {cin} input channels, got {c}")

@@ -553,6 +553,33 @@ int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, 
   return conv_wgrad_enqueue(a, N, (hipStream_t)stream);
 }
 
+// BatchNorm2d with batch statistics (training mode) around the HIP convolutions: scratch >= 2 C doubles (zeroed here)
+int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, float* save,
+                           double* scratch, float momentum, float eps, int relu, int n, int C, int HW, void* stream) {
+  GC_CHECK_ARG(x && gamma && beta && y && save && scratch && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "bad arguments");
+  GC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or neither");
+  hipStream_t st = (hipStream_t)stream;
+  GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
+  const unsigned chunks = (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64);
+  bn2d_stats_kernel<<<dim3(C, chunks), 256, 0, st>>>(x, scratch, n, C, HW);
+  bn2d_finish_kernel<<<(C + 63) / 64, 64, 0, st>>>(scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, C);
+  bn2d_apply_kernel<<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, save, gamma, beta, y, C, HW, relu);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+// dx overwritten; dgamma / dbeta ACCUMULATED (+=, may be null); y = the forward's output (ReLU mask when relu != 0)
+int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
+                           float* dbeta, double* scratch, int relu, int n, int C, int HW, void* stream) {
+  GC_CHECK_ARG(x && y && dy && save && gamma && dx && scratch && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
+  const unsigned chunks = (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64);
+  bn2d_bwd_reduce_kernel<<<dim3(C, chunks), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu);
+  bn2d_bwd_apply_kernel<<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, y, dy, save, gamma, scratch, dx, dgamma, dbeta, (long long)n * HW, C, HW, relu);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 // deformable 3x3 convolution split into sampling + GEMM for the training path of MessageExtractorv2 (train_kernels.h)
 int gencomm_dcn_sample_fwd(const float* x, const float* offset, float* col, int n, int C, int H, int W, void* stream) {
   GC_CHECK_ARG(x && offset && col && n >= 1 && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad arguments");

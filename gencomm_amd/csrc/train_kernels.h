@@ -318,4 +318,83 @@ __global__ __launch_bounds__(256) void dcn_scatter_bwd_kernel(const float* __res
   doff[((size_t)n * 18 + 2 * k + 1) * HW + pix] = gx;
 }
 
+// ---- BatchNorm2d in TRAINING mode (batch statistics) for the conv stacks around the hot path -------------------------------
+// (base_bev_backbone.py:47-52: conv -> BatchNorm2d(eps 1e-3, momentum 0.01) -> ReLU; stage 1 of the reference trains them).
+//   bn2d_stats_kernel      per-channel sum / sum of squares over (n, HW) in f64 (grid: channel x chunks)
+//   bn2d_finish_kernel     mean, rstd (biased variance) -> save[c][2]; running statistics updated with the UNBIASED variance
+//   bn2d_apply_kernel      y = act(gamma (x - mean) rstd + beta)
+//   bn2d_bwd_reduce_kernel sums of g and g xhat per channel (g = dy masked by y > 0 when the block has a ReLU)
+//   bn2d_bwd_apply_kernel  dx = gamma rstd (g - mean(g) - xhat mean(g xhat));  d gamma = sum g xhat, d beta = sum g
+__global__ __launch_bounds__(256) void bn2d_stats_kernel(const float* __restrict__ x, double* __restrict__ acc /*[C][2]*/, int n, int C, int HW) {
+  __shared__ double s_red[4][2];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (long long i = (long long)blockIdx.y * 256 + tid; i < (long long)n * HW; i += (long long)gridDim.y * 256) {
+    const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+    const float v = x[((size_t)b * C + c) * HW + p];
+    s += v; q += (double)v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((tid & 63) == 0) { s_red[tid >> 6][0] = s; s_red[tid >> 6][1] = q; }
+  __syncthreads();
+  if (tid < 2) atomicAdd(&acc[c * 2 + tid], s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]);
+}
+__global__ void bn2d_finish_kernel(const double* __restrict__ acc, float* __restrict__ save /*[C][2] mean, rstd*/, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps, long long count, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = acc[c * 2] / (double)count;
+  const double var = fmax(acc[c * 2 + 1] / (double)count - m * m, 0.0);
+  save[c * 2] = (float)m;
+  save[c * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+__global__ __launch_bounds__(256) void bn2d_apply_kernel(const float* __restrict__ x, const float* __restrict__ save, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y, int C, int HW, int relu) {
+  const int c = blockIdx.y, b = blockIdx.z, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const size_t e = ((size_t)b * C + c) * HW + p;
+  const float v = fmaf((x[e] - save[c * 2]) * save[c * 2 + 1], gamma[c], beta[c]);
+  y[e] = relu ? fmaxf(v, 0.f) : v;
+}
+__global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                              const float* __restrict__ save, double* __restrict__ acc /*[C][2] sum g, sum g xhat*/,
+                                                              int n, int C, int HW, int relu) {
+  __shared__ double s_red[4][2];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float mean = save[c * 2], rstd = save[c * 2 + 1];
+  double s = 0.0, q = 0.0;
+  for (long long i = (long long)blockIdx.y * 256 + tid; i < (long long)n * HW; i += (long long)gridDim.y * 256) {
+    const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+    const size_t e = ((size_t)b * C + c) * HW + p;
+    const float g = (relu && !(y[e] > 0.f)) ? 0.f : dy[e];
+    s += g; q += (double)g * ((x[e] - mean) * rstd);
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((tid & 63) == 0) { s_red[tid >> 6][0] = s; s_red[tid >> 6][1] = q; }
+  __syncthreads();
+  if (tid < 2) atomicAdd(&acc[c * 2 + tid], s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]);
+}
+__global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                             const float* __restrict__ save, const float* __restrict__ gamma, const double* __restrict__ acc,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             long long count, int C, int HW, int relu) {
+  const int c = blockIdx.y, b = blockIdx.z, p = blockIdx.x * 256 + threadIdx.x;
+  const float mean = save[c * 2], rstd = save[c * 2 + 1];
+  const float mg = (float)(acc[c * 2] / (double)count), mgx = (float)(acc[c * 2 + 1] / (double)count);
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    if (dgamma != nullptr) dgamma[c] += (float)acc[c * 2 + 1];
+    if (dbeta != nullptr) dbeta[c] += (float)acc[c * 2];
+  }
+  if (p >= HW) return;
+  const size_t e = ((size_t)b * C + c) * HW + p;
+  const float g = (relu && !(y[e] > 0.f)) ? 0.f : dy[e];
+  const float xh = (x[e] - mean) * rstd;
+  dx[e] = gamma[c] * rstd * (g - mg - xh * mgx);
+}
+
 }  // namespace gc

@@ -1,8 +1,9 @@
 """``PointPillar`` encoder front half -- host-side mirror of ``opencood/models/heter_encoders.py:22-50``
 (``PillarVFE`` ``sub_modules/pillar_vfe.py:57-155`` + ``PointPillarScatter``
 ``sub_modules/point_pillar_scatter.py:9-76``), SURVEY.md 8f-2. Same constructor arguments, attribute
-names (``pillar_vfe.pfn_layers.0.{linear,norm}``, ``scatter``) and ``state_dict`` keys; eval mode runs
-one fused HIP kernel (augment -> Linear -> folded BatchNorm -> ReLU -> max -> scatter)."""
+names (``pillar_vfe.pfn_layers.0.{linear,norm}``, ``scatter``) and ``state_dict`` keys; inference (and a frozen
+encoder inside a training model) runs one fused HIP kernel (augment -> Linear -> folded BatchNorm -> ReLU -> max -> scatter);
+training the encoder itself (stage 1) runs the per-pillar network in differentiable torch tensor ops."""
 from __future__ import annotations
 
 import ctypes
@@ -71,20 +72,45 @@ class PointPillar(nn.Module):
                 and self.scatter.num_bev_features == 64):
             raise NotImplementedError("gencomm_amd.PointPillar: the HIP kernel covers the shipped configuration "
                                       "(use_norm, use_absolute_xyz, no distance feature, num_filters [64])")
-        pfn = v.pfn_layers[0]
-        if pfn.norm.training:
-            # a frozen encoder inside a model in train mode (stage 2: fix_bn keeps its BatchNorm in eval mode) is fine
-            raise NotImplementedError("gencomm_amd.PointPillar: training-mode BatchNorm (batch statistics) is not implemented; use .eval() "
-                                      "(or freeze the encoder as stage 2 does)")
 
     def forward(self, data_dict, modality_name):
         inp = data_dict[f"inputs_{modality_name}"]
         return self.encode(inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"])
 
+    def _encode_train(self, vf, coords, npts, batch_size):
+        """Training mode (stage 1 trains the encoder: BatchNorm1d with batch statistics, gradients to `linear` / `norm`): the
+        per-pillar network -- 10-feature augmentation, Linear 10 -> 64, BatchNorm1d over all M x 32 point slots, ReLU, max over the
+        slots (pillar_vfe.py:31-54, :105-155) -- and the scatter (point_pillar_scatter.py:42-76) in differentiable torch tensor
+        ops on the GPU; the fused HIP kernel is the inference / frozen-encoder path. A frozen encoder inside a training model
+        (stage 2: fix_bn keeps the BatchNorm in eval mode, no parameter requires a gradient) never comes here."""
+        import torch.nn.functional as F
+        v, pfn = self.pillar_vfe, self.pillar_vfe.pfn_layers[0]
+        vx, vy, vz = v.voxel_size
+        xo, yo, zo = vx / 2 + v.point_cloud_range[0], vy / 2 + v.point_cloud_range[1], vz / 2 + v.point_cloud_range[2]
+        c = coords.to(vf.dtype)
+        mean = vf[:, :, :3].sum(dim=1, keepdim=True) / npts.to(vf.dtype).view(-1, 1, 1)
+        f_cluster = vf[:, :, :3] - mean
+        f_center = torch.stack([vf[:, :, 0] - (c[:, 3].unsqueeze(1) * vx + xo), vf[:, :, 1] - (c[:, 2].unsqueeze(1) * vy + yo),
+                                vf[:, :, 2] - (c[:, 1].unsqueeze(1) * vz + zo)], dim=-1)
+        feats = torch.cat([vf, f_cluster, f_center], dim=-1)
+        mask = (npts.view(-1, 1) > torch.arange(vf.shape[1], device=vf.device).view(1, -1)).unsqueeze(-1).to(vf.dtype)
+        x = F.linear(feats * mask, pfn.linear.weight)
+        x = pfn.norm(x.permute(0, 2, 1)).permute(0, 2, 1)                   # nn.BatchNorm1d in its own mode (train: batch statistics)
+        pillar = torch.max(F.relu(x), dim=1)[0]                              # [M, 64]
+        out = torch.zeros(batch_size, 64, self.scatter.ny * self.scatter.nx, dtype=vf.dtype, device=vf.device)
+        idx = (coords[:, 1] + coords[:, 2] * self.scatter.nx + coords[:, 3]).long()
+        out[coords[:, 0].long(), :, idx] = pillar
+        return out.view(batch_size, 64, self.scatter.ny, self.scatter.nx)
+
     def encode(self, voxel_features, voxel_coords, voxel_num_points, batch_size=None):
         """[M,P,4], [M,4] (b,z,y,x), [M] -> [B,64,ny,nx]."""
         self._check_supported()
         require_gpu(voxel_features, "PointPillar.forward")
+        pfn0 = self.pillar_vfe.pfn_layers[0]
+        if pfn0.norm.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            if batch_size is None:
+                batch_size = int(voxel_coords[:, 0].max().item()) + 1 if voxel_features.shape[0] > 0 else 1
+            return self._encode_train(voxel_features.float(), voxel_coords, voxel_num_points, batch_size)
         vf = f32c(voxel_features)
         M, P = vf.shape[0], vf.shape[1]
         coords = voxel_coords.to(torch.int32).contiguous()

@@ -42,15 +42,60 @@ def conv2d_dgrad(dy: torch.Tensor, w: torch.Tensor, pad: int) -> torch.Tensor:
     return conv2d(dy, w.detach().flip(2, 3).transpose(0, 1).contiguous(), None, k - 1 - pad)
 
 
-def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, k: int, pad: int, bias: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, k: int, pad: int, bias: bool, stride: int = 1) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     dy, x = _c(dy), _c(x)
     n, cout = dy.shape[:2]
     cin, H, W = x.shape[1:]
     dw = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=x.device)
     db = torch.zeros(cout, dtype=torch.float32, device=x.device) if bias else None
-    _lib.check(_lib.lib().gencomm_conv2d_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), n, cin, H, W, cout, k, 1, pad, stream_ptr(x.device)),
+    _lib.check(_lib.lib().gencomm_conv2d_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), n, cin, H, W, cout, k, int(stride), pad, stream_ptr(x.device)),
                "gencomm_conv2d_wgrad")
     return dw, db
+
+
+def conv2d_dgrad_strided(dy: torch.Tensor, w: torch.Tensor, pad: int, stride: int, in_hw: Tuple[int, int]) -> torch.Tensor:
+    """Input gradient of a stride-s convolution: dy is spread onto the stride-1 output grid (zeros in between: a strided copy),
+    then the stride-1 input-gradient convolution runs on the HIP kernel. `in_hw` = (H, W) of the forward input."""
+    if stride == 1:
+        return conv2d_dgrad(dy, w, pad)
+    k = w.shape[2]
+    H, W = in_hw
+    up = torch.zeros(dy.shape[0], dy.shape[1], H + 2 * pad - k + 1, W + 2 * pad - k + 1, dtype=torch.float32, device=dy.device)
+    up[:, :, ::stride, ::stride] = dy
+    return conv2d_dgrad(up, w, pad)
+
+
+def bn2d_train_fwd(x: torch.Tensor, bn, relu: bool):
+    """(y, save): BatchNorm2d with batch statistics (+ ReLU) on the HIP kernels; updates bn.running_mean / running_var /
+    num_batches_tracked exactly as nn.BatchNorm2d in training mode does."""
+    x = _c(x)
+    n, C, H, W = x.shape
+    y = torch.empty_like(x)
+    save = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+    if track:
+        bn.num_batches_tracked += 1
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    _lib.check(_lib.lib().gencomm_bn2d_train_fwd(ptr(x), ptr(_c(bn.weight)), ptr(_c(bn.bias)), ptr(bn.running_mean) if track else None,
+                                                 ptr(bn.running_var) if track else None, ptr(y), ptr(save), ptr(scratch), momentum, float(bn.eps),
+                                                 int(relu), n, C, H * W, stream_ptr(x.device)), "gencomm_bn2d_train_fwd")
+    return y, save
+
+
+def bn2d_train_bwd(x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, save: torch.Tensor, gamma: torch.Tensor, relu: bool):
+    """(dx, dgamma, dbeta) of y = act(BN_batch(x))."""
+    x, y, dy = _c(x), _c(y), _c(dy)
+    n, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.zeros(C, dtype=torch.float32, device=x.device)
+    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib().gencomm_bn2d_train_bwd(ptr(x), ptr(y), ptr(dy), ptr(save), ptr(_c(gamma)), ptr(dx), ptr(dg), ptr(db), ptr(scratch), int(relu),
+                                                 n, C, H * W, stream_ptr(x.device)), "gencomm_bn2d_train_bwd")
+    return dx, dg, db
 
 
 def ln_fwd(x: torch.Tensor, gamma, beta, eps: float, residual: bool) -> torch.Tensor:

@@ -370,6 +370,15 @@ int gencomm_win_attn_bwd(const float* qkv, const float* pos_embedding, const flo
 int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, const float* fc1_w, const float* ln_w, const float* ln_b,
                             const float* fc2_w, const float* residual, float* out, float* scratch, int n, int C, int HW, void* stream);
 
+/* BatchNorm2d with BATCH statistics (training mode; base_bev_backbone.py:47-52: eps 1e-3, momentum 0.01) around the HIP convolutions of
+ * the backbone / shrink stacks: y = act(gamma (x - mean_batch) / sqrt(var_batch + eps) + beta) over NCHW, running statistics updated as
+ * nn.BatchNorm2d does (unbiased variance; pass null to leave them alone); save [C][2] = (mean, rstd) for the backward; scratch >= 2 C
+ * doubles. Backward: dx overwritten, dgamma / dbeta accumulated, y = the forward's output (supplies the ReLU mask). */
+int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, float* save,
+                           double* scratch, float momentum, float eps, int relu, int n, int C, int HW, void* stream);
+int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
+                           float* dbeta, double* scratch, int relu, int n, int C, int HW, void* stream);
+
 /* Training path of MessageExtractorv2's deformable 3x3 convolution (message_extractor_v2.py:78,:108; DCNv1, padding 1, one offset
  * group), split into its sampling half and its GEMM half so that the backward is GEMMs on the general kernels + one scatter:
  *   gencomm_dcn_sample_fwd   col[n][c * 9 + k][p] = bilinear sample of x[n][c] at tap k's displaced position (zero outside)

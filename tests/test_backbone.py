@@ -159,3 +159,51 @@ def test_grad_mode_keeps_the_autograd_graph_through_the_conv_stacks():
     for k in got:
         scale = float(want[k].abs().max())
         assert float((got[k] - want[k]).abs().max()) <= 2e-3 * scale + 1e-7, (k, float((got[k] - want[k]).abs().max()), scale)
+
+
+@pytest.mark.gpu
+def test_training_mode_batch_statistics_forward_backward_and_running_stats():
+    """Stage 1 of the reference trains the backbone with BatchNorm2d in TRAINING mode (batch statistics, base_bev_backbone.py:47-52,
+    eps 1e-3, momentum 0.01). HIP path (convolution, batch statistics, normalisation, their backward kernels; stride-2 and transposed
+    convolutions included) against the same nn.Sequential layers run by torch in train mode: forward, every gradient, and the
+    running-statistics update."""
+    import copy
+    g = load_case("backbone")
+    bb, sh, heads, x = _modules(g, "cuda:0")
+    bb.train(); sh.train(); heads.train()
+    ref_bb = copy.deepcopy(bb)
+    x = x[:, :, :32, :48].contiguous()
+    xa = x.clone().requires_grad_(True)
+    y = bb({"spatial_features": xa})["spatial_features_2d"]
+    out = heads[0](sh(y))
+    out.square().mean().backward()
+    # the same layers through torch (train mode: batch statistics, running stats updated)
+    xb = x.clone().requires_grad_(True)
+    feats, h = [], xb
+    for blk in ref_bb.blocks:
+        h = blk(h)
+        feats.append(h)
+    y2 = torch.cat([ref_bb.deblocks[i](f) for i, f in enumerate(feats)], dim=1)
+    z2 = torch.nn.functional.relu(torch.nn.functional.conv2d(
+        torch.nn.functional.relu(torch.nn.functional.conv2d(y2, sh.layers[0].double_conv[0].weight.detach(), sh.layers[0].double_conv[0].bias.detach(),
+                                                            stride=sh.layers[0].double_conv[0].stride, padding=sh.layers[0].double_conv[0].padding)),
+        sh.layers[0].double_conv[2].weight.detach(), sh.layers[0].double_conv[2].bias.detach(), padding=sh.layers[0].double_conv[2].padding))
+    out2 = torch.nn.functional.conv2d(z2, heads[0].weight.detach(), heads[0].bias.detach())
+    out2.square().mean().backward()
+    assert_close(y.detach().cpu().numpy(), y2.detach().cpu().numpy(), 2e-3, 2e-4, "backbone forward, training-mode BatchNorm (HIP vs torch/MIOpen)")
+    got, want = dict(bb.named_parameters()), dict(ref_bb.named_parameters())
+    worst = 0.0
+    for k in want:
+        assert got[k].grad is not None, k
+        scale = float(want[k].grad.abs().max())
+        err = float((got[k].grad - want[k].grad).abs().max())
+        assert err <= 5e-3 * scale + 1e-7, (k, err, scale)
+        worst = max(worst, err / (scale + 1e-30))
+    scale = float(xb.grad.abs().max())
+    assert float((xa.grad - xb.grad).abs().max()) <= 5e-3 * scale + 1e-8
+    for (k, b1), (_, b2) in zip(bb.named_buffers(), ref_bb.named_buffers()):
+        if b1.is_floating_point():
+            assert_close(b1.cpu().numpy(), b2.cpu().numpy(), 1e-4, 1e-6, "running statistic " + k)
+        else:
+            assert int(b1) == int(b2), k
+    print(f"backbone training mode: {len(want)} parameter gradients + input, worst relative error vs torch {worst:.2e}")

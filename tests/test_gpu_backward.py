@@ -295,3 +295,37 @@ def test_stage2_training_step_reaches_only_the_new_agents_message_extractor(new_
             tot += float(p.grad.abs().sum())
     assert tot > 0.0
     print(f"stage-2 training step: loss {float(loss):.4f}, sum |grad| over message_extractor_m2 {tot:.3e}")
+
+
+def test_stage1_training_step_reaches_every_trained_module():
+    """Stage 1 of the reference trains the whole model (train.py; BatchNorm with batch statistics in the encoder and the backbone,
+    GenComm's training branch, Enhancer, fusion, heads). One training step through the stage-1 shell in train mode: finite gradients on
+    the encoder, backbone, shrinker, message extractor, GenComm, the live Enhancer block and the heads; running statistics move."""
+    import copy, json, os
+    from gencomm_amd import synth
+    from gencomm_amd.heter_model_baseline_w_gencomm_stage1 import HeterModelBaselineWGenCommStage1
+    with open(os.path.join(REPO, "tests", "golden", "shell_state_dict_keys.json")) as f:
+        args = copy.deepcopy(json.load(f)["args"])
+    model = HeterModelBaselineWGenCommStage1(args)
+    synth.fill_params_(model, 3)
+    synth.fill_bn_stats_(model, 4)
+    model = model.to(DEV).train()
+    rm0 = model.backbone_m1.blocks[0][2].running_mean.clone()
+    rl = [2, 1]
+    pil = synth.make_pillars(600, 3, 128, 64, 9, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
+    ptm = synth.make_pairwise_t_matrix(rl, 5, 10, max_shift=4.0)
+    data = {"agent_modality_list": ["m1"] * 3, "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(DEV),
+            "inputs_m1": {k: torch.from_numpy(pil[k]).to(DEV) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}}
+    out = model(data)
+    loss = (out["cls_preds"].square().mean() + out["reg_preds"].square().mean() + out["dir_preds"].square().mean()
+            + (out["pred_feature"] - out["gt_feature"].detach()).square().mean())
+    loss.backward()
+    groups = {}
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+            groups[n.split(".")[0]] = groups.get(n.split(".")[0], 0.0) + float(p.grad.abs().sum())
+    for g in ("encoder_m1", "backbone_m1", "shrinker_m1", "message_extractor_m1", "gencomm", "enhancer", "cls_head", "reg_head", "dir_head"):
+        assert groups.get(g, 0.0) > 0.0, (g, sorted(groups))
+    assert not torch.equal(rm0, model.backbone_m1.blocks[0][2].running_mean)      # batch statistics were used and tracked
+    print("stage-1 training step: loss %.4f, gradient mass per module: %s" % (float(loss), {k: "%.2e" % v for k, v in sorted(groups.items())}))
