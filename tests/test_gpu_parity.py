@@ -320,3 +320,29 @@ def test_max_fusion_vs_oracle():
         got = MaxFusion()(x.to(DEV), torch.tensor(rl), affine).cpu()
     err = (got - ref).abs()
     assert (err <= 1e-5 + 1e-4 * ref.abs()).all(), err.max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_inputs_are_accepted_and_computed_in_fp32(dtype):
+    """Under AMP (train_ddp.py:174 wraps the forward in autocast) upstream reference modules hand the hot path fp16 / bf16
+    tensors. The modules accept them, compute in fp32 and return fp32: bit-identical to the same call on the up-converted inputs."""
+    from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, synth
+    C, H, W, T, rl = 32, 32, 48, 3, [2, 1]
+    n = sum(rl)
+    gen, enh, fus = GenComm(synth.default_gencomm_cfg(C, T)).eval().to(DEV), Enhancer(C, [8, 8], 4).eval().to(DEV), AttFusion(C)
+    synth.fill_params_(gen, 2)
+    synth.fill_params_(enh, 3)
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(rl, C, H, W, 4, max_shift=5.0).items()}
+    affine = normalize_pairwise_tfm(inp["pairwise_t_matrix"], H * 0.8, W * 0.8, 1)
+    feat, cond = inp["feat"].to(DEV).to(dtype), inp["cond"].to(DEV).to(dtype)
+    outs = []
+    with torch.no_grad():
+        for f, c in ((feat, cond), (feat.float(), cond.float())):
+            pred = gen(f, c, inp["record_len"], seed=11)["pred_feature"]
+            fused = fus(enh(pred.to(f.dtype), affine, inp["record_len"]), inp["record_len"], affine)
+            outs.append((pred, fused))
+    for a, b in zip(outs[0], outs[1]):
+        assert a.dtype == torch.float32 and torch.isfinite(a).all()
+    assert torch.equal(outs[0][0], outs[1][0])                                  # GenComm: same fp32 computation on the same values
+    rel = float((outs[0][1] - outs[1][1]).abs().max() / outs[1][1].abs().max())
+    assert rel < 2e-2, rel                                                      # Enhancer fed the ROUNDED prediction (what AMP would hand over)
