@@ -84,7 +84,8 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     const size_t sh = ((size_t)C * 65 + 256 + 128) * sizeof(float);
     if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)enh_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     TimedLaunch tl(KF_ENH_LN, st);
-    enh_ln_kernel<<<dim3((HW + 63) / 64, n), 256, sh, st>>>(a);
+    if (C == 64) enh_ln64_kernel<<<dim3((HW + 255) / 256, n), 256, 0, st>>>(a);   // registers + per-wave transpose, no workgroup barriers
+    else enh_ln_kernel<<<dim3((HW + 63) / 64, n), 256, sh, st>>>(a);
   }
   if (m.split() && (p.dc == 16 || p.dc == 32) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
     const int nslice = (9 * p.dc + 31) / 32;

@@ -83,6 +83,58 @@ __global__ __launch_bounds__(256) void enh_ln_kernel(const EnhLnArgs a) {
   }
 }
 
+// The same for C = 64 (the benchmark geometry) without workgroup barriers in the arithmetic: a lane owns ONE pixel and keeps its 64
+// channels in registers (64 coalesced 256-byte loads per wave), both LayerNorms are in-lane reductions, and the token-major rows go
+// out through a per-wave LDS transpose so that every store instruction writes 1 KB contiguous.  The barrier-per-moment kernel above
+// spent 0.86 of its wave cycles parked (profiles/r2_pmc_sq.json).
+__global__ __launch_bounds__(256) void enh_ln64_kernel(const EnhLnArgs a) {
+  constexpr int C = 64, S = 65;
+  __shared__ float tile[4][64 * S];   // per wave: [pixel][channel] padded
+  const int tid = threadIdx.x, wv = tid >> 6, p = tid & 63;
+  const int n = blockIdx.y, p0 = (blockIdx.x * 4 + wv) * 64;
+  if (p0 >= a.HW) return;             // whole wave out of range (no barriers below)
+  const int np = min(64, a.HW - p0);
+  const bool pv = p < np;
+  const float* __restrict__ xp = a.x + (size_t)n * C * a.HW + p0 + p;
+  float v[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) v[c] = pv ? xp[(size_t)c * a.HW] : 0.f;
+  const float invC = 1.0f / (float)C;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) s += v[c];
+  float m = s * invC, q = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { const float d = v[c] - m; q = fmaf(d, d, q); }
+  float r = 1.0f / sqrtf(q * invC + 1e-5f);
+#pragma unroll
+  for (int c = 0; c < C; ++c) v[c] = v[c] + fmaf((v[c] - m) * r, as_const(a.g1)[c], as_const(a.b1)[c]);   // x + LN1(x)
+  s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) s += v[c];
+  m = s * invC; q = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { const float d = v[c] - m; q = fmaf(d, d, q); }
+  r = 1.0f / sqrtf(q * invC + 1e-5f);
+  float* __restrict__ tw = tile[wv];
+  float* __restrict__ Yp = a.Y + ((size_t)n * a.HW + p0) * C;
+  float* __restrict__ Zp = a.Z + ((size_t)n * a.HW + p0) * C;
+  float* __restrict__ Zcp = a.Zc + ((size_t)n * a.HW + p0) * a.dc;
+  const int tot = np * C;
+  // Y: through the wave's LDS tile (row = pixel), read back flat so that lanes write consecutive words
+#pragma unroll
+  for (int c = 0; c < C; ++c) tw[p * S + c] = v[c];
+  __builtin_amdgcn_wave_barrier();
+  for (int i = p; i < tot; i += 64) Yp[i] = tw[(i >> 6) * S + (i & 63)];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < C; ++c) tw[p * S + c] = fmaf((v[c] - m) * r, as_const(a.g2)[c], as_const(a.b2)[c]);   // LN2
+  __builtin_amdgcn_wave_barrier();
+  for (int i = p; i < tot; i += 64) Zp[i] = tw[(i >> 6) * S + (i & 63)];
+  const int totc = np * a.dc;
+  for (int i = p; i < totc; i += 64) { const int pp = i / a.dc, c = i - pp * a.dc; Zcp[i] = tw[pp * S + c]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2: FRFN.partial_conv3 -- 3x3 conv (no bias) on the first dc = C/4 channels, the rest untouched
 // (enhancer.py:232-234).  Reads Zc with halo, overwrites Z[:, :dc] in place.
