@@ -348,32 +348,46 @@ __global__ __launch_bounds__(256) void gemm_f16s_mfma_kernel(const GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
+  // software pipeline: the next K chunk's tokens and weights travel from global memory into registers while the current chunk
+  // is on the matrix cores (the unpipelined loop spent 0.89 of its wave cycles parked: profiles/r2_pmc_sq.json)
+  const int kq = tid & 7;
+  float4 va[4], vb[2];
+  auto fetch = [&](int k0) {
+    const int gk = k0 + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gm = m0 + (tid >> 3) + 32 * i;
+      va[i] = (gm < a.M && gk + 3 < a.K) ? *reinterpret_cast<const float4*>(Ap + (size_t)gm * a.K + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gn = n0 + (tid >> 3) + 32 * i;
+      vb[i] = (gn < a.N && gk + 3 < a.K) ? *reinterpret_cast<const float4*>(a.Bw + (size_t)gn * a.K + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < a.K; k0 += KC) {
     __syncthreads();
     {
-      const int kq = tid & 7, gk = k0 + 4 * kq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + 32 * i, gm = m0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gm < a.M && gk + 3 < a.K) v = *reinterpret_cast<const float4*>(Ap + (size_t)gm * a.K + gk);
+        const int row = (tid >> 3) + 32 * i;
         uint2 hi, lo;
-        enh_split4(v, 1.0f, hi, lo);
+        enh_split4(va[i], 1.0f, hi, lo);
         *reinterpret_cast<uint2*>(Ah + row * RB + 8 * kq) = hi;
         *reinterpret_cast<uint2*>(Al + row * RB + 8 * kq) = lo;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 3) + 32 * i, gn = n0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gn < a.N && gk + 3 < a.K) v = *reinterpret_cast<const float4*>(a.Bw + (size_t)gn * a.K + gk);
+        const int row = (tid >> 3) + 32 * i;
         uint2 hi, lo;
-        enh_split4(v, WS, hi, lo);
+        enh_split4(vb[i], WS, hi, lo);
         *reinterpret_cast<uint2*>(Bh + row * RB + 8 * kq) = hi;
         *reinterpret_cast<uint2*>(Bl + row * RB + 8 * kq) = lo;
       }
     }
     __syncthreads();
+    if (k0 + KC < a.K) fetch(k0 + KC);
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
       const int ko = 32 * ks + 16 * h;  // byte offset of this lane's 8 halves in the row
