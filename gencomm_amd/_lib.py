@@ -108,6 +108,10 @@ _SIGNATURES = {
     "gencomm_sp_conv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_sp_dense_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "gencomm_mean_vfe_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "gencomm_bnrow_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _i, _i, _i, _p]),
+    "gencomm_bnrow_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "gencomm_sp_rules_inv_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "gencomm_sp_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_voxelize_workspace_bytes": (_ll, [_i]),
     "gencomm_voxelize_fwd": (_i, [_p, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p, _p, _p, _p, _p, _ll, _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -300,7 +300,7 @@ long long gencomm_sp_prepared_floats(int K, int Cin, int Cout) {
   return (long long)K * sp_cin_padded(Cin) * (long long)align_up((size_t)Cout, 32);
 }
 int gencomm_sp_prepare(const float* w, float* prepared, int K, int Cin, int Cout, int layout, void* stream) {
-  GC_CHECK_ARG(w && prepared && (layout == 0 || layout == 1), "bad arguments");
+  GC_CHECK_ARG(w && prepared && layout >= 0 && layout <= 3, "bad arguments");
   const long long total = gencomm_sp_prepared_floats(K, Cin, Cout);
   if (total < 0) return GC_ERR_ARG;
   sp_prep_w_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, prepared, K, Cin, Cout, sp_cin_padded(Cin), (int)align_up((size_t)Cout, 32), layout);
@@ -315,6 +315,58 @@ int gencomm_sp_conv_fwd(const float* x, const int* nbr, const float* prepared, c
   SpConvArgs a{x, nbr, prepared, scale, shift, y, n_out, K, Cin, Cout, (int)align_up((size_t)Cout, 32), relu};
   return sp_conv_enqueue(a, (hipStream_t)stream);
 }
+// ---- training of the sparse layers -------------------------------------------------------------------------------------
+int gencomm_bnrow_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, float* save,
+                            double* scratch, float momentum, float eps, int relu, int n, int C, void* stream) {
+  GC_CHECK_ARG(x && gamma && beta && y && save && scratch && n >= 1 && (C == 16 || C == 32 || C == 64 || C == 128), "BatchNorm over rows: C in {16, 32, 64, 128}");
+  GC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or neither");
+  hipStream_t st = (hipStream_t)stream;
+  GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
+  const int slots = 256 / C;
+  bnrow_stats_kernel<<<std::max(1, std::min((n + slots * 16 - 1) / (slots * 16), 512)), 256, 0, st>>>(x, scratch, n, C);
+  bn2d_finish_rows_kernel<<<(C + 63) / 64, 64, 0, st>>>(scratch, save, running_mean, running_var, momentum, eps, (long long)n, C);
+  const long long total = (long long)n * C;
+  bnrow_apply_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, save, gamma, beta, y, total, C, relu);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_bnrow_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
+                            float* dbeta, double* scratch, int relu, int n, int C, void* stream) {
+  GC_CHECK_ARG(x && y && dy && save && gamma && dx && scratch && n >= 1 && (C == 16 || C == 32 || C == 64 || C == 128), "BatchNorm over rows: C in {16, 32, 64, 128}");
+  hipStream_t st = (hipStream_t)stream;
+  GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
+  const int slots = 256 / C;
+  bnrow_bwd_reduce_kernel<<<std::max(1, std::min((n + slots * 16 - 1) / (slots * 16), 512)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, relu);
+  const long long total = (long long)n * C;
+  bnrow_bwd_apply_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, y, dy, save, gamma, scratch, dx, dgamma, dbeta, total, (long long)n, C, relu);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_sp_rules_inv_fwd(const long long* in_keys, int n_in, const long long* out_keys, int n_out, int B, const int* in_dims3, const int* kernel3,
+                             const int* stride3, const int* pad3, int* inv, void* stream) {
+  SpConvGeom g{};
+  if (int rc = sp_geom(g, B, in_dims3, kernel3, stride3, pad3)) return rc;
+  GC_CHECK_ARG(n_out >= 0 && n_in >= 0, "negative count");
+  if (n_in == 0) return GC_OK;
+  GC_CHECK_ARG(in_keys && inv && (n_out == 0 || out_keys), "null pointer");
+  const int K = g.k[0] * g.k[1] * g.k[2];
+  sp_rules_inv_kernel<<<dim3((n_in + 255) / 256, K), 256, 0, (hipStream_t)stream>>>(in_keys, n_in, out_keys, n_out, g, inv);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+// dw: raw layout 0 [Cout][K][Cin], ACCUMULATED (+=)
+int gencomm_sp_wgrad(const float* x, const float* dy, const int* nbr, float* dw, int n_out, int K, int Cin, int Cout, void* stream) {
+  GC_CHECK_ARG(n_out >= 0 && K >= 1 && K <= 65535 && Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64, "sparse wgrad: at most 64 channels on either side");
+  if (n_out == 0) return GC_OK;
+  GC_CHECK_ARG(x && dy && nbr && dw, "null pointer");
+  SpWgradArgs a{x, dy, nbr, dw, n_out, K, Cin, Cout, 0};
+  a.rows_per_block = 1024;
+  while (a.rows_per_block > 64 && (long long)((n_out + a.rows_per_block - 1) / a.rows_per_block) * K < 512) a.rows_per_block >>= 1;
+  sp_wgrad_kernel<<<dim3((n_out + a.rows_per_block - 1) / a.rows_per_block, K), 256, 0, (hipStream_t)stream>>>(a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 int gencomm_sp_dense_fwd(const float* feat, const long long* keys, int n, int C, int B, const int* dims3, float* out, void* stream) {
   SpGrid g{};
   if (int rc = sp_grid(g, B, dims3, "bad grid")) return rc;

@@ -175,7 +175,13 @@ __global__ __launch_bounds__(256) void sp_prep_w_kernel(const float* __restrict_
   const int cp = (int)(r % (CinP / 2)), o = (int)(r / (CinP / 2));
   const int ci = 2 * cp + lane;
   float v = 0.f;
-  if (ci < Cin && co < Cout) v = layout == 0 ? w[((size_t)co * K + o) * Cin + ci] : w[((size_t)o * Cin + ci) * Cout + co];
+  // layout 2: the input-gradient convolution of a layout-0 weight [Cout_f = Cin][K][Cin_f = Cout]: in / out channels swapped,
+  // offsets mirrored when `mirror` (SubM layers: dx[i] = sum_o W_o^T dy[site at coord_i - delta_o])
+  if (ci < Cin && co < Cout) {
+    if (layout == 0) v = w[((size_t)co * K + o) * Cin + ci];
+    else if (layout == 1) v = w[((size_t)o * Cin + ci) * Cout + co];
+    else v = w[((size_t)ci * K + (layout == 3 ? K - 1 - o : o)) * Cout + co];
+  }
   out[i] = v;
 }
 
@@ -321,6 +327,156 @@ __global__ __launch_bounds__(256) void sp_dense_kernel(const float* __restrict__
   int b, z, y, x;
   sp_decode(g, key, b, z, y, x);
   out[((((size_t)b * C + c) * g.D + z) * g.H + y) * g.W + x] = feat[i];
+}
+
+// =====================================================================================================================
+// Training of the sparse layers (stage 1 trains the SECOND encoder: sparse_backbone_3d.py:12-31 with BatchNorm1d in train mode).
+//   BatchNorm1d over the ACTIVE rows [n][C] (batch statistics, eps 1e-3, momentum 0.01) + ReLU, forward and backward
+//   input gradient   = the same gather-GEMM kernel on dy with transposed weights and the inverse rulebook
+//                      (SubM layers: the forward rulebook read with mirrored offsets; strided layers: sp_rules_inv_kernel)
+//   weight gradient  = dW[o][ci][co] += sum_j x[nbr[o][j]][ci] dy[j][co]: one workgroup per (offset, chunk of output sites),
+//                      rows staged through LDS, 16 accumulators per thread, f32 atomics at the end
+// =====================================================================================================================
+// per-channel sum / sum of squares over rows (f64 atomics): 256 threads = (256 / C) row slots x C channels, C in {16, 32, 64, 128}
+__global__ __launch_bounds__(256) void bnrow_stats_kernel(const float* __restrict__ x, double* __restrict__ acc, int n, int C) {
+  __shared__ double s_red[256][2];
+  const int tid = threadIdx.x, c = tid % C, slot = tid / C, slots = 256 / C;
+  double s = 0.0, q = 0.0;
+  for (long long r = (long long)blockIdx.x * slots + slot; r < n; r += (long long)gridDim.x * slots) {
+    const float v = x[(size_t)r * C + c];
+    s += v; q += (double)v * v;
+  }
+  s_red[tid][0] = s; s_red[tid][1] = q;
+  __syncthreads();
+  if (slot == 0) {
+    for (int k = 1; k < slots; ++k) { s += s_red[k * C + c][0]; q += s_red[k * C + c][1]; }
+    atomicAdd(&acc[c * 2], s);
+    atomicAdd(&acc[c * 2 + 1], q);
+  }
+}
+__global__ void bn2d_finish_rows_kernel(const double* __restrict__ acc, float* __restrict__ save /*[C][2] mean, rstd*/, float* __restrict__ running_mean,
+                                        float* __restrict__ running_var, float momentum, float eps, long long count, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = acc[c * 2] / (double)count;
+  const double var = fmax(acc[c * 2 + 1] / (double)count - m * m, 0.0);
+  save[c * 2] = (float)m;
+  save[c * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {   // nn.BatchNorm1d: running_var takes the unbiased estimate
+    const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+__global__ __launch_bounds__(256) void bnrow_apply_kernel(const float* __restrict__ x, const float* __restrict__ save, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y, long long total, int C, int relu) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const float v = fmaf((x[i] - save[c * 2]) * save[c * 2 + 1], gamma[c], beta[c]);
+  y[i] = relu ? fmaxf(v, 0.f) : v;
+}
+__global__ __launch_bounds__(256) void bnrow_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                               const float* __restrict__ save, double* __restrict__ acc, int n, int C, int relu) {
+  __shared__ double s_red[256][2];
+  const int tid = threadIdx.x, c = tid % C, slot = tid / C, slots = 256 / C;
+  const float mean = save[c * 2], rstd = save[c * 2 + 1];
+  double s = 0.0, q = 0.0;
+  for (long long r = (long long)blockIdx.x * slots + slot; r < n; r += (long long)gridDim.x * slots) {
+    const size_t e = (size_t)r * C + c;
+    const float g = (relu && !(y[e] > 0.f)) ? 0.f : dy[e];
+    s += g; q += (double)g * ((x[e] - mean) * rstd);
+  }
+  s_red[tid][0] = s; s_red[tid][1] = q;
+  __syncthreads();
+  if (slot == 0) {
+    for (int k = 1; k < slots; ++k) { s += s_red[k * C + c][0]; q += s_red[k * C + c][1]; }
+    atomicAdd(&acc[c * 2], s);
+    atomicAdd(&acc[c * 2 + 1], q);
+  }
+}
+__global__ __launch_bounds__(256) void bnrow_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                              const float* __restrict__ save, const float* __restrict__ gamma, const double* __restrict__ acc,
+                                                              float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long long total,
+                                                              long long count, int C, int relu) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < C) {
+    if (dgamma != nullptr) dgamma[i] += (float)acc[i * 2 + 1];
+    if (dbeta != nullptr) dbeta[i] += (float)acc[i * 2];
+  }
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const float mean = save[c * 2], rstd = save[c * 2 + 1];
+  const float mg = (float)(acc[c * 2] / (double)count), mgx = (float)(acc[c * 2 + 1] / (double)count);
+  const float g = (relu && !(y[i] > 0.f)) ? 0.f : dy[i];
+  const float xh = (x[i] - mean) * rstd;
+  dx[i] = gamma[c] * rstd * (g - mg - xh * mgx);
+}
+
+// inverse rulebook of a strided SparseConv3d: inv[o][i] = the output site that reads input site i through kernel offset o, or -1
+__global__ __launch_bounds__(256) void sp_rules_inv_kernel(const long long* __restrict__ in_keys, int n_in, const long long* __restrict__ out_keys, int n_out,
+                                                           const SpConvGeom g, int* __restrict__ inv) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;
+  if (i >= n_in) return;
+  const long long key = in_keys[i];
+  int res = -1;
+  if (key != kSpNoKey) {
+    int b, z, y, x;
+    sp_decode(g.in, key, b, z, y, x);
+    const int kx = o % g.k[2], ky = (o / g.k[2]) % g.k[1], kz = o / (g.k[2] * g.k[1]);
+    const int tz = z + g.pad[0] - kz, ty = y + g.pad[1] - ky, tx = x + g.pad[2] - kx;
+    if (tz >= 0 && ty >= 0 && tx >= 0 && tz % g.stride[0] == 0 && ty % g.stride[1] == 0 && tx % g.stride[2] == 0) {
+      const int oz = tz / g.stride[0], oy = ty / g.stride[1], ox = tx / g.stride[2];
+      if (oz < g.out.D && oy < g.out.H && ox < g.out.W) res = sp_find(out_keys, n_out, sp_encode(g.out, b, oz, oy, ox));
+    }
+  }
+  inv[(size_t)o * n_in + i] = res;
+}
+// weight gradient: dW raw layout 0 ([Cout][K][Cin]); x [n_in][Cin], dy [n_out][Cout], nbr [K][n_out]
+struct SpWgradArgs {
+  const float* x; const float* dy; const int* nbr; float* dw;
+  int n_out, K, Cin, Cout, rows_per_block;
+};
+__global__ __launch_bounds__(256) void sp_wgrad_kernel(const SpWgradArgs a) {
+  __shared__ float sx[64 * 64], sy[64 * 64];   // [row][channel] of up to 64 gathered rows (Cin, Cout <= 64)
+  const int o = blockIdx.y, tid = threadIdx.x;
+  const int j0 = blockIdx.x * a.rows_per_block, j1 = min(j0 + a.rows_per_block, a.n_out);
+  const int Cin = a.Cin, Cout = a.Cout;
+  // thread -> accumulators (ci, co0 + 0..15): 256 threads cover 64 x 64 when each owns 16 consecutive co of one ci ... generically:
+  const int per = (Cin * Cout + 255) / 256;          // accumulators per thread (<= 16)
+  float acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int jb = j0; jb < j1; jb += 64) {
+    const int nr = min(64, j1 - jb);
+    __syncthreads();
+    for (int i = tid; i < 64 * Cin; i += 256) {
+      const int r = i / Cin, c = i - r * Cin;
+      float v = 0.f;
+      if (r < nr) { const int idx = a.nbr[(size_t)o * a.n_out + jb + r]; if (idx >= 0) v = a.x[(size_t)idx * Cin + c]; }
+      sx[r * 64 + c] = v;
+    }
+    for (int i = tid; i < 64 * Cout; i += 256) {
+      const int r = i / Cout, c = i - r * Cout;
+      sy[r * 64 + c] = r < nr ? a.dy[(size_t)(jb + r) * Cout + c] : 0.f;
+    }
+    __syncthreads();
+    for (int e = 0; e < per; ++e) {
+      const int flat = tid * per + e;
+      if (flat >= Cin * Cout) break;
+      const int ci = flat / Cout, co = flat - ci * Cout;
+      float s = 0.f;
+      for (int r = 0; r < 64; ++r) s = fmaf(sx[r * 64 + ci], sy[r * 64 + co], s);
+      acc[e] += s;
+    }
+  }
+  for (int e = 0; e < per; ++e) {
+    const int flat = tid * per + e;
+    if (flat >= Cin * Cout) break;
+    const int ci = flat / Cout, co = flat - ci * Cout;
+    if (acc[e] != 0.f) atomicAdd(&a.dw[((size_t)co * a.K + o) * Cin + ci], acc[e]);
+  }
 }
 
 }  // namespace gc

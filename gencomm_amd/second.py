@@ -6,8 +6,9 @@ with the reference's constructor arguments, forward signature and ``state_dict``
 The containers below only hold parameters under the names spconv's modules give them (``SparseSequential`` registers its
 children as "0", "1", ...; ``SubMConv3d`` / ``SparseConv3d`` own one ``weight``, bias=False). Weight layout: spconv 2.x
 ``[Cout, kD, kH, kW, Cin]`` (the version the reference's README installs); a checkpoint written with spconv 1.x
-(``[kD, kH, kW, Cin, Cout]``) is recognised by its shape when it is loaded. Inference only: BatchNorm1d uses its running
-statistics and the module raises in training mode (no backward kernels for the sparse layers).
+(``[kD, kH, kW, Cin, Cout]``) is recognised by its shape when it is loaded. Inference runs one fused gather-GEMM per layer;
+training (BatchNorm1d with batch statistics over the active rows) and gradients go through ``_SparseLayerFn`` (HIP forward and
+backward kernels; weight / input gradients for up to 64 channels on either side, i.e. ``num_features_out: 64`` as the shipped yamls).
 spconv is not part of the reference checkout, so the arithmetic is **parity unpinned** (oracle: ``oracle/second_port.py``).
 """
 from __future__ import annotations
@@ -111,6 +112,8 @@ class SparseTensor:
         return int(self.keys.shape[0])
 
     def dense(self) -> torch.Tensor:
+        if torch.is_grad_enabled() and self.features.requires_grad:
+            return _DenseFn.apply(self.features, self)
         C_ = self.features.shape[1]
         D, H, W = self.shape
         out = torch.empty(self.batch, C_, D, H, W, dtype=torch.float32, device=self.features.device)
@@ -128,9 +131,7 @@ def _rules(out_keys, n_out, x: SparseTensor, kernel, stride, pad) -> torch.Tenso
 
 
 def sparse_conv_bn_relu(x: SparseTensor, conv: _SparseConvBase, bn: nn.BatchNorm1d, relu: bool = True) -> SparseTensor:
-    """One post_act_block on the HIP path."""
-    if bn.training:
-        raise NotImplementedError("SECOND on the HIP path is inference-only (BatchNorm1d batch statistics / sparse backward are not implemented); call .eval()")
+    """One post_act_block on the HIP path (inference: fused; training / gradients: `_SparseLayerFn`)."""
     l, dev = _lib.lib(), x.features.device
     st = stream_ptr(dev)
     K = int(np.prod(conv.kernel_size))
@@ -158,14 +159,137 @@ def sparse_conv_bn_relu(x: SparseTensor, conv: _SparseConvBase, bn: nn.BatchNorm
         keys = keys[:n_out].clone()
         nbr = _rules(keys, n_out, x, conv.kernel_size, conv.stride, conv.padding)
         out = SparseTensor(keys, None, x.batch, list(od))
-    prep, ss = conv.prepared(bn, dev)
     if TRACE is not None:
         TRACE.append((conv.in_channels, conv.out_channels, nbr))
+    needs_grad = torch.is_grad_enabled() and (x.features.requires_grad or any(p.requires_grad for p in (conv.weight, bn.weight, bn.bias)))
+    if bn.training or needs_grad:
+        out.features = _SparseLayerFn.apply(x.features, conv, bn, relu, (x, out, nbr), conv.weight, bn.weight, bn.bias)
+        return out
+    prep, ss = conv.prepared(bn, dev)
     y = torch.empty(out.n, conv.out_channels, dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_sp_conv_fwd(ptr(x.features), ptr(nbr), ptr(prep), ptr(ss[0]), ptr(ss[1]), ptr(y), out.n, K, conv.in_channels,
                                      conv.out_channels, int(relu), st), "gencomm_sp_conv_fwd")
     out.features = y
     return out
+
+
+def _raw_conv(feat, nbr, n_out, conv_w, K, cin, cout, layout, dev):
+    """Bare gather-GEMM (no norm, no activation) with a weight prepared in `layout` (0 forward, 2 / 3 input gradient)."""
+    l, st = _lib.lib(), stream_ptr(dev)
+    prep = torch.empty(_lib.check_size(l.gencomm_sp_prepared_floats(K, cin, cout), "gencomm_sp_prepared_floats"), dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_sp_prepare(ptr(f32c(conv_w.detach())), ptr(prep), K, cin, cout, layout, st), "gencomm_sp_prepare")
+    ones = torch.ones(cout, dtype=torch.float32, device=dev)
+    zeros = torch.zeros(cout, dtype=torch.float32, device=dev)
+    y = torch.empty(n_out, cout, dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_sp_conv_fwd(ptr(feat), ptr(nbr), ptr(prep), ptr(ones), ptr(zeros), ptr(y), n_out, K, cin, cout, 0, st), "gencomm_sp_conv_fwd")
+    return y
+
+
+class _SparseLayerFn(torch.autograd.Function):
+    """conv (no bias) -> BatchNorm1d -> ReLU of one sparse layer with gradients (stage 1 trains the encoder; batch statistics when the
+    BatchNorm is in train mode): HIP gather-GEMM forward, HIP BatchNorm-over-rows kernels, and a HIP backward -- weight gradient by
+    `gencomm_sp_wgrad`, input gradient by the same gather-GEMM on dy with transposed weights (SubM: forward rulebook, mirrored
+    offsets; strided layers: inverse rulebook)."""
+
+    @staticmethod
+    def forward(ctx, feat, conv, bn, relu, info, *params):
+        x, out, nbr = info
+        l, dev = _lib.lib(), feat.device
+        st = stream_ptr(dev)
+        K = int(np.prod(conv.kernel_size))
+        n_out, cin, cout = out.n, conv.in_channels, conv.out_channels
+        feat = f32c(feat.detach())
+        pre = _raw_conv(feat, nbr, n_out, conv.weight, K, cin, cout, 0, dev)
+        y = torch.empty_like(pre)
+        save = torch.empty(cout, 2, dtype=torch.float32, device=dev)
+        if bn.training:
+            scratch = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+            track = bn.track_running_stats and bn.running_mean is not None
+            momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+            if track:
+                bn.num_batches_tracked += 1
+                if bn.momentum is None:
+                    momentum = 1.0 / float(bn.num_batches_tracked)
+            if n_out > 0:
+                _lib.check(l.gencomm_bnrow_train_fwd(ptr(pre), ptr(f32c(bn.weight.detach())), ptr(f32c(bn.bias.detach())),
+                                                     ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(y), ptr(save),
+                                                     ptr(scratch), momentum, float(bn.eps), int(relu), n_out, cout, st), "gencomm_bnrow_train_fwd")
+        else:   # eval-mode statistics with gradients: the same normalisation with the running statistics as (mean, rstd)
+            save[:, 0] = bn.running_mean.float()
+            save[:, 1] = torch.rsqrt(bn.running_var.float() + bn.eps)
+            v = (pre - save[:, 0]) * save[:, 1] * bn.weight.detach().float() + bn.bias.detach().float()
+            y = torch.relu(v) if relu else v
+        ctx.conv, ctx.bn, ctx.relu, ctx.info, ctx.train = conv, bn, relu, info, bn.training
+        ctx.save_for_backward(feat, pre, y, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        feat, pre, y, save = ctx.saved_tensors
+        conv, bn, relu = ctx.conv, ctx.bn, ctx.relu
+        x, out, nbr = ctx.info
+        l, dev = _lib.lib(), feat.device
+        st = stream_ptr(dev)
+        K = int(np.prod(conv.kernel_size))
+        n_out, n_in, cin, cout = out.n, x.n, conv.in_channels, conv.out_channels
+        gy = f32c(gy)
+        dg = torch.zeros(cout, dtype=torch.float32, device=dev)
+        db = torch.zeros(cout, dtype=torch.float32, device=dev)
+        if ctx.train:
+            dpre = torch.empty_like(pre)
+            scratch = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+            if n_out > 0:
+                _lib.check(l.gencomm_bnrow_train_bwd(ptr(pre), ptr(y), ptr(gy), ptr(save), ptr(f32c(bn.weight.detach())), ptr(dpre), ptr(dg), ptr(db),
+                                                     ptr(scratch), int(relu), n_out, cout, st), "gencomm_bnrow_train_bwd")
+        else:
+            g = gy * (y > 0) if relu else gy
+            dg = (g * (pre - save[:, 0]) * save[:, 1]).sum(0)
+            db = g.sum(0)
+            dpre = (g * (save[:, 1] * bn.weight.detach().float())).contiguous()
+        dw = None
+        if ctx.needs_input_grad[5]:
+            if cin > 64 or cout > 64:
+                raise NotImplementedError("sparse weight gradient: at most 64 channels on either side (VoxelBackBone8x with num_features_out 64)")
+            dwf = torch.zeros(cout, K, cin, dtype=torch.float32, device=dev)
+            _lib.check(l.gencomm_sp_wgrad(ptr(feat), ptr(dpre), ptr(nbr), ptr(dwf), n_out, K, cin, cout, st), "gencomm_sp_wgrad")
+            dw = dwf.view(cout, *conv.kernel_size, cin)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cout > 64:
+                raise NotImplementedError("sparse input gradient: at most 64 output channels")
+            if conv.subm:
+                dx = _raw_conv(dpre, nbr, n_in, conv.weight, K, cout, cin, 3, dev)          # forward rulebook, mirrored offsets
+            else:
+                inv = torch.empty(K, n_in, dtype=torch.int32, device=dev)
+                _lib.check(l.gencomm_sp_rules_inv_fwd(ptr(x.keys), n_in, ptr(out.keys), n_out, x.batch, _i3(x.shape), _i3(conv.kernel_size), _i3(conv.stride),
+                                                      _i3(conv.padding), ptr(inv), st), "gencomm_sp_rules_inv_fwd")
+                dx = _raw_conv(dpre, inv, n_in, conv.weight, K, cout, cin, 2, dev)
+        return (dx, None, None, None, None, dw, dg if ctx.needs_input_grad[6] else None, db if ctx.needs_input_grad[7] else None)
+
+
+class _DenseFn(torch.autograd.Function):
+    """SparseConvTensor.dense() with a gradient: the backward gathers the dense gradient at the active sites."""
+
+    @staticmethod
+    def forward(ctx, feat, sp):
+        ctx.sp = sp
+        C_ = feat.shape[1]
+        D, H, W = sp.shape
+        out = torch.empty(sp.batch, C_, D, H, W, dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.lib().gencomm_sp_dense_fwd(ptr(f32c(feat.detach())), ptr(sp.keys), sp.n, C_, sp.batch, _i3(sp.shape), ptr(out),
+                                                   stream_ptr(out.device)), "gencomm_sp_dense_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sp = ctx.sp
+        D, H, W = sp.shape
+        k = sp.keys
+        xx = k % W
+        yy = (k // W) % H
+        zz = (k // (W * H)) % D
+        bb = k // (W * H * D)
+        return g[bb, :, zz, yy, xx].contiguous(), None
 
 
 def _run(seq: nn.Sequential, x: SparseTensor) -> SparseTensor:
@@ -280,10 +404,6 @@ class SECOND(nn.Module):  # heter_encoders.py:52-81
     def forward(self, data_dict, modality_name):
         inp = data_dict[f'inputs_{modality_name}']
         voxel_features, voxel_coords, voxel_num_points = inp['voxel_features'], inp['voxel_coords'], inp['voxel_num_points']
-        # a frozen encoder inside a model in train mode (stage 2: fix_bn keeps its BatchNorm in eval mode) is fine
-        if any(isinstance(m, nn.BatchNorm1d) and m.training for m in self.modules()):
-            raise NotImplementedError("SECOND on the HIP path is inference-only (BatchNorm1d batch statistics / sparse backward are not "
-                                      "implemented); call .eval() or freeze the encoder as stage 2 does")
         batch_size = int(voxel_coords[:, 0].max()) + 1          # heter_encoders.py:70 (one host read, as in the reference)
         keys, perm = index_voxels(voxel_coords, batch_size, self.spconv_block.sparse_shape)
         batch_dict = {'voxel_features': voxel_features, 'voxel_coords': voxel_coords, 'voxel_num_points': voxel_num_points,

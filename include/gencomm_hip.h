@@ -401,7 +401,7 @@ int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dc
  *   gencomm_sp_rules_fwd    rulebook nbr [K][n_out] int32: input row of out_coord * stride - pad + offset, -1 if inactive
  *                           (SubMConv3d: out_keys = in_keys, stride 1, pad = k / 2)
  *   gencomm_sp_prepare      weights -> kernel layout; layout 0 = spconv 2.x [Cout][kD][kH][kW][Cin], 1 = spconv 1.x
- *                           [kD][kH][kW][Cin][Cout]
+ *                           [kD][kH][kW][Cin][Cout]; 2 / 3 = the input-gradient convolution of a layout-0 weight (see below)
  *   gencomm_sp_conv_fwd     y[j][co] = act(scale[co] * sum_o sum_ci w[o][ci][co] x[nbr[o][j]][ci] + shift[co]): gather-GEMM on
  *                           v_mfma_f32_32x32x2_f32; scale / shift = folded BatchNorm1d (gencomm_conv2d_fold)
  *   gencomm_sp_dense_fwd    SparseConvTensor.dense(): out [B][C][D][H][W] (zeroed here)
@@ -424,6 +424,18 @@ int gencomm_sp_conv_fwd(const float* x, const int* nbr, const float* prepared, c
 int gencomm_sp_dense_fwd(const float* feat, const long long* keys, int n, int C, int B, const int* dims3, float* out, void* stream);
 int gencomm_mean_vfe_fwd(const float* voxels, const int* num_points, const int* perm, float* out, int n, int max_points, int nfeat,
                          void* stream);
+/* Training of the sparse layers (stage 1 trains the SECOND encoder): BatchNorm1d over the active rows [n][C] with batch statistics
+ * (+ ReLU), forward and backward (as gencomm_bn2d_train_*; C in {16, 32, 64, 128}); gencomm_sp_rules_inv_fwd = inverse rulebook of
+ * a strided layer (inv [K][n_in]: the output site that reads input site i through offset o); the input gradient is gencomm_sp_conv_fwd
+ * on dy with weights prepared in layout 2 (channels swapped) + the inverse rulebook, or layout 3 (channels swapped, offsets mirrored)
+ * + the forward rulebook for SubM layers; gencomm_sp_wgrad accumulates dW in the raw layout 0 [Cout][K][Cin] (<= 64 channels). */
+int gencomm_bnrow_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, float* save,
+                            double* scratch, float momentum, float eps, int relu, int n, int C, void* stream);
+int gencomm_bnrow_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
+                            float* dbeta, double* scratch, int relu, int n, int C, void* stream);
+int gencomm_sp_rules_inv_fwd(const long long* in_keys, int n_in, const long long* out_keys, int n_out, int B, const int* in_dims3,
+                             const int* kernel3, const int* stride3, const int* pad3, int* inv, void* stream);
+int gencomm_sp_wgrad(const float* x, const float* dy, const int* nbr, float* dw, int n_out, int K, int Cin, int Cout, void* stream);
 
 #ifdef __cplusplus
 }

@@ -52,8 +52,15 @@ def torch_weight(w: torch.Tensor, kernel: Sequence[int]) -> torch.Tensor:
     return w.permute(4, 3, 0, 1, 2).contiguous()           # 1.x: [kD, kH, kW, Cin, Cout]
 
 
+TRAIN_BN = False   # tests flip this to restate BatchNorm1d in TRAINING mode: statistics over the active rows of the batch (biased variance)
+
+
 def _bn_relu(sd: SD, p: str, y: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     g, b, mu, var = (sd[f"{p}.{k}"].view(1, -1, 1, 1, 1) for k in ("weight", "bias", "running_mean", "running_var"))
+    if TRAIN_BN:
+        cnt = mask.sum()
+        mu = (y * mask).sum((0, 2, 3, 4), keepdim=True) / cnt
+        var = (((y - mu) ** 2) * mask).sum((0, 2, 3, 4), keepdim=True) / cnt
     return torch.relu((y - mu) / torch.sqrt(var + BN_EPS) * g + b) * mask
 
 

@@ -297,7 +297,8 @@ def test_stage2_training_step_reaches_only_the_new_agents_message_extractor(new_
     print(f"stage-2 training step: loss {float(loss):.4f}, sum |grad| over message_extractor_m2 {tot:.3e}")
 
 
-def test_stage1_training_step_reaches_every_trained_module():
+@pytest.mark.parametrize("encoder", ["point_pillar", "second"])
+def test_stage1_training_step_reaches_every_trained_module(encoder):
     """Stage 1 of the reference trains the whole model (train.py; BatchNorm with batch statistics in the encoder and the backbone,
     GenComm's training branch, Enhancer, fusion, heads). One training step through the stage-1 shell in train mode: finite gradients on
     the encoder, backbone, shrinker, message extractor, GenComm, the live Enhancer block and the heads; running statistics move."""
@@ -306,16 +307,28 @@ def test_stage1_training_step_reaches_every_trained_module():
     from gencomm_amd.heter_model_baseline_w_gencomm_stage1 import HeterModelBaselineWGenCommStage1
     with open(os.path.join(REPO, "tests", "golden", "shell_state_dict_keys.json")) as f:
         args = copy.deepcopy(json.load(f)["args"])
+    if encoder == "second":   # the m3 modality of the shipped stage1/m3_att.yaml as the (only) agent type
+        args["m1"].update({"core_method": "second",
+                           "encoder_args": {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": args["lidar_range"], "mean_vfe": {"num_point_features": 4},
+                                            "spconv": {"num_features_in": 4, "num_features_out": 64}, "map2bev": {"feature_num": 128}},
+                           "backbone_args": {"layer_nums": [3, 5, 8], "layer_strides": [1, 2, 2], "num_filters": [64, 128, 256],
+                                             "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128], "inplanes": 128}})
     model = HeterModelBaselineWGenCommStage1(args)
     synth.fill_params_(model, 3)
     synth.fill_bn_stats_(model, 4)
     model = model.to(DEV).train()
     rm0 = model.backbone_m1.blocks[0][2].running_mean.clone()
     rl = [2, 1]
-    pil = synth.make_pillars(600, 3, 128, 64, 9, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
     ptm = synth.make_pairwise_t_matrix(rl, 5, 10, max_shift=4.0)
-    data = {"agent_modality_list": ["m1"] * 3, "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(DEV),
-            "inputs_m1": {k: torch.from_numpy(pil[k]).to(DEV) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}}
+    if encoder == "second":
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from test_second import _voxels
+        vf, vc, vn = _voxels(np.random.RandomState(5), [3000, 2000, 2500], 512, 256, 40)
+        inputs = {"voxel_features": vf.to(DEV), "voxel_coords": vc.to(DEV), "voxel_num_points": vn.to(DEV)}
+    else:
+        pil = synth.make_pillars(600, 3, 128, 64, 9, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
+        inputs = {k: torch.from_numpy(pil[k]).to(DEV) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
+    data = {"agent_modality_list": ["m1"] * 3, "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(DEV), "inputs_m1": inputs}
     out = model(data)
     loss = (out["cls_preds"].square().mean() + out["reg_preds"].square().mean() + out["dir_preds"].square().mean()
             + (out["pred_feature"] - out["gt_feature"].detach()).square().mean())

@@ -129,10 +129,11 @@ def test_spconv1_checkpoint_layout_is_recognised_on_load():
         assert torch.equal(v, sd[k]), k
 
 
-def test_training_mode_is_refused():
+def test_cpu_tensors_are_refused_without_a_gpu():
+    from gencomm_amd._lib import GenCommHipError
     from gencomm_amd.second import SECOND
     net = SECOND(_args(48, 32)).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(GenCommHipError):
         net({"inputs_m3": {"voxel_features": torch.zeros(1, 5, 4), "voxel_coords": torch.zeros(1, 4, dtype=torch.int32),
                            "voxel_num_points": torch.ones(1, dtype=torch.int32)}}, "m3")
 
@@ -197,3 +198,40 @@ def test_hip_second_refuses_cpu_tensors():
     vf, vc, vn = _voxels(np.random.RandomState(1), [20], 48, 32, 40)
     with pytest.raises(GenCommHipError):
         net({"inputs_m3": {"voxel_features": vf, "voxel_coords": vc, "voxel_num_points": vn}}, "m3")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train_bn", [True, False], ids=["batch_statistics", "running_statistics"])
+def test_hip_second_backward_vs_oracle_autograd(train_bn):
+    """Stage 1 trains the encoder: BatchNorm1d with batch statistics over the active rows, gradients to every sparse convolution and
+    BatchNorm parameter. HIP forward + backward (gather-GEMM input gradients with mirrored / inverse rulebooks, sparse weight gradient,
+    BatchNorm-over-rows kernels) against float64 autograd through the dense-volume oracle; and with the running statistics (a model
+    in eval mode that still needs gradients)."""
+    import second_port as S
+    nx, ny = 48, 32
+    net = _module(_args(nx, ny), 21)
+    vf, vc, vn = _voxels(np.random.RandomState(22), [400, 150], nx, ny, 40)
+    sd = {k: (v.detach().double().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.detach().double() if v.is_floating_point() else v)
+          for k, v in net.state_dict().items()}
+    S.TRAIN_BN = train_bn
+    try:
+        ref = S.second_forward(sd, "", vf.double(), vc, vn, [nx, ny, 40])
+        w = torch.randn(ref.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+        names = [k for k, v in sd.items() if v.requires_grad]
+        rg = torch.autograd.grad((ref * w).sum(), [sd[k] for k in names])
+    finally:
+        S.TRAIN_BN = False
+    net = net.cuda()
+    net.train(train_bn)
+    out = net({"inputs_m3": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}}, "m3")
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), 2e-4, 2e-5, "SECOND forward with gradients")
+    (out * w.float().cuda()).sum().backward()
+    got = dict(net.named_parameters())
+    worst = 0.0
+    for k, r in zip(names, rg):
+        assert got[k].grad is not None, k
+        scale = float(r.abs().max())
+        err = float((got[k].grad.detach().cpu().double() - r).abs().max())
+        assert err <= 2e-3 * scale + 1e-8, (k, err, scale)
+        worst = max(worst, err / (scale + 1e-30))
+    print(f"SECOND backward ({'batch' if train_bn else 'running'} statistics): {len(names)} parameter gradients, worst relative error {worst:.2e}")
