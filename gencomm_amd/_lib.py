@@ -94,6 +94,8 @@ _SIGNATURES = {
     "gencomm_iou3d_nms_fwd": (_i, [_p, _i, C.c_float, _i, _p, _p, _p, _ll, _p]),
     "gencomm_bn2d_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _i, _i, _i, _i, _p]),
     "gencomm_bn2d_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_slot_max_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "gencomm_slot_max_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "gencomm_dcn_sample_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_dcn_scatter_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_sp_out_dims": (_i, [_p, _p, _p, _p, _p]),

@@ -580,6 +580,24 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
   return GC_OK;
 }
 
+// max over the P point slots of every pillar (training path of the PointPillars encoder): x [C][M][P] -> out [M][C], arg [M][C] (uint8)
+int gencomm_slot_max_fwd(const float* x, float* out, unsigned char* arg, int C, int M, int P, void* stream) {
+  GC_CHECK_ARG(x && out && arg && C >= 1 && M >= 0 && P >= 1 && P <= 255, "bad arguments");
+  if (M == 0) return GC_OK;
+  const long long total = (long long)C * M;
+  slot_max_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, out, arg, C, M, P);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_slot_max_bwd(const float* dout, const unsigned char* arg, float* dx, int C, int M, int P, void* stream) {
+  GC_CHECK_ARG(dout && arg && dx && C >= 1 && M >= 0 && P >= 1 && P <= 255, "bad arguments");
+  if (M == 0) return GC_OK;
+  const long long total = (long long)C * M * P;
+  slot_max_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dout, arg, dx, C, M, P);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 // deformable 3x3 convolution split into sampling + GEMM for the training path of MessageExtractorv2 (train_kernels.h)
 int gencomm_dcn_sample_fwd(const float* x, const float* offset, float* col, int n, int C, int H, int W, void* stream) {
   GC_CHECK_ARG(x && offset && col && n >= 1 && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad arguments");

@@ -397,4 +397,27 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
   dx[e] = gamma[c] * rstd * (g - mg - xh * mgx);
 }
 
+// ---- max over the point slots of a pillar (PFNLayer, pillar_vfe.py:49-52) for the training path of the PointPillars encoder -----
+// x [C][M][P] (channel-major rows of the 1x1-conv layout [1, C, 1, M P]) -> out [M][C] and the arg-max slot; backward routes the
+// gradient to that slot (ties: the first maximal slot, as torch.max).
+__global__ __launch_bounds__(256) void slot_max_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, unsigned char* __restrict__ arg, int C, int M, int P) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)C * M) return;
+  const int c = (int)(i / M), m = (int)(i - (long long)c * M);
+  const float* __restrict__ p = x + ((size_t)c * M + m) * P;
+  float best = p[0];
+  int bi = 0;
+  for (int k = 1; k < P; ++k) if (p[k] > best) { best = p[k]; bi = k; }
+  out[(size_t)m * C + c] = best;
+  arg[(size_t)m * C + c] = (unsigned char)bi;
+}
+__global__ __launch_bounds__(256) void slot_max_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ arg, float* __restrict__ dx, int C, int M, int P) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)C * M * P) return;
+  const int k = (int)(i % P);
+  const long long cm = i / P;
+  const int c = (int)(cm / M), m = (int)(cm - (long long)c * M);
+  dx[i] = arg[(size_t)m * C + c] == k ? dout[(size_t)m * C + c] : 0.f;
+}
+
 }  // namespace gc

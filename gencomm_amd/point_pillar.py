@@ -3,7 +3,7 @@
 ``sub_modules/point_pillar_scatter.py:9-76``), SURVEY.md 8f-2. Same constructor arguments, attribute
 names (``pillar_vfe.pfn_layers.0.{linear,norm}``, ``scatter``) and ``state_dict`` keys; inference (and a frozen
 encoder inside a training model) runs one fused HIP kernel (augment -> Linear -> folded BatchNorm -> ReLU -> max -> scatter);
-training the encoder itself (stage 1) runs the per-pillar network in differentiable torch tensor ops."""
+training the encoder itself (stage 1) runs the per-pillar network layer by layer on HIP kernels with a HIP backward (`_PillarNetFn`)."""
 from __future__ import annotations
 
 import ctypes
@@ -57,6 +57,53 @@ class PointPillarScatter(nn.Module):  # point_pillar_scatter.py:9-17
         assert self.nz == 1
 
 
+class _PillarNetFn(torch.autograd.Function):
+    """PFNLayer (pillar_vfe.py:31-54) with gradients: Linear (no bias) -> BatchNorm1d -> ReLU -> max over the P slots, on HIP kernels:
+    1x1 convolution + its weight gradient, BatchNorm with batch statistics (train mode) or the running statistics (eval mode with
+    gradients), slot max with arg-max routing."""
+
+    @staticmethod
+    def forward(ctx, x4, pfn, M, P, *params):
+        from . import train_ops as T
+        l, dev = _lib.lib(), x4.device
+        w = pfn.linear.weight.detach()
+        Cout = w.shape[0]
+        pre = T.conv2d(x4, w[:, :, None, None], None, 0)                                       # [1, 64, 1, M P]
+        bn = pfn.norm
+        if bn.training:
+            y, save = T.bn2d_train_fwd(pre, bn, True)
+        else:
+            save = torch.stack([bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)], 1).contiguous()
+            y = torch.relu((pre - save[:, 0].view(1, -1, 1, 1)) * (save[:, 1] * bn.weight.detach().float()).view(1, -1, 1, 1) + bn.bias.detach().float().view(1, -1, 1, 1))
+        out = torch.empty(M, Cout, dtype=torch.float32, device=dev)
+        arg = torch.empty(M, Cout, dtype=torch.uint8, device=dev)
+        _lib.check(l.gencomm_slot_max_fwd(ptr(y), ptr(out), ptr(arg), Cout, M, P, stream_ptr(dev)), "gencomm_slot_max_fwd")
+        ctx.pfn, ctx.M, ctx.P, ctx.train = pfn, M, P, bn.training
+        ctx.save_for_backward(x4, pre, y, save, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import train_ops as T
+        x4, pre, y, save, arg = ctx.saved_tensors
+        pfn, M, P = ctx.pfn, ctx.M, ctx.P
+        bn = pfn.norm
+        l, dev = _lib.lib(), x4.device
+        Cout = pre.shape[1]
+        dy = torch.empty_like(y)
+        _lib.check(l.gencomm_slot_max_bwd(ptr(f32c(gout)), ptr(arg), ptr(dy), Cout, M, P, stream_ptr(dev)), "gencomm_slot_max_bwd")
+        if ctx.train:
+            dpre, dg, db = T.bn2d_train_bwd(pre, y, dy, save, bn.weight, True)
+        else:
+            g = dy * (y > 0)
+            dg = (g * (pre - save[:, 0].view(1, -1, 1, 1)) * save[:, 1].view(1, -1, 1, 1)).sum((0, 2, 3))
+            db = g.sum((0, 2, 3))
+            dpre = g * (save[:, 1] * bn.weight.detach().float()).view(1, -1, 1, 1)
+        dw, _ = T.conv2d_wgrad(dpre, x4, 1, 0, False)
+        return (None, None, None, None, dw[:, :, 0, 0] if ctx.needs_input_grad[4] else None,
+                dg if ctx.needs_input_grad[5] else None, db if ctx.needs_input_grad[6] else None)
+
+
 class PointPillar(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -78,25 +125,25 @@ class PointPillar(nn.Module):
         return self.encode(inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"])
 
     def _encode_train(self, vf, coords, npts, batch_size):
-        """Training mode (stage 1 trains the encoder: BatchNorm1d with batch statistics, gradients to `linear` / `norm`): the
-        per-pillar network -- 10-feature augmentation, Linear 10 -> 64, BatchNorm1d over all M x 32 point slots, ReLU, max over the
-        slots (pillar_vfe.py:31-54, :105-155) -- and the scatter (point_pillar_scatter.py:42-76) in differentiable torch tensor
-        ops on the GPU; the fused HIP kernel is the inference / frozen-encoder path. A frozen encoder inside a training model
-        (stage 2: fix_bn keeps the BatchNorm in eval mode, no parameter requires a gradient) never comes here."""
-        import torch.nn.functional as F
+        """Training / gradient path (stage 1 trains the encoder; BatchNorm1d with batch statistics when in train mode): the 10-feature
+        augmentation of the raw points is elementwise tensor arithmetic (no parameters), then `_PillarNetFn` -- Linear 10 -> 64 as a
+        1x1 convolution over the [1, 10, 1, M P] point-slot layout, BatchNorm + ReLU, max over the slots, all on HIP kernels with a HIP
+        backward -- and the scatter by indexed assignment (point_pillar_scatter.py:42-76). The fused one-launch kernel stays the
+        inference / frozen-encoder path."""
         v, pfn = self.pillar_vfe, self.pillar_vfe.pfn_layers[0]
         vx, vy, vz = v.voxel_size
         xo, yo, zo = vx / 2 + v.point_cloud_range[0], vy / 2 + v.point_cloud_range[1], vz / 2 + v.point_cloud_range[2]
-        c = coords.to(vf.dtype)
-        mean = vf[:, :, :3].sum(dim=1, keepdim=True) / npts.to(vf.dtype).view(-1, 1, 1)
-        f_cluster = vf[:, :, :3] - mean
-        f_center = torch.stack([vf[:, :, 0] - (c[:, 3].unsqueeze(1) * vx + xo), vf[:, :, 1] - (c[:, 2].unsqueeze(1) * vy + yo),
-                                vf[:, :, 2] - (c[:, 1].unsqueeze(1) * vz + zo)], dim=-1)
-        feats = torch.cat([vf, f_cluster, f_center], dim=-1)
-        mask = (npts.view(-1, 1) > torch.arange(vf.shape[1], device=vf.device).view(1, -1)).unsqueeze(-1).to(vf.dtype)
-        x = F.linear(feats * mask, pfn.linear.weight)
-        x = pfn.norm(x.permute(0, 2, 1)).permute(0, 2, 1)                   # nn.BatchNorm1d in its own mode (train: batch statistics)
-        pillar = torch.max(F.relu(x), dim=1)[0]                              # [M, 64]
+        with torch.no_grad():
+            c = coords.to(vf.dtype)
+            mean = vf[:, :, :3].sum(dim=1, keepdim=True) / npts.to(vf.dtype).view(-1, 1, 1)
+            f_cluster = vf[:, :, :3] - mean
+            f_center = torch.stack([vf[:, :, 0] - (c[:, 3].unsqueeze(1) * vx + xo), vf[:, :, 1] - (c[:, 2].unsqueeze(1) * vy + yo),
+                                    vf[:, :, 2] - (c[:, 1].unsqueeze(1) * vz + zo)], dim=-1)
+            mask = (npts.view(-1, 1) > torch.arange(vf.shape[1], device=vf.device).view(1, -1)).unsqueeze(-1).to(vf.dtype)
+            feats = torch.cat([vf, f_cluster, f_center], dim=-1) * mask                     # [M, P, 10]
+            M, P, F = feats.shape
+            x4 = feats.permute(2, 0, 1).reshape(1, F, 1, M * P).contiguous()               # channel-major point slots
+        pillar = _PillarNetFn.apply(x4, pfn, M, P, pfn.linear.weight, pfn.norm.weight, pfn.norm.bias)    # [M, 64]
         out = torch.zeros(batch_size, 64, self.scatter.ny * self.scatter.nx, dtype=vf.dtype, device=vf.device)
         idx = (coords[:, 1] + coords[:, 2] * self.scatter.nx + coords[:, 3]).long()
         out[coords[:, 0].long(), :, idx] = pillar

@@ -379,6 +379,12 @@ int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta
 int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
                            float* dbeta, double* scratch, int relu, int n, int C, int HW, void* stream);
 
+/* Training path of the PointPillars per-pillar network (pillar_vfe.py:31-54): the Linear layer runs as a 1x1 convolution over the
+ * [1, C, 1, M P] point-slot layout (gencomm_conv2d_fwd / _wgrad), BatchNorm1d with batch statistics as gencomm_bn2d_train_*, and the
+ * max over the P slots of a pillar here: x [C][M][P] -> out [M][C] with the arg-max slot (first maximum), backward = routing. */
+int gencomm_slot_max_fwd(const float* x, float* out, unsigned char* arg, int C, int M, int P, void* stream);
+int gencomm_slot_max_bwd(const float* dout, const unsigned char* arg, float* dx, int C, int M, int P, void* stream);
+
 /* Training path of MessageExtractorv2's deformable 3x3 convolution (message_extractor_v2.py:78,:108; DCNv1, padding 1, one offset
  * group), split into its sampling half and its GEMM half so that the backward is GEMMs on the general kernels + one scatter:
  *   gencomm_dcn_sample_fwd   col[n][c * 9 + k][p] = bilinear sample of x[n][c] at tap k's displaced position (zero outside)

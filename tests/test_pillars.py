@@ -55,3 +55,44 @@ def test_hip_pillar_encoder_vs_reference_golden():
     assert np.array_equal(occ, g["occupied_index"])          # integer cell indexing: bit-exact
     assert_close(sub(sp, 13), g["spatial_sample"], 1e-5, 1e-6, "spatial_features")
     assert abs(sp.abs().double().mean().item() - float(g["spatial_absmean"])) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train_bn", [True, False], ids=["batch_statistics", "running_statistics"])
+def test_hip_pillar_encoder_training_vs_torch_autograd(train_bn):
+    """Stage 1 trains the encoder: the per-pillar network on HIP kernels with a HIP backward (`_PillarNetFn`) against the same layers
+    written with torch ops (pillar_vfe.py:31-54, :105-155): output, gradients of the Linear weight and the BatchNorm affine, and the
+    running-statistics update in train mode."""
+    import copy
+    import torch.nn.functional as F
+    g, enc, pil = _setup()
+    enc = enc.to("cuda:0")
+    enc.train(train_bn)
+    ref = copy.deepcopy(enc)
+    pil = {k: v.to("cuda:0") for k, v in pil.items()}
+    out = enc({"inputs_m1": pil}, "m1")
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(8)).cuda()
+    (out * w).sum().backward()
+    # the same network in torch ops
+    pfn = ref.pillar_vfe.pfn_layers[0]
+    vf, c, npts = pil["voxel_features"], pil["voxel_coords"].float(), pil["voxel_num_points"]
+    vx, vy, vz = ARGS["voxel_size"]
+    r0 = ARGS["lidar_range"]
+    mean = vf[:, :, :3].sum(1, keepdim=True) / npts.float().view(-1, 1, 1)
+    fc = torch.stack([vf[:, :, 0] - (c[:, 3:4] * vx + vx / 2 + r0[0]), vf[:, :, 1] - (c[:, 2:3] * vy + vy / 2 + r0[1]),
+                      vf[:, :, 2] - (c[:, 1:2] * vz + vz / 2 + r0[2])], -1)
+    mask = (npts.view(-1, 1) > torch.arange(vf.shape[1], device=vf.device).view(1, -1)).unsqueeze(-1).float()
+    x = F.linear(torch.cat([vf, vf[:, :, :3] - mean, fc], -1) * mask, pfn.linear.weight)
+    x = pfn.norm(x.permute(0, 2, 1)).permute(0, 2, 1)
+    pillar = torch.max(F.relu(x), dim=1)[0]
+    sp = torch.zeros(out.shape[0], 64, out.shape[2] * out.shape[3], device=vf.device)
+    sp[pil["voxel_coords"][:, 0].long(), :, (pil["voxel_coords"][:, 2] * out.shape[3] + pil["voxel_coords"][:, 3]).long()] = pillar
+    sp = sp.view_as(out)
+    (sp * w).sum().backward()
+    assert_close(out.detach().cpu().numpy(), sp.detach().cpu().numpy(), 1e-4, 1e-5, "pillar encoder, gradient path")
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        scale = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) <= 2e-3 * scale + 1e-7, k
+    for (k, b1), (_, b2) in zip(enc.named_buffers(), ref.named_buffers()):
+        if b1.is_floating_point():
+            assert_close(b1.cpu().numpy(), b2.cpu().numpy(), 1e-4, 1e-6, "running statistic " + k)
