@@ -167,8 +167,20 @@ class _Conv2dHipFn(torch.autograd.Function):
         return (gx, None, None, None, None, *gp)
 
 
+def _stride1_view(conv: nn.Conv2d) -> nn.Conv2d:
+    """A 1x1 convolution with stride s reads every s-th pixel: the same layer with stride 1 on the subsampled input. The shadow module
+    shares the Parameter objects (gradients land on the original) and is cached on it."""
+    sh = getattr(conv, "_gc_stride1", None)
+    if sh is None or sh.weight is not conv.weight or sh.bias is not conv.bias:
+        sh = nn.Conv2d(conv.in_channels, conv.out_channels, 1, stride=1, bias=conv.bias is not None)
+        sh.weight, sh.bias = conv.weight, conv.bias
+        object.__setattr__(conv, "_gc_stride1", sh)
+    return sh
+
+
 def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
-               pad: Optional[int] = None, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+               pad: Optional[int] = None, out: Optional[torch.Tensor] = None, out_coff: int = 0,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(BN(conv(x))) as one HIP launch. ``conv`` is an ``nn.Conv2d`` (3x3 stride 1|2, or 1x1) or an
     ``nn.ConvTranspose2d`` whose kernel equals its stride; ``pad`` overrides ``conv.padding`` (ZeroPad2d(1)
     in front of a padding-0 conv). ``out``/``out_coff``: write into a channel slice of a larger tensor.
@@ -176,6 +188,16 @@ def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = 
     through ``_Conv2dHipFn`` (eval-mode BatchNorm) or ``_ConvBnTrainFn`` (batch statistics), HIP forward and HIP backward: the graph
     is never cut silently."""
     require_gpu(x, "conv2d_hip")
+    if isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride[0] > 1 and conv.stride[0] == conv.stride[1]:
+        s_ = conv.stride[0]
+        return conv2d_hip(x[:, :, ::s_, ::s_].contiguous(), _stride1_view(conv), bn, relu, pad, out, out_coff, residual)
+    if residual is not None:
+        # `residual` is added to BN(conv(x)) and the ReLU (if any) comes AFTER the sum (ResNet BasicBlock, resblock.py:48-62)
+        grad_path = torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad or any(
+            p is not None and p.requires_grad for p in (conv.weight, conv.bias) + ((bn.weight, bn.bias) if bn is not None else ())))
+        if grad_path or (bn is not None and bn.training) or out is not None:
+            y = conv2d_hip(x, conv, bn, False, pad) + residual
+            return torch.relu(y) if relu else y
     if torch.is_grad_enabled():
         params = [p for p in (conv.weight, conv.bias) + ((bn.weight, bn.bias) if bn is not None else ()) if p is not None]
         if x.requires_grad or any(p.requires_grad for p in params):
@@ -234,6 +256,13 @@ def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = 
         out_coff = 0
     if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != n or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError(f"output buffer must be contiguous f32 [n, *, {Ho}, {Wo}], got {tuple(out.shape)}")
+    if residual is not None:   # inference: conv + folded BatchNorm + identity + ReLU in one launch
+        res = f32c(residual)
+        if tuple(res.shape) != (n, cout, Ho, Wo) or ups != 1:
+            raise ValueError(f"residual must be [n, {cout}, {Ho}, {Wo}], got {tuple(res.shape)}")
+        _lib.check(l.gencomm_conv2d_act_res_fwd(ptr(x), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(res), ptr(out), n, cin, H, W, cout, gkh, gkw,
+                                                stride, p, 3 if relu else 0, st), "gencomm_conv2d_act_res_fwd")
+        return out
     _lib.check(l.gencomm_conv2d_fwd(ptr(x), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(out), n, cin, H, W, cout, gkh, gkw,
                                     stride, p, int(relu), ups, out.shape[1], out_coff, st), "gencomm_conv2d_fwd")
     return out

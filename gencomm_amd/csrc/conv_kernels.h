@@ -29,7 +29,7 @@ struct Conv2dArgs {
   const float* shift;  // [Cout]
   float* y;            // [N][out_ctotal][Ho*ups][Wo*ups], this layer writes channels [out_coff, out_coff + Cout)
   int Cin, H, W, CoutP, Ho, Wo;
-  int stride, pad, relu /* 0 none, 1 ReLU, 2 erf-GELU */, ups, out_ctotal, out_coff;
+  int stride, pad, relu /* 0 none, 1 ReLU, 2 erf-GELU, 3 ReLU after the residual */, ups, out_ctotal, out_coff;
   const float* res = nullptr;  // optional residual, same layout as y, added after the activation
 };
 
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(const Conv2dArgs a) {
     else if (a.relu == 2) v = gelu_erf_f(v);
     const size_t oi = (size_t)co * oplane + (size_t)(oy * s + dy) * (a.Wo * s) + (ox * s + dx);
     if (a.res != nullptr) v += a.res[((size_t)n * a.out_ctotal + a.out_coff) * oplane + oi];
+    if (a.relu == 3) v = fmaxf(v, 0.f);   // ReLU AFTER the residual add (ResNet BasicBlock)
     yn[oi] = v;
   }
 }

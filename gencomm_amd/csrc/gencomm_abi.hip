@@ -528,11 +528,11 @@ int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale
   Conv2dArgs a{x, prepared, scale, shift, y, Cin, H, W, Cout * ups * ups, Ho, Wo, stride, pad, relu, ups, out_ctotal, out_coff};
   return conv2d_enqueue(a, N, KH, KW, (hipStream_t)stream);
 }
-// the same with act in {0 none, 1 ReLU, 2 erf-GELU} and an optional residual (layout of y) added after the activation
+// the same with act in {0 none, 1 ReLU, 2 erf-GELU, 3 ReLU applied AFTER the residual add} and an optional residual (layout of y)
 int gencomm_conv2d_act_res_fwd(const float* x, const float* prepared, const float* scale, const float* shift, const float* residual, float* y,
                                int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
   GC_CHECK_ARG(x && prepared && scale && shift && y, "null pointer");
-  GC_CHECK_ARG(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && stride >= 1 && pad >= 0 && act >= 0 && act <= 2, "bad dims");
+  GC_CHECK_ARG(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && stride >= 1 && pad >= 0 && act >= 0 && act <= 3, "bad dims");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
   Conv2dArgs a{x, prepared, scale, shift, y, Cin, H, W, Cout, Ho, Wo, stride, pad, act, 1, Cout, 0};

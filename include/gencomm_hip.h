@@ -239,8 +239,9 @@ int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const floa
 int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale, const float* shift, float* y,
                        int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
                        int ups, int out_ctotal, int out_coff, void* stream);
-/* the same (no transposed-conv mode, whole-tensor output) with act in {0 none, 1 ReLU, 2 erf-GELU (nn.GELU)} and an optional
- * residual [N][Cout][Ho][Wo] added after the activation: Linear + GELU and Linear + skip connection in one launch */
+/* the same (no transposed-conv mode, whole-tensor output) with act in {0 none, 1 ReLU, 2 erf-GELU (nn.GELU), 3 ReLU applied after
+ * the residual add (ResNet BasicBlock)} and an optional residual [N][Cout][Ho][Wo]: Linear + GELU, Linear + skip connection,
+ * conv + BatchNorm + identity + ReLU in one launch */
 int gencomm_conv2d_act_res_fwd(const float* x, const float* prepared, const float* scale, const float* shift, const float* residual,
                                float* y, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int act,
                                void* stream);

@@ -376,6 +376,47 @@ def run_shell_case() -> None:
           f"|cls| mean {out['cls_preds'].abs().mean().item():.4f}")
 
 
+def late_args() -> dict:
+    """A reduced `model.args` block of opv2v/Single/m1_pointpillar_pretrain.yaml:99-146 (heter_model_late: PointPillars ego-only, no
+    fusion -- BASELINE.json configs[0]): 128 x 64 pillars of 0.4 m, light ResNet backbone [3] + multiscale ResNet layers [3, 5, 8]."""
+    rng_ = [-25.6, -12.8, -3, 25.6, 12.8, 1]
+    return {"ego_modality": "m1", "lidar_range": rng_, "anchor_number": 2, "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]},
+            "m1": {"core_method": "point_pillar", "sensor_type": "lidar",
+                   "encoder_args": {"voxel_size": [0.4, 0.4, 4], "lidar_range": rng_,
+                                    "pillar_vfe": {"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+                                    "point_pillar_scatter": {"num_features": 64}},
+                   "backbone_args": {"layer_nums": [3], "layer_strides": [2], "num_filters": [64]},
+                   "aligner_args": {"core_method": "identity"},
+                   "layers_args": {"layer_nums": [3, 5, 8], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+                                   "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]},
+                   "shrink_header": {"kernal_size": [3], "stride": [1], "padding": [1], "dim": [256], "input_dim": 384},
+                   "head_args": {"in_head": 256}}}
+
+
+def run_late_case() -> None:
+    """The reference's own single-agent model (heter_model_late.py: PointPillar encoder -> ResNetBEVBackbone -> multiscale ResNet
+    layers -> deblocks -> DownsampleConv -> heads) on CPU, one agent, synthetic pillars: BASELINE.json configs[0] as a plumbing check."""
+    import copy
+    import json
+    from opencood.models.heter_model_late import HeterModelLate
+    args = late_args()
+    model = HeterModelLate(copy.deepcopy(args)).eval()
+    synth.fill_params_(model, WEIGHT_SEED + 80)
+    synth.fill_bn_stats_(model, WEIGHT_SEED + 81)
+    nx, ny = 128, 64
+    pil = synth.make_pillars(2500, 1, nx, ny, DATA_SEED + 80, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
+    data = {"inputs_m1": {"voxel_features": torch.from_numpy(pil["voxel_features"]), "voxel_coords": torch.from_numpy(pil["voxel_coords"]),
+                          "voxel_num_points": torch.from_numpy(pil["voxel_num_points"])}}
+    with torch.no_grad():
+        out = model(data)
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "late.npz"), weight_seed=WEIGHT_SEED + 80, bn_seed=WEIGHT_SEED + 81, data_seed=DATA_SEED + 80, M=2500,
+                        nx=nx, ny=ny, cls_preds=out["cls_preds"].numpy(), reg_preds=out["reg_preds"].numpy(), dir_preds=out["dir_preds"].numpy())
+    with open(os.path.join(OUT, "late_state_dict_keys.json"), "w") as f:
+        json.dump({"args": args, "state_dict": keys}, f, indent=0)
+    print(f"late: {len(keys)} state_dict keys, cls {tuple(out['cls_preds'].shape)} |cls| mean {out['cls_preds'].abs().mean().item():.4f}")
+
+
 POSTPROC_PARAMS = {
     "core_method": "VoxelPostprocessor", "gt_range": [-35.2, -20.0, -3, 35.2, 20.0, 1],
     "anchor_args": {"cav_lidar_range": [-35.2, -20.0, -3, 35.2, 20.0, 1], "l": 3.9, "w": 1.6, "h": 1.56, "r": [0, 90],
@@ -562,7 +603,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()

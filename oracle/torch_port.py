@@ -433,6 +433,49 @@ def bev_backbone_forward(sd, prefix, x, cfg):
     return torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
 
 
+def resnet_layer_forward(sd, prefix, x, n_blocks: int, stride: int):
+    """One `layer{i}` of ResNetModified (sub_modules/resblock.py:184-211): `n_blocks` BasicBlocks (:48-62), the first with `stride`
+    and a 1x1-conv + BatchNorm downsample branch when the stride or the width changes (keys decide); BatchNorm eps 1e-5 (torch default)."""
+    for b in range(n_blocks):
+        p = f"{prefix}.{b}"
+        st = stride if b == 0 else 1
+        identity = x
+        out = F.relu(_bn_eval(F.conv2d(x, sd[f"{p}.conv1.weight"], None, stride=st, padding=1), sd, f"{p}.bn1", 1e-5))
+        out = _bn_eval(F.conv2d(out, sd[f"{p}.conv2.weight"], None, padding=1), sd, f"{p}.bn2", 1e-5)
+        if f"{p}.downsample.0.weight" in sd:
+            identity = _bn_eval(F.conv2d(x, sd[f"{p}.downsample.0.weight"], None, stride=st), sd, f"{p}.downsample.1", 1e-5)
+        x = F.relu(out + identity)
+    return x
+
+
+def resnet_deblocks_forward(sd, prefix, feats, cfg):
+    """ResNetBEVBackbone.decode_multiscale_feature (base_bev_backbone_resnet.py:118-136): ConvTranspose2d(k = stride) + BatchNorm(eps 1e-3) + ReLU."""
+    ups = [F.relu(_bn_eval(F.conv_transpose2d(f, sd[f"{prefix}.deblocks.{i}.0.weight"], None, stride=cfg["upsample_strides"][i]),
+                           sd, f"{prefix}.deblocks.{i}.1")) for i, f in enumerate(feats)]
+    return torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+
+
+def late_model_forward(sd, args, voxel_features, voxel_coords, voxel_num_points, m: str = "m1"):
+    """HeterModelLate.forward for a lidar / PointPillars agent (heter_model_late.py:72-115): encoder -> light ResNet backbone (no
+    deblocks: its single level IS the first scale) -> `layers` levels 1.. (level 0 of `layers` is never used) -> deblocks -> shrink -> heads."""
+    a = args[m]
+    enc = a["encoder_args"]
+    grid = [int(round((enc["lidar_range"][3 + i] - enc["lidar_range"][i]) / enc["voxel_size"][i])) for i in range(3)]
+    pf = pillar_vfe_forward({k[len(f"encoder_{m}.pillar_vfe."):]: v for k, v in sd.items() if k.startswith(f"encoder_{m}.pillar_vfe.")},
+                            voxel_features, voxel_num_points, voxel_coords, enc["voxel_size"], enc["lidar_range"])
+    B = int(voxel_coords[:, 0].max()) + 1
+    x = pillar_scatter(pf, voxel_coords, B, grid[0], grid[1])
+    bcfg, lcfg = a["backbone_args"], a["layers_args"]
+    x = resnet_layer_forward(sd, f"backbone_{m}.resnet.layer0", x, bcfg["layer_nums"][0], bcfg["layer_strides"][0])
+    feats = [x]
+    for i in range(1, len(lcfg["num_upsample_filter"])):
+        x = resnet_layer_forward(sd, f"layers_{m}.resnet.layer{i}", x, lcfg["layer_nums"][i], lcfg["layer_strides"][i])
+        feats.append(x)
+    x = resnet_deblocks_forward(sd, f"layers_{m}", feats, lcfg)
+    x = downsample_conv_forward(sd, f"shrink_conv_{m}", x, a["shrink_header"])
+    return {k: F.conv2d(x, sd[f"{k[:3]}_head_{m}.weight"], sd[f"{k[:3]}_head_{m}.bias"]) for k in ("cls_preds", "reg_preds", "dir_preds")}
+
+
 def downsample_conv_forward(sd, prefix, x, cfg):
     pre = prefix + "." if prefix else ""
     for i, (st, pd) in enumerate(zip(cfg["stride"], cfg["padding"])):
