@@ -97,7 +97,8 @@ int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int
   if (dim_head == 32) hgt_attn_kernel<32><<<grid, 256, 0, st>>>(a);
   else if (dim_head == 64) hgt_attn_kernel<64><<<grid, 256, 0, st>>>(a);
   else if (dim_head == 16) hgt_attn_kernel<16><<<grid, 256, 0, st>>>(a);
-  else return fail(GC_ERR_ARG, "hgt attention: dim_head must be 16, 32 or 64");
+  else if (dim_head == 8) hgt_attn_kernel<8><<<grid, 256, 0, st>>>(a);
+  else return fail(GC_ERR_ARG, "hgt attention: dim_head must be 8, 16, 32 or 64");
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -136,6 +137,7 @@ int gencomm_hgt_attn_bwd(const float* qkv, const int* scene_off, const float* do
   if (dim_head == 32) hgt_attn_bwd_kernel<32><<<grid, 256, 0, st>>>(a);
   else if (dim_head == 64) hgt_attn_bwd_kernel<64><<<grid, 256, 0, st>>>(a);
   else if (dim_head == 16) hgt_attn_bwd_kernel<16><<<grid, 256, 0, st>>>(a);
+  else if (dim_head == 8) hgt_attn_bwd_kernel<8><<<grid, 256, 0, st>>>(a);
   else return fail(GC_ERR_ARG, "hgt attention: dim_head must be 16, 32 or 64");
   GC_HIP(hipGetLastError());
   return GC_OK;

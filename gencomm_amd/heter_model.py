@@ -103,8 +103,11 @@ class HeterModelBaselineWGenComm(nn.Module):
         elif method == "v2xvit":
             from .v2xvit import V2XViTFusion
             self.fusion_net = V2XViTFusion(args["v2xvit"])  # stage1.py:122-123
+        elif method == "where2comm":
+            from .where2comm import Where2commFusion
+            self.fusion_net = Where2commFusion(args["where2comm"])  # stage1.py:126-127
         elif method in _OTHER_FUSIONS:
-            raise NotImplementedError(f"fusion_method '{method}' is outside this build ('att', 'max' and 'v2xvit' are implemented)")
+            raise NotImplementedError(f"fusion_method '{method}' is outside this build ('att', 'max', 'v2xvit' and 'where2comm' are implemented)")
         else:
             raise ValueError(f"unknown fusion_method '{method}'")
 

@@ -576,6 +576,36 @@ def run_v2xvit_case() -> None:
           f"mean |out| {float(out.abs().mean()):.4f} finite {bool(torch.isfinite(out).all())}")
 
 
+def run_where2comm_case() -> None:
+    """Where2commFusion (fusion_in_one.py:466-519 + where2comm_attn.py:64-102: nn.MultiheadAttention over the agents per pixel + FFN),
+    the reference's own module: forward, and the gradients of sum(out * probe) w.r.t. the input and every parameter."""
+    import json
+    sys.modules.setdefault("turtle", types.SimpleNamespace(update=None))     # `from turtle import update` (unused; needs tkinter)
+    from opencood.models.fuse_modules.fusion_in_one import Where2commFusion
+    from opencood.utils.transformation_utils import normalize_pairwise_tfm
+    C, H, W, rl = 128, 16, 32, [3, 1, 2]
+    net = Where2commFusion(C).eval()
+    seed_w, seed_d = WEIGHT_SEED + 80, DATA_SEED + 80
+    synth.fill_params_(net, seed_w)
+    inp = synth.make_inputs(rl, C, H, W, seed_d, max_shift=4.0)
+    x = torch.from_numpy(inp["feat"]).requires_grad_(True)
+    record_len = torch.from_numpy(inp["record_len"])
+    affine = normalize_pairwise_tfm(torch.from_numpy(inp["pairwise_t_matrix"]), H * 0.8, W * 0.8, 1)
+    out = net(x, record_len, affine)
+    probe = torch.from_numpy(synth.noise_stream(seed_d, 99, tuple(out.shape)))
+    (out * probe).sum().backward()
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(OUT, "where2comm_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+    grads = {"g_" + k.replace(".", "__"): p.grad.numpy() for k, p in net.named_parameters() if p.numel() <= 4096}
+    grads["g_in_proj_weight_sub"] = net.mha_fusion.attn.in_proj_weight.grad.numpy()[::7, ::5]
+    np.savez_compressed(os.path.join(OUT, "where2comm.npz"), C=C, H=H, W=W, record_len=np.array(rl), weight_seed=seed_w, data_seed=seed_d,
+                        max_shift=4.0, stride=3, fused=sub(out.detach().numpy(), 3), fused_shape=np.array(out.shape),
+                        dx=sub(x.grad.numpy(), 3), **grads)
+    print(f"where2comm: {len(keys)} state_dict tensors, out {tuple(out.shape)} mean |out| {float(out.abs().mean()):.4f} "
+          f"mean |dx| {float(x.grad.abs().mean()):.5f}")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -603,7 +633,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()

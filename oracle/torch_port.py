@@ -299,6 +299,33 @@ def max_fusion(xx: Tensor, record_len, affine_matrix: Tensor) -> Tensor:
     return torch.stack(out)
 
 
+def where2comm_fusion(sd: SD, xx: Tensor, record_len, affine_matrix: Tensor, n_head: int = 8) -> Tensor:
+    """Where2commFusion.forward (fusion_in_one.py:477-519) with EncodeLayer.forward (where2comm_attn.py:81-102) and
+    nn.MultiheadAttention written out: sequence = the scene's agents, batch = pixels; q of the ego token only; heads are contiguous
+    channel chunks, q scaled by 1 / sqrt(C / heads); dropout p = 0."""
+    _, C, H, W = xx.shape
+    dh = C // n_head
+    wi, bi = sd["mha_fusion.attn.in_proj_weight"], sd["mha_fusion.attn.in_proj_bias"]
+    out, o = [], 0
+    for b, n in enumerate(regroup_lens(record_len)):
+        x = warp_affine_simple(xx[o:o + n], affine_matrix[b][0, :n], (H, W))
+        tok = x.permute(0, 2, 3, 1).flatten(1, 2)                                   # [n, HW, C]
+        q = F.linear(tok[0:1], wi[:C], bi[:C]).view(1, H * W, n_head, dh)
+        k = F.linear(tok, wi[C:2 * C], bi[C:2 * C]).view(n, H * W, n_head, dh)
+        v = F.linear(tok, wi[2 * C:], bi[2 * C:]).view(n, H * W, n_head, dh)
+        score = (q * k).sum(-1) / np.sqrt(dh)                                       # [n, HW, heads]: ego query against agent j
+        att = F.softmax(score, dim=0)
+        ctx = (att.unsqueeze(-1) * v).sum(0).reshape(1, H * W, C)
+        ctx = F.linear(ctx, sd["mha_fusion.attn.out_proj.weight"], sd["mha_fusion.attn.out_proj.bias"])
+        o1 = F.layer_norm(tok[0:1] + ctx, (C,), sd["mha_fusion.norm1.weight"], sd["mha_fusion.norm1.bias"], 1e-5)
+        ff = F.linear(F.relu(F.linear(o1, sd["mha_fusion.linear1.weight"], sd["mha_fusion.linear1.bias"])),
+                      sd["mha_fusion.linear2.weight"], sd["mha_fusion.linear2.bias"])
+        o2 = F.layer_norm(o1 + ff, (C,), sd["mha_fusion.norm2.weight"], sd["mha_fusion.norm2.bias"], 1e-5)
+        out.append(o2.permute(0, 2, 1).reshape(C, H, W))
+        o += n
+    return torch.stack(out)
+
+
 # --------------------------------------------------------------------------------------
 # whole path
 # --------------------------------------------------------------------------------------

@@ -231,7 +231,7 @@ def test_message_extractor_backward_vs_oracle_autograd(C, H, W, n):
     print(f"MessageExtractorv2 backward C={C} {H}x{W}: {len(names)} parameter gradients + input, worst relative error {worst:.2e}")
 
 
-@pytest.mark.parametrize("new_agent,fusion", [("point_pillar", "att"), ("second", "att"), ("second", "v2xvit")])
+@pytest.mark.parametrize("new_agent,fusion", [("point_pillar", "att"), ("second", "att"), ("second", "v2xvit"), ("point_pillar", "where2comm")])
 def test_stage2_training_step_reaches_only_the_new_agents_message_extractor(new_agent, fusion):
     """Stage 2 (heter_model_baseline_w_gencomm_stage2.py:99-101, :180-185): every module is frozen except the message
     extractor of the new (non-ego) modality. One training step through the stage-2 shell on the HIP path: loss.backward()
@@ -248,6 +248,8 @@ def test_stage2_training_step_reaches_only_the_new_agents_message_extractor(new_
         from helpers import load_case
         args["fusion_method"] = "v2xvit"
         args["v2xvit"] = json.loads(str(load_case("v2xvit")["args"]))
+    if fusion == "where2comm":                        # Diffcomm/*/m1_diffcomm_where2comm.yaml:130-131
+        args["fusion_method"], args["where2comm"] = "where2comm", 128
     if new_agent == "second":
         args["m2"].update({"core_method": "second",
                            "encoder_args": {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": args["lidar_range"], "mean_vfe": {"num_point_features": 4},

@@ -156,6 +156,39 @@ def test_v2xvit_shell_forward_runs_on_the_hip_path():
     assert_close(seen["out"].numpy(), ref.numpy(), 1e-4, 1e-5, "V2X-ViT fused map inside the shell")
 
 
+@pytest.mark.gpu
+def test_where2comm_shell_forward_runs_on_the_hip_path():
+    """Stage-1 shell with `fusion_method: where2comm` (MoreModality/Diffcomm/*/m1_diffcomm_where2comm.yaml:130-131) end to end on the GPU:
+    the fused map must equal Where2commFusion applied to the Enhancer output by the oracle."""
+    from oracle import torch_port as O
+    g = load_case("shell")
+    spec = _spec()
+    dev = "cuda:0"
+    args = copy.deepcopy(spec["args"])
+    args["fusion_method"], args["where2comm"] = "where2comm", 128
+    model = _resolve("heter_model_baseline_w_gencomm_stage1")(args).eval()
+    assert sorted(k for k in model.state_dict() if k.startswith("fusion_net."))[0] == "fusion_net.mha_fusion.attn.in_proj_bias"
+    synth.fill_params_(model, int(g["weight_seed"]))
+    synth.fill_bn_stats_(model, int(g["bn_seed"]))
+    model = model.to(dev)
+    rl = [int(v) for v in g["record_len"]]
+    pil = synth.make_pillars(int(g["M"]), sum(rl), int(g["nx"]), int(g["ny"]), int(g["data_seed"]), voxel_size=[0.4, 0.4, 4.0],
+                             pc_range=spec["args"]["lidar_range"])
+    ptm = synth.make_pairwise_t_matrix(rl, 5, int(g["pose_seed"]), max_shift=float(g["max_shift"]))
+    data = {"agent_modality_list": ["m1"] * sum(rl), "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(dev),
+            "inputs_m1": {k: torch.from_numpy(pil[k]).to(dev) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}}
+    seen = {}
+    hook = model.fusion_net.register_forward_hook(lambda mod, inp, out: seen.update(x=inp[0].detach().cpu(), aff=inp[2], out=out.detach().cpu()))
+    with torch.no_grad(), shell_noise(model.gencomm, int(g["noise_seed"]), sum(rl), 128, 16, 32, dev):
+        out = model(data)
+    hook.remove()
+    assert torch.isfinite(out["cls_preds"]).all() and out["cls_preds"].shape[0] == len(rl)
+    sd = {k: v.detach().cpu() for k, v in model.fusion_net.state_dict().items()}
+    with torch.no_grad():
+        ref = O.where2comm_fusion(sd, seen["x"], rl, seen["aff"].cpu())
+    assert_close(seen["out"].numpy(), ref.numpy(), 1e-4, 1e-5, "Where2comm fused map inside the shell")
+
+
 def _second_shell_args():
     """m3 of opv2v/GenComm_yamls/gencomm/stage1/m3_att.yaml:101-133 (SECOND encoder, 0.1 m voxels, stride-1 first backbone block)
     on the golden shell's lidar range."""
