@@ -293,8 +293,11 @@ __device__ __forceinline__ void wave_reduce16(const float (&part)[16], float (&t
 // beyond is 1.2e-6), angle from its high 16 bits (in revolutions, the unit of v_sin_f32 / v_cos_f32).
 // Round 1 used Philox4x32-10 with 32-bit uniforms, one call per FOUR normals: 20 quarter-rate v_mad_u64_u32 + 8
 // transcendentals per 4 normals made the sampler step VALU-bound (56 k of 70 k issue cycles per tile-wave); this
-// form spends 14 multiplies + 16 transcendentals per EIGHT normals.
+// form spends 14 multiplies + 14 three-way xors (v_bitop3_b32) + 16 transcendentals per EIGHT normals.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // v_bitop3_b32, truth table of a ^ b ^ c: one instruction instead of two v_xor
+}
 __device__ __forceinline__ void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
@@ -304,21 +307,32 @@ __device__ __forceinline__ void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t 
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    const uint32_t n0 = xor3(hi1, c1, k0), n2 = xor3(hi0, c3, k1);
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Box-Muller pair of one word, scaled by sg: (sg * r * cos, sg * r * sin) on the raw hardware transcendentals
-// (-2 ln u = (-2 ln 2) * v_log_f32(u) with u in [2^-17, 1): never 0, never denormal).
-__device__ __forceinline__ void bm_pair(uint32_t w, float sg, float& zc, float& zs) {
+// Box-Muller pair of one word with standard deviation sg, on the raw hardware transcendentals: radius
+// sqrt(k2 * log2 u), k2 = -2 ln 2 * sg^2 (bm_k2; u in [2^-17, 1): never 0, never denormal), times (cos, sin).  The scale
+// rides inside the square root (one multiply per pair less than sg * sqrt(..)); k2 = 0 gives (+-0, +-0), which is how
+// callers blank the lanes whose pixels lie outside the image without a branch.
+__device__ __forceinline__ float bm_k2(float sg) { return -1.3862943611198906f * sg * sg; }
+__device__ __forceinline__ void bm_pair(uint32_t w, float k2, float& zc, float& zs) {
   const float k = 1.52587890625e-5f;  // 2^-16
   const float ur = fmaf((float)(w & 0xffffu), k, 0.5f * k), ut = (float)(w >> 16) * k;
-  const float m = sg * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ur));
+  const float m = __builtin_amdgcn_sqrtf(k2 * __builtin_amdgcn_logf(ur));
   zc = m * __builtin_amdgcn_cosf(ut);
   zs = m * __builtin_amdgcn_sinf(ut);
+}
+// the pair as one packed fp16x2 dword (cosine branch in the low half)
+typedef _Float16 nz_half2_t __attribute__((ext_vector_type(2)));
+typedef float nz_float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bm_pair_h(uint32_t w, float k2) {
+  float zc, zs;
+  bm_pair(w, k2, zc, zs);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((nz_float2_t){zc, zs}, nz_half2_t));
 }
 
 // 8 N(0,1) floats of one counter: z[2j], z[2j+1] = the pair of word j (q_sample's initial noise: element index / 8)
@@ -326,7 +340,7 @@ __device__ __forceinline__ void normal8(uint64_t ctr, uint32_t stream, uint64_t 
   uint32_t r[4];
   philox4x32_7((uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bm_pair(r[j], 1.0f, z[2 * j], z[2 * j + 1]);
+  for (int j = 0; j < 4; ++j) bm_pair(r[j], -1.3862943611198906f, z[2 * j], z[2 * j + 1]);
 }
 
 // The sampler's step noise, CANONICAL FIELD (identical in the latent and the literal sampler structure, independent of
@@ -335,23 +349,21 @@ __device__ __forceinline__ void normal8(uint64_t ctr, uint32_t stream, uint64_t 
 // word j belongs to pixel (x & ~3) + j, its cosine branch to the even channel, its sine branch to the odd one.
 // Rounding sigma*z to fp16 (relative 2^-11, unbiased) is what lets the noise convolution run on the f16 matrix pipe
 // with ONE operand term; both sampler structures add exactly this value.
-// h[j] = packed (even channel, odd channel) fp16 pair of pixel j -- one dword of the LDS record of that pixel.
-typedef _Float16 nz_half2_t __attribute__((ext_vector_type(2)));
-typedef float nz_float2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void noise_pair_quad_h(uint64_t elem, uint32_t stream, uint64_t seed, float sg, uint32_t (&h)[4]) {
-  uint32_t r[4];
+// noise_words = the four words of a quad; bm_pair_h(word j, k2) = packed (even channel, odd channel) fp16 pair of pixel j
+// -- one dword of the LDS record of that pixel.  k2 = bm_k2(sigma_t) everywhere (0 for lanes outside the image).
+__device__ __forceinline__ void noise_words(uint64_t elem, uint32_t stream, uint64_t seed, uint32_t (&r)[4]) {
   philox4x32_7((uint32_t)elem, (uint32_t)(elem >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+}
+__device__ __forceinline__ void noise_pair_quad_h(uint64_t elem, uint32_t stream, uint64_t seed, float k2, uint32_t (&h)[4]) {
+  uint32_t r[4];
+  noise_words(elem, stream, seed, r);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float zc, zs;
-    bm_pair(r[j], sg, zc, zs);
-    h[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector((nz_float2_t){zc, zs}, nz_half2_t));
-  }
+  for (int j = 0; j < 4; ++j) h[j] = bm_pair_h(r[j], k2);
 }
 // the same values as floats: z[j] = even channel, pixel j; z[4 + j] = odd channel, pixel j
-__device__ __forceinline__ void noise_pair_quad(uint64_t elem, uint32_t stream, uint64_t seed, float sg, float (&z)[8]) {
+__device__ __forceinline__ void noise_pair_quad(uint64_t elem, uint32_t stream, uint64_t seed, float k2, float (&z)[8]) {
   uint32_t h[4];
-  noise_pair_quad_h(elem, stream, seed, sg, h);
+  noise_pair_quad_h(elem, stream, seed, k2, h);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const nz_half2_t v = __builtin_bit_cast(nz_half2_t, h[j]);

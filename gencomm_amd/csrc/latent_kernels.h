@@ -305,7 +305,7 @@ __global__ __launch_bounds__((TW / 4) * TH) void latent_step_kernel(const Latent
 #pragma unroll
         for (int k = 0; k < 8; ++k) z[k] = 0.f;
         if (gy2 >= 0 && gy2 < H && gxq >= 0 && gxq < W)
-          noise_pair_quad((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + 2 * cp) * plane + (size_t)gy2 * W + gxq), a.stream_id, seed, sg, z);
+          noise_pair_quad((uint64_t)(((size_t)n * a.C + (size_t)ch * 8 + 2 * cp) * plane + (size_t)gy2 * W + gxq), a.stream_id, seed, bm_k2(sg), z);
       };
 #pragma unroll
       for (int cp = 0; cp < 4; ++cp) {

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
         if (oc0 + 2 * ip >= C) continue;
         float z8[8];
         if (POST == 2)  // canonical step-noise field, already scaled by sigma_t and rounded to fp16 (common.h)
-          noise_pair_quad((uint64_t)(((size_t)n * C + oc0 + 2 * ip) * plane + (size_t)gy * W + gx), a.stream_id, seed, sg, z8);
+          noise_pair_quad((uint64_t)(((size_t)n * C + oc0 + 2 * ip) * plane + (size_t)gy * W + gx), a.stream_id, seed, bm_k2(sg), z8);
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           const int i = 2 * ip + ii, oc = oc0 + i;
@@ -613,16 +613,23 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
       // canonical step-noise field (common.h): nu = fp16(sigma_t * z), one Philox call per (channel pair, aligned quad)
       // gives the packed (even, odd channel) dword of each of the quad's four pixel records.  Only the hi plane is
       // written: nu IS an fp16 number, so the noise convolution needs one operand term (conv_tile_mfma_hionly).
-      auto pair_quad = [&](int cp, int r, int gx2, uint32_t (&h)[4]) {
+      // No branch around the generator: lanes whose quad lies outside the image run it with k2 = 0 and get (+-0, +-0).
+      // The remainder rows and the halo columns need only two / one of a quad's four words: Box-Muller on those only.
+      const float k2 = bm_k2(sg);
+      auto words = [&](int cp, int r, int gx2, uint32_t (&w)[4]) -> float {
         const int gy2 = y0 - 1 + r;
-        h[0] = h[1] = h[2] = h[3] = 0u;
-        if (gy2 >= 0 && gy2 < H && gx2 >= 0 && gx2 < W)
-          noise_pair_quad_h((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + 2 * cp) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, sg, h);
+        noise_words((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + 2 * cp) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, w);
+        return (gy2 >= 0 && gy2 < H && gx2 >= 0 && gx2 < W) ? k2 : 0.f;
       };
       {
         uint32_t h[4][4];
 #pragma unroll
-        for (int cp = 0; cp < 4; ++cp) pair_quad(cp, r0, x0 + 4 * qx, h[cp]);
+        for (int cp = 0; cp < 4; ++cp) {
+          uint32_t w[4];
+          const float kk = words(cp, r0, x0 + 4 * qx, w);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[cp][j] = bm_pair_h(w[j], kk);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           *reinterpret_cast<uint4*>(tile + r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16) = make_uint4(h[0][j], h[1][j], h[2][j], h[3][j]);
@@ -630,18 +637,20 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
       {  // rows 16, 17: thread = (channel tid / 32, row 16 + (tid / 16 & 1), quad); the even channel's thread writes
          // the pair's dwords of pixels 0, 1, the odd channel's thread those of pixels 2, 3 (whole dwords, see hc_store_rem)
         const int cr = tid >> 5, rrw = TH + ((tid >> 4) & 1);
-        uint32_t h[4];
-        pair_quad(cr >> 1, rrw, x0 + 4 * qx, h);
-        const int jb = (cr & 1) ? 2 : 0;
+        uint32_t w[4];
+        const float kk = words(cr >> 1, rrw, x0 + 4 * qx, w);
+        const bool odd = (cr & 1) != 0;
+        const int jb = odd ? 2 : 0;
+        const uint32_t wsel[2] = {odd ? w[2] : w[0], odd ? w[3] : w[1]};
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-          *reinterpret_cast<uint32_t*>(tile + rrw * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4) = h[jb + k];
+          *reinterpret_cast<uint32_t*>(tile + rrw * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4) = bm_pair_h(wsel[k], kk);
       }
       if (tid < HC_LH * 8) {
         const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
-        uint32_t h[4];  // the aligned quad that owns the halo pixel: x0-4..x0-1 (pixel 3) or x0+64.. (pixel 0)
-        pair_quad(cp, r, side ? x0 + TW : x0 - 4, h);
-        *reinterpret_cast<uint32_t*>(tile + hc_addr(r, side ? HC_TW : -1) + cp * 4) = side ? h[0] : h[3];
+        uint32_t w[4];  // the aligned quad that owns the halo pixel: x0-4..x0-1 (pixel 3) or x0+64.. (pixel 0)
+        const float kk = words(cp, r, side ? x0 + TW : x0 - 4, w);
+        *reinterpret_cast<uint32_t*>(tile + hc_addr(r, side ? HC_TW : -1) + cp * 4) = bm_pair_h(side ? w[0] : w[3], kk);
       }
     }
     __syncthreads();

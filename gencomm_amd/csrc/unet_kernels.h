@@ -801,7 +801,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOut
         // independent of the tiling and shared with the latent sampler (latent_kernels.h, latenth_kernels.h)
         float z8[8];
         const size_t e_even = e - (size_t)(oc & 1) * plane - (PPL == 4 ? 0 : (size_t)(gx & 3));
-        noise_pair_quad((uint64_t)e_even, a.stream_id, seed, sg, z8);
+        noise_pair_quad((uint64_t)e_even, a.stream_id, seed, bm_k2(sg), z8);
 #pragma unroll
         for (int p = 0; p < PPL; ++p) z[p] = z8[4 * (oc & 1) + (PPL == 4 ? p : (gx & 3))];
       }
