@@ -214,11 +214,18 @@ __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ til
 // this lane's tap t = 4c + lane/16: window row t / 3, column shift t % 3 - 1), row pair 0 of wave `wave`.
 __device__ __forceinline__ void hc_lane_offsets(int (&off)[4][3], int wave, int lane) {
   const int n = lane & 15, kg = lane >> 4;
+  // hc_addr(row, 4n + j + s), s = dx - 1, is linear in j (one phase = HC_PHASE bytes per pixel step) except where the pixel
+  // index leaves the lane's own slot: s = -1 at j = 0 (phase 3 of the slot before) and s = +1 at j = 3 (phase 0 of the slot
+  // after).  One base per tap group and two wrap fixes instead of twelve full address computations.
+  constexpr int WRAP = 4 * HC_PHASE - 16;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) off[j][c] = hc_addr(4 * wave + dyp, 4 * n + j + dx - 1);
+    const int t = 4 * c + kg, dyp = t / 3, sx = t - 3 * dyp - 1;
+    const int base = (4 * wave + dyp) * HC_ROW + (n + 1) * 16 + sx * HC_PHASE;
+    off[0][c] = base + (sx < 0 ? WRAP : 0);
+    off[1][c] = base + HC_PHASE;
+    off[2][c] = base + 2 * HC_PHASE;
+    off[3][c] = base + 3 * HC_PHASE - (sx > 0 ? WRAP : 0);
   }
 }
 
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   TileRegs<TW, TH, NT, 8> R;
   float2 hreg = make_float2(0.f, 0.f);
   if (wvec) {
-    stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   }
   if (GN) {
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
       }
   }
   if (NSRC == 2 && wvec) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
-    stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   }
   __syncthreads();
@@ -491,15 +498,18 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
         float s = 0.f, q = 0.f;
         if (vec_ok && gy < a.H) {
           *reinterpret_cast<float4*>(dp) = make_float4(out[p][i][0], out[p][i][1], out[p][i][2], out[p][i][3]);
+          s = out[p][i][0] + out[p][i][1];  // no "0 + x" / "x * x + 0" instructions in the common path
+          q = out[p][i][0] * out[p][i][0];
+          q = fmaf(out[p][i][1], out[p][i][1], q);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { s += out[p][i][j]; q = fmaf(out[p][i][j], out[p][i][j], q); }
+          for (int j = 2; j < 4; ++j) { s += out[p][i][j]; q = fmaf(out[p][i][j], out[p][i][j], q); }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (gy < a.H && gx + j < a.W) { dp[j] = out[p][i][j]; s += out[p][i][j]; q = fmaf(out[p][i][j], out[p][i][j], q); }
         }
-        part[i] += s;
-        part[4 + i] += q;
+        part[i] = p == 0 ? s : part[i] + s;
+        part[4 + i] = p == 0 ? q : part[4 + i] + q;
       }
     }
   }

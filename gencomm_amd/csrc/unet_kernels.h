@@ -144,12 +144,20 @@ struct TileRegs {
 
 // Issue every global load of this thread's share of the tile (fast path: W % 4 == 0, or for UP
 // Win % 2 == 0, so a quad that starts inside the image lies inside it entirely and is aligned).
-template <int TW, int TH, int NT, int NCH, bool UP>
+// CLAMP (callers that blank out-of-image quads through zeroed GroupNorm coefficients, i.e. whose staging computes
+// silu(0 * x + 0) there): every quad is loaded, from the nearest in-image position, so the registers need neither a
+// zero fill nor a predicated load (a finite value times a zero coefficient is what the staging needs; the range guard
+// in front of the f16-pipe kernels keeps non-finite inputs away from them).
+template <int TW, int TH, int NT, int NCH, bool UP, bool CLAMP = false>
 __device__ __forceinline__ void stage_load(TileRegs<TW, TH, NT, NCH>& R, const float* __restrict__ sp,
                                            unsigned plane_in, int Win, int H, int W, int x0, int y0, int tid) {
   using TR = TileRegs<TW, TH, NT, NCH>;
   auto load_quad = [&](int c, int r, int qx) {
     const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
+    if constexpr (CLAMP && !UP) {
+      const int cy = min(max(gy, 0), H - 1), cx = min(gx, W - 4);
+      return *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)cy * (unsigned)Win + (unsigned)cx));
+    }
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < TR::LH && gy >= 0 && gy < H && gx < W) {
       if (!UP) {
