@@ -179,7 +179,172 @@ __global__ void conv_prep_w_kernel(const PrepWArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 stride-1 convolution (the Linear layers of the fusion transformers, message-extractor / head projections, the
+// training helpers) on the f16 matrix pipe with the exact hi/lo split arithmetic of conv8h_kernels.h / enhancer_kernels.h:
+// three v_mfma_f32_32x32x16_f16 per product block (hi*hi, hi*lo, lo*hi), fp32 accumulation, 22-bit products.
+//   out[co][p] = act(scale[co] * sum_ci W[co][ci] x[ci][p] + shift[co]) (+ res)
+// GEMM rows M = output channels (A = weights), columns N = pixels (B = x): for a fixed accumulator register the 32 lanes of a
+// half-wave hold 32 consecutive pixels of one channel, so NCHW stores are 128-byte runs.  Both operands are K-major in
+// memory (x is [ci][p], the prepared weights [ci][co]) while the MFMA wants 8 consecutive k per lane: the loader gives
+// every thread 8 consecutive k of ONE column (dword loads, coalesced across the column index), splits them and writes one
+// 16-byte record per plane -- the transposition costs nothing.  Workgroup = 128 channels x 64 pixels, 4 waves (32 channels
+// each), K in chunks of 32 with the next chunk in flight during the MFMAs.
+// Range: the weights are pre-multiplied by 2^6 (|w| < 1e3 assumed, as in the Enhancer GEMM); the activations get a RUNNING
+// power-of-two scale: every chunk's max|x| is reduced over the workgroup, the scale puts the largest |x| seen so far into
+// [2^13, 2^14) -- up for small inputs such as gradients, down for large ones -- and when it has to drop the accumulators are
+// rescaled (exact).  Any finite fp32 input gives finite, fp32-grade results relative to the tile's largest input.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 c1h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 c1h2_t __attribute__((ext_vector_type(2)));
+typedef float c1f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void c1_split8(const float (&v)[8], float mul, uint4& hi, uint4& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = v[2 * i] * mul, a1 = v[2 * i + 1] * mul;
+    const c1h2_t hh = __builtin_convertvector((c1f2_t){a0, a1}, c1h2_t);
+    const c1h2_t ll = __builtin_convertvector((c1f2_t){a0 - (float)hh[0], a1 - (float)hh[1]}, c1h2_t);
+    h[i] = __builtin_bit_cast(uint32_t, hh);
+    l[i] = __builtin_bit_cast(uint32_t, ll);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <int BN>  // pixels per workgroup: 64, or 32 when the launch would otherwise have too few workgroups to hide its load latency
+__global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
+  constexpr int BM = 128, KC = 32, RB = 80;  // row bytes: 32 halves + 8 pad (conflict-free ds_read_b128 phases)
+  constexpr float WS = 64.0f;
+  __shared__ __align__(16) unsigned char Ah[BM * RB], Al[BM * RB], Bh[BN * RB], Bl[BN * RB];
+  __shared__ float s_max[2][4];
+  fp16_ovfl_clamp();  // a weight beyond the assumed range saturates instead of turning into inf
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int HW = a.H * a.W, n = blockIdx.z;
+  const int p0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const float* __restrict__ xn = a.x + (size_t)n * a.Cin * HW;
+
+  f32x16c acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  // loader roles: B: thread = (pixel tid & 63, k group tid >> 6) -> 8 consecutive k; A: (channel tid & 127, k groups (tid >> 7) and + 2)
+  const int bp = tid & (BN - 1), bk = (tid / BN) & 3, am = tid & 127, ak = tid >> 7;
+  const bool bload = tid < 4 * BN;
+  float vb[8], va[2][8];
+  auto fetch = [&](int k0) {
+    const int gp = p0 + bp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 8 * bk + j;
+      vb[j] = (bload && gp < HW && k < a.Cin) ? xn[(size_t)k * HW + gp] : 0.f;
+    }
+    const int gm = m0 + am;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 8 * (ak + 2 * i) + j;
+        va[i][j] = (gm < a.CoutP && k < a.Cin) ? a.w[(size_t)k * a.CoutP + gm] : 0.f;
+      }
+  };
+  float xs = 1.0f, run_max = 0.f;  // running activation scale (power of two, workgroup-uniform) and the max|x| behind it
+  fetch(0);
+  int par = 0;
+  for (int k0 = 0; k0 < a.Cin; k0 += KC, par ^= 1) {
+    // max|x| of this chunk over the workgroup
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(vb[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (l == 0) s_max[par][w] = mx;
+    __syncthreads();  // also: every wave is done with the previous chunk in LDS
+    run_max = fmaxf(run_max, fmaxf(fmaxf(s_max[par][0], s_max[par][1]), fmaxf(s_max[par][2], s_max[par][3])));
+    if (run_max > 0.f) {  // scale = the power of two that puts the largest |x| seen so far into [2^13, 2^14) (fp16 max 65504; small
+      int e;              // inputs -- gradients -- are scaled UP so that their low parts stay normal fp16 numbers)
+      (void)frexpf(run_max, &e);  // run_max = f * 2^e, f in [0.5, 1)
+      const float ns = ldexpf(1.0f, min(14 - e, 100));
+      if (ns != xs) {     // the exponent grew (or this is the first non-zero chunk): rescale what is accumulated (exact)
+        const float ratio = ns / xs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] *= ratio; acc1[i] *= ratio; }
+        xs = ns;
+      }
+    }
+    {
+      uint4 hi, lo;
+      c1_split8(vb, xs, hi, lo);
+      if (bload) {
+        *reinterpret_cast<uint4*>(Bh + bp * RB + 16 * bk) = hi;
+        *reinterpret_cast<uint4*>(Bl + bp * RB + 16 * bk) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        c1_split8(va[i], WS, hi, lo);
+        *reinterpret_cast<uint4*>(Ah + am * RB + 16 * (ak + 2 * i)) = hi;
+        *reinterpret_cast<uint4*>(Al + am * RB + 16 * (ak + 2 * i)) = lo;
+      }
+    }
+    __syncthreads();
+    if (k0 + KC < a.Cin) fetch(k0 + KC);
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      const int ko = 32 * ks + 16 * h;  // byte offset of this lane's 8 halves in the row
+      const c1h8_t ah = *reinterpret_cast<const c1h8_t*>(Ah + (32 * w + r) * RB + ko);
+      const c1h8_t al = *reinterpret_cast<const c1h8_t*>(Al + (32 * w + r) * RB + ko);
+      const c1h8_t b0h = *reinterpret_cast<const c1h8_t*>(Bh + r * RB + ko);
+      const c1h8_t b0l = *reinterpret_cast<const c1h8_t*>(Bl + r * RB + ko);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
+      if constexpr (BN == 64) {
+        const c1h8_t b1h = *reinterpret_cast<const c1h8_t*>(Bh + (32 + r) * RB + ko);
+        const c1h8_t b1l = *reinterpret_cast<const c1h8_t*>(Bl + (32 + r) * RB + ko);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: register = output channel row, lane (r) = pixel column
+  const float unscale = 1.0f / (WS * xs);
+  float* __restrict__ yn = a.y + ((size_t)n * a.out_ctotal + a.out_coff) * HW;
+  const float* __restrict__ rn = a.res != nullptr ? a.res + ((size_t)n * a.out_ctotal + a.out_coff) * HW : nullptr;
+#pragma unroll
+  for (int t = 0; t < BN / 32; ++t) {
+    const int gp = p0 + 32 * t + r;
+    if (gp >= HW) continue;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = m0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (co >= a.CoutP) continue;
+      float v = fmaf((t == 0 ? acc0[reg] : acc1[reg]) * unscale, a.scale[co], a.shift[co]);
+      if (a.relu == 1) v = fmaxf(v, 0.f);
+      else if (a.relu == 2) v = gelu_erf_f(v);
+      const size_t oi = (size_t)co * HW + gp;
+      if (rn != nullptr) v += rn[oi];
+      if (a.relu == 3) v = fmaxf(v, 0.f);
+      yn[oi] = v;
+    }
+  }
+}
+
 inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_t st) {
+  // measured on MI355X (V2X-ViT / Where2comm Linear layers, 2-5 agents, 64x128 .. 96x352): against the exact-fp32 kernel below the
+  // split kernel wins from 256 output channels up (qkv 384 / 768: 71 -> 51 us, 544 -> 434 us) and loses at 128 (25 -> 34 us: one
+  // weight block per pixel tile, nothing to amortise its staging over)
+  if (KH == 1 && KW == 1 && a.stride == 1 && a.pad == 0 && a.ups == 1 && a.Cin >= 16 && a.CoutP >= 256 && modes_snapshot().split()) {
+    const int HW = a.H * a.W, mb = (a.CoutP + 127) / 128;
+    const bool narrow = (long long)((HW + 63) / 64) * mb * N < 1024;  // fewer than 4 workgroups per CU: halve the pixel tile
+    const dim3 g1(narrow ? (HW + 31) / 32 : (HW + 63) / 64, mb, N);
+    if (g1.y > 65535 || g1.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");
+    if (narrow) conv1x1_f16s_kernel<32><<<g1, 256, 0, st>>>(a);
+    else conv1x1_f16s_kernel<64><<<g1, 256, 0, st>>>(a);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   const int tiles = ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
   const dim3 grid(tiles, (a.CoutP + 63) / 64, N);
   if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");

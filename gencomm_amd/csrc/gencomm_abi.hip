@@ -616,7 +616,11 @@ int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dc
 int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream) {
   GC_CHECK_ARG(x && gamma && beta && out && n >= 1 && n <= 65535 && C >= 1 && HW >= 1, "bad arguments");
   LnArgs a{x, gamma, beta, nullptr, out, nullptr, eps, C, HW, residual, 0};
-  ln_nchw_fwd_kernel<<<dim3((HW + 255) / 256, n), 256, 0, (hipStream_t)stream>>>(a);
+  const dim3 g4((HW + 63) / 64, n);
+  if (C <= 64) ln_nchw_fwd4_kernel<16><<<g4, 256, 0, (hipStream_t)stream>>>(a);
+  else if (C <= 128) ln_nchw_fwd4_kernel<32><<<g4, 256, 0, (hipStream_t)stream>>>(a);
+  else if (C <= 256) ln_nchw_fwd4_kernel<64><<<g4, 256, 0, (hipStream_t)stream>>>(a);
+  else ln_nchw_fwd_kernel<<<dim3((HW + 255) / 256, n), 256, 0, (hipStream_t)stream>>>(a);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
