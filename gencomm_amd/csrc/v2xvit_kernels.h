@@ -162,8 +162,121 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const WinArgs a) {
   for (int c = 0; c < DH; ++c) op[(size_t)c * HW] = o[c] * rden;
 }
 
+// The same attention on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, as the lane-per-query form)
+// for windows of 64 or 256 tokens.  Workgroup = 256 tokens (one 16x16 window or four 8x8 windows) of one head; its keys and values
+// sit in LDS as [token][DH + 1] rows (odd stride: conflict-free fills and operand reads).  8 waves: a wave owns one block of 32 queries (two
+// waves per SIMD, so one wave's softmax arithmetic runs under the other's MFMAs) and walks its window's keys in blocks of 32, flash style:
+//   S^T[key][query] = K Q^T   A = K rows from LDS, B = Q (scaled) from registers (DH / 2 MFMAs); the block comes out with a lane owning
+//                             ONE query column and 16 of the 32 keys (the other 16 in lane ^ 32), so the softmax statistics are
+//                             register-local plus one exchange;
+//   + relative position bias, running max / denominator, P = exp(S - max);
+//   O^T[d][query] += V^T P    A = V rows from LDS in the key order the P registers already have, B = P straight from the registers.
+// 64 MFMAs per 32 x 32 block at DH = 64 against 8 k broadcast LDS reads + 4 k FMAs per lane in the form above.
+using f32x16w = __attribute__((ext_vector_type(16))) float;
+template <int DH, int WS>
+__global__ __launch_bounds__(512) void win_attn_mfma_kernel(const WinArgs a) {
+  constexpr int T = WS * WS, WPB = 256 / T, LD = DH + 1, NKB = T / 32, PW = 2 * WS - 1;
+  static_assert(T % 64 == 0 && DH % 32 == 0, "64 / 256-token windows, head width a multiple of 32");
+  extern __shared__ float wa_smem[];  // K [256][LD], V [256][LD], pos [PW * PW]
+  float* sK = wa_smem;
+  float* sV = wa_smem + 256 * LD;
+  float* sP = sV + 256 * LD;
+  const int n = blockIdx.z, m = blockIdx.y, tid = threadIdx.x;
+  const int nw = a.W / WS, nwin = (a.H / WS) * nw;
+  const int win0 = blockIdx.x * WPB;
+  const int inner = a.heads * DH, HW = a.H * a.W;
+  const float* __restrict__ base = a.qkv + (size_t)n * 3 * inner * HW;
+  {  // fill: threads 0..255 = the tokens' K rows, threads 256..511 = their V rows; 32 loads in flight per thread
+    const int row = tid & 255, isv = tid >> 8;
+    const int wl = row / T, tok = row - wl * T, win = win0 + wl;
+    const bool live = win < nwin;
+    const int wy = live ? win / nw : 0, wx = live ? win - wy * nw : 0;
+    const int pix = (wy * WS + tok / WS) * a.W + wx * WS + tok % WS;
+    for (int i = tid; i < PW * PW; i += 512) sP[i] = a.pos[i];
+    const float* __restrict__ src = base + (size_t)((1 + isv) * inner + m * DH) * HW + pix;
+    float* __restrict__ dst = (isv ? sV : sK) + row * LD;
+#pragma unroll
+    for (int c0 = 0; c0 < DH; c0 += 32) {
+      float v[32];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) v[c] = live ? src[(size_t)(c0 + c) * HW] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) dst[c0 + c] = v[c];
+    }
+  }
+  __syncthreads();
+  // wave = one block of 32 queries
+  const int wave = tid >> 6, l = tid & 63, qi = l & 31, h = l >> 5;
+  const int wl = (wave * 32) / T, win = win0 + wl;
+  if (win >= nwin) return;  // wave-uniform; no barrier follows
+  const int wy = win / nw, wx = win - wy * nw;
+  const float* __restrict__ kw = sK + wl * T * LD;
+  const float* __restrict__ vw = sV + wl * T * LD;
+  const int qtok = (wave * 32) % T + qi, qy = qtok / WS, qx = qtok % WS;
+  const int qpix = (wy * WS + qy) * a.W + wx * WS + qx;
+  float qv[DH / 2];
+#pragma unroll
+  for (int s = 0; s < DH / 2; ++s) qv[s] = base[(size_t)(m * DH + 2 * s + h) * HW + qpix] * a.scale;
+  f32x16w o[DH / 32];
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+  float mrun = -INFINITY, den = 0.f;
+  const int pbase = (WS - 1 - qy) * PW + (WS - 1 - qx);
+#pragma unroll 1
+  for (int kb = 0; kb < NKB; ++kb) {
+    f32x16w sc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+    const float* __restrict__ kr = kw + (32 * kb + qi) * LD + h;
+#pragma unroll
+    for (int s = 0; s < DH / 2; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], qv[s], sc, 0, 0, 0);
+    float bm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * kb + 8 * (r >> 2) + 4 * h + (r & 3);
+      sc[r] += sP[pbase + (key / WS) * PW + key % WS];  // relative_indices[query][key] = idx[key] - idx[query] + WS - 1 (mswin.py:12-16, :34-35)
+      bm = fmaxf(bm, sc[r]);
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float nm = fmaxf(mrun, bm), corr = __expf(mrun - nm);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = __expf(sc[r] - nm); ps += sc[r]; }
+    den = den * corr + ps;
+    mrun = nm;
+#pragma unroll
+    for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[db][i] *= corr;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int key = 32 * kb + 8 * (t >> 2) + 4 * h + (t & 3);
+#pragma unroll
+      for (int db = 0; db < DH / 32; ++db)  // the head's 32-wide halves alternate: consecutive MFMAs never share an accumulator
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vw[key * LD + 32 * db + qi], sc[t], o[db], 0, 0, 0);
+    }
+  }
+  den += __shfl_xor(den, 32, 64);
+  const float rden = 1.0f / den;
+  float* __restrict__ op = a.out + ((size_t)n * inner + m * DH) * HW + qpix;
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) op[(size_t)(32 * db + 8 * (r >> 2) + 4 * h + (r & 3)) * HW] = o[db][r] * rden;
+}
+
 template <int DH, int WS>
 inline int win_attn_launch(const WinArgs& a, int n, hipStream_t st) {
+  if constexpr (WS * WS >= 64 && DH % 32 == 0) {
+    const size_t shm = ((size_t)2 * 256 * (DH + 1) + (2 * WS - 1) * (2 * WS - 1)) * sizeof(float);
+    if (shm > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)win_attn_mfma_kernel<DH, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    const int nwin_ = (a.H / WS) * (a.W / WS), wpb = 256 / (WS * WS);
+    win_attn_mfma_kernel<DH, WS><<<dim3((nwin_ + wpb - 1) / wpb, a.heads, n), 512, shm, st>>>(a);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   constexpr int T = WS * WS, WPB = 256 / T;
   const size_t sh = ((size_t)2 * WPB * T * DH + (2 * WS - 1) * (2 * WS - 1)) * sizeof(float);
   if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)win_attn_kernel<DH, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
