@@ -256,6 +256,22 @@ __device__ __forceinline__ float wave_total(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Maximum of NON-NEGATIVE per-lane values over the wave, the same DPP ladder (lanes without a source contribute 0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max0(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return fmaxf(v, __builtin_bit_cast(float, moved));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  v = dpp_max0<0x111, 0xf>(v);
+  v = dpp_max0<0x112, 0xf>(v);
+  v = dpp_max0<0x114, 0xf>(v);
+  v = dpp_max0<0x118, 0xf>(v);
+  v = dpp_max0<0x142, 0xa>(v);
+  v = dpp_max0<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // 16 per-lane partials -> wave totals with a recursive-halving exchange instead of 16 full ladders:
 // lanes trade halves of the vector across lane bits 0 and 1 (quad_perm DPP), the surviving 4 values
 // are summed down each 16-lane row (row_shr 4/8) and across the 4 rows (two ds_bpermute steps).

@@ -231,13 +231,15 @@ __global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
   // loader roles: B: thread = (pixel tid & 63, k group tid >> 6) -> 8 consecutive k; A: (channel tid & 127, k groups (tid >> 7) and + 2)
   const int bp = tid & (BN - 1), bk = (tid / BN) & 3, am = tid & 127, ak = tid >> 7;
   const bool bload = tid < 4 * BN;
-  float vb[8], va[2][8];
-  auto fetch = [&](int k0) {
+  // two chunks of operands in flight: vb / va hold the chunk about to be staged, wb / wa the one after it (requested a whole iteration
+  // before it is needed, so that only the first chunk's memory latency is exposed)
+  float vb[8], va[2][8], wb[8], wa[2][8];
+  auto fetch = [&](int k0, float (&b)[8], float (&aw)[2][8]) {
     const int gp = p0 + bp;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = k0 + 8 * bk + j;
-      vb[j] = (bload && gp < HW && k < a.Cin) ? xn[(size_t)k * HW + gp] : 0.f;
+      b[j] = (bload && gp < HW && k < a.Cin) ? xn[(size_t)k * HW + gp] : 0.f;
     }
     const int gm = m0 + am;
 #pragma unroll
@@ -245,19 +247,19 @@ __global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = k0 + 8 * (ak + 2 * i) + j;
-        va[i][j] = (gm < a.CoutP && k < a.Cin) ? a.w[(size_t)k * a.CoutP + gm] : 0.f;
+        aw[i][j] = (gm < a.CoutP && k < a.Cin) ? a.w[(size_t)k * a.CoutP + gm] : 0.f;
       }
   };
   float xs = 1.0f, run_max = 0.f;  // running activation scale (power of two, workgroup-uniform) and the max|x| behind it
-  fetch(0);
+  fetch(0, vb, va);
+  fetch(KC, wb, wa);  // all zeros beyond Cin
   int par = 0;
   for (int k0 = 0; k0 < a.Cin; k0 += KC, par ^= 1) {
     // max|x| of this chunk over the workgroup
     float mx = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(vb[j]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_max_nonneg(mx);  // DPP ladder: no LDS round trips in the chunk loop's critical path
     if (l == 0) s_max[par][w] = mx;
     __syncthreads();  // also: every wave is done with the previous chunk in LDS
     run_max = fmaxf(run_max, fmaxf(fmaxf(s_max[par][0], s_max[par][1]), fmaxf(s_max[par][2], s_max[par][3])));
@@ -287,7 +289,10 @@ __global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
       }
     }
     __syncthreads();
-    if (k0 + KC < a.Cin) fetch(k0 + KC);
+    // rotate: the chunk after next travels during this chunk's MFMAs and the whole next iteration
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vb[j] = wb[j]; va[0][j] = wa[0][j]; va[1][j] = wa[1][j]; }
+    if (k0 + 2 * KC < a.Cin) fetch(k0 + 2 * KC, wb, wa);
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
       const int ko = 32 * ks + 16 * h;  // byte offset of this lane's 8 halves in the row
