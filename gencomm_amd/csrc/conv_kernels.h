@@ -336,7 +336,153 @@ __global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 convolution (stride 1 or 2) on the f16 matrix pipe with the same exact hi/lo split arithmetic: the BEV backbones' layers.
+// Same tile as conv2d_igemm_kernel (64 output channels x 4x16 output pixels, 4 waves = 2 channel halves x 2 row pairs) and the same
+// epilogue; K is walked in chunks of 16 input channels x 9 taps = 9 MFMA steps of v_mfma_f32_32x32x16_f16 x 3 split terms
+// (27 x 32 cycles per wave and chunk against 72 x 64 for the fp32 form).  LDS holds the input patch pixel-major and the weight slab
+// [tap][channel-out], both as 80-byte records {16 hi halves | 16 lo halves | pad}: an MFMA operand is one 16-byte read per plane and
+// the odd record stride (5 x 16 B) keeps the 16 lanes of a ds_read_b128 phase on distinct banks.  NCHW is channel-strided, the MFMA
+// wants 8 consecutive channels per lane: every loader item is 8 channel values of ONE pixel (or one tap / output channel), dword
+// loads coalesced across the pixel / channel-out index, split and written as one record half.  Activations carry the running
+// power-of-two scale of conv1x1_f16s_kernel; weights are pre-multiplied by 2^6.  Cin % 16 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_f16s_kernel(const Conv2dArgs a) {
+  constexpr int TY = 4, TX = 16, CC = 16, REC = 80;
+  constexpr int PH = (TY - 1) * STRIDE + 3, PW = (TX - 1) * STRIDE + 3, NPX = PH * PW;
+  constexpr int NPI = NPX * 2, NWI = 9 * 64 * 2;                       // loader items: (pixel, channel octet), (tap, channel-out, channel octet)
+  constexpr int PIT = (NPI + 255) / 256, WIT = (NWI + 255) / 256;     // items per thread
+  constexpr float WS = 64.0f;
+  __shared__ __align__(16) unsigned char Ps[NPX * REC], Wsl[9 * 64 * REC];
+  __shared__ float s_max[2][4];
+  fp16_ovfl_clamp();
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int tiles_x = (a.Wo + TX - 1) / TX;
+  const int ty0 = (blockIdx.x / tiles_x) * TY, tx0 = (blockIdx.x % tiles_x) * TX;
+  const int co0 = blockIdx.y * 64, n = blockIdx.z;
+  const int iy0 = ty0 * STRIDE - a.pad, ix0 = tx0 * STRIDE - a.pad;
+  const size_t plane = (size_t)a.H * a.W;
+  const float* __restrict__ xn = a.x + (size_t)n * a.Cin * plane;
+
+  const int pyl = 2 * (wv >> 1) + (r >> 4), pxl = r & 15;
+  const int b_base = ((pyl * STRIDE) * PW + pxl * STRIDE) * REC + 16 * h;   // + (ky * PW + kx) * REC per tap; lo plane at + 32
+  const int a_base = (32 * (wv & 1) + r) * REC + 16 * h;                    // + tap * 64 * REC
+
+  f32x16c acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  float rp[PIT][8], rw[WIT][8];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < PIT; ++j) {
+      const int it = tid + 256 * j, px = it >> 1, g = it & 1;
+      const int py = px / PW, pxx = px - py * PW;
+      const int gy = iy0 + py, gx = ix0 + pxx;
+      const bool ok = it < NPI && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const float* __restrict__ src = xn + (size_t)(c0 + 8 * g) * plane + (ok ? (size_t)gy * a.W + gx : 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rp[j][e] = ok ? src[(size_t)e * plane] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < WIT; ++j) {
+      const int it = tid + 256 * j, co = it & 63, tg = it >> 6, tap = tg >> 1, g = tg & 1;
+      const bool ok = it < NWI && co0 + co < a.CoutP;
+      const float* __restrict__ src = a.w + ((size_t)(c0 + 8 * g) * 9 + tap) * a.CoutP + (ok ? co0 + co : 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rw[j][e] = ok ? src[(size_t)e * 9 * a.CoutP] : 0.f;
+    }
+  };
+  float xs = 1.0f, run_max = 0.f;
+  fetch(0);
+  int par = 0;
+  for (int c0 = 0; c0 < a.Cin; c0 += CC, par ^= 1) {
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < PIT; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(rp[j][e]));
+    mx = wave_max_nonneg(mx);
+    if (l == 0) s_max[par][wv] = mx;
+    __syncthreads();  // also: every wave is done with the previous chunk in LDS
+    run_max = fmaxf(run_max, fmaxf(fmaxf(s_max[par][0], s_max[par][1]), fmaxf(s_max[par][2], s_max[par][3])));
+    if (run_max > 0.f) {
+      int e2;
+      (void)frexpf(run_max, &e2);
+      const float ns = ldexpf(1.0f, min(14 - e2, 100));
+      if (ns != xs) {
+        const float ratio = ns / xs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] *= ratio;
+        xs = ns;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PIT; ++j) {
+      const int it = tid + 256 * j, px = it >> 1, g = it & 1;
+      if (it < NPI) {
+        uint4 hi, lo;
+        c1_split8(rp[j], xs, hi, lo);
+        *reinterpret_cast<uint4*>(Ps + px * REC + 16 * g) = hi;
+        *reinterpret_cast<uint4*>(Ps + px * REC + 32 + 16 * g) = lo;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WIT; ++j) {
+      const int it = tid + 256 * j, co = it & 63, tg = it >> 6, tap = tg >> 1, g = tg & 1;
+      if (it < NWI) {
+        uint4 hi, lo;
+        c1_split8(rw[j], WS, hi, lo);
+        *reinterpret_cast<uint4*>(Wsl + (tap * 64 + co) * REC + 16 * g) = hi;
+        *reinterpret_cast<uint4*>(Wsl + (tap * 64 + co) * REC + 32 + 16 * g) = lo;
+      }
+    }
+    __syncthreads();
+    if (c0 + CC < a.Cin) fetch(c0 + CC);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const unsigned char* ap = Wsl + tap * 64 * REC + a_base;
+      const unsigned char* bp = Ps + (ky * PW + kx) * REC + b_base;
+      const c1h8_t ah = *reinterpret_cast<const c1h8_t*>(ap), al = *reinterpret_cast<const c1h8_t*>(ap + 32);
+      const c1h8_t bh = *reinterpret_cast<const c1h8_t*>(bp), bl = *reinterpret_cast<const c1h8_t*>(bp + 32);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane = pixel (pyl, pxl), register = output channel row (as conv2d_igemm_kernel, ups == 1)
+  const int oy = ty0 + pyl, ox = tx0 + pxl;
+  if (oy >= a.Ho || ox >= a.Wo) return;
+  const float unscale = 1.0f / (WS * xs);
+  const size_t oplane = (size_t)a.Ho * a.Wo;
+  float* __restrict__ yn = a.y + ((size_t)n * a.out_ctotal + a.out_coff) * oplane;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int co = co0 + 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (co >= a.CoutP) continue;
+    float v = fmaf(acc[reg] * unscale, a.scale[co], a.shift[co]);
+    if (a.relu == 1) v = fmaxf(v, 0.f);
+    else if (a.relu == 2) v = gelu_erf_f(v);
+    const size_t oi = (size_t)co * oplane + (size_t)oy * a.Wo + ox;
+    if (a.res != nullptr) v += a.res[((size_t)n * a.out_ctotal + a.out_coff) * oplane + oi];
+    if (a.relu == 3) v = fmaxf(v, 0.f);
+    yn[oi] = v;
+  }
+}
+
 inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_t st) {
+  if (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2) && a.ups == 1 && a.Cin % 16 == 0 && a.CoutP >= 32 && modes_snapshot().split()) {
+    const int tiles3 = ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
+    const dim3 g3(tiles3, (a.CoutP + 63) / 64, N);
+    if (g3.y > 65535 || g3.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");
+    if (a.stride == 1) conv3x3_f16s_kernel<1><<<g3, 256, 0, st>>>(a);
+    else conv3x3_f16s_kernel<2><<<g3, 256, 0, st>>>(a);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   // measured on MI355X (V2X-ViT / Where2comm Linear layers, 2-5 agents, 64x128 .. 96x352): against the exact-fp32 kernel below the
   // split kernel wins from 256 output channels up (qkv 384 / 768: 71 -> 51 us, 544 -> 434 us) and loses at 128 (25 -> 34 us: one
   // weight block per pixel tile, nothing to amortise its staging over)
