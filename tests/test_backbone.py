@@ -207,3 +207,40 @@ def test_training_mode_batch_statistics_forward_backward_and_running_stats():
         else:
             assert int(b1) == int(b2), k
     print(f"backbone training mode: {len(want)} parameter gradients + input, worst relative error vs torch {worst:.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,stride,cin,cout,H,W", [
+    (3, 1, 32, 48, 19, 37),       # split 3x3 kernel: two 16-channel chunks, ragged pixel tiles, Cout below a 64-row tile
+    (3, 2, 64, 130, 22, 41),      # stride 2, Cout crosses two tiles
+    (1, 1, 64, 320, 13, 29),      # split 1x1 kernel (>= 256 outputs): 64-pixel tiles, ragged
+    (1, 1, 128, 256, 9, 11),      # few workgroups: the 32-pixel tile variant
+])
+@pytest.mark.parametrize("case", ["unit", "tiny", "huge", "late_large_channels", "all_zero_then_data"])
+def test_split_conv_kernels_hold_fp32_grade_accuracy_over_the_whole_input_range(k, stride, cin, cout, H, W, case):
+    """The f16-pipe convolutions (conv3x3_f16s_kernel / conv1x1_f16s_kernel) carry a running power-of-two activation scale. Against
+    float64 on CPU: |error| <= 4e-6 of sum |w| |x| (fp32 accumulation order + 22-bit products) for inputs of magnitude 1, 1e-6 (gradients)
+    and 1e5 (beyond fp16's range), for channels that grow by 1e4 in the LAST chunk (the scale has to drop and the accumulators are
+    rescaled), and for leading all-zero chunks; the exact-fp32 mode must agree too."""
+    from gencomm_amd import _lib
+    from gencomm_amd.bev_backbone import conv2d_hip
+    torch.manual_seed(k * 1000 + cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2)
+    x = torch.randn(2, cin, H, W)
+    if case == "tiny":
+        x *= 1e-6
+    elif case == "huge":
+        x *= 1e5
+    elif case == "late_large_channels":
+        x[:, -16:] *= 1e4
+    elif case == "all_zero_then_data":
+        x[:, :16] = 0.0
+    with torch.no_grad():
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=stride, padding=k // 2)
+        mag = torch.nn.functional.conv2d(x.abs().double(), conv.weight.abs().double(), None, stride=stride, padding=k // 2) + conv.bias.abs().double().view(1, -1, 1, 1)
+        for mode in (0, 1):
+            with _lib.mode(_lib.MODE_ARITH, mode):
+                got = conv2d_hip(x.cuda(), conv.cuda(), None, relu=False).cpu().double()
+            assert torch.isfinite(got).all(), (case, mode)
+            worst = float(((got - ref).abs() / mag).max())
+            assert worst <= 4e-6, (case, "split" if mode == 0 else "exact fp32", worst)
