@@ -313,22 +313,26 @@ __global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
     }
   }
 
-  // epilogue: register = output channel row, lane (r) = pixel column
+  // epilogue: register = GEMM row (output channel, or channel x sub-pixel of a ConvTranspose2d with kernel == stride), lane (r) = pixel column
   const float unscale = 1.0f / (WS * xs);
-  float* __restrict__ yn = a.y + ((size_t)n * a.out_ctotal + a.out_coff) * HW;
-  const float* __restrict__ rn = a.res != nullptr ? a.res + ((size_t)n * a.out_ctotal + a.out_coff) * HW : nullptr;
+  const int ups = a.ups, s2 = ups * ups;
+  const size_t oplane = (size_t)HW * s2;
+  float* __restrict__ yn = a.y + ((size_t)n * a.out_ctotal + a.out_coff) * oplane;
+  const float* __restrict__ rn = a.res != nullptr ? a.res + ((size_t)n * a.out_ctotal + a.out_coff) * oplane : nullptr;
 #pragma unroll
   for (int t = 0; t < BN / 32; ++t) {
     const int gp = p0 + 32 * t + r;
     if (gp >= HW) continue;
+    const int oy = gp / a.W, ox = gp - oy * a.W;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int co = m0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      if (co >= a.CoutP) continue;
+      const int gco = m0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (gco >= a.CoutP) continue;
+      const int co = gco / s2, sub = gco - co * s2, dy = sub / ups, dx = sub - dy * ups;
       float v = fmaf((t == 0 ? acc0[reg] : acc1[reg]) * unscale, a.scale[co], a.shift[co]);
       if (a.relu == 1) v = fmaxf(v, 0.f);
       else if (a.relu == 2) v = gelu_erf_f(v);
-      const size_t oi = (size_t)co * HW + gp;
+      const size_t oi = (size_t)co * oplane + (size_t)(oy * ups + dy) * (a.W * ups) + (ox * ups + dx);
       if (rn != nullptr) v += rn[oi];
       if (a.relu == 3) v = fmaxf(v, 0.f);
       yn[oi] = v;
@@ -486,7 +490,7 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
   // measured on MI355X (V2X-ViT / Where2comm Linear layers, 2-5 agents, 64x128 .. 96x352): against the exact-fp32 kernel below the
   // split kernel wins from 256 output channels up (qkv 384 / 768: 71 -> 51 us, 544 -> 434 us) and loses at 128 (25 -> 34 us: one
   // weight block per pixel tile, nothing to amortise its staging over)
-  if (KH == 1 && KW == 1 && a.stride == 1 && a.pad == 0 && a.ups == 1 && a.Cin >= 16 && a.CoutP >= 256 && modes_snapshot().split()) {
+  if (KH == 1 && KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin >= 16 && a.CoutP >= 256 && modes_snapshot().split()) {  // ups > 1: ConvTranspose2d deblocks
     const int HW = a.H * a.W, mb = (a.CoutP + 127) / 128;
     const bool narrow = (long long)((HW + 63) / 64) * mb * N < 1024;  // fewer than 4 workgroups per CU: halve the pixel tile
     const dim3 g1(narrow ? (HW + 31) / 32 : (HW + 63) / 64, mb, N);
