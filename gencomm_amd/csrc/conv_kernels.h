@@ -323,6 +323,21 @@ __global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
   for (int t = 0; t < BN / 32; ++t) {
     const int gp = p0 + 32 * t + r;
     if (gp >= HW) continue;
+    if (ups == 1) {  // plain 1x1 convolution: no index arithmetic beyond row * HW + pixel (the divisions below cost 13 us on a 44 us launch)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = m0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (co >= a.CoutP) continue;
+        float v = fmaf((t == 0 ? acc0[reg] : acc1[reg]) * unscale, a.scale[co], a.shift[co]);
+        if (a.relu == 1) v = fmaxf(v, 0.f);
+        else if (a.relu == 2) v = gelu_erf_f(v);
+        const size_t oi = (size_t)co * HW + gp;
+        if (rn != nullptr) v += rn[oi];
+        if (a.relu == 3) v = fmaxf(v, 0.f);
+        yn[oi] = v;
+      }
+      continue;
+    }
     const int oy = gp / a.W, ox = gp - oy * a.W;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {

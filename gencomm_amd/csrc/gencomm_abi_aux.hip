@@ -91,8 +91,9 @@ int gencomm_warp_affine_fwd(const float* x, const double* theta, float* out, int
 
 int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int B, int heads, int dim_head, int HW, void* stream) {
   GC_CHECK_ARG(qkv && scene_off && out && B >= 1 && B <= 65535 && heads >= 1 && heads <= 65535 && HW >= 1, "bad arguments");
+  GC_CHECK_ARG(B <= 65535 / 8, "too many scenes in one launch");
   HgtArgs a{qkv, scene_off, out, heads, HW, 1.0f / sqrtf((float)dim_head)};
-  const dim3 grid((HW + 255) / 256, heads, B);
+  const dim3 grid((HW + 255) / 256, heads, B * 8);  // 8 query-agent slots per scene (v2xvit_kernels.h)
   hipStream_t st = (hipStream_t)stream;
   if (dim_head == 32) hgt_attn_kernel<32><<<grid, 256, 0, st>>>(a);
   else if (dim_head == 64) hgt_attn_kernel<64><<<grid, 256, 0, st>>>(a);

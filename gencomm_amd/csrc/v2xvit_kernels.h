@@ -63,13 +63,15 @@ struct HgtArgs {
 template <int DH>
 __global__ __launch_bounds__(256) void hgt_attn_kernel(const HgtArgs a) {
   constexpr int MAXN = 8;
-  const int b = blockIdx.z, m = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  // grid.z = scene x query agent (MAXN slots per scene, the unused ones exit): one thread per (pixel, head, QUERY AGENT), so a scene of
+  // N agents puts N times the waves on the machine instead of looping over its queries in one thread (2 agents x 64x128: 43 -> see DESIGN 7)
+  const int b = blockIdx.z / MAXN, qi = blockIdx.z % MAXN, m = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
   const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
-  if (p >= a.HW || N < 1 || N > MAXN) return;
+  if (p >= a.HW || N < 1 || N > MAXN || qi >= N) return;
   const int inner = a.heads * DH;
   const size_t agent = (size_t)3 * inner * a.HW;
   const float* __restrict__ base = a.qkv + (size_t)off * agent + p;
-  for (int i = 0; i < N; ++i) {
+  for (int i = qi; i == qi; ++i) {
     float q[DH];
 #pragma unroll
     for (int c = 0; c < DH; ++c) q[c] = base[i * agent + (size_t)(m * DH + c) * a.HW];
