@@ -120,6 +120,22 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(const Conv2dArgs a) {
   const int s = a.ups, s2 = s * s;
   const size_t oplane = (size_t)a.Ho * s * a.Wo * s;
   float* __restrict__ yn = a.y + ((size_t)n * a.out_ctotal + a.out_coff) * oplane;
+  if (s == 1) {  // plain convolution: no sub-pixel arithmetic (integer divisions by a run-time value, 16 times per lane)
+    const size_t po = (size_t)oy * a.Wo + ox;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = co0 + 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (co >= a.CoutP) continue;
+      float v = fmaf(acc[reg], a.scale[co], a.shift[co]);
+      if (a.relu == 1) v = fmaxf(v, 0.f);
+      else if (a.relu == 2) v = gelu_erf_f(v);
+      const size_t oi = (size_t)co * oplane + po;
+      if (a.res != nullptr) v += a.res[((size_t)n * a.out_ctotal + a.out_coff) * oplane + oi];
+      if (a.relu == 3) v = fmaxf(v, 0.f);
+      yn[oi] = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int gco = co0 + 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
