@@ -1,5 +1,8 @@
-// General 2-D convolution for the layers AROUND the hot path (gfx950, wave64, exact fp32 on the
-// matrix cores): BaseBEVBackbone blocks/deblocks, DownsampleConv, the detection heads.
+// General 2-D convolution for the layers AROUND the hot path (gfx950, wave64): BaseBEVBackbone blocks/deblocks, DownsampleConv,
+// the detection heads, the Linear layers of the fusion transformers.  Three kernels behind conv2d_enqueue:
+//   conv2d_igemm_kernel   exact fp32 on v_mfma_f32_32x32x2_f32 -- every shape; the only one in GENCOMM_MODE_ARITH = 1
+//   conv3x3_f16s_kernel   3x3 stride 1 / 2 with Cin % 16 == 0 on the f16 pipe, exact hi/lo split (default arithmetic mode)
+//   conv1x1_f16s_kernel   1x1 (and ConvTranspose2d, kernel == stride) with >= 256 GEMM rows, same arithmetic
 //
 // Reference call sites: opencood/models/sub_modules/base_bev_backbone.py:40-92 (ZeroPad2d(1) + 3x3
 // stride-s conv, BatchNorm2d(eps 1e-3), ReLU; ConvTranspose2d(k = stride) deblocks),

@@ -232,7 +232,10 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  *          (and/or conv_bias) when absent.
  * fwd:     y[:, out_coff:out_coff+Cout] = act(conv(x) * scale + shift); supported: 3x3 stride 1|2 any pad, 1x1 stride 1;
  *          ups = s > 1 runs ConvTranspose2d(kernel = stride = s) (KH = KW = 1 on the prepared matrix, output H*s x W*s).
- *          y has out_ctotal channels (write into a slice of a concat buffer without a copy). */
+ *          y has out_ctotal channels (write into a slice of a concat buffer without a copy).
+ *          Arithmetic follows GENCOMM_MODE_ARITH: 1 = exact fp32 MFMA for every shape; 0 (default) = 3x3 with Cin % 16 == 0 and
+ *          1x1 / ConvTranspose2d with >= 256 GEMM rows on the f16 matrix pipe from exact fp16 hi/lo operand splits (22-bit
+ *          products, fp32 accumulation) with a running power-of-two activation scale: any finite fp32 input is safe. */
 int gencomm_conv2d_prepare(const float* weight, float* prepared, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
 int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const float* bn_running_mean, const float* bn_running_var,
                         const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream);
