@@ -303,9 +303,166 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvArgs a) {
   }
 }
 
+// The same gather-GEMM on the f16 matrix pipe (Cin = 32 or 64: the layers that take two thirds of the encoder's time) with the exact
+// hi/lo split of conv8h_kernels.h: per kernel offset CIN / 16 steps of v_mfma_f32_32x32x16_f16 x 3 split terms (12 MFMAs of 32 cycles
+// at Cin = 64 against 32 of 64 cycles).  Gathered rows are channel-contiguous already, so a thread splits the 8 / 16 channels it
+// fetched and writes 16-byte record pieces; the prepared weights [offset][k pair][co][2] are read as 4 float2 per (co, k octet).
+// LDS records {CIN hi halves | CIN lo halves | 16 B pad} (an odd number of 16-byte units: conflict-free ds_read_b128 phases).
+// Activations carry the running power-of-two scale of conv1x1_f16s_kernel (workgroup max per offset; accumulators rescaled when the
+// exponent grows), weights are pre-multiplied by 2^6.
+typedef _Float16 sph8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 sph2_t __attribute__((ext_vector_type(2)));
+typedef float spf2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sp_split8(const float (&v)[8], float mul, uint4& hi, uint4& lo) {  // exact two-term fp16 split of 8 scaled floats
+  uint32_t hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = v[2 * i] * mul, a1 = v[2 * i + 1] * mul;
+    const sph2_t x = __builtin_convertvector((spf2_t){a0, a1}, sph2_t);
+    const sph2_t y = __builtin_convertvector((spf2_t){a0 - (float)x[0], a1 - (float)x[1]}, sph2_t);
+    hh[i] = __builtin_bit_cast(uint32_t, x);
+    ll[i] = __builtin_bit_cast(uint32_t, y);
+  }
+  hi = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+  lo = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+template <int CIN>
+__global__ __launch_bounds__(256) void sp_conv_f16s_kernel(const SpConvArgs a) {
+  static_assert(CIN == 32 || CIN == 64, "split kernel: 32 or 64 input channels");
+  constexpr int EPT = CIN / 4, REC = CIN * 4 + 16, LO = CIN * 2, WIT = CIN / 32;  // WIT weight items (co, k octet) per thread
+  constexpr float WS = 64.0f;
+  __shared__ __align__(16) unsigned char As[64 * REC], Bs[64 * REC];
+  __shared__ unsigned int s_mask;
+  __shared__ float s_max[2][4];
+  fp16_ovfl_clamp();
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int site0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int sh = wv >> 1, ch = wv & 1;
+  const bool co_live = co0 + ch * 32 < a.CoutP;   // wave-uniform
+  const int gsite = site0 + l;
+  const int c0 = wv * EPT;
+
+  if (tid == 0) s_mask = 0u;
+  __syncthreads();
+  {
+    unsigned int m = 0u;
+    if (gsite < a.n_out)
+      for (int o = wv; o < a.K; o += 4) m |= (a.nbr[(size_t)o * a.n_out + gsite] >= 0) ? (1u << o) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d);
+    if (l == 0 && m) atomicOr(&s_mask, m);
+  }
+  __syncthreads();
+  unsigned int mask = s_mask;
+
+  f32x16s acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  float va[EPT], vb[WIT][8];
+  auto fetch = [&](int o) {
+    const int idx = gsite < a.n_out ? a.nbr[(size_t)o * a.n_out + gsite] : -1;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) va[e] = 0.f;
+    if (idx >= 0) {
+      const float* __restrict__ src = a.x + (size_t)idx * CIN + c0;
+#pragma unroll
+      for (int e = 0; e < EPT; e += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + e);
+        va[e] = v.x; va[e + 1] = v.y; va[e + 2] = v.z; va[e + 3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WIT; ++j) {
+      const int it = tid + 256 * j, co = it & 63, g = it >> 6;   // k octet g: k pairs 4 g .. 4 g + 3
+      const bool ok = co0 + co < a.CoutP;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 v = ok ? *reinterpret_cast<const float2*>(a.w + (((size_t)o * (CIN / 2) + 4 * g + q) * a.CoutP + co0 + co) * 2) : make_float2(0.f, 0.f);
+        vb[j][2 * q] = v.x; vb[j][2 * q + 1] = v.y;
+      }
+    }
+  };
+  float xs = 1.0f, run_max = 0.f;
+  int par = 0;
+  if (mask != 0u) {
+    fetch(__builtin_ctz(mask));
+    while (true) {
+      float mx = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) mx = fmaxf(mx, fabsf(va[e]));
+      mx = wave_max_nonneg(mx);
+      if (l == 0) s_max[par][wv] = mx;
+      __syncthreads();   // every wave is done with the previous offset's tiles
+      run_max = fmaxf(run_max, fmaxf(fmaxf(s_max[par][0], s_max[par][1]), fmaxf(s_max[par][2], s_max[par][3])));
+      par ^= 1;
+      if (run_max > 0.f) {
+        int e2;
+        (void)frexpf(run_max, &e2);
+        const float ns = ldexpf(1.0f, min(14 - e2, 100));
+        if (ns != xs) {
+          const float ratio = ns / xs;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] *= ratio;
+          xs = ns;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; e += 8) {
+        const float v8[8] = {va[e], va[e + 1], va[e + 2], va[e + 3], va[e + 4], va[e + 5], va[e + 6], va[e + 7]};
+        uint4 hi, lo;
+        sp_split8(v8, xs, hi, lo);
+        *reinterpret_cast<uint4*>(As + l * REC + (c0 + e) * 2) = hi;
+        *reinterpret_cast<uint4*>(As + l * REC + LO + (c0 + e) * 2) = lo;
+      }
+#pragma unroll
+      for (int j = 0; j < WIT; ++j) {
+        const int it = tid + 256 * j, co = it & 63, g = it >> 6;
+        uint4 hi, lo;
+        sp_split8(vb[j], WS, hi, lo);
+        *reinterpret_cast<uint4*>(Bs + co * REC + 16 * g) = hi;
+        *reinterpret_cast<uint4*>(Bs + co * REC + LO + 16 * g) = lo;
+      }
+      __syncthreads();
+      mask &= mask - 1u;
+      if (mask != 0u) fetch(__builtin_ctz(mask));   // next offset's rows and weights travel while the matrix cores run
+      if (co_live) {
+#pragma unroll
+        for (int ks = 0; ks < CIN / 16; ++ks) {
+          const unsigned char* ap = As + (sh * 32 + r) * REC + 32 * ks + 16 * h;
+          const unsigned char* bp = Bs + (ch * 32 + r) * REC + 32 * ks + 16 * h;
+          const sph8_t ah = *reinterpret_cast<const sph8_t*>(ap), al = *reinterpret_cast<const sph8_t*>(ap + LO);
+          const sph8_t bh = *reinterpret_cast<const sph8_t*>(bp), bl = *reinterpret_cast<const sph8_t*>(bp + LO);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        }
+      }
+      if (mask == 0u) break;
+    }
+  }
+  if (!co_live) return;
+  const int co = co0 + ch * 32 + r;
+  if (co >= a.Cout) return;
+  const float sc = a.scale[co] / (WS * xs), sf = a.shift[co];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int site = site0 + sh * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (site >= a.n_out) continue;
+    float v = fmaf(acc[reg], sc, sf);
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.y[(size_t)site * a.Cout + co] = v;
+  }
+}
+
 inline int sp_conv_enqueue(const SpConvArgs& a, hipStream_t st) {
   if (a.K > 32) return fail(GC_ERR_ARG, "sparse conv: at most 32 kernel offsets (3 x 3 x 3)");
   const dim3 grid((a.n_out + 63) / 64, (a.CoutP + 63) / 64);
+  if (modes_snapshot().split() && (a.Cin == 32 || a.Cin == 64)) {
+    if (a.Cin == 32) sp_conv_f16s_kernel<32><<<grid, 256, 0, st>>>(a);
+    else sp_conv_f16s_kernel<64><<<grid, 256, 0, st>>>(a);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   if (a.Cin <= 4) sp_conv_kernel<4><<<grid, 256, 0, st>>>(a);
   else if (a.Cin <= 16) sp_conv_kernel<16><<<grid, 256, 0, st>>>(a);
   else if (a.Cin <= 32) sp_conv_kernel<32><<<grid, 256, 0, st>>>(a);
