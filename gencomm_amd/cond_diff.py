@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .runtime import f32c, ptr, record_len_list, require_gpu, stream_ptr
+from .runtime import dev_ints, f32c, ptr, record_len_list, require_gpu, stream_ptr
 from .unet import DiffusionUNet
 
 
@@ -131,7 +131,7 @@ class GenComm(nn.Module):
         prepared = den.prepared_params(T, dev)
         ws = den.denoise_workspace(n, H, W, dev)
         sched = self._sched_table(dev)
-        rows = torch.tensor(list(src_rows), dtype=torch.int32, device=dev)
+        rows = dev_ints(src_rows, dev)
         out = torch.empty((n, C, H, W), dtype=torch.float32, device=dev)
         n0 = sn = None
         if noise is not None:
@@ -177,8 +177,8 @@ class GenComm(nn.Module):
         (cond_diff.py:369-371, :378-379). Only defined when T > 2, like the reference's indexing."""
         if self.num_timesteps > 2:
             ego = spatial_features[0].unsqueeze(0).float()
-            for key, tt in (("t1", 1), ("t2", 2)):
-                data_dict[key] = self.q_sample(ego, torch.tensor([tt], device=ego.device), torch.randn_like(ego))
+            for key, tt in (("t1", 1), ("t2", 2)):  # q_sample with the index tensor cached on the device (no host-to-device copy per call)
+                data_dict[key] = self.q_sample(ego, dev_ints([tt], ego.device, torch.int64), torch.randn_like(ego))
 
     # ------------------------------------------------------------------ reference API
     def forward(self, spatial_features, conditions, record_len=None, noise=None, seed=None):

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .runtime import f32c, ptr, record_len_list, require_gpu, stream_ptr
+from .runtime import dev_ints, f32c, ptr, record_len_list, require_gpu, stream_ptr
 
 MAX_AGENTS_PER_SCENE = 8
 
@@ -76,7 +76,7 @@ class AttFusion(nn.Module):
         off = [0]
         for k in lens:
             off.append(off[-1] + k)
-        scene_off = torch.tensor(off, dtype=torch.int32, device=xx.device)
+        scene_off = dev_ints(off, xx.device)
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=xx.device)
         _lib.check(getattr(_lib.lib(), self._entry)(ptr(xx), ptr(theta), ptr(scene_off), ptr(out), B, n, C, H, W,
                                                     stream_ptr(xx.device)), self._entry)
@@ -90,7 +90,7 @@ class AttFusion(nn.Module):
         off = [0]
         for k in lens:
             off.append(off[-1] + k)
-        scene_off = torch.tensor(off, dtype=torch.int32, device=xx.device)
+        scene_off = dev_ints(off, xx.device)
         gx = torch.empty_like(xx)
         _lib.check(_lib.lib().gencomm_warp_attfuse_bwd(ptr(xx), ptr(theta), ptr(scene_off), ptr(grad_out), ptr(gx), B, n, C, H, W,
                                                        stream_ptr(xx.device)), "gencomm_warp_attfuse_bwd")

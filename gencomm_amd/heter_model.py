@@ -28,6 +28,7 @@ from .enhancer import Enhancer
 from .fusion import AttFusion, MaxFusion, normalize_pairwise_tfm
 from .message_extractor import MessageExtractorv2
 from .point_pillar import PointPillar
+from .runtime import record_len_list
 from .second import SECOND
 
 _ENCODERS = {"pointpillar": PointPillar, "second": SECOND}  # heter_encoders.py (resolved by lower-cased class name, stage1.py:54-61)
@@ -151,7 +152,9 @@ class HeterModelBaselineWGenComm(nn.Module):
         output_dict = {}
         agent_modality_list = data_dict["agent_modality_list"]
         affine_matrix = normalize_pairwise_tfm(data_dict["pairwise_t_matrix"], self.H, self.W, self.fake_voxel_size)
-        record_len = data_dict["record_len"]
+        # scene lengths as Python ints ONCE (one device-to-host synchronisation if the collate put them on the GPU; the reference's regroup
+        # does a .cpu() in each of its three callers, fusion_in_one.py:48-51): GenComm, Enhancer and the fusion net take the list
+        record_len = record_len_list(data_dict["record_len"])
         counts = Counter(agent_modality_list)
         feats, msgs = {}, {}
         for m in self.modality_name_list:

@@ -122,7 +122,11 @@ class PointPillar(nn.Module):
 
     def forward(self, data_dict, modality_name):
         inp = data_dict[f"inputs_{modality_name}"]
-        return self.encode(inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"])
+        # the number of agents of this modality is known on the host when the shell calls (heter_model.py): no `coords[:, 0].max().item()`
+        # synchronisation at the very start of the model (the reference derives it that way, point_pillar_scatter.py:45)
+        mods = data_dict.get("agent_modality_list")
+        batch = mods.count(modality_name) if isinstance(mods, (list, tuple)) and modality_name in mods else None
+        return self.encode(inp["voxel_features"], inp["voxel_coords"], inp["voxel_num_points"], batch_size=batch)
 
     def _encode_train(self, vf, coords, npts, batch_size):
         """Training / gradient path (stage 1 trains the encoder; BatchNorm1d with batch statistics when in train mode): the 10-feature

@@ -92,6 +92,23 @@ class PackedParams:
         return True
 
 
+_INT_CONSTS: dict = {}
+
+
+def dev_ints(values, device, dtype=torch.int32) -> torch.Tensor:
+    """A small integer table (scene offsets, source rows ...) as a device tensor, cached by value: building it with
+    ``torch.tensor(list, device=...)`` on every forward is a pageable host-to-device copy, i.e. a host synchronisation in the middle
+    of the model (the host then issues the ~100 launches that follow at its own pace instead of running ahead of the GPU)."""
+    key = (tuple(int(v) for v in values), str(device), dtype)
+    t = _INT_CONSTS.get(key)
+    if t is None:
+        if len(_INT_CONSTS) > 4096:
+            _INT_CONSTS.clear()
+        t = torch.tensor(list(key[0]), dtype=dtype, device=device)
+        _INT_CONSTS[key] = t
+    return t
+
+
 def record_len_list(record_len) -> List[int]:
     """Scene lengths as Python ints (one D2H sync when given a device tensor; the reference's
     ``regroup`` does the same ``.cpu()`` on every call, fusion_in_one.py:48-51)."""

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import _lib, train_ops as T
 from .fusion import MAX_AGENTS_PER_SCENE, gather_ego_thetas
-from .runtime import f32c, ptr, record_len_list, require_gpu, stream_ptr
+from .runtime import dev_ints, f32c, ptr, record_len_list, require_gpu, stream_ptr
 
 
 # ----------------------------------------------------------------------------------------- parameter containers
@@ -258,7 +258,7 @@ class V2XViTFusion(nn.Module):
         off = [0]
         for k in lens:
             off.append(off[-1] + k)
-        scene_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        scene_off = dev_ints(off, dev)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .v2xvit_bwd import V2XViTFunction
             return V2XViTFunction.apply(self, x, theta, scene_off, B, *self.parameters())

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib, train_ops as T
 from .fusion import MAX_AGENTS_PER_SCENE, gather_ego_thetas, record_len_list
-from .runtime import f32c, ptr, require_gpu, stream_ptr
+from .runtime import dev_ints, f32c, ptr, require_gpu, stream_ptr
 from .v2xvit_bwd import _lin, _lin_bwd
 
 
@@ -117,7 +117,7 @@ class Where2commFusion(nn.Module):
         off = [0]
         for v in lens:
             off.append(off[-1] + v)
-        scene_off = torch.tensor(off, dtype=torch.int32, device=x.device)
+        scene_off = dev_ints(off, x.device)
         x = f32c(x)
         params = list(self.mha_fusion.parameters())
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
