@@ -23,9 +23,14 @@ struct FuseArgs {
   int mode;              // 0 = ego-row attention (AttFusion), 1 = element-wise max over agents (MaxFusion)
 };
 
+// Workgroup = 64 pixels x 4 channel quarters (wave cq owns channels cq, cq + 4, ...): four times the workgroups and a quarter of the
+// dependent gathers per thread of the one-lane-per-pixel form (2 agents x 128 x 64 x 128: 117 -> see DESIGN section 7); the four partial
+// scores of a pixel meet in LDS.
 template <int N>
-__device__ __forceinline__ void fuse_body(const FuseArgs& a, int b, int off, int pix) {
+__device__ __forceinline__ void fuse_body(const FuseArgs& a, int b, int off, int pix_raw, int cq, int pl, float (*s_part)[4][64]) {
   const int H = a.H, W = a.W, HW = H * W;
+  const bool live = pix_raw < HW;
+  const int pix = live ? pix_raw : HW - 1;
   const int h = pix / W, w = pix - h * W;
   // affine_grid base coordinates, align_corners=False: (2i+1)/size - 1, in float64 like theta
   const double xb = (2.0 * w + 1.0) / (double)W - 1.0;
@@ -64,23 +69,28 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, int b, int off, int
   const float* __restrict__ xs = a.x + (size_t)off * a.C * HW;
   if (a.mode == 1) {  // MaxFusion (fusion_in_one.py:87-124): max over the warped agents, zeros where an agent is out of range
     float* __restrict__ op = a.out + (size_t)b * a.C * HW + pix;
-    for (int c = 0; c < a.C; ++c) {
+    for (int c = cq; c < a.C; c += 4) {
       float o = sample(0, xs + (size_t)c * HW);
 #pragma unroll
       for (int j = 1; j < N; ++j) o = fmaxf(o, sample(j, xs + ((size_t)j * a.C + c) * HW));
-      op[(size_t)c * HW] = o;
+      if (live) op[(size_t)c * HW] = o;
     }
     return;
   }
   float score[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) score[j] = 0.f;
-  for (int c = 0; c < a.C; ++c) {
+  for (int c = cq; c < a.C; c += 4) {
     const float v0 = sample(0, xs + (size_t)c * HW);
     score[0] = fmaf(v0, v0, score[0]);
 #pragma unroll
     for (int j = 1; j < N; ++j) score[j] = fmaf(v0, sample(j, xs + ((size_t)j * a.C + c) * HW), score[j]);
   }
+#pragma unroll
+  for (int j = 0; j < N; ++j) s_part[j][cq][pl] = score[j];
+  __syncthreads();  // every thread of the workgroup gets here: dead pixels were clamped, not retired
+#pragma unroll
+  for (int j = 0; j < N; ++j) score[j] = (s_part[j][0][pl] + s_part[j][1][pl]) + (s_part[j][2][pl] + s_part[j][3][pl]);
   const float inv = 1.0f / sqrtf((float)a.C);
   float mx = -INFINITY;
 #pragma unroll
@@ -92,28 +102,29 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, int b, int off, int
 #pragma unroll
   for (int j = 0; j < N; ++j) score[j] *= rden;
   float* __restrict__ op = a.out + (size_t)b * a.C * HW + pix;
-  for (int c = 0; c < a.C; ++c) {
+  for (int c = cq; c < a.C; c += 4) {
     float o = 0.f;
 #pragma unroll
     for (int j = 0; j < N; ++j) o = fmaf(score[j], sample(j, xs + ((size_t)j * a.C + c) * HW), o);
-    op[(size_t)c * HW] = o;
+    if (live) op[(size_t)c * HW] = o;
   }
 }
 
 __global__ __launch_bounds__(256) void warp_attfuse_kernel(const FuseArgs a) {
+  __shared__ float s_part[8][4][64];
   const int b = blockIdx.y;
-  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= a.H * a.W) return;
+  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;   // block-uniform
+  const int pl = threadIdx.x & 63, cq = threadIdx.x >> 6;
+  const int pix = blockIdx.x * 64 + pl;
   switch (N) {
-    case 1: fuse_body<1>(a, b, off, pix); break;
-    case 2: fuse_body<2>(a, b, off, pix); break;
-    case 3: fuse_body<3>(a, b, off, pix); break;
-    case 4: fuse_body<4>(a, b, off, pix); break;
-    case 5: fuse_body<5>(a, b, off, pix); break;
-    case 6: fuse_body<6>(a, b, off, pix); break;
-    case 7: fuse_body<7>(a, b, off, pix); break;
-    case 8: fuse_body<8>(a, b, off, pix); break;
+    case 1: fuse_body<1>(a, b, off, pix, cq, pl, s_part); break;
+    case 2: fuse_body<2>(a, b, off, pix, cq, pl, s_part); break;
+    case 3: fuse_body<3>(a, b, off, pix, cq, pl, s_part); break;
+    case 4: fuse_body<4>(a, b, off, pix, cq, pl, s_part); break;
+    case 5: fuse_body<5>(a, b, off, pix, cq, pl, s_part); break;
+    case 6: fuse_body<6>(a, b, off, pix, cq, pl, s_part); break;
+    case 7: fuse_body<7>(a, b, off, pix, cq, pl, s_part); break;
+    case 8: fuse_body<8>(a, b, off, pix, cq, pl, s_part); break;
     default: break;  // host validates 1 <= N <= 8 where it can; otherwise the scene is left untouched
   }
 }
@@ -123,7 +134,7 @@ inline int warp_attfuse_enqueue(const float* x, const double* theta, const int* 
   (void)n;
   FuseArgs a{x, theta, scene_off, out, C, H, W, mode};
   TimedLaunch tl(KF_WARP_ATTFUSE, st);
-  warp_attfuse_kernel<<<dim3((H * W + 255) / 256, B), 256, 0, st>>>(a);
+  warp_attfuse_kernel<<<dim3((H * W + 63) / 64, B), 256, 0, st>>>(a);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

@@ -71,7 +71,8 @@ inline int msgext_enqueue(const MsgExtPlan& p, const float* raw, const float* x,
   }
   {
     DcnArgs a{x, F(w.off), F(w.wDcn), raw + p.db, F(w.b1), F(w.colsum), C, H, W};
-    dcn_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(a);
+    if ((long long)cdiv(HW, 256) * n < 512) dcn_csplit_kernel<<<dim3(cdiv(HW, 64), n), 256, 0, st>>>(a);   // small maps: 4x the workgroups, a quarter of the chain per wave
+    else dcn_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(a);
   }
   {
     MsgGateArgs a{F(w.colsum), raw + p.a1w, raw + p.a1b, raw + p.a3w, raw + p.a3b, F(w.gate), 1.0f / (float)HW};

@@ -159,6 +159,70 @@ __global__ __launch_bounds__(256) void dcn_kernel(const DcnArgs a) {
   if (tid < 64) atomicAdd(&a.colsum[(size_t)n * 64 + tid], s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]);
 }
 
+// The same convolution for SMALL maps (the shipped 64 x 128 features: dcn_kernel would launch 32 workgroups per agent, each wave a chain
+// of 4.6 k dependent gathers and 18 k MFMAs): workgroup = 64 pixels, wave q = every fourth 8-channel chunk of the INPUT (the gathers are
+// what binds this kernel: splitting the output channels over the waves instead repeats them four times and was slower), all 64 output
+// channels as partial sums; the four partial accumulators of a pixel meet in LDS and wave q finishes output channels 16 q .. 16 q + 15.
+__global__ __launch_bounds__(256) void dcn_csplit_kernel(const DcnArgs a) {
+  __shared__ float s_acc[4][64][64];  // [wave][output channel][pixel lane]
+  const int n = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int HW = a.H * a.W;
+  const int pix = blockIdx.x * 64 + lane;
+  const bool ok = pix < HW;
+  const int y = ok ? pix / a.W : 0, x = ok ? pix - y * a.W : 0;
+  float off[18];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) off[k] = ok ? a.off[((size_t)n * 18 + k) * HW + pix] : 0.f;
+  f32x4 acc[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ xn = a.x + (size_t)n * a.C * HW;
+  const float fH = (float)a.H, fW = (float)a.W;
+#pragma unroll 1
+  for (int ch = q; ch < a.C / 8; ch += 4) {
+    float wr[72];
+    load_wregs<72>(wr, a.w + (size_t)ch * 4608, 4608, lane);
+    const float* __restrict__ xc = xn + (size_t)ch * 8 * HW;
+    static_for<0, 9>([&](auto TAP) {
+      constexpr int k = decltype(TAP)::value, ky = k / 3, kx = k % 3;
+      const float py = (float)(y - 1 + ky) + off[2 * k], px = (float)(x - 1 + kx) + off[2 * k + 1];
+      const bool inside = ok && py > -1.f && py < fH && px > -1.f && px < fW;
+      const float fy = floorf(py), fx = floorf(px);
+      const int iy = (int)fy, ix = (int)fx;
+      const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+      const bool y0ok = inside && iy >= 0, y1ok = inside && iy + 1 <= a.H - 1;
+      const bool x0ok = ix >= 0, x1ok = ix + 1 <= a.W - 1;
+      const int i00 = iy * a.W + ix;
+      const float w00 = (y0ok && x0ok) ? hy * hx : 0.f, w01 = (y0ok && x1ok) ? hy * lx : 0.f;
+      const float w10 = (y1ok && x0ok) ? ly * hx : 0.f, w11 = (y1ok && x1ok) ? ly * lx : 0.f;
+      const int j00 = (y0ok && x0ok) ? i00 : 0, j01 = (y0ok && x1ok) ? i00 + 1 : 0;
+      const int j10 = (y1ok && x0ok) ? i00 + a.W : 0, j11 = (y1ok && x1ok) ? i00 + a.W + 1 : 0;
+      static_for<0, 8>([&](auto IC) {
+        constexpr int ic = decltype(IC)::value;
+        const float* __restrict__ pl = xc + (size_t)ic * HW;
+        const float v = w00 * pl[j00] + w01 * pl[j01] + w10 * pl[j10] + w11 * pl[j11];
+        static_for<0, 16>([&](auto OG) {
+          constexpr int og = decltype(OG)::value;
+          acc[og] = mfma_wbcast<og>(wr[ic * 9 + k], v, acc[og]);
+        });
+      });
+    });
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_acc[q][g * 4 + i][lane] = acc[g][i];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int oc = 16 * q + j;
+    const float v = (s_acc[0][oc][lane] + s_acc[1][oc][lane]) + (s_acc[2][oc][lane] + s_acc[3][oc][lane]) + as_const(a.bias)[oc];
+    if (ok) a.b1[((size_t)n * 64 + oc) * HW + pix] = v;
+    const float t = wave_total(ok ? v : 0.f);
+    if (lane == 0) atomicAdd(&a.colsum[(size_t)n * 64 + oc], t);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // M3: SE gate per agent: mean -> 1x1 (64 -> 32) -> ReLU -> 1x1 (32 -> 64) -> sigmoid
 // ---------------------------------------------------------------------------------------------
