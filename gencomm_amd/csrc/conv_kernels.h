@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16s_kernel(const Conv2dArgs a) {
 // the odd record stride (5 x 16 B) keeps the 16 lanes of a ds_read_b128 phase on distinct banks.  NCHW is channel-strided, the MFMA
 // wants 8 consecutive channels per lane: every loader item is 8 channel values of ONE pixel (or one tap / output channel), dword
 // loads coalesced across the pixel / channel-out index, split and written as one record half.  Activations carry the running
-// power-of-two scale of conv1x1_f16s_kernel; weights are pre-multiplied by 2^6.  Cin % 16 == 0.
+// power-of-two scale of conv1x1_f16s_kernel; weights are pre-multiplied by 2^6.  Cin % 8 == 0 (a last half-filled chunk is zero-padded).
 // ---------------------------------------------------------------------------------------------
 template <int STRIDE>
 __global__ __launch_bounds__(256) void conv3x3_f16s_kernel(const Conv2dArgs a) {
@@ -418,16 +418,16 @@ __global__ __launch_bounds__(256) void conv3x3_f16s_kernel(const Conv2dArgs a) {
       const int it = tid + 256 * j, px = it >> 1, g = it & 1;
       const int py = px / PW, pxx = px - py * PW;
       const int gy = iy0 + py, gx = ix0 + pxx;
-      const bool ok = it < NPI && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      const float* __restrict__ src = xn + (size_t)(c0 + 8 * g) * plane + (ok ? (size_t)gy * a.W + gx : 0);
+      const bool ok = it < NPI && c0 + 8 * g < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;   // Cin % 8 == 0: the last chunk may hold one octet
+      const float* __restrict__ src = xn + (size_t)(ok ? c0 + 8 * g : 0) * plane + (ok ? (size_t)gy * a.W + gx : 0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) rp[j][e] = ok ? src[(size_t)e * plane] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < WIT; ++j) {
       const int it = tid + 256 * j, co = it & 63, tg = it >> 6, tap = tg >> 1, g = tg & 1;
-      const bool ok = it < NWI && co0 + co < a.CoutP;
-      const float* __restrict__ src = a.w + ((size_t)(c0 + 8 * g) * 9 + tap) * a.CoutP + (ok ? co0 + co : 0);
+      const bool ok = it < NWI && c0 + 8 * g < a.Cin && co0 + co < a.CoutP;
+      const float* __restrict__ src = a.w + ((size_t)(ok ? c0 + 8 * g : 0) * 9 + tap) * a.CoutP + (ok ? co0 + co : 0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) rw[j][e] = ok ? src[(size_t)e * 9 * a.CoutP] : 0.f;
     }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16s_kernel(const Conv2dArgs a) {
 }
 
 inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_t st) {
-  if (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2) && a.ups == 1 && a.Cin % 16 == 0 && a.CoutP >= 32 && modes_snapshot().split()) {
+  if (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2) && a.ups == 1 && a.Cin % 8 == 0 && a.CoutP >= 32 && modes_snapshot().split()) {
     const int tiles3 = ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
     const dim3 g3(tiles3, (a.CoutP + 63) / 64, N);
     if (g3.y > 65535 || g3.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");

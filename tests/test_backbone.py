@@ -213,6 +213,8 @@ def test_training_mode_batch_statistics_forward_backward_and_running_stats():
 @pytest.mark.parametrize("k,stride,cin,cout,H,W", [
     (3, 1, 32, 48, 19, 37),       # split 3x3 kernel: two 16-channel chunks, ragged pixel tiles, Cout below a 64-row tile
     (3, 2, 64, 130, 22, 41),      # stride 2, Cout crosses two tiles
+    (3, 1, 24, 40, 15, 21),       # Cin % 16 == 8: the last chunk holds one octet
+    (3, 1, 8, 66, 12, 33),        # a single half-filled chunk (the dgrad of conv_in)
     (1, 1, 64, 320, 13, 29),      # split 1x1 kernel (>= 256 outputs): 64-pixel tiles, ragged
     (1, 1, 128, 256, 9, 11),      # few workgroups: the 32-pixel tile variant
 ])
