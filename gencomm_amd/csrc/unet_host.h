@@ -213,7 +213,8 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
                        P + at.kw, P + at.kb, P + at.vw, P + at.vb, Q, K, V, 1.0 / (2.0 * HW), HW};
         attn_qkv_kernel<<<dim3(cdiv(HW, 256), c.n), 256, 0, c.st>>>(qa);
         AttnFlashArgs fa{Q, K, V, c.tensor_ptr(o.src[0]), P + at.pw, P + at.pb, c.tensor_ptr(o.dst), c.stat_ptr(o.dst), HW};
-        attn_flash_kernel<<<dim3(cdiv(HW, 256), c.n), 256, 0, c.st>>>(fa);
+        if (HW >= 128) attn_flash_mfma_kernel<<<dim3(cdiv(HW, 64), c.n), 512, 0, c.st>>>(fa);   // fp32 matrix cores
+        else attn_flash_kernel<<<dim3(cdiv(HW, 256), c.n), 256, 0, c.st>>>(fa);
         break;
       }
       case OP_CONV_OUT: {

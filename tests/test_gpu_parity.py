@@ -206,6 +206,30 @@ def test_attnblock_unet_vs_reference_golden():
             assert_close(y.cpu().numpy(), g[f"unet_out_t{t}"], RTOL, ATOL, f"unet(attn) t={t}")
 
 
+@pytest.mark.parametrize("C,H,W,n", [(8, 24, 40, 2), (16, 36, 52, 3), (8, 64, 72, 1)])
+def test_attnblock_on_the_matrix_cores_vs_oracle(C, H, W, n):
+    """AttnBlocks at half resolution with 240 / 468 / 1 152 tokens (the fixture's 24 stay on the lane-per-query kernel): the fp32-MFMA
+    flash kernel (partial 32-key blocks, several 256-key tiles, partial query groups) against the oracle's dense N x N softmax."""
+    import copy
+    from gencomm_amd import GenComm, synth
+    from oracle import torch_port as O
+    cfg = copy.deepcopy(synth.default_gencomm_cfg(C, 3))
+    cfg["model"]["attn_resolutions"] = [64]
+    gen = GenComm(cfg).eval()
+    synth.fill_params_(gen, 17)
+    assert gen.denoiser.attn_mask == 0b10
+    inp = synth.make_inputs([n], C, H, W, 18)
+    x = torch.cat([torch.from_numpy(inp["cond"]), torch.from_numpy(inp["feat"])], 1)
+    sd = {k: v.detach() for k, v in gen.state_dict().items()}
+    gen = gen.to(DEV)
+    with torch.no_grad():
+        for t in (0, 2):
+            tt = torch.full((n,), t, dtype=torch.long)
+            ref = O.unet_forward(sd, "denoiser", x, tt.float(), cfg["model"])
+            got = gen.denoiser(x.to(DEV), tt.float().to(DEV), T=3).cpu()
+            assert_close(got.numpy(), ref.numpy(), RTOL, ATOL, f"unet(attn, {H // 2 * (W // 2)} tokens) t={t}")
+
+
 @pytest.mark.parametrize("C,H,W,n", [(16, 12, 20, 2), (64, 36, 52, 3), (128, 64, 128, 2)])
 def test_message_extractor_vs_oracle(C, H, W, n):
     """MessageExtractorv2: offset conv -> deformable conv -> SE gate -> 1x1 fuse, against
