@@ -2,7 +2,7 @@
 // the detection heads, the Linear layers of the fusion transformers.  Three kernels behind conv2d_enqueue:
 //   conv2d_igemm_kernel   exact fp32 on v_mfma_f32_32x32x2_f32 -- every shape; the only one in GENCOMM_MODE_ARITH = 1
 //   conv3x3_f16s_kernel   3x3 stride 1 / 2 with Cin % 16 == 0 on the f16 pipe, exact hi/lo split (default arithmetic mode)
-//   conv1x1_f16s_kernel   1x1 (and ConvTranspose2d, kernel == stride) with >= 256 GEMM rows, same arithmetic
+//   conv1x1_f16s_kernel   1x1 (and ConvTranspose2d, kernel == stride) with >= 128 GEMM rows, same arithmetic
 //
 // Reference call sites: opencood/models/sub_modules/base_bev_backbone.py:40-92 (ZeroPad2d(1) + 3x3
 // stride-s conv, BatchNorm2d(eps 1e-3), ReLU; ConvTranspose2d(k = stride) deblocks),
@@ -522,9 +522,9 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
     return GC_OK;
   }
   // measured on MI355X (V2X-ViT / Where2comm Linear layers, 2-5 agents, 64x128 .. 96x352): against the exact-fp32 kernel below the
-  // split kernel wins from 256 output channels up (qkv 384 / 768: 71 -> 51 us, 544 -> 434 us) and loses at 128 (25 -> 34 us: one
-  // weight block per pixel tile, nothing to amortise its staging over)
-  if (KH == 1 && KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin >= 16 && a.CoutP >= 256 && modes_snapshot().split()) {  // ups > 1: ConvTranspose2d deblocks
+  // split kernel wins clearly from 256 output channels up (qkv 384 / 768: 71 -> 44 us, 544 -> 315 us); at 128 it is level on the
+  // smallest shape and ahead on the larger ones (V2X-ViT forward, 4 agents x 96x352: 10.1 -> 9.6 ms) since it got two chunks in flight
+  if (KH == 1 && KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin >= 16 && a.CoutP >= 128 && modes_snapshot().split()) {  // ups > 1: ConvTranspose2d deblocks
     const int HW = a.H * a.W, mb = (a.CoutP + 127) / 128;
     const bool narrow = (long long)((HW + 63) / 64) * mb * N < 1024;  // fewer than 4 workgroups per CU: halve the pixel tile
     const dim3 g1(narrow ? (HW + 31) / 32 : (HW + 63) / 64, mb, N);

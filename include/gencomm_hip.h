@@ -234,7 +234,7 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  *          ups = s > 1 runs ConvTranspose2d(kernel = stride = s) (KH = KW = 1 on the prepared matrix, output H*s x W*s).
  *          y has out_ctotal channels (write into a slice of a concat buffer without a copy).
  *          Arithmetic follows GENCOMM_MODE_ARITH: 1 = exact fp32 MFMA for every shape; 0 (default) = 3x3 with Cin % 16 == 0 and
- *          1x1 / ConvTranspose2d with >= 256 GEMM rows on the f16 matrix pipe from exact fp16 hi/lo operand splits (22-bit
+ *          1x1 / ConvTranspose2d with >= 128 GEMM rows on the f16 matrix pipe from exact fp16 hi/lo operand splits (22-bit
  *          products, fp32 accumulation) with a running power-of-two activation scale: any finite fp32 input is safe. */
 int gencomm_conv2d_prepare(const float* weight, float* prepared, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
 int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const float* bn_running_mean, const float* bn_running_var,
