@@ -95,6 +95,13 @@ int gencomm_hgt_attn_fwd(const float* qkv, const int* scene_off, float* out, int
   HgtArgs a{qkv, scene_off, out, heads, HW, 1.0f / sqrtf((float)dim_head)};
   const dim3 grid((HW + 255) / 256, heads, B * 8);  // 8 query-agent slots per scene (v2xvit_kernels.h)
   hipStream_t st = (hipStream_t)stream;
+  if ((long long)HW * heads * B >= 131072 && (dim_head == 16 || dim_head == 32)) {   // enough (pixel, head) threads to fill the machine: every value loaded once
+    const dim3 gs((HW + 255) / 256, heads, B);
+    if (dim_head == 32) hgt_attn_stream_kernel<32><<<gs, 256, 0, st>>>(a);
+    else hgt_attn_stream_kernel<16><<<gs, 256, 0, st>>>(a);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   if (dim_head == 32) hgt_attn_kernel<32><<<grid, 256, 0, st>>>(a);
   else if (dim_head == 64) hgt_attn_kernel<64><<<grid, 256, 0, st>>>(a);
   else if (dim_head == 16) hgt_attn_kernel<16><<<grid, 256, 0, st>>>(a);

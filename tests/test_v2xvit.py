@@ -171,3 +171,29 @@ def test_hip_v2xvit_train_mode_dropout_is_consistent():
     an = float((xg.grad * d).sum())
     print(f"V2X-ViT train-mode dropout: directional derivative analytic {an:.6e}, finite difference {fd:.6e}")
     assert abs(an - fd) <= 3e-2 * abs(fd) + 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("DH,heads,H,W,lens", [(32, 8, 136, 128, [3, 1]), (16, 8, 96, 200, [2, 4]), (32, 4, 16, 24, [5])])
+def test_agent_attention_kernels_vs_torch(DH, heads, H, W, lens):
+    """gencomm_hgt_attn_fwd directly: the streaming kernel of the large maps (every q / k / v value read once, all N x N scores in
+    registers; taken from 131 072 (pixel, head) threads up) and the per-query-agent kernel of the small ones against plain torch."""
+    from gencomm_amd import _lib
+    from gencomm_amd.runtime import ptr, stream_ptr
+    torch.manual_seed(DH + H)
+    n, inner, HW = sum(lens), heads * DH, H * W
+    qkv = torch.randn(n, 3 * inner, H, W)
+    off = [0]
+    for v in lens:
+        off.append(off[-1] + v)
+    q, k, v = (qkv[:, i * inner:(i + 1) * inner].reshape(n, heads, DH, HW) for i in range(3))
+    ref = torch.empty(n, heads, DH, HW)
+    for b in range(len(lens)):
+        sl = slice(off[b], off[b + 1])
+        s = torch.einsum("ihdp,jhdp->hpij", q[sl], k[sl]) / DH ** 0.5
+        ref[sl] = torch.einsum("hpij,jhdp->ihdp", s.softmax(-1), v[sl])
+    dev = torch.device("cuda:0")
+    qd, out = qkv.to(dev).contiguous(), torch.empty(n, inner, H, W, device=dev)
+    so = torch.tensor(off, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().gencomm_hgt_attn_fwd(ptr(qd), ptr(so), ptr(out), len(lens), heads, DH, HW, stream_ptr(dev)), "gencomm_hgt_attn_fwd")
+    assert_close(out.cpu().numpy(), ref.reshape(n, inner, H, W).numpy(), 1e-4, 1e-5, f"agent attention DH={DH} {H}x{W} {lens}")
