@@ -223,11 +223,12 @@ def main():
         cnt = (ctypes.c_int * N_FAMILIES)()
         byt = (ctypes.c_double * N_FAMILIES)()
         _lib.check(lib.gencomm_timer_start_mask((1 << N_FAMILIES) - 1, runs * (T + 4) * 40), "gencomm_timer_start_mask")
-        with torch.no_grad():
+        with torch.no_grad(), _lib.kernel_log() as kl:
             for i in range(runs):
                 pipes[0].run(scenes[0][0], scenes[0][1], seed=3000 + i)
         torch.cuda.synchronize(device)
         _lib.check(lib.gencomm_timer_stop_families(ms, cnt, byt, N_FAMILIES), "gencomm_timer_stop_families")
+        family_pass.instantiations = {k: v // runs for k, v in kl.counts.items()}   # launches per scene batch
         return {f: {"ms": ms[f], "launches": cnt[f], "bytes": byt[f], "name": lib.gencomm_timer_kernel_name(f).decode()}
                 for f in range(N_FAMILIES) if cnt[f] > 0}
 
@@ -282,6 +283,7 @@ def main():
     arith_mode = lib.gencomm_get_mode(_lib.MODE_ARITH)
     split_default = arith_mode == 0
     roofs = rooflines(family_pass(), "Arithmetic: see config.arithmetic.") if timed else {}
+    instantiations = getattr(family_pass, "instantiations", None)
     # the same workload with the exact-fp32 MFMA kernels everywhere, the arithmetic that is identical to the reference's:
     # the full step count, timed the same way (rank 0), with its own family pass
     exact = None
@@ -312,7 +314,12 @@ def main():
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
                                    f"T={T} x0-param ancestral steps, {B} scene(s)/step/GPU",
                        "agents": N, "C": C, "H": H, "W": W, "T": T, "enhancer": not args.no_enhancer,
-                       "noise": "in-kernel Philox4x32-7 + Box-Muller (16-bit uniforms), step noise rounded to fp16",
+                       "noise": ("in-kernel Philox4x32-7 + Box-Muller: 16-bit angle; radius uniform on a 16-bit midpoint grid, refined by 32 more "
+                                 "Philox bits below u = 2^-12 (|z| > 4.08), so radii reach 8.2 sigma (tail mass lost: 2e-16; round 2 stopped at "
+                                 "4.85 sigma = 1.2e-6); the step noise added is nu = fp16(sigma_t z): relative rounding <= 2^-11 = 4.9e-4, "
+                                 "variance added 8e-8 relative; q_sample's eps is unrounded fp32. The reference draws torch.randn "
+                                 "(cond_diff.py:307); KS / tail / correlation tests on 1.4e8 samples of this field: tests/test_gpu_noise_stats.py; "
+                                 "the field is exported (gencomm_step_noise_fwd) and replayed through the oracle: tests/test_gpu_philox_replay.py"),
                        "arithmetic": ("fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
                                       "exact two-term fp16 splits of both operands (22-bit products: slightly narrower than an fp32 FMA, same parity "
                                       "tolerance; range-guarded, see DESIGN.md section 4); the arithmetic-identical-to-the-reference mode is "
@@ -323,7 +330,9 @@ def main():
                                       "NOT the fp32 headline: accuracy of bf16 storage, see tests/test_gpu_bf16.py"),
                        "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph),
                        "modes": {k: lib.gencomm_get_mode(v) for k, v in mode_keys.items()},
-                       "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+                       "parallelism": f"replicas x{world} (scene-sharded, no collective)",
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                       "instantiations_per_scene_batch": instantiations},
             "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
                                   "achieved_tflops": flops * args.steps * B / elapsed / 1e12,
                                   "achieved_gbs": byts * args.steps * B / elapsed / 1e9},

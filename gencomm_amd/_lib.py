@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP = range(6)
 
 _lock = threading.Lock()
@@ -36,6 +36,8 @@ _SIGNATURES = {
     "gencomm_timer_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "gencomm_timer_start_mask": (_i, [C.c_ulonglong, _i]),
     "gencomm_timer_stop_families": (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), _i]),
+    "gencomm_klog_start": (_i, []),
+    "gencomm_klog_stop": (_i, [C.c_char_p, _i]),
     "gencomm_unet_num_params": (_i, [_i, _i, _i, _i]),
     "gencomm_unet_param_info": (_i, [_i, _i, _i, _i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
     "gencomm_unet_raw_floats": (_ll, [_i, _i, _i, _i]),
@@ -52,6 +54,7 @@ _SIGNATURES = {
     "gencomm_denoise_fwd_dseed": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, C.c_ulonglong, _p,
                                        _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_q_sample_fwd": (_i, [_p, _p, _i, _p, _p, C.c_ulonglong, C.c_uint, _p, _i, _i, _i, _i, _p]),
+    "gencomm_step_noise_fwd": (_i, [_p, C.c_ulonglong, C.c_uint, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_enhancer_num_params": (_i, [_i]),
     "gencomm_enhancer_param_info": (_i, [_i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
     "gencomm_enhancer_raw_floats": (_ll, [_i]),
@@ -209,6 +212,24 @@ class mode:
 
     def __exit__(self, *exc):
         check(lib().gencomm_set_mode(self.key, self.prev), "gencomm_set_mode")
+        return False
+
+
+class kernel_log:
+    """``with _lib.kernel_log() as kl: ...; kl.counts`` -- the kernel instantiations the hot path's launch sites chose inside the
+    block (name -> number of launches). Diagnostic, process-wide like the modes."""
+
+    def __enter__(self):
+        check(lib().gencomm_klog_start(), "gencomm_klog_start")
+        self.counts = {}
+        return self
+
+    def __exit__(self, *exc):
+        buf = C.create_string_buffer(1 << 16)
+        check(lib().gencomm_klog_stop(buf, len(buf)), "gencomm_klog_stop")
+        for line in buf.value.decode().splitlines():
+            name, _, cnt = line.rpartition("\t")
+            self.counts[name] = int(cnt)
         return False
 
 

@@ -114,6 +114,18 @@ struct TimedLaunch {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Diagnostic kernel log (gencomm_klog_start / gencomm_klog_stop): while armed, every launch site of the hot path notes
+// the exact kernel instantiation it chose, so a benchmark / test can state WHICH kernels ran (the timed Philox
+// instantiations are different templates from the explicit-noise ones the golden tests inject noise into).
+// ---------------------------------------------------------------------------------------------
+bool klog_armed();                  // defined in gencomm_abi.hip
+void klog_note(const char* name);
+#define GC_KLOG(name)                                   \
+  do {                                                  \
+    if (::gc::klog_armed()) ::gc::klog_note(name);      \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
 // Wave-uniform read-only tables (conv weights, biases, schedule rows) are read through the
 // constant address space so that they always come in via the scalar cache (s_load_dwordxN into
 // SGPRs) whatever the compiler can or cannot prove about aliasing; they are written only by
@@ -305,8 +317,13 @@ __device__ __forceinline__ void wave_reduce16(const float (&part)[16], float (&t
 // ---------------------------------------------------------------------------------------------
 // Noise: Philox4x32-7 counter RNG (Salmon et al., SC'11: 7 rounds is the fewest that passes BigCrush; the customary
 // 10 are a safety margin a sampler's noise field does not need) + Box-Muller.  One call yields four 32-bit words =
-// four Box-Muller pairs: word j -> radius from its low 16 bits (u = (k + 1/2) / 65536: |z| <= 4.85, the tail mass
-// beyond is 1.2e-6), angle from its high 16 bits (in revolutions, the unit of v_sin_f32 / v_cos_f32).
+// four Box-Muller pairs = EIGHT normals: word j -> angle from its high 16 bits (in revolutions, the unit of
+// v_sin_f32 / v_cos_f32), radius uniform from its low 16 bits, u = (k + 1/2) / 65536 (midpoint rule: masses exact to
+// O(2^-32)) -- REFINED where the 16-bit grid is too coarse for the tail: a word with k < 16 (u < 2.4e-4, radius > 4.08)
+// takes 32 further bits from a second Philox block of the same counter (c3 = 1), u = (k 2^32 + f + 1/2) 2^-48.  The
+// radius is therefore continuous to 2^-49 (|z| up to 8.24; round 2 stopped at 4.85 and gave the whole k = 0 bin one
+// radius).  The second block is needed by 1 call in 1 000 per lane, 6 % per wave: one v_min3/v_min/v_cmp/branch in
+// the common path.
 // Round 1 used Philox4x32-10 with 32-bit uniforms, one call per FOUR normals: 20 quarter-rate v_mad_u64_u32 + 8
 // transcendentals per 4 normals made the sampler step VALU-bound (56 k of 70 k issue cycles per tile-wave); this
 // form spends 14 multiplies + 14 three-way xors (v_bitop3_b32) + 16 transcendentals per EIGHT normals.
@@ -330,33 +347,62 @@ __device__ __forceinline__ void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Box-Muller pair of one word with standard deviation sg, on the raw hardware transcendentals: radius
-// sqrt(k2 * log2 u), k2 = -2 ln 2 * sg^2 (bm_k2; u in [2^-17, 1): never 0, never denormal), times (cos, sin).  The scale
-// rides inside the square root (one multiply per pair less than sg * sqrt(..)); k2 = 0 gives (+-0, +-0), which is how
-// callers blank the lanes whose pixels lie outside the image without a branch.
+// The four words of one counter with their radius uniforms (see above): w[j] >> 16 is the angle of pair j.
+constexpr uint32_t kNoiseRefineBelow = 16u;
+struct NoiseWords {
+  uint32_t w[4];
+  float ur[4];
+};
+__device__ __forceinline__ void noise_words(uint64_t ctr, uint32_t stream, uint64_t seed, NoiseWords& q) {
+  philox4x32_7((uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), q.w);
+  const float k16 = 1.52587890625e-5f;  // 2^-16
+  uint32_t k[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    k[j] = q.w[j] & 0xffffu;
+    q.ur[j] = fmaf((float)k[j], k16, 0.5f * k16);
+  }
+  if (min(min(k[0], k[1]), min(k[2], k[3])) < kNoiseRefineBelow) {
+    uint32_t f[4];
+    philox4x32_7((uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 1u, (uint32_t)seed, (uint32_t)(seed >> 32), f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k[j] < kNoiseRefineBelow) q.ur[j] = fmaf((float)k[j], k16, fmaf((float)f[j], 3.5527136788005009e-15f /* 2^-48 */, 1.7763568394002505e-15f /* 2^-49 */));
+  }
+}
+
+// Box-Muller pair with standard deviation sg, on the raw hardware transcendentals: radius sqrt(k2 * log2 u), k2 =
+// -2 ln 2 * sg^2 (bm_k2; u in [2^-49, 1): never 0, never denormal), times (cos, sin) of the angle.  The scale rides inside
+// the square root (one multiply per pair less than sg * sqrt(..)); k2 = 0 gives (+-0, +-0), which is how callers blank
+// the lanes whose pixels lie outside the image without a branch.
 __device__ __forceinline__ float bm_k2(float sg) { return -1.3862943611198906f * sg * sg; }
-__device__ __forceinline__ void bm_pair(uint32_t w, float k2, float& zc, float& zs) {
-  const float k = 1.52587890625e-5f;  // 2^-16
-  const float ur = fmaf((float)(w & 0xffffu), k, 0.5f * k), ut = (float)(w >> 16) * k;
+__device__ __forceinline__ void bm_pair(float ur, uint32_t w, float k2, float& zc, float& zs) {
+  const float ut = (float)(w >> 16) * 1.52587890625e-5f;
   const float m = __builtin_amdgcn_sqrtf(k2 * __builtin_amdgcn_logf(ur));
   zc = m * __builtin_amdgcn_cosf(ut);
   zs = m * __builtin_amdgcn_sinf(ut);
+  // The products are opaque to the optimiser from here on: otherwise it may fuse `m * cos` with the CALLER's fp16 conversion
+  // into one v_fma_mixlo_f16 (a single rounding of the exact product) in some kernels and not in others -- it did so in
+  // conv_out_kernel<64,16,4,2> only, `#pragma clang fp contract(off)` does not stop it -- and the "canonical" field then
+  // differs by an fp16 ulp between kernels wherever the fp32 product lands on an fp16 tie (2^-13 of the values; found by
+  // tests/test_gpu_philox_replay.py).  Rounded to fp32 first, everywhere; costs no instruction.
+  asm("" : "+v"(zc), "+v"(zs));
 }
 // the pair as one packed fp16x2 dword (cosine branch in the low half)
 typedef _Float16 nz_half2_t __attribute__((ext_vector_type(2)));
 typedef float nz_float2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t bm_pair_h(uint32_t w, float k2) {
+__device__ __forceinline__ uint32_t bm_pair_h(float ur, uint32_t w, float k2) {
   float zc, zs;
-  bm_pair(w, k2, zc, zs);
+  bm_pair(ur, w, k2, zc, zs);
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((nz_float2_t){zc, zs}, nz_half2_t));
 }
 
 // 8 N(0,1) floats of one counter: z[2j], z[2j+1] = the pair of word j (q_sample's initial noise: element index / 8)
 __device__ __forceinline__ void normal8(uint64_t ctr, uint32_t stream, uint64_t seed, float z[8]) {
-  uint32_t r[4];
-  philox4x32_7((uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  NoiseWords q;
+  noise_words(ctr, stream, seed, q);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bm_pair(r[j], -1.3862943611198906f, z[2 * j], z[2 * j + 1]);
+  for (int j = 0; j < 4; ++j) bm_pair(q.ur[j], q.w[j], -1.3862943611198906f, z[2 * j], z[2 * j + 1]);
 }
 
 // The sampler's step noise, CANONICAL FIELD (identical in the latent and the literal sampler structure, independent of
@@ -364,17 +410,15 @@ __device__ __forceinline__ void normal8(uint64_t ctr, uint32_t stream, uint64_t 
 // aligned pixel quad x & ~3: counter = element index of (n, c & ~1, y, x & ~3) in the [n][C][H][W] tensor, stream = t;
 // word j belongs to pixel (x & ~3) + j, its cosine branch to the even channel, its sine branch to the odd one.
 // Rounding sigma*z to fp16 (relative 2^-11, unbiased) is what lets the noise convolution run on the f16 matrix pipe
-// with ONE operand term; both sampler structures add exactly this value.
-// noise_words = the four words of a quad; bm_pair_h(word j, k2) = packed (even channel, odd channel) fp16 pair of pixel j
-// -- one dword of the LDS record of that pixel.  k2 = bm_k2(sigma_t) everywhere (0 for lanes outside the image).
-__device__ __forceinline__ void noise_words(uint64_t elem, uint32_t stream, uint64_t seed, uint32_t (&r)[4]) {
-  philox4x32_7((uint32_t)elem, (uint32_t)(elem >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-}
+// with ONE operand term; both sampler structures add exactly this value.  gencomm_step_noise_fwd (noise_kernels.h)
+// writes the field out with these same functions: the parity tests replay it through the oracle.
+// bm_pair_h(ur[j], w[j], k2) = packed (even channel, odd channel) fp16 pair of pixel j -- one dword of the LDS record
+// of that pixel.  k2 = bm_k2(sigma_t) everywhere (0 for lanes outside the image).
 __device__ __forceinline__ void noise_pair_quad_h(uint64_t elem, uint32_t stream, uint64_t seed, float k2, uint32_t (&h)[4]) {
-  uint32_t r[4];
-  noise_words(elem, stream, seed, r);
+  NoiseWords q;
+  noise_words(elem, stream, seed, q);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) h[j] = bm_pair_h(r[j], k2);
+  for (int j = 0; j < 4; ++j) h[j] = bm_pair_h(q.ur[j], q.w[j], k2);
 }
 // the same values as floats: z[j] = even channel, pixel j; z[4 + j] = odd channel, pixel j
 __device__ __forceinline__ void noise_pair_quad(uint64_t elem, uint32_t stream, uint64_t seed, float k2, float (&z)[8]) {

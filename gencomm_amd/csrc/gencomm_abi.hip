@@ -7,6 +7,7 @@
 #include "enhancer_host.h"
 #include "fusion_kernels.h"
 #include "msgext_host.h"
+#include "noise_kernels.h"
 #include "pillar_kernels.h"
 #include "train_kernels.h"
 #include "unet_bwd_host.h"
@@ -14,6 +15,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
 #include <stdlib.h>
 #include <string.h>
 
@@ -27,6 +31,14 @@ KernelTimer& kernel_timer() {
   return t;
 }
 static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {1}, {-1}, {1}};  // defaults, see ModeKey
+static std::atomic<bool> g_klog_armed{false};
+static std::mutex g_klog_mu;
+static std::map<std::string, int> g_klog;
+bool klog_armed() { return g_klog_armed.load(std::memory_order_relaxed); }
+void klog_note(const char* name) {
+  std::lock_guard<std::mutex> lk(g_klog_mu);
+  ++g_klog[name];
+}
 Modes modes_snapshot() {
   Modes m;
   for (int i = 0; i < MODE_COUNT; ++i) m.v[i] = g_modes[i].load(std::memory_order_relaxed);
@@ -125,6 +137,25 @@ int gencomm_timer_stop(double* total_ms, int* launches) {
   if (total_ms) *total_ms = sum;
   if (launches) *launches = cnt;
   return rc;
+}
+
+// ------------------------------------------------------------------------------------ kernel log
+int gencomm_klog_start(void) {
+  std::lock_guard<std::mutex> lk(g_klog_mu);
+  g_klog.clear();
+  g_klog_armed.store(true, std::memory_order_relaxed);
+  return GC_OK;
+}
+int gencomm_klog_stop(char* buf, int cap) {
+  g_klog_armed.store(false, std::memory_order_relaxed);
+  std::lock_guard<std::mutex> lk(g_klog_mu);
+  std::string out;
+  for (const auto& kv : g_klog) out += kv.first + "\t" + std::to_string(kv.second) + "\n";
+  g_klog.clear();
+  GC_CHECK_ARG(buf != nullptr && cap > 0, "null buffer");
+  GC_CHECK_ARG((int)out.size() < cap, "buffer too small for the kernel log");
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return GC_OK;
 }
 
 #ifdef GC_STAMPS
@@ -305,6 +336,7 @@ static void launch_q_sample(const QSampleArgs& q, int n, bool philox, hipStream_
   TimedLaunch tl(KF_Q_SAMPLE, st);
   // 8 octets (64 elements) per thread: few enough workgroups that the max|x| commit (one atomic each) stays cheap on small maps
   const dim3 qgrid((unsigned)std::max<long long>(1, std::min<long long>((q.per_agent / 64 + 255) / 256, 2048)), n);
+  GC_KLOG(philox ? "q_sample_kernel<true> (in-kernel Philox)" : "q_sample_kernel<false> (explicit noise)");
   if (philox) q_sample_kernel<true><<<qgrid, 256, 0, st>>>(q);
   else q_sample_kernel<false><<<qgrid, 256, 0, st>>>(q);
 }
@@ -316,6 +348,17 @@ int gencomm_q_sample_fwd(const float* sched_row, const float* feat, int n_feat_r
   GC_CHECK_ARG(n >= 1 && n <= 65535 && n_feat_rows >= 1 && C >= 1 && H >= 1 && W >= 1, "bad n/C/H/W");
   QSampleArgs q{feat, src_row, noise, sched_row, out, seed, stream_id, (long long)C * H * W, nullptr, nullptr};
   launch_q_sample(q, n, noise == nullptr, (hipStream_t)stream);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_step_noise_fwd(const float* sched_row, unsigned long long seed, unsigned int stream_id, float* out,
+                           int n, int C, int H, int W, int unrounded, void* stream) {
+  GC_CHECK_ARG(sched_row && out, "null pointer");
+  GC_CHECK_ARG(n >= 1 && n <= 65535 && C >= 2 && (C & 1) == 0 && H >= 1 && W >= 1, "bad n/C/H/W (C must be even)");
+  StepNoiseArgs a{out, sched_row, seed, stream_id, C, H, W, unrounded ? 1 : 0, (long long)n * (C / 2) * H * ((W + 3) / 4)};
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((a.items + 255) / 256, 65536));
+  step_noise_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

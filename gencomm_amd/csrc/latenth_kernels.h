@@ -616,7 +616,7 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
       // No branch around the generator: lanes whose quad lies outside the image run it with k2 = 0 and get (+-0, +-0).
       // The remainder rows and the halo columns need only two / one of a quad's four words: Box-Muller on those only.
       const float k2 = bm_k2(sg);
-      auto words = [&](int cp, int r, int gx2, uint32_t (&w)[4]) -> float {
+      auto words = [&](int cp, int r, int gx2, NoiseWords& w) -> float {
         const int gy2 = y0 - 1 + r;
         noise_words((uint64_t)(((size_t)n * a.C + (size_t)cc * 8 + 2 * cp) * plane + (size_t)gy2 * W + gx2), a.stream_id, seed, w);
         return (gy2 >= 0 && gy2 < H && gx2 >= 0 && gx2 < W) ? k2 : 0.f;
@@ -625,10 +625,10 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
         uint32_t h[4][4];
 #pragma unroll
         for (int cp = 0; cp < 4; ++cp) {
-          uint32_t w[4];
+          NoiseWords w;
           const float kk = words(cp, r0, x0 + 4 * qx, w);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) h[cp][j] = bm_pair_h(w[j], kk);
+          for (int j = 0; j < 4; ++j) h[cp][j] = bm_pair_h(w.ur[j], w.w[j], kk);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -637,20 +637,21 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
       {  // rows 16, 17: thread = (channel tid / 32, row 16 + (tid / 16 & 1), quad); the even channel's thread writes
          // the pair's dwords of pixels 0, 1, the odd channel's thread those of pixels 2, 3 (whole dwords, see hc_store_rem)
         const int cr = tid >> 5, rrw = TH + ((tid >> 4) & 1);
-        uint32_t w[4];
+        NoiseWords w;
         const float kk = words(cr >> 1, rrw, x0 + 4 * qx, w);
         const bool odd = (cr & 1) != 0;
         const int jb = odd ? 2 : 0;
-        const uint32_t wsel[2] = {odd ? w[2] : w[0], odd ? w[3] : w[1]};
+        const uint32_t wsel[2] = {odd ? w.w[2] : w.w[0], odd ? w.w[3] : w.w[1]};
+        const float usel[2] = {odd ? w.ur[2] : w.ur[0], odd ? w.ur[3] : w.ur[1]};
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-          *reinterpret_cast<uint32_t*>(tile + rrw * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4) = bm_pair_h(wsel[k], kk);
+          *reinterpret_cast<uint32_t*>(tile + rrw * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4) = bm_pair_h(usel[k], wsel[k], kk);
       }
       if (tid < HC_LH * 8) {
         const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
-        uint32_t w[4];  // the aligned quad that owns the halo pixel: x0-4..x0-1 (pixel 3) or x0+64.. (pixel 0)
+        NoiseWords w;  // the aligned quad that owns the halo pixel: x0-4..x0-1 (pixel 3) or x0+64.. (pixel 0)
         const float kk = words(cp, r, side ? x0 + TW : x0 - 4, w);
-        *reinterpret_cast<uint32_t*>(tile + hc_addr(r, side ? HC_TW : -1) + cp * 4) = bm_pair_h(side ? w[0] : w[3], kk);
+        *reinterpret_cast<uint32_t*>(tile + hc_addr(r, side ? HC_TW : -1) + cp * 4) = bm_pair_h(side ? w.ur[0] : w.ur[3], side ? w.w[0] : w.w[3], kk);
       }
     }
     __syncthreads();

@@ -50,9 +50,11 @@ inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, h
   const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
   const int variant = UP ? 16 : (RES == 2 ? 8 : (RES == 1 ? 4 : (NSRC == 2 ? 2 : 1)));  // MODE_CONV8H_MASK: diagnostic
   if (t == TILE_64x16 && a.wh != nullptr && m.split() && (m.v[MODE_CONV8H_MASK] & variant)) {
+    GC_KLOG(UP ? "conv8h_kernel<1,0,UP,0>" : NSRC == 2 ? "conv8h_kernel<2,GN,0,0>" : RES == 2 ? "conv8h_kernel<1,GN,0,2>" : RES == 1 ? "conv8h_kernel<1,GN,0,1>" : GN ? "conv8h_kernel<1,GN,0,0>" : "conv8h_kernel<1,0,0,0>");
     conv8h_kernel<NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a);
     return;
   }
+  GC_KLOG(t == TILE_64x16 ? "conv8_kernel<64,16,4,...> (exact fp32)" : t == TILE_32x16 ? "conv8_kernel<32,16,4,...> (exact fp32)" : "conv8_kernel<32,8,1,...> (exact fp32)");
   switch (t) {
     case TILE_64x16: conv8_kernel<64, 16, 4, NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a); break;
     case TILE_32x16: conv8_kernel<32, 16, 4, NSRC, GN, UP, RES><<<grid, 128, 0, st>>>(a); break;
@@ -65,6 +67,7 @@ inline void launch_conv8b(const Conv8BArgs& a, int n, hipStream_t st) {
   const double elt = 2.0;  // bf16 maps (the fp32 hs0 map appears in two launches per call: counted as bf16, a lower bound)
   const double abytes = elt * n * ((double)NSRC * 8 * a.Hin * a.Win + (RES == 1 ? 8.0 : RES == 2 ? 16.0 : 0.0) * a.H * a.W + 8.0 * a.H * a.W);
   TimedLaunch tl(UP ? KF_UP : (NSRC == 2 ? KF_CONV16 : (RES == 1 ? KF_CONV8_RES1 : RES == 2 ? KF_CONV8_RES2 : KF_CONV8)), st, abytes);
+  GC_KLOG("conv8b_kernel<...> (bf16 storage)");
   conv8b_kernel<NSRC, GN, UP, RES><<<dim3(cdiv(a.W, 64), cdiv(a.H, 16), n), 256, 0, st>>>(a);
 }
 
@@ -113,10 +116,14 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         if (tc == TILE_64x16 && c.m.split() && (Wl & 3) == 0) {
           ConvInHArgs ah{cond, x_t, P + p.p_wch, P + p.p_wxh, P + p.p_wc5h + HL_W5TAB, P + p.conv_in.b, c.tensor_ptr(o.dst),
                          c.stat_ptr(o.dst), p.C, Hl, Wl, c.m.xcd(), c.amax()};
+          GC_KLOG("conv_in_h_kernel");
           conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
-        } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
-        else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
-        else conv_in_kernel<32, 8, 1><<<grid, 256, 0, c.st>>>(a);
+        } else {
+          GC_KLOG("conv_in_kernel<tile> (exact fp32)");
+          if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);
+          else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, c.st>>>(a);
+          else conv_in_kernel<32, 8, 1><<<grid, 256, 0, c.st>>>(a);
+        }
         break;
       }
       case OP_RES_CONV1: {
@@ -180,6 +187,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         DownArgs a{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst),
                    c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin], !c.is_f32(o.src[0]), !c.is_f32(o.dst)};
         TimedLaunch tl(KF_DOWN, c.st, 4.0 * c.n * 8.0 * ((double)a.Hin * a.Win + (double)Hl * Wl));
+        GC_KLOG((a.Win & 3) == 0 ? "down8x2_kernel" : "down8_kernel");
         if ((a.Win & 3) == 0) down8x2_kernel<<<dim3(cdiv(Hl * ((Wl + 1) / 2), 256), 1, c.n), 256, 0, c.st>>>(a);
         else down8_kernel<<<dim3(cdiv(Hl * Wl, 256), 1, c.n), 256, 0, c.st>>>(a);
         break;
@@ -239,12 +247,16 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         TimedLaunch tl(KF_CONV_OUT, c.st);
         if (c.m.split() && (Wl & 3) == 0 && pick_tile(c.m, c.n, Hl, Wl) == TILE_64x16) {
           const dim3 gh(cdiv(Wl, 64), cdiv(Hl, 16), c.n);
+          GC_KLOG(post == 0 ? "conv_out_h_kernel<0> (x0_hat)" : post == 1 ? "conv_out_h_kernel<1> (explicit noise)" : "conv_out_h_kernel<2> (in-kernel Philox)");
           if (post == 0) conv_out_h_kernel<0><<<gh, 256, 0, c.st>>>(co);
           else if (post == 1) conv_out_h_kernel<1><<<gh, 256, 0, c.st>>>(co);
           else conv_out_h_kernel<2><<<gh, 256, 0, c.st>>>(co);
-        } else if (post == 0) GC_LAUNCH_CO(0);
-        else if (post == 1) GC_LAUNCH_CO(1);
-        else GC_LAUNCH_CO(2);
+        } else {
+          GC_KLOG(post == 0 ? "conv_out_kernel<tile,0> (exact fp32, x0_hat)" : post == 1 ? "conv_out_kernel<tile,1> (exact fp32, explicit noise)" : "conv_out_kernel<tile,2> (exact fp32, in-kernel Philox)");
+          if (post == 0) GC_LAUNCH_CO(0);
+          else if (post == 1) GC_LAUNCH_CO(1);
+          else GC_LAUNCH_CO(2);
+        }
 #undef GC_LAUNCH_CO
         break;
       }
@@ -301,14 +313,17 @@ inline int latent_step_enqueue(const UNetCall& c, const float* sched_row, const 
   const bool small_h = c.m.split() && (c.W & 3) == 0 && c.W >= 64 && c.H >= 16 && c.m.v[MODE_TILE_WANT] == 0;
   if ((pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16 || small_h) && c.m.split()) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
+    GC_KLOG(noise ? "latent_step_h_kernel<1> (explicit noise)" : "latent_step_h_kernel<2> (in-kernel Philox)");
     if (noise) latent_step_h_kernel<1><<<grid, 256, 0, c.st>>>(a);
     else latent_step_h_kernel<2><<<grid, 256, 0, c.st>>>(a);
   } else if (pick_tile(c.m, c.n, c.H, c.W) == TILE_64x16) {
     const dim3 grid(cdiv(c.W, 64), cdiv(c.H, 16), c.n);
+    GC_KLOG(noise ? "latent_step_kernel<64,16,1> (exact fp32, explicit noise)" : "latent_step_kernel<64,16,2> (exact fp32, in-kernel Philox)");
     if (noise) latent_step_kernel<64, 16, 1><<<grid, 256, 0, c.st>>>(a);
     else latent_step_kernel<64, 16, 2><<<grid, 256, 0, c.st>>>(a);
   } else {
     const dim3 grid(cdiv(c.W, 32), cdiv(c.H, 16), c.n);
+    GC_KLOG(noise ? "latent_step_kernel<32,16,1> (exact fp32, explicit noise)" : "latent_step_kernel<32,16,2> (exact fp32, in-kernel Philox)");
     if (noise) latent_step_kernel<32, 16, 1><<<grid, 128, 0, c.st>>>(a);
     else latent_step_kernel<32, 16, 2><<<grid, 128, 0, c.st>>>(a);
   }

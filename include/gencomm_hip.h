@@ -5,7 +5,8 @@
  * Conventions
  *   - every tensor pointer is DEVICE memory, float32, contiguous, NCHW unless stated;
  *   - the caller owns every buffer, including the scratch workspace (query *_workspace_bytes);
- *     the library allocates nothing, keeps no global state and is re-entrant per stream;
+ *     the library allocates nothing and is re-entrant per stream; its only process-global state is
+ *     the mode table (gencomm_set_mode) and the two diagnostics (kernel timer, kernel log), see below;
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); all work is
  *     enqueued on it and nothing synchronises the host, so calls may be captured in a hipGraph;
  *   - every entry point returns 0 on success, non-zero on error (1 bad argument / unsupported
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 4
+#define GENCOMM_ABI_VERSION 5
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -93,6 +94,13 @@ int gencomm_timer_start(int family, int capacity);
 int gencomm_timer_start_mask(unsigned long long family_mask, int capacity);
 int gencomm_timer_stop(double* total_ms, int* launches);
 int gencomm_timer_stop_families(double* ms, int* launches, double* algorithmic_bytes, int n_families);
+
+/* Diagnostic kernel log: between gencomm_klog_start and gencomm_klog_stop every launch site of the hot path notes the exact
+ * kernel instantiation it chose; gencomm_klog_stop writes "name<TAB>count<NEWLINE>" lines into buf (status 1 when cap is
+ * too small).  bench.py prints it so that the timed instantiations (in-kernel Philox noise: latent_step_h_kernel<2>,
+ * conv_out_h_kernel<2>) are named next to the number.  Process-global diagnostic state like the timer. */
+int gencomm_klog_start(void);
+int gencomm_klog_stop(char* buf, int cap);
 
 /* ----------------------------------------------------------------------------------------------
  * UNet parameters.  The "raw" blob is the concatenation of the module's parameters in EXECUTION
@@ -171,6 +179,16 @@ int gencomm_denoise_fwd_dseed(const float* prepared, const float* sched,
 int gencomm_q_sample_fwd(const float* sched_row, const float* feat, int n_feat_rows, const int* src_row,
                          const float* noise, unsigned long long seed, unsigned int stream_id,
                          float* out, int n, int C, int H, int W, void* stream);
+
+/* The sampler's in-kernel step noise of (seed, timestep stream_id = t), written out: out[n,C,H,W] = nu_t = fp16(sigma_t z)
+ * as float32 -- the exact values gencomm_denoise_fwd adds at step t when noise0 / step_noise are NULL (same device
+ * functions, same counter layout, in both sampler structures and every tile size); sched_row = device float[5] row of t
+ * ([4] = sigma_t).  unrounded != 0 writes sigma_t z before the fp16 rounding instead (statistics tests).  The reference
+ * draws torch.randn per step (cond_diff.py:307, MDD_utils.py:232-235); this entry exists so that a run with in-kernel
+ * noise can be replayed through the oracle with explicit noise (step_noise[T-1-t] = nu_t / sigma_t).  q_sample's
+ * initial noise is read back with gencomm_q_sample_fwd (zero feat, sched_row {0, 1, ..}, stream_id = T). */
+int gencomm_step_noise_fwd(const float* sched_row, unsigned long long seed, unsigned int stream_id, float* out,
+                           int n, int C, int H, int W, int unrounded, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Enhancer (live parameters only: block_1.{norm1,norm2,mlp.*}, split_attn.*), raw blob enumerated

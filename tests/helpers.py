@@ -82,3 +82,31 @@ def shell_noise(gencomm, seed, n, C, H, W, device):
         yield
     finally:
         del gencomm.forward
+
+
+def philox_noise(gen, seed, n, C, H, W, device, unrounded=False):
+    """The in-kernel noise of ``gen(..., seed=seed)`` written out as explicit tensors for the oracle:
+    noise0 = q_sample's eps (read back through the product's own q_sample kernel: zero x_start, schedule row {0, 1}, Philox
+    stream T) and step_noise[T-1-t] = nu_t / sigma_t, nu_t = the canonical step field of timestep t from
+    ``gencomm_step_noise_fwd`` (same device functions as the sampler kernels); entry T-1 (t = 0) is unused, as in the
+    reference (cond_diff.py:307 draws it and discards it)."""
+    from gencomm_amd import _lib
+    from gencomm_amd.runtime import ptr, stream_ptr
+    dev = torch.device(device)
+    T = gen.num_timesteps
+    sched = gen._sched_table(dev)
+    l = _lib.lib()
+    row01 = torch.tensor([0.0, 1.0, 0.0, 0.0, 0.0], device=dev)
+    zero = torch.zeros(1, C, H, W, device=dev)
+    rows = torch.zeros(n, dtype=torch.int32, device=dev)
+    n0 = torch.empty(n, C, H, W, device=dev)
+    _lib.check(l.gencomm_q_sample_fwd(ptr(row01), ptr(zero), 1, ptr(rows), None, seed, T, ptr(n0), n, C, H, W, stream_ptr(dev)),
+               "gencomm_q_sample_fwd")
+    sn = torch.zeros(T, n, C, H, W, device=dev)
+    for t in range(1, T):
+        nu = sn[T - 1 - t]
+        _lib.check(l.gencomm_step_noise_fwd(ptr(sched[t]), seed, t, ptr(nu), n, C, H, W, 1 if unrounded else 0, stream_ptr(dev)),
+                   "gencomm_step_noise_fwd")
+        nu.div_(sched[t, 4])
+    torch.cuda.synchronize()
+    return n0, sn

@@ -157,7 +157,14 @@ def test_code_object_has_no_packed_fp32_instructions(tmp_path):
     subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
     objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
     assert objs, os.listdir(tmp_path)
-    asm = subprocess.run([objdump, "-d", str(tmp_path / objs[0])], check=True, capture_output=True, text=True).stdout
+    asm = "\n".join(subprocess.run([objdump, "-d", str(tmp_path / o)], check=True, capture_output=True, text=True).stdout for o in sorted(objs))
     import re
     assert not re.search(r"v_pk_(fma|mul|add)_f32", asm)
     assert "v_mfma_f32_16x16x32_f16" in asm and "v_mfma_f32_4x4x1" in asm
+    # the step noise is ONE field in every kernel: no kernel that runs Box-Muller (v_sin_f32) may round the product straight
+    # to fp16 (v_fma_mix{lo,hi}_f16 = a single rounding; the other kernels round to fp32 first) -- csrc/common.h bm_pair
+    parts = re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", asm)
+    noisy = [(n, b) for n, b in zip(parts[1::2], parts[2::2]) if "v_sin_f32" in b and ("latent_step" in n or "conv_out" in n or "step_noise" in n)]
+    assert len(noisy) >= 6, [n for n, _ in noisy]
+    for n, b in noisy:
+        assert "v_fma_mixlo_f16" not in b and "v_fma_mixhi_f16" not in b, n
