@@ -160,9 +160,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    failed = [(cmd, pr.returncode) for cmd, pr in procs if pr.wait() != 0]   # every compile has finished before anything is raised
+    if failed:
+        raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))

@@ -86,30 +86,6 @@ def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise
 
 
 # ----------------------------------------------------------------------------------------- Enhancer
-def enhancer_forward(enh, x):
-    """Differentiable torch restatement of Enhancer.forward (enhancer.py:367-383, :346-357, :222-250, :315-333) -- used by the
-    tests to check the HIP backward; the product path below does not call it."""
-    b1, sa = enh.block_1, enh.split_attn
-    B, C, H, W = x.shape
-    tok = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
-    tok = tok + F.layer_norm(tok, (C,), b1.norm1.weight, b1.norm1.bias, 1e-5)
-    z = F.layer_norm(tok, (C,), b1.norm2.weight, b1.norm2.bias, 1e-5)
-    m = b1.mlp
-    dc = C // 4
-    zi = z.transpose(1, 2).reshape(B, C, H, W)
-    zi = torch.cat([F.conv2d(zi[:, :dc], m.partial_conv3.weight, None, padding=1), zi[:, dc:]], dim=1)
-    hdn = F.gelu(F.linear(zi.reshape(B, C, H * W).transpose(1, 2), m.linear1[0].weight, m.linear1[0].bias))
-    h1, h2 = hdn.chunk(2, dim=-1)
-    hid = h1.shape[-1]
-    h1 = F.gelu(F.conv2d(h1.transpose(1, 2).reshape(B, hid, H, W), m.dwconv[0].weight, m.dwconv[0].bias, padding=1, groups=hid))
-    tok = tok + F.linear(h1.reshape(B, hid, H * W).transpose(1, 2) * h2, m.linear2[0].weight, m.linear2[0].bias)
-    s = tok.view(B, H, W, C)
-    g = F.linear(s.mean((1, 2), keepdim=True), sa.fc1.weight)
-    g = F.relu(F.layer_norm(g, (C,), sa.bn1.weight, sa.bn1.bias, 1e-5))
-    a = torch.sigmoid(F.linear(g, sa.fc2.weight))
-    return (s * a).permute(0, 3, 1, 2).contiguous()
-
-
 class EnhancerFunction(torch.autograd.Function):
     """HIP forward (gencomm_enhancer_fwd, the fused inference kernels) and a backward composed of HIP primitives
     (gencomm_amd/train_ops.py): the stage is recomputed layer by layer in NCHW with the exact-fp32 general convolution
@@ -189,22 +165,6 @@ class EnhancerFunction(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------- fusion
-def att_fusion_forward(xx, lens: List[int], affine_matrix):
-    """Differentiable torch restatement of warp + ego-row attention (fusion_in_one.py:131-151) -- used by the tests to check
-    the HIP backward; the product path below does not call it."""
-    _, C, H, W = xx.shape
-    out, o = [], 0
-    for b, n in enumerate(lens):
-        M = affine_matrix[b][0, :n].to(xx.device)
-        grid = F.affine_grid(M, [n, C, H, W], align_corners=False).to(xx)
-        x = F.grid_sample(xx[o:o + n], grid, align_corners=False)
-        x = x.view(n, C, -1).permute(2, 0, 1)
-        score = torch.bmm(x[:, :1], x.transpose(1, 2)) / math.sqrt(C)   # ego row only
-        out.append(torch.bmm(F.softmax(score, -1), x)[:, 0].permute(1, 0).view(C, H, W))
-        o += n
-    return torch.stack(out)
-
-
 class AttFusionFunction(torch.autograd.Function):
     """HIP forward (gencomm_warp_attfuse_fwd) and HIP backward (gencomm_warp_attfuse_bwd: softmax / dot-product backward
     per pixel + the bilinear gather's adjoint with float atomics)."""

@@ -136,7 +136,7 @@ class _ConvBnTrainFn(torch.autograd.Function):
 
 class _Conv2dHipFn(torch.autograd.Function):
     """act(BN_eval(conv(x))) with gradients: HIP forward; HIP backward (dgrad / wgrad kernels; stride-2 and transposed convolutions
-    included) -- the differentiable torch expression of the layer is only the fallback for shapes `_conv_backward` does not cover.
+    included); a shape the HIP backward does not cover raises (no torch / MIOpen fallback).
     Gradients reach the input and the conv / BatchNorm-affine parameters: the graph is never cut."""
 
     @staticmethod
@@ -156,15 +156,10 @@ class _Conv2dHipFn(torch.autograd.Function):
         if hip is not None:
             dx, grads = hip
             return (dx, None, None, None, None, *[grads.get(p) if p.requires_grad else None for p in params])
-        with torch.enable_grad():
-            xd = x.detach().requires_grad_(True)
-            yy = _torch_expr(xd, ctx.conv, ctx.bn, ctx.relu, ctx.pad)
-            wanted = [xd] + [p for p in params if p.requires_grad]
-            grads = torch.autograd.grad(yy, wanted, gy.contiguous(), allow_unused=True)
-        gx = grads[0] if ctx.needs_input_grad[0] else None
-        it = iter(grads[1:])
-        gp = [next(it) if p.requires_grad else None for p in params]
-        return (gx, None, None, None, None, *gp)
+        # no torch / MIOpen fallback in the product path: a layer shape the HIP backward does not cover is an error
+        raise NotImplementedError(
+            f"HIP backward of this convolution is not implemented ({type(ctx.conv).__name__} kernel {tuple(ctx.conv.kernel_size)} stride "
+            f"{tuple(ctx.conv.stride)}); covered: 1x1 / 3x3 stride 1, 3x3 stride 2, ConvTranspose2d with kernel == stride")
 
 
 def _stride1_view(conv: nn.Conv2d) -> nn.Conv2d:
@@ -235,7 +230,9 @@ def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = 
     l = _lib.lib()
     st = stream_ptr(x.device)
     bnp = (bn.weight, bn.bias, bn.running_mean, bn.running_var) if bn is not None else (None,) * 4
-    key = _versions(w, conv.bias, *bnp) + (str(x.device),)
+    # num_batches_tracked is part of the key: the HIP training kernels update running_mean / running_var through raw pointers, which
+    # does not bump those tensors' versions -- the counter is incremented by a torch op on the same paths (train_ops.bn2d_train_fwd)
+    key = _versions(w, conv.bias, *bnp, getattr(bn, "num_batches_tracked", None)) + (str(x.device),)
     cache = getattr(conv, "_gc_cache", None)
     if cache is None or cache[0] != key:
         wd = f32c(w.detach())

@@ -147,12 +147,14 @@ class GenComm(nn.Module):
         return out
 
     def _needs_grad(self, *tensors) -> bool:
-        """The autograd path (explicit noise tensors, recompute backward) is taken only when something can receive a gradient:
-        a differentiable input, or -- in training mode -- a trainable denoiser parameter. An eval-mode module called with
-        plain inputs outside ``torch.no_grad()`` still runs the allocation-free HIP-only path."""
+        """The autograd path (explicit noise tensors, HIP backward) is taken whenever something can receive a gradient: grad mode is
+        on and an input or a denoiser parameter requires grad -- in eval mode too (the reference's eval branch is differentiable,
+        cond_diff.py:361-381; fine-tuning the denoiser under ``model.eval()`` gets its gradients). Inference runs under
+        ``torch.no_grad()`` (as the reference's callers do, inference.py:135, train.py:177) or with frozen parameters and takes the
+        allocation-free HIP-only path."""
         if not torch.is_grad_enabled():
             return False
-        return any(t.requires_grad for t in tensors) or (self.training and any(p.requires_grad for p in self.denoiser.parameters()))
+        return any(t.requires_grad for t in tensors) or any(p.requires_grad for p in self.denoiser.parameters())
 
     def _run(self, feat, cond, src_rows, noise, seed) -> torch.Tensor:
         """HIP forward; when gradients are required, the chain of per-step HIP UNet calls with HIP backward

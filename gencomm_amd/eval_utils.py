@@ -24,6 +24,9 @@ def _to_numpy(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
 
+_IOU_MEMO: dict = {}   # last (a, b) -> IoU matrix
+
+
 def _signed_area(p: np.ndarray) -> np.ndarray:
     """p [..., K, 2] -> signed area [...]."""
     x, y = p[..., 0], p[..., 1]
@@ -38,12 +41,19 @@ def quad_iou_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     out = np.zeros((len(a), len(b)), dtype=np.float64)
     if len(a) == 0 or len(b) == 0:
         return out
+    # one frame is scored at three IoU thresholds (inference.py:171-185): the matrix is computed once per (a, b)
+    memo_key = (a.tobytes(), b.tobytes())
+    if _IOU_MEMO.get("key") == memo_key:
+        return _IOU_MEMO["iou"].copy()
     sa, sb = _signed_area(a), _signed_area(b)
     a = np.where((sa < 0)[:, None, None], a[:, ::-1], a)   # counter-clockwise
     b = np.where((sb < 0)[:, None, None], b[:, ::-1], b)
     area_a, area_b = np.abs(sa), np.abs(sb)
+    # only pairs whose axis-aligned bounding boxes overlap can intersect (the clip below is a Python loop per pair)
+    amin, amax, bmin, bmax = a.min(1), a.max(1), b.min(1), b.max(1)
+    cand = np.all((amin[:, None, :] <= bmax[None, :, :]) & (bmin[None, :, :] <= amax[:, None, :]), axis=-1)
     for j in range(len(b)):
-        for i in range(len(a)):
+        for i in np.nonzero(cand[:, j])[0]:
             poly = a[i]
             for e in range(4):
                 p0, p1 = b[j, e], b[j, (e + 1) % 4]
@@ -62,6 +72,7 @@ def quad_iou_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
             inter = abs(float(_signed_area(poly))) if len(poly) >= 3 else 0.0
             union = area_a[i] + area_b[j] - inter
             out[i, j] = inter / union if union > 0 else 0.0
+    _IOU_MEMO["key"], _IOU_MEMO["iou"] = memo_key, out.copy()
     return out
 
 

@@ -48,44 +48,6 @@ class BEVDeformableExtractor(nn.Module):
                                   nn.Conv2d(32, 64, kernel_size=1), nn.Sigmoid())
 
 
-def _deform_conv3x3_torch(x, offset, weight, bias):
-    """Differentiable restatement of the 3x3 / padding-1 deformable convolution (DCNv1 as torchvision defines it: offset
-    channel 2k / 2k+1 = vertical / horizontal displacement of tap k, bilinear sampling, zero outside the map) with torch
-    gathers. DIAGNOSTIC ONLY (tools/diag_msgext_bwd.py checks the HIP backward pieces against its autograd): neither the
-    forward nor the backward of the module calls it."""
-    n, C, H, W = x.shape
-    O = weight.shape[0]
-    ys = torch.arange(H, dtype=x.dtype, device=x.device).view(1, H, 1)
-    xs = torch.arange(W, dtype=x.dtype, device=x.device).view(1, 1, W)
-    xf = x.reshape(n, C, H * W)
-    out = x.new_zeros(n, O, H, W)
-    wk = weight.reshape(O, C, 9)
-    for k in range(9):
-        py = ys - 1 + (k // 3) + offset[:, 2 * k]
-        px = xs - 1 + (k % 3) + offset[:, 2 * k + 1]
-        inside = (py > -1) & (py < H) & (px > -1) & (px < W)
-        y0, x0 = torch.floor(py), torch.floor(px)
-        ly, lx = py - y0, px - x0
-        val = 0
-        for yy, xx, wgt in ((y0, x0, (1 - ly) * (1 - lx)), (y0, x0 + 1, (1 - ly) * lx), (y0 + 1, x0, ly * (1 - lx)), (y0 + 1, x0 + 1, ly * lx)):
-            ok = (inside & (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)).to(x.dtype)
-            idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long().view(n, 1, H * W).expand(n, C, H * W)
-            val = val + torch.gather(xf, 2, idx).view(n, C, H, W) * (wgt * ok).unsqueeze(1)
-        out = out + torch.einsum("oc,nchw->nohw", wk[:, :, k], val)
-    return out + bias.view(1, O, 1, 1)
-
-
-def _extractor_torch(x, ow, ob, dw, db, f0w, f0b, f2w, f2b, a1w, a1b, a3w, a3b):
-    """BEVDeformableExtractor.forward (message_extractor_v2.py:103-118) in differentiable torch ops (diagnostic only)."""
-    import torch.nn.functional as F
-    off = F.conv2d(x, ow, ob, padding=1)
-    b1 = _deform_conv3x3_torch(x, off, dw, db)
-    g = b1.mean((2, 3), keepdim=True)
-    g = torch.sigmoid(F.conv2d(F.relu(F.conv2d(g, a1w, a1b)), a3w, a3b))
-    h = F.relu(F.conv2d(b1 * g, f0w, f0b))
-    return F.conv2d(h, f2w, f2b)
-
-
 class _MsgExtFn(torch.autograd.Function):
     """HIP forward (gencomm_msgext_fwd, the fused inference kernels) and a backward composed of HIP primitives
     (gencomm_amd/train_ops.py) -- stage 2 of the reference trains exactly this module (stage2.py:99-101) with every other

@@ -59,7 +59,10 @@ class _SparseConvBase(nn.Module):
     def prepared(self, bn: nn.BatchNorm1d, device):
         """(kernel-layout weights, folded BatchNorm scale / shift), cached per parameter version."""
         bnp = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
-        key = tuple(t._version for t in (self.weight,) + bnp) + tuple(t.data_ptr() for t in (self.weight,) + bnp) + (str(device),)
+        # num_batches_tracked: the HIP training kernels move the running statistics through raw pointers (no version bump on them)
+        nbt = bn.num_batches_tracked
+        key = tuple(t._version for t in (self.weight,) + bnp) + tuple(t.data_ptr() for t in (self.weight,) + bnp) \
+            + ((nbt.data_ptr(), nbt._version) if nbt is not None else None, str(device))
         cache = getattr(self, "_gc_cache", None)
         if cache is None or cache[0] != key:
             l, st = _lib.lib(), stream_ptr(device)

@@ -11,7 +11,7 @@ attentions (``gencomm_win_attn_fwd``). What is left to torch is elementwise glue
 gate on [n, C] vectors). As GenComm's shells call it (fusion_in_one.py:383-401): prior encoding all zero -- every agent has
 type 0, no relative temporal encoding -- and the identity spatial correction, for which STTF resamples every map at its own
 pixel centres (identity). Padded agents are not materialised: the reference masks their attention columns, and their rows
-never reach a real agent. Inference only: calling it with gradients enabled on a differentiable input raises.
+never reach a real agent. With gradients enabled the call goes through ``v2xvit_bwd.V2XViTFunction`` (HIP forward + HIP backward).
 """
 from __future__ import annotations
 

@@ -148,7 +148,7 @@ def test_enhancer_backward_hip_vs_torch_autograd(C, H, W, rl):
     """EnhancerFunction.backward (LayerNorm / conv / depthwise / GELU gradient kernels, gencomm_amd/train_ops.py) against
     torch autograd through the differentiable restatement of the stage: input gradient and every live parameter gradient."""
     from gencomm_amd import Enhancer, normalize_pairwise_tfm, synth
-    from gencomm_amd.autograd import enhancer_forward
+    from torch_restatements import enhancer_forward
     enh = Enhancer(C, [8, 8], 4).to(DEV)
     synth.fill_params_(enh, 3 + C)
     inp = synth.make_inputs(rl, C, H, W, 4)
@@ -175,7 +175,7 @@ def test_fusion_backward_hip_vs_torch_autograd(C, H, W, rl, shift):
     """gencomm_warp_attfuse_bwd (softmax / dot-product backward + the bilinear gather's adjoint) against torch autograd through
     affine_grid + grid_sample + softmax attention, with agents partly and wholly out of range."""
     from gencomm_amd import AttFusion, normalize_pairwise_tfm, synth
-    from gencomm_amd.autograd import att_fusion_forward
+    from torch_restatements import att_fusion_forward
     inp = synth.make_inputs(rl, C, H, W, 9, max_shift=shift)
     affine = normalize_pairwise_tfm(torch.from_numpy(inp["pairwise_t_matrix"]), H * 0.8, W * 0.8, 1)
     x = torch.from_numpy(inp["feat"]).to(DEV).requires_grad_(True)

@@ -170,7 +170,7 @@ def test_training_gradients_match_reference():
 
 def test_enhancer_and_fusion_gradients_flow():
     from gencomm_amd import AttFusion, Enhancer, normalize_pairwise_tfm, synth
-    from gencomm_amd.autograd import att_fusion_forward, enhancer_forward
+    from torch_restatements import att_fusion_forward, enhancer_forward
     C, H, W, rl = 16, 12, 20, [2, 1]
     enh = Enhancer(C, [8, 8], 4).to(DEV)
     synth.fill_params_(enh, 3)

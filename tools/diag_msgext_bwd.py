@@ -5,7 +5,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch, torch.nn.functional as F
 from gencomm_amd import MessageExtractorv2, synth, train_ops as T
-from gencomm_amd.message_extractor import _deform_conv3x3_torch, _extractor_torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from torch_restatements import deform_conv3x3_torch as _deform_conv3x3_torch, extractor_torch as _extractor_torch
 C, H, W, n = 128, 32, 48, 1
 me = MessageExtractorv2(C, 2).train(); synth.fill_params_(me, 41)
 with torch.no_grad():
