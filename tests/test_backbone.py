@@ -246,3 +246,31 @@ def test_split_conv_kernels_hold_fp32_grade_accuracy_over_the_whole_input_range(
             assert torch.isfinite(got).all(), (case, mode)
             worst = float(((got - ref).abs() / mag).max())
             assert worst <= 4e-6, (case, "split" if mode == 0 else "exact fp32", worst)
+
+
+@pytest.mark.gpu
+def test_eval_fold_cache_follows_running_statistics_moved_by_the_hip_training_kernels():
+    """eval forward (builds the folded scale / shift cache) -> train-mode forward under no_grad (the HIP kernel moves
+    running_mean / running_var through raw pointers, no parameter changes) -> eval forward must use the NEW statistics."""
+    import torch.nn as nn
+    from gencomm_amd.bev_backbone import conv2d_hip
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    conv = nn.Conv2d(16, 32, 3, padding=1, bias=False).to(dev)
+    bn = nn.BatchNorm2d(32, eps=1e-3, momentum=0.01).to(dev)
+    ref_conv, ref_bn = nn.Conv2d(16, 32, 3, padding=1, bias=False).to(dev), nn.BatchNorm2d(32, eps=1e-3, momentum=0.01).to(dev)
+    ref_conv.load_state_dict(conv.state_dict())
+    x = torch.randn(2, 16, 24, 40, device=dev) * 3 + 1
+
+    def both(train):
+        for m in (conv, bn, ref_conv, ref_bn):
+            m.train(train)
+        with torch.no_grad():
+            return conv2d_hip(x, conv, bn, relu=True), torch.relu(ref_bn(ref_conv(x)))
+
+    for train in (False, True, False, True, True, False):
+        got, want = both(train)
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), (train, float((got - want).abs().max()))
+    assert torch.allclose(bn.running_mean, ref_bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var, ref_bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 3
