@@ -6,13 +6,21 @@
 // v_fma) -- so conv8_kernel's 576 MFMAs and ~700 VALU instructions per tile-wave simply add up.  The f16/bf16
 // matrix pipe is separate (an MFMA holds the vector issue port for 8 of its 16 cycles) and 16x faster per MAC.
 //
-// Arithmetic: every fp32 operand x is split EXACTLY into x = hi + lo + e with hi = fp16(x), lo = fp16(x - hi),
-// |e| <= 2^-22 |x| (the residual x - hi is exact in fp32).  A product is formed as hi*hi' + hi*lo' + lo*hi'
-// (three v_mfma_f32_16x16x32_f16, each fp16 x fp16 product exact, fp32 accumulation); the dropped lo*lo' term is
-// <= 2^-22 |x||w|.  Relative error of a product <= 3 * 2^-22 = 7e-7 (fp32 FMA: 6e-8): the same parity tolerance
-// (rtol 1e-4 / atol 1e-5 vs the fp32 oracle) is met with the same margin as the exact kernels' reordering error.
-// Weights are pre-scaled by a power of two so that their low parts stay normal fp16 numbers (unscaled in the
-// epilogue, exact).  GENCOMM_CONV8=f32 selects the exact-fp32 conv8_kernel instead (unet_host.h).
+// Arithmetic (round 3: every operand carries all 24 bits of its fp32 value).  An activation x is split EXACTLY into three
+// terms x = hi + lo + t: hi = fp16(x), lo = fp16(x - hi), t = x - hi - lo (each difference is exact in fp32; t is 0 or
+// +-1 unit in the last place of x, i.e. a power of two, because two 11-bit terms and the sign of lo cover 23 of the 24
+// bits).  hi and lo live in fp16 planes of the LDS tile, t -- scaled by 2^20 -- in a bf8 (e5m2) plane, where a power of
+// two is exact.  A weight w (pre-scaled by a power of two so that the largest lies in [2^13, 2^14)) is split the same way
+// into three fp16 terms w1 + w2 + w3 (exact) and additionally rounded once to bf8, wb = bf8(w 2^-20).  A product block is
+// SIX matrix instructions into the same fp32 accumulators:
+//     hi w1 + lo w1 + hi w2 + lo w2 + hi w3        (five v_mfma_f32_16x16x32_f16: every fp16 x fp16 product exact)
+//   + t  wb                                        (one v_mfma_f32_16x16x32_bf8_bf8: the 2^-23-sized term to 3 bits)
+// The terms left out are lo w3, t w2, t w3 (<= 2^-33 |x w|) and the bf8 rounding of w in the last one
+// (2^-23 * 2^-3 = 2^-26 |x w|): a product is accurate to 2^-26 -- finer than the 2^-24 rounding of the fp32 accumulation
+// that the reference's own arithmetic has.  Round 2 used three instructions (hi w1 + lo w1 + hi w2) on two-term splits:
+// 2^-22 |x w| per product, "22-bit products".  Ranges: |x| < 65504 (range guard, common.h); t is carried for
+// |x| >= 2^-12 (below: absolute error <= 2^-36 per product), w3 for |w| >= 2^-14 max|w|.
+// GENCOMM_MODE_ARITH = 1 selects the exact-fp32 conv8_kernel instead (unet_host.h).
 //
 // Mapping (one workgroup = 64x16 output pixels, 4 waves, wave w = rows 4w..4w+3):
 //   MFMA M = 16 = 8 output channels x 2 vertically adjacent output rows (r = 0, 1),
@@ -26,6 +34,7 @@
 //   8 channels) writes one 16-B record per pixel, again 256 contiguous bytes per 16 lanes.
 #pragma once
 #include "unet_kernels.h"
+#include "unet_plan.h"
 
 namespace gc {
 
@@ -38,7 +47,14 @@ constexpr int HC_SLOTS = 18;
 constexpr int HC_PHASE = HC_SLOTS * 16;  // bytes
 constexpr int HC_ROW = 4 * HC_PHASE;     // 1152
 constexpr int HC_PLANE = HC_LH * HC_ROW; // 20736: hi plane, then lo plane
-constexpr int HC_WTAB = 3 * 2 * 64 * 4;  // dwords of one prepared 8-input-channel weight table (+ 64 for the scale)
+constexpr int HC_WTAB = 3 * 2 * 64 * 4;  // dwords of one prepared two-term 8-input-channel weight table (+ 64 for the scale)
+// three-term tables (conv8h_kernel): per tap group c: [term 3][lane 64][4 dwords] fp16, then [lane 64][2 dwords] bf8
+constexpr int HC_WC3 = 3 * 64 * 4 + 64 * 2;  // 896 dwords per tap group
+constexpr int HC_WTAB3 = 3 * HC_WC3;         // 2688 dwords per 8-input-channel source (+ 64 floats for the scale after the last)
+static_assert(HC_WTAB3 == kWtab3, "unet_plan.h sizes the prepared blob with kWtab3");
+constexpr int HC_TPLANE = HC_PLANE / 2;      // 10368 bytes: the bf8 third-term plane (8-byte pixel records, same pixel order)
+constexpr int HC_TOFF = 2 * HC_PLANE;        // its byte offset in the tile
+constexpr float HC_TSCALE = 1048576.0f;      // 2^20: t is stored as bf8(t 2^20), the bf8 weight as bf8(w 2^-20)
 
 // exact two-term fp16 split of a pair of floats: hi = rne16(x), lo = rne16(x - hi)
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -53,6 +69,26 @@ __device__ __forceinline__ void split_one(float a, uint16_t& hi, uint16_t& lo) {
   const _Float16 l = (_Float16)(a - (float)h);
   hi = __builtin_bit_cast(uint16_t, h);
   lo = __builtin_bit_cast(uint16_t, l);
+}
+
+// exact three-term split of a pair: hi / lo packed fp16 pairs, ta / tb = the third terms scaled by 2^20 (see the header)
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& hi, uint32_t& lo, float& ta, float& tb) {
+  const half2_t h = __builtin_convertvector((float2_t){a, b}, half2_t);
+  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  const half2_t l = __builtin_convertvector((float2_t){ra, rb}, half2_t);
+  ta = (ra - (float)l[0]) * HC_TSCALE;
+  tb = (rb - (float)l[1]) * HC_TSCALE;
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+// two / four scaled third terms -> bf8 bytes (v_cvt_pk_bf8_f32: OCP e5m2, round to nearest even; powers of two are exact)
+__device__ __forceinline__ uint32_t bf8x2(float a, float b) {
+  return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t bf8x4(float a, float b, float c, float d) {
+  int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+  return (uint32_t)v;
 }
 
 __device__ __forceinline__ int hc_addr(int row, int px /* -1 .. 64 */) {
@@ -109,9 +145,57 @@ __device__ __forceinline__ void hc_store_halo(unsigned char* tile, int tid, floa
   *reinterpret_cast<uint32_t*>(tile + LO + addr) = lo;
 }
 
+// ---- three-term writers (hi / lo fp16 planes + bf8 third-term plane at HC_TOFF, 8-byte records at half the byte offsets) ----
+__device__ __forceinline__ void hc_store_main3(unsigned char* tile, int r0, int qx, const float (&e)[8][4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint4 hi, lo;
+    float t[8];
+    split3_pair(e[0][j], e[1][j], hi.x, lo.x, t[0], t[1]);
+    split3_pair(e[2][j], e[3][j], hi.y, lo.y, t[2], t[3]);
+    split3_pair(e[4][j], e[5][j], hi.z, lo.z, t[4], t[5]);
+    split3_pair(e[6][j], e[7][j], hi.w, lo.w, t[6], t[7]);
+    const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
+    *reinterpret_cast<uint4*>(tile + addr) = hi;
+    *reinterpret_cast<uint4*>(tile + HC_PLANE + addr) = lo;
+    *reinterpret_cast<uint2*>(tile + HC_TOFF + (addr >> 1)) = make_uint2(bf8x4(t[0], t[1], t[2], t[3]), bf8x4(t[4], t[5], t[6], t[7]));
+  }
+}
+// rows 16, 17 (thread = one channel's quad, lane ^ 32 = the other channel of the pair; see hc_store_rem): the pair's two
+// bf8 bytes of a pixel are one 16-bit store, written by ONE lane (different lanes of an instruction never share a dword)
+__device__ __forceinline__ void hc_store_rem3(unsigned char* tile, int tid, const float (&e)[4]) {
+  const int cr = tid >> 5, rr = HC_TH + ((tid >> 4) & 1), qx = tid & 15;
+  const bool odd = (cr & 1) != 0;
+  const float s0 = odd ? e[0] : e[2], s1 = odd ? e[1] : e[3];
+  const float p0 = __shfl_xor(s0, 32, 64), p1 = __shfl_xor(s1, 32, 64);
+  const float m0 = odd ? e[2] : e[0], m1 = odd ? e[3] : e[1];
+  const int jb = odd ? 2 : 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float mine = k ? m1 : m0, theirs = k ? p1 : p0;
+    uint32_t hi, lo;
+    float ta, tb;
+    split3_pair(odd ? theirs : mine, odd ? mine : theirs, hi, lo, ta, tb);  // low half = even channel
+    const int addr = rr * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4;
+    *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+    *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
+    *reinterpret_cast<uint16_t*>(tile + HC_TOFF + (addr >> 1)) = (uint16_t)bf8x2(ta, tb);
+  }
+}
+__device__ __forceinline__ void hc_store_halo3(unsigned char* tile, int tid, float e0, float e1) {
+  const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
+  uint32_t hi, lo;
+  float ta, tb;
+  split3_pair(e0, e1, hi, lo, ta, tb);
+  const int addr = hc_addr(r, side ? HC_TW : -1) + cp * 4;
+  *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+  *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
+  *reinterpret_cast<uint16_t*>(tile + HC_TOFF + (addr >> 1)) = (uint16_t)bf8x2(ta, tb);
+}
+
 // GroupNorm+SiLU (GN) or a plain scale (!GN), split, and write this thread's share of the tile (registers filled by
 // stage_load / halo_load_h).
-template <bool GN>
+template <bool GN, bool T3 = false>
 __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileRegs<HC_TW, HC_TH, HC_NT, 8>& R,
                                               float2 hreg, int H, int W, int x0, int y0, const float (*ab)[2], int tid,
                                               float mul = 1.0f) {
@@ -134,7 +218,8 @@ __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileReg
         for (int j = 0; j < 4; ++j) e[c][j] *= mul;
       }
     }
-    hc_store_main<HC_PLANE>(tile, r0, qx, e);
+    if constexpr (T3) hc_store_main3(tile, r0, qx, e);
+    else hc_store_main<HC_PLANE>(tile, r0, qx, e);
   }
   {
     const int cr = tid >> 5, rr = TR::RPP + ((tid >> 4) & 1), qx = tid & 15;
@@ -149,7 +234,8 @@ __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileReg
 #pragma unroll
       for (int j = 0; j < 4; ++j) e[j] *= mul;
     }
-    hc_store_rem<HC_PLANE>(tile, tid, e);
+    if constexpr (T3) hc_store_rem3(tile, tid, e);
+    else hc_store_rem<HC_PLANE>(tile, tid, e);
   }
   if (tid < HC_LH * 8) {
     const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
@@ -163,7 +249,8 @@ __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileReg
       e0 *= mul;
       e1 *= mul;
     }
-    hc_store_halo<HC_PLANE>(tile, tid, e0, e1);
+    if constexpr (T3) hc_store_halo3(tile, tid, e0, e1);
+    else hc_store_halo<HC_PLANE>(tile, tid, e0, e1);
   }
 }
 
@@ -186,7 +273,7 @@ __device__ __forceinline__ float2 halo_load_h(const float* __restrict__ sp, unsi
 }
 
 // Slow path for widths that are not a multiple of 4 (tests only): one element at a time.
-template <bool GN, bool UP>
+template <bool GN, bool UP, bool T3 = false>
 __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ tile, const float* __restrict__ sp, unsigned plane_in,
                                                  int Win, int H, int W, int x0, int y0, const float (*ab)[2], int tid,
                                                  float mul = 1.0f) {
@@ -207,6 +294,10 @@ __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ til
     const int addr = hc_addr(r, col - 1) + c * 2;
     *reinterpret_cast<uint16_t*>(tile + addr) = hi;
     *reinterpret_cast<uint16_t*>(tile + HC_PLANE + addr) = lo;
+    if constexpr (T3) {
+      const float t = ((e - (float)__builtin_bit_cast(_Float16, hi)) - (float)__builtin_bit_cast(_Float16, lo)) * HC_TSCALE;
+      tile[HC_TOFF + (addr >> 1)] = (unsigned char)(bf8x2(t, 0.f) & 0xffu);
+    }
   }
 }
 
@@ -273,6 +364,82 @@ __device__ __forceinline__ void conv_tile_mfma_h(const unsigned char* tile, cons
   }
 }
 
+// Three-term form (see the header): six matrix instructions per product block.  tab = the prepared table of this 8-channel
+// source (prep_conv8h_kernel): the A operands of tap group c + 1 are requested while group c is on the matrix pipe (the
+// tables are a few KB shared by every workgroup: cache hits), so only two groups' worth of operand registers are live.
+struct WA3 {
+  half8_t w[3];
+  long wb;
+};
+__device__ __forceinline__ void load_wa3(WA3& o, const float* __restrict__ tab, int c, int lane) {
+  const float* __restrict__ t = tab + c * HC_WC3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o.w[k] = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(t + (k * 64 + lane) * 4));
+  o.wb = *reinterpret_cast<const long*>(t + 768 + lane * 2);
+}
+// DIAG (unit-test instantiation only): `mask` selects which of the six terms are issued -- bit 0 hi w1, 1 lo w1, 2 hi w2,
+// 3 lo w2, 4 hi w3, 5 t wb -- so that every operand plane and table is checked on its own (tests/test_gpu_conv8.py).
+template <bool DIAG = false>
+__device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const float* __restrict__ tab, f32x4 (&acc)[2][4],
+                                                const int (&off)[4][3], int lane, int mask = 63) {
+  // ORDER MATTERS.  On gfx950 a v_mfma_f32_16x16x32_f16 issued fewer than 6 wait states after a v_mfma_f32_16x16x32_bf8_bf8
+  // whose result it accumulates onto (or the other way round) reads a STALE half of the accumulator: the hardware forwards
+  // SrcC only between matrix instructions of one input type, hipcc (ROCm 7.2) assumes it always does and schedules such a
+  // pair back to back (tools/probes/mfma_mixed_dep_probe.hip: half of the results wrong at 0..4 wait states, none from 6;
+  // in this kernel it showed as a lost bias on two of an accumulator's four registers).  Per tap group the two row pairs'
+  // bf8 instructions therefore come first, as two fenced passes, then the f16 passes of row pair 0, then those of row pair 1:
+  // whatever order hipcc picks INSIDE a pass, at least four matrix instructions (16 wait states) lie between instructions of
+  // different type on the same registers.  tests/test_abi.py checks the code object for violations.
+  WA3 cur, nxt;
+  load_wa3(cur, tab, 0, lane);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (c < 2) load_wa3(nxt, tab, c + 1, lane);
+    long bt[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bt[p][j] = *reinterpret_cast<const long*>(tile + HC_TOFF + ((off[j][c] + p * 2 * HC_ROW) >> 1));
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (!DIAG || (mask & 32))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(cur.wb, bt[p][j], acc[p][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      half8_t bh[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = off[j][c] + p * 2 * HC_ROW;
+        bh[j] = *reinterpret_cast<const half8_t*>(tile + o);
+        bl[j] = *reinterpret_cast<const half8_t*>(tile + HC_PLANE + o);
+      }
+      // passes of four independent accumulators, the small terms first so that they meet before they meet the large ones
+      if (!DIAG || (mask & 16))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[2], bh[j], acc[p][j], 0, 0, 0);
+      if (!DIAG || (mask & 8))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[1], bl[j], acc[p][j], 0, 0, 0);
+      if (!DIAG || (mask & 4))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[1], bh[j], acc[p][j], 0, 0, 0);
+      if (!DIAG || (mask & 2))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[0], bl[j], acc[p][j], 0, 0, 0);
+      if (!DIAG || (mask & 1))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[0], bh[j], acc[p][j], 0, 0, 0);
+      if (p == 0) __builtin_amdgcn_sched_barrier(0);   // row pair 1's f16 instructions stay behind row pair 0's
+    }
+    if (c < 2) cur = nxt;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // B operand is an fp16 number already (the sampler's step noise): hi plane only, two MFMA passes (w_hi, w_lo).
 __device__ __forceinline__ void conv_tile_mfma_hionly(const unsigned char* tile, const half8_t (&wa)[3][2],
                                                       f32x4 (&acc)[2][4], const int (&off)[4][3]) {
@@ -335,10 +502,10 @@ __device__ __forceinline__ void hc_stats_commit(float (&part)[8], float (*s_red)
   }
 }
 
-template <int NSRC, bool GN, bool UP, int RES>
+template <int NSRC, bool GN, bool UP, int RES, bool DIAG = false>
 __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
-  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
+  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE + HC_TPLANE];  // hi | lo (fp16) | third term (bf8)
   __shared__ float s_ab[16][2];
   __shared__ float s_red[NT / 64][16];
 #ifdef HC_LDS_PAD  // diagnostic builds: inflate the LDS footprint to limit workgroups per CU
@@ -362,8 +529,6 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   const bool wave_live = y0 + 4 * wave < a.H;
 
   GC_STAMP(0);
-  half8_t wa[3][2];
-  if (NSRC == 1) load_wa(wa, a.wh, lane);  // two-source layers: behind the first staging (register pressure)
   // raw (not normalised) input: exact power-of-two range reduction from a device-side bound on max|src| (common.h)
   float mul = 1.0f;
   if (!GN) {
@@ -379,7 +544,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
     }
     mul = act_scale(bound);
   }
-  const float inv_s = a.wh[NSRC * HC_WTAB] / mul;  // one scale for the whole (concatenated) weight tensor
+  const float inv_s = a.wh[NSRC * HC_WTAB3] / mul;  // one scale for the whole (concatenated) weight tensor
   const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + 4 * ch);
   const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
   TileRegs<TW, TH, NT, 8> R;
@@ -403,7 +568,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   // the accumulators start at bias * scale (exact: the scale is a power of two), so the epilogue is one multiply
   f32x4 acc[2][4];
   {
-    const float sc = a.wh[NSRC * HC_WTAB + 1] * mul;
+    const float sc = a.wh[NSRC * HC_WTAB3 + 1] * mul;
     const f32x4 b0 = {bias[0] * sc, bias[1] * sc, bias[2] * sc, bias[3] * sc};
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -411,9 +576,8 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
       for (int j = 0; j < 4; ++j) acc[p][j] = b0;
   }
 
-  if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[0], tid, mul);
-  else stage_tile_scalar_h<GN, UP>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid, mul);
-  if (NSRC == 2) load_wa(wa, a.wh, lane);
+  if (wvec) stage_store_h<GN, true>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[0], tid, mul);
+  else stage_tile_scalar_h<GN, UP, true>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid, mul);
   int off[4][3];
   hc_lane_offsets(off, wave, lane);
   // identity residual: requested once the staging registers are free, so that it arrives during the matrix phase
@@ -440,15 +604,14 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   }
   __syncthreads();
   GC_STAMP(2);
-  if (wave_live) conv_tile_mfma_h<NSRC == 2>(tile, wa, acc, off);
+  if (wave_live) conv_tile_mfma3<DIAG>(tile, a.wh, acc, off, lane, a.term_mask);
   GC_STAMP(3);
   if (NSRC == 2) {
     __syncthreads();
-    if (wvec) stage_store_h<GN>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[8], tid);
-    else stage_tile_scalar_h<GN, UP>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
-    load_wa(wa, a.wh + HC_WTAB, lane);  // behind the staging: 24 fewer live registers while the tile is converted
+    if (wvec) stage_store_h<GN, true>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[8], tid);
+    else stage_tile_scalar_h<GN, UP, true>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
     __syncthreads();
-    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+    if (wave_live) conv_tile_mfma3(tile, a.wh + HC_WTAB3, acc, off, lane);
   }
 
   GC_STAMP(4);
@@ -518,9 +681,11 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   GC_STAMP(6);
 }
 
-// Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 tables of HC_WTAB dwords + 64 floats (1 / scale).
+// Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 three-term tables of HC_WTAB3 dwords + 64 floats (1 / scale, scale).
 // A operand of MFMA c, lane l: row m = l % 16 = (r = m / 8, oc = m % 8), K group l / 16 -> tap t = 4c + l/16 of the 4x3
 // window (window row dyp = t / 3, column dx = t % 3), 8 input channels; tap row of the kernel = dyp - r (zero outside 0..2).
+// Per tap group: fp16 terms w1, w2, w3 of w * scale ([term][lane][4 dwords], channels 2d, 2d+1 in dword d), then the
+// bf8 rounding of w * scale * 2^-20 ([lane][2 dwords], channel k in byte k).
 __global__ __launch_bounds__(256) void prep_conv8h_kernel(const float* __restrict__ w, float* __restrict__ dst, int IC) {
   __shared__ float s_max[256];
   const int tid = threadIdx.x;
@@ -532,30 +697,42 @@ __global__ __launch_bounds__(256) void prep_conv8h_kernel(const float* __restric
     if (tid < s) s_max[tid] = fmaxf(s_max[tid], s_max[tid + s]);
     __syncthreads();
   }
-  // power-of-two scale that puts the largest weight in [2^7, 2^8): low parts stay normal fp16 numbers down to
-  // |w| ~ 2^-13 of the largest weight; all-zero weights -> scale 1
+  // power-of-two scale that puts the largest weight in [2^13, 2^14): the third terms of weights down to 2^-14 of the
+  // largest stay on fp16's 2^-24 grid (exact), the bf8 copies (x 2^-20) of weights down to 2^-7 of it stay normal;
+  // all-zero weights -> scale 1
   const float wmax = s_max[0];
   int ex = 0;
   if (wmax > 0.f) (void)frexpf(wmax, &ex);  // wmax = f * 2^ex, f in [0.5, 1)
-  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 14 - ex) : 1.0f;
   const int nsrc = IC / 8;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(dst);
-  for (int i = tid; i < nsrc * HC_WTAB; i += 256) {
-    const int s = i / HC_WTAB, rem = i - s * HC_WTAB;
-    const int d = rem & 3, l = (rem >> 2) & 63, h = (rem >> 8) & 1, c = rem >> 9;
+  auto weight = [&](int s, int c, int l, int ch) -> float {  // scaled weight of (source s, tap group c, lane l, channel ch)
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
     const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
-    uint16_t v[2];
-    for (int e = 0; e < 2; ++e) {
-      const int ic = s * 8 + 2 * d + e;
-      const float x = (dy >= 0 && dy <= 2) ? w[((oc * IC + ic) * 3 + dy) * 3 + dx] * scale : 0.f;
-      const _Float16 hi = (_Float16)x;
-      const _Float16 lo = (_Float16)(x - (float)hi);
-      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    return (dy >= 0 && dy <= 2) ? w[((oc * IC + s * 8 + ch) * 3 + dy) * 3 + dx] * scale : 0.f;
+  };
+  for (int i = tid; i < nsrc * HC_WTAB3; i += 256) {
+    const int s = i / HC_WTAB3, rem = i - s * HC_WTAB3;
+    const int c = rem / HC_WC3, q = rem - c * HC_WC3;
+    if (q < 768) {
+      const int d = q & 3, l = (q >> 2) & 63, term = q >> 8;
+      uint16_t v[2];
+      for (int e = 0; e < 2; ++e) {
+        const float x = weight(s, c, l, 2 * d + e);
+        const _Float16 w1 = (_Float16)x;
+        const float r1 = x - (float)w1;
+        const _Float16 w2 = (_Float16)r1;
+        const _Float16 w3 = (_Float16)(r1 - (float)w2);
+        v[e] = __builtin_bit_cast(uint16_t, term == 0 ? w1 : term == 1 ? w2 : w3);
+      }
+      out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    } else {
+      const int d = (q - 768) & 1, l = (q - 768) >> 1;
+      const float k = 1.0f / HC_TSCALE;
+      out[i] = bf8x4(weight(s, c, l, 4 * d) * k, weight(s, c, l, 4 * d + 1) * k, weight(s, c, l, 4 * d + 2) * k, weight(s, c, l, 4 * d + 3) * k);
     }
-    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
   }
-  if (tid < 64) dst[nsrc * HC_WTAB + tid] = (tid & 1) ? scale : 1.0f / scale;  // [0] = 1 / scale, [1] = scale
+  if (tid < 64) dst[nsrc * HC_WTAB3 + tid] = (tid & 1) ? scale : 1.0f / scale;  // [0] = 1 / scale, [1] = scale
 }
 
 }  // namespace gc

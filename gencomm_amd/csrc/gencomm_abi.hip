@@ -312,13 +312,13 @@ int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, 
   GC_CHECK_ARG(n >= 1 && n <= 65535 && H >= 1 && W >= 1, "bad n/H/W");
   hipStream_t st = (hipStream_t)stream;
   float* p_w = scratch;            // [8][9][8]
-  float* p_wh = scratch + 1024;    // fp16 hi/lo tables + scale
-  float* p_b = scratch + 3072;     // bias copy (16-B aligned)
+  float* p_wh = scratch + 1024;    // three-term tables + scale (HC_WTAB3 + 64 = 2752 floats)
+  float* p_b = scratch + 3840;     // bias copy (16-B aligned)
   prep_conv_w_kernel<<<cdiv(576, 256), 256, 0, st>>>(w_oihw, p_w, 8, 8, 8);
   prep_conv8h_kernel<<<1, 256, 0, st>>>(w_oihw, p_wh, 8);
   GC_HIP(hipMemcpyAsync(p_b, bias, 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (dstat) GC_HIP(hipMemsetAsync(dstat, 0, (size_t)n * 16 * sizeof(double), st));
-  float* p_amax = scratch + 3088;  // device bound on max|src|: the f16-pipe kernel's range guard
+  float* p_amax = scratch + 3856;  // device bound on max|src|: the f16-pipe kernel's range guard
   GC_HIP(hipMemsetAsync(p_amax, 0, sizeof(float), st));
   amax_kernel<<<256, 256, 0, st>>>(src, (long long)n * 8 * H * W, p_amax);
   const Modes m = modes_snapshot();
@@ -327,6 +327,12 @@ int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, 
   a.H = a.Hin = H; a.W = a.Win = W;
   a.xcd = m.xcd();
   a.amax = p_amax;
+  if (split & 0x100) {  // diagnostic: only the selected terms of the three-term product (64x16 tiles, any map size)
+    a.term_mask = split & 63;
+    conv8h_kernel<1, false, false, 0, true><<<dim3(cdiv(W, 64), cdiv(H, 16), n), 256, 0, st>>>(a);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   launch_conv8<1, false, false, 0>(m, pick_tile(m, n, H, W), a, n, st);
   GC_HIP(hipGetLastError());
   return GC_OK;

@@ -316,6 +316,7 @@ struct Conv8Args {
   int H, W, Hin, Win;
   int xcd;                // 1: XCD-aware workgroup -> tile mapping (common.h xcd_block)
   const float* amax;      // !GN on the f16 pipe: device bound on max|src| (or null: bound from sstat[0], or none)
+  int term_mask;          // diagnostic instantiation of conv8h_kernel only (gencomm_conv8_fwd): which of the six terms run
 };
 
 template <int TW, int TH, int PPL, int NSRC, bool GN, bool UP, int RES>

@@ -12,6 +12,8 @@
 
 namespace gc {
 
+constexpr int kWtab3 = 3 * (3 * 64 * 4 + 64 * 2);  // = HC_WTAB3 (conv8h_kernels.h, static_assert there)
+
 struct ParamEntry {
   std::string name;
   long long numel;
@@ -24,7 +26,7 @@ struct ResBlockPlan {
   long long n1w, n1b, c1w, c1b, tpw, tpb, n2w, n2b, c2w, c2b, ninw, ninb;
   // prepared offsets
   long long p_c1w, p_c2w, p_ninw, p_bias1 /*[T][8]*/, p_bias2 /*[8]*/;
-  long long p_c1wh, p_c2wh;  // fp16 hi/lo A-operand tables (conv8h_kernels.h): cin/8 * 1536 dwords + 64
+  long long p_c1wh, p_c2wh;  // three-term A-operand tables (conv8h_kernels.h): cin/8 * kWtab3 dwords + 64
   long long p_c1wb, p_c2wb;  // bf16 A-operand tables (conv8b_kernels.h): cin/8 * 768 dwords
 };
 
@@ -194,7 +196,7 @@ struct UNetPlan {
     conv_out.p_wh = padd((long long)((C + 15) / 16) * 1536 + 64);
     for (int l = 0; l < L; ++l) {
       if (down[l].w >= 0) down[l].p_w = padd(8 * 8 * 9);
-      if (up[l].w >= 0) { up[l].p_w = padd(8 * 8 * 9); up[l].p_wh = padd(1536 + 64); up[l].p_wb = padd(768); }
+      if (up[l].w >= 0) { up[l].p_w = padd(8 * 8 * 9); up[l].p_wh = padd(kWtab3 + 64); up[l].p_wb = padd(768); }
     }
     p_wc5 = padd(1600); p_wc1 = padd(5184); p_bring = padd(72); p_bsum = padd(8);
     p_wc5h = padd(4096 + 64); p_wxh = padd((long long)(C / 8) * 1536); p_wch = padd(1536);
@@ -204,8 +206,8 @@ struct UNetPlan {
       b.p_ninw = b.cin != 8 ? padd(8LL * b.cin) : -1;
       b.p_bias1 = padd((long long)T * 8);
       b.p_bias2 = padd(8);
-      b.p_c1wh = padd((long long)(b.cin / 8) * 1536 + 64);
-      b.p_c2wh = padd(1536 + 64);
+      b.p_c1wh = padd((long long)(b.cin / 8) * kWtab3 + 64);
+      b.p_c2wh = padd(kWtab3 + 64);
       b.p_c1wb = padd((long long)(b.cin / 8) * 768);
       b.p_c2wb = padd(768);
     }

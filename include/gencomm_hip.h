@@ -138,8 +138,10 @@ int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, 
 
 /* One 8 -> 8 channel 3x3 convolution (pad 1, bias) as the UNet's ResnetBlock / Upsample layers run it
  * (unet.py:52, :99-118), without norm or residual: dst[n,8,H,W] = conv(src[n,8,H,W], w[8,8,3,3]) + bias; dstat (nullable)
- * receives per-(sample, channel) {sum, sum of squares} of dst as [n][8][2] doubles. split != 0: fp16 hi/lo split
- * kernel on 64x16 tiles (conv8h_kernels.h), else the exact-fp32 kernel. scratch >= 4096 floats. Unit-test entry. */
+ * receives per-(sample, channel) {sum, sum of squares} of dst as [n][8][2] doubles. split = 1: the f16-pipe kernel with
+ * exact three-term operand splits on 64x16 tiles (conv8h_kernels.h); 0: the exact-fp32 kernel; 0x100 | mask: diagnostic
+ * instantiation that issues only the selected terms of the six-instruction product (bit 0 hi w1, 1 lo w1, 2 hi w2, 3 lo w2,
+ * 4 hi w3, 5 t wb), so that each operand plane / table is tested alone. scratch >= 4096 floats. Unit-test entry. */
 int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, float* dst, double* dstat,
                       float* scratch, int n, int H, int W, int split, void* stream);
 

@@ -168,3 +168,43 @@ def test_code_object_has_no_packed_fp32_instructions(tmp_path):
     assert len(noisy) >= 6, [n for n, _ in noisy]
     for n, b in noisy:
         assert "v_fma_mixlo_f16" not in b and "v_fma_mixhi_f16" not in b, n
+
+
+def _mfma_hazard_violations(asm):
+    """gfx950 / ROCm 7.2: a matrix instruction that accumulates onto the result of a matrix instruction of ANOTHER input type
+    (bf8 <-> f16) reads a stale half of the accumulator when it issues fewer than 6 wait states later; hipcc assumes SrcC
+    forwarding and places such pairs back to back (tools/probes/mfma_mixed_dep_probe.hip). Returns the offending pairs: a
+    dependent pair of different types with fewer than two other matrix instructions (>= 8 issue cycles) in between."""
+    import re
+    pat = re.compile(r"^\s*(v_mfma_f32_16x16x32_(bf8_bf8|f16|bf16|fp8_fp8|bf8_fp8|fp8_bf8))\s+(v\[\d+:\d+\]),\s*\S+,\s*\S+,\s*(v\[\d+:\d+\]|0)")
+    bad = []
+    for name, body in zip(*(lambda p: (p[1::2], p[2::2]))(re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", asm))):
+        recent = []   # (type, dst) of the matrix instructions issued so far, newest last; cleared by anything that waits long
+        for line in body.split("\n"):
+            m = pat.match(line)
+            if m is None:
+                continue
+            typ, dst, srcc = ("8" if "8" in m.group(2) else "16"), m.group(3), m.group(4)
+            for age, (t0, d0) in enumerate(reversed(recent[-2:])):
+                if d0 == srcc and t0 != typ:
+                    bad.append((name, line.strip(), age))
+            recent.append((typ, dst))
+    return bad
+
+
+def test_code_object_keeps_mixed_type_matrix_instructions_apart(tmp_path):
+    import shutil, subprocess
+    from gencomm_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("llvm-objdump or the built library is not available")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    asm = "\n".join(subprocess.run([objdump, "-d", str(tmp_path / o)], check=True, capture_output=True, text=True).stdout for o in sorted(objs))
+    assert "v_mfma_f32_16x16x32_bf8_bf8" in asm          # the third-term instruction of the three-term products is there
+    bad = _mfma_hazard_violations(asm)
+    assert not bad, bad[:5]
+    # the detector itself: the pair hipcc produced before the order was pinned
+    sample = "\n0000 <k>:\n\tv_mfma_f32_16x16x32_bf8_bf8 v[18:21], v[22:23], v[18:19], v[2:5]\n\tv_mfma_f32_16x16x32_f16 v[18:21], v[36:39], v[58:61], v[18:21]\n"
+    assert len(_mfma_hazard_violations(sample)) == 1

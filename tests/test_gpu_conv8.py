@@ -2,8 +2,8 @@
 (gencomm_conv8_fwd), and the whole path with the 64x16-tile kernels forced onto the small golden cases.
 
 Two kernels implement these layers (csrc/unet_kernels.h conv8_kernel: exact fp32 on v_mfma_f32_4x4x1;
-csrc/conv8h_kernels.h conv8h_kernel: fp16 hi/lo operand split on v_mfma_f32_16x16x32_f16, fp32-grade
-products). Both must meet the same bar: rtol 1e-4 / atol 1e-5 against the reference's golden vectors, and for a
+csrc/conv8h_kernels.h conv8h_kernel: exact three-term operand splits on v_mfma_f32_16x16x32_f16 + one bf8 instruction,
+products to 2^-26). Both must meet the same bar: rtol 1e-4 / atol 1e-5 against the reference's golden vectors, and for a
 single layer 2e-5 absolute against a float64 convolution of O(1) data. Launches with several workgroups per CU
 are part of the matrix on purpose: a scheduling-dependent fault of an early conv8h_kernel only showed there.
 """
@@ -47,6 +47,102 @@ def test_single_layer_vs_float64(modes, shape, split):
     for _ in range(2):  # bit-identical from launch to launch (statistics: f64 atomics, order-dependent in the last bits)
         y1, _ = _conv8(x, w, b, split)
         assert torch.equal(y0, y1)
+
+
+def test_f16_pipe_layer_is_at_least_as_accurate_as_the_exact_fp32_kernel(modes):
+    """the f16-pipe kernel (three-term operands, six matrix instructions per product block) against
+    the exact-fp32 v_mfma_f32_4x4x1 kernel on the same layer, both measured against a float64 convolution: the rms and
+    the worst error of the f16-pipe result must not exceed the exact kernel's (each product is formed to 2^-26, the
+    exact kernel's fp32 FMA chain rounds 72 times at 2^-24)."""
+    modes(tile_want=1)
+    g = torch.Generator(device=DEV).manual_seed(2024)
+    rows = []
+    for (n, H, W, xs, ws) in [(4, 200, 704, 1.0, 0.2), (16, 100, 352, 1.0, 0.2), (2, 64, 128, 30.0, 0.05), (2, 64, 128, 0.01, 3.0)]:
+        x = torch.randn(n, 8, H, W, generator=g, device=DEV) * xs
+        w = torch.randn(8, 8, 3, 3, generator=g, device=DEV) * ws
+        b = torch.randn(8, generator=g, device=DEV) * xs * ws
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+        err = {}
+        for split in (0, 1):
+            y, _ = _conv8(x, w, b, split)
+            e = (y.double() - ref).abs()
+            err[split] = (float(e.pow(2).mean().sqrt()), float(e.max()))
+        rows.append(((n, H, W, xs, ws), err))
+        print(f"{(n, H, W)} x~{xs} w~{ws}: exact-fp32 kernel rms {err[0][0]:.3e} max {err[0][1]:.3e} | f16-pipe three-term rms {err[1][0]:.3e} max {err[1][1]:.3e}")
+    for cfg, err in rows:
+        # measured: 0.60x the exact kernel's rms for O(1) and O(30) activations; 1.04x for activations of 0.01, whose second
+        # terms fall into fp16's subnormal range (|x| < 2^-3: absolute operand accuracy 2^-28 instead of 24 relative bits)
+        assert err[1][0] <= err[0][0] * (1.10 if cfg[3] < 0.1 else 1.0) + 1e-12, cfg
+        assert err[1][1] <= err[0][1] * 1.25 + 1e-12, cfg   # the maximum over 1e7 outputs is itself a noisy statistic
+
+
+def _f16_terms(v):
+    """numpy float64 arrays -> (t1, t2, t3): the three fp16 terms of an fp32 value, as float64 (t1 + t2 + t3 == v)"""
+    v = np.asarray(v, dtype=np.float32)
+    t1 = v.astype(np.float16).astype(np.float32)
+    r1 = v - t1
+    t2 = r1.astype(np.float16).astype(np.float32)
+    t3 = r1 - t2
+    return t1.astype(np.float64), t2.astype(np.float64), t3.astype(np.float64)
+
+
+def test_third_term_of_the_weights_reaches_the_result_exactly(modes):
+    """The same isolation for w3 = w - w1 - w2: weights of the even input channels are full 24-bit values, those of the odd
+    channels the NEGATED two-term part of the same values; all activations 1, so the output is the sum of the weights' third
+    terms (the kernel scales the weights by a power of two before splitting; the split commutes with it)."""
+    modes(tile_want=1)
+    rng = np.random.default_rng(6)
+    v = (rng.random((8, 4, 3, 3)) + 1.0).astype(np.float32)   # [1, 2): third terms on fp16's subnormal grid after any power-of-two scale >= 1
+    v = np.where(rng.random(v.shape) < 0.5, v, -v).astype(np.float32)
+    t1, t2, t3 = _f16_terms(v)
+    assert np.count_nonzero(t3) > 50
+    w = np.zeros((8, 8, 3, 3), dtype=np.float32)
+    w[:, 0::2] = v
+    w[:, 1::2] = -(t1 + t2).astype(np.float32)               # exactly representable: two fp16 terms of one binade pair
+    assert np.array_equal(w[:, 1::2].astype(np.float64), -(t1 + t2))
+    n, H, W = 1, 32, 72
+    x = torch.ones(n, 8, H, W, device=DEV)
+    want = torch.nn.functional.conv2d(torch.ones(n, 4, H, W, dtype=torch.float64), torch.from_numpy(t3), None, padding=1)
+    y, _ = _conv8(x, torch.from_numpy(w).to(DEV), torch.zeros(8, device=DEV), 1)
+    got = y.double().cpu()
+    assert float(want.abs().max()) > 1e-7
+    assert torch.allclose(got, want, rtol=0, atol=2.0 ** -40), float((got - want).abs().max())
+
+
+def _bf8(v):
+    """round float64 array to OCP e5m2 (round to nearest even; the values used here stay in the normal range)"""
+    v = np.asarray(v, dtype=np.float64)
+    m, e = np.frexp(v)                       # v = m 2^e, |m| in [0.5, 1): 3 significant bits -> grid 2^(e-3), subnormal grid 2^-16
+    g = np.maximum(e - 3, -16)
+    return np.ldexp(np.round(np.ldexp(v, -g)), g)
+
+
+@pytest.mark.parametrize("term", range(6), ids=["hi_w1", "lo_w1", "hi_w2", "lo_w2", "hi_w3", "t_wb"])
+def test_each_term_of_the_six_instruction_product_alone(modes, term):
+    """The diagnostic instantiation issues ONE of the six terms; the expected output is the float64 convolution of that
+    activation term with that weight term (terms computed on the host with numpy float16 / an e5m2 rounding). Covers the
+    staging of every plane (main rows, remainder rows, halo columns, tile seams, partial last tile), the three fp16 weight
+    tables, the bf8 weight table, the 2^20 scale of the third term and the K order of both matrix instructions."""
+    modes(tile_want=1)
+    rng = np.random.default_rng(40 + term)
+    n, H, W = 2, 40, 136
+    x = (rng.uniform(0.25, 4.0, (n, 8, H, W)) * rng.choice([-1.0, 1.0], (n, 8, H, W))).astype(np.float32)   # |x| >= 2^-12: third terms in bf8's range
+    w = (rng.standard_normal((8, 8, 3, 3)) * 0.3).astype(np.float32)
+    scale = 2.0 ** (14 - np.frexp(np.abs(w).max())[1])          # the kernel's power-of-two weight scale
+    xt = _f16_terms(x)
+    wt = _f16_terms((w.astype(np.float64) * scale).astype(np.float32))
+    wb = _bf8(w.astype(np.float64) * scale * 2.0 ** -20) * 2.0 ** 20
+    ax = [xt[0], xt[1], xt[0], xt[1], xt[0], _bf8(xt[2] * 2.0 ** 20) * 2.0 ** -20][term]
+    aw = [wt[0], wt[0], wt[1], wt[1], wt[2], wb][term] / scale
+    if term == 5:
+        assert np.array_equal(_bf8(xt[2] * 2.0 ** 20), xt[2] * 2.0 ** 20) and np.count_nonzero(xt[2]) > 1000   # third terms are powers of two: exact in bf8
+    want = torch.nn.functional.conv2d(torch.from_numpy(ax), torch.from_numpy(aw), None, padding=1)
+    y, _ = _conv8(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), torch.zeros(8, device=DEV), 0x100 | (1 << term))
+    got = y.double().cpu()
+    scale_out = float(want.abs().max())
+    err = float((got - want).abs().max())
+    print(f"term {term}: max |expected| {scale_out:.3e}, max abs err {err:.3e}")
+    assert scale_out > 0 and err <= 2e-6 * scale_out, (term, err, scale_out)   # fp32 accumulation of <= 72 products of one term
 
 
 def test_split_operands_cover_the_fp16_range(modes):
