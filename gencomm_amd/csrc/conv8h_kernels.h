@@ -458,6 +458,30 @@ __device__ __forceinline__ void conv_tile_mfma_hionly(const unsigned char* tile,
   }
 }
 
+// The same with a B operand that IS an fp16 number (the sampler's step noise): hi plane only, the three weight terms --
+// three f16 instructions per product block, exact products (no bf8 instruction: nothing to keep apart).
+__device__ __forceinline__ void conv_tile_mfma3_hionly(const unsigned char* tile, const float* __restrict__ tab, f32x4 (&acc)[2][4],
+                                                       const int (&off)[4][3], int lane) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    half8_t w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[k] = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(tab + c * HC_WC3 + (k * 64 + lane) * 4));
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      half8_t b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c] + p * 2 * HC_ROW);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], b[j], acc[p][j], 0, 0, 0);
+    }
+  }
+}
+
 // prepared weight table of one 8-input-channel source: [c 3][hi/lo 2][lane 64][4 dwords]; after the last table
 // 64 floats: even entries 1 / scale, odd entries scale
 __device__ __forceinline__ void load_wa(half8_t (&wa)[3][2], const float* __restrict__ tab, int lane) {

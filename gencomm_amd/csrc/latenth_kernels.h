@@ -1,5 +1,7 @@
 // Latent sampler step (latent_kernels.h: conv_out -> ancestral update -> conv_in of one step, collapsed by linearity)
-// on the f16 matrix pipe with fp16 hi/lo operand splits -- the arithmetic and LDS layout of conv8h_kernels.h.
+// on the f16 matrix pipe with the exact three-term operand splits, the arithmetic and LDS layout of conv8h_kernels.h
+// (hi / lo fp16 planes + a bf8 third-term plane; weights w1 + w2 + w3 in fp16 and a bf8 copy; six matrix instructions
+// per product block, five for the fp16-exact step noise).
 //
 //   hs0_{t-1} = k + c2*(hs0_t - k) + c1*[ Wc5 (*) A_t + bsum + fix ] + s*( W_x (*) eps_t )
 //
@@ -16,10 +18,13 @@ namespace gc {
 
 constexpr int HL_LH5 = HC_TH + 4;            // 20 tile rows (2-pixel halo)
 constexpr int HL_PLANE5 = HL_LH5 * HC_ROW;   // 23040 bytes per hi / lo plane
-constexpr int HL_W5TAB = 8 * 2 * 64 * 4;     // dwords: [c 8][hi/lo][lane][4], then 64 floats (even 1/scale, odd scale)
+constexpr int HL_W5TAB3 = 8 * HC_WC3;        // dwords: 8 tap groups in conv8h's three-term layout, then 64 floats (even 1/scale, odd scale)
+constexpr int HL_TPLANE5 = HL_PLANE5 / 2;    // 11520 bytes: bf8 third-term plane of the 20-row tile
+constexpr int HL_RING = (2 * (HC_TW + 4) + 2 * HL_LH5) * 8;  // floats: exact A' of the image's outermost ring inside the tile (border fix)
 
-// fp16 hi/lo A-operand tables of the composite kernel and of conv_in's x part, with ONE power-of-two scale (both
-// accumulate into the same registers).  wc5: prepared [8 i][25 d][8 o] (prep_latent_kernel, same stream, earlier).
+// Three-term A-operand tables (conv8h_kernels.h: per tap group [term 3][lane][4 dwords] fp16 + [lane][2 dwords] bf8) of the
+// composite kernel, of conv_in's x part and of its message chunk, with ONE power-of-two scale (they accumulate into the
+// same registers).  wc5: prepared [8 i][25 d][8 o] (prep_latent_kernel, same stream, earlier).
 __global__ __launch_bounds__(256) void prep_latent_h_kernel(const float* __restrict__ wc5, const float* __restrict__ w_in /*[8][C+2][3][3]*/,
                                                            float* __restrict__ dst5, float* __restrict__ dstx,
                                                            float* __restrict__ dstc, int C) {
@@ -38,65 +43,78 @@ __global__ __launch_bounds__(256) void prep_latent_h_kernel(const float* __restr
   const float wmax = s_max[0];
   int ex = 0;
   if (wmax > 0.f) (void)frexpf(wmax, &ex);
-  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
-  auto pack = [&](float x0, float x1, int h) {
-    uint16_t v[2];
-    const float xs[2] = {x0 * scale, x1 * scale};
-    for (int e = 0; e < 2; ++e) {
-      const _Float16 hi = (_Float16)xs[e];
-      const _Float16 lo = (_Float16)(xs[e] - (float)hi);
-      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 14 - ex) : 1.0f;  // largest weight in [2^13, 2^14), see prep_conv8h_kernel
+  // entry q of a tap group's HC_WC3 dwords from the scaled weights of the eight channels of (group, lane)
+  auto entry = [&](int q, const float (&wv)[8]) -> uint32_t {
+    if (q < 768) {
+      const int d = q & 3, term = q >> 8;
+      uint16_t v[2];
+      for (int e = 0; e < 2; ++e) {
+        const float x = wv[2 * d + e];
+        const _Float16 w1 = (_Float16)x;
+        const float r1 = x - (float)w1;
+        const _Float16 w2 = (_Float16)r1;
+        const _Float16 w3 = (_Float16)(r1 - (float)w2);
+        v[e] = __builtin_bit_cast(uint16_t, term == 0 ? w1 : term == 1 ? w2 : w3);
+      }
+      return (uint32_t)v[0] | ((uint32_t)v[1] << 16);
     }
-    return (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    const int d = (q - 768) & 1;
+    const float k = 1.0f / HC_TSCALE;
+    return bf8x4(wv[4 * d] * k, wv[4 * d + 1] * k, wv[4 * d + 2] * k, wv[4 * d + 3] * k);
   };
+  auto lane_of = [](int q) { return q < 768 ? (q >> 2) & 63 : (q - 768) >> 1; };
   uint32_t* __restrict__ o5 = reinterpret_cast<uint32_t*>(dst5);
-  for (int i = tid; i < HL_W5TAB; i += 256) {
-    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, c = i >> 9;
+  for (int i = tid; i < HL_W5TAB3; i += 256) {
+    const int c = i / HC_WC3, q = i - c * HC_WC3, l = lane_of(q);
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
     const int t = 4 * c + kg, dyp = t / 5, dx = t - 5 * dyp, dy = dyp - r;
     const bool live = t < 30 && dy >= 0 && dy <= 4;
-    const float x0 = live ? wc5[((2 * d) * 25 + dy * 5 + dx) * 8 + oc] : 0.f;
-    const float x1 = live ? wc5[((2 * d + 1) * 25 + dy * 5 + dx) * 8 + oc] : 0.f;
-    o5[i] = pack(x0, x1, h);
+    float wv[8];
+    for (int ch = 0; ch < 8; ++ch) wv[ch] = live ? wc5[(ch * 25 + dy * 5 + dx) * 8 + oc] * scale : 0.f;
+    o5[i] = entry(q, wv);
   }
-  if (tid < 64) dst5[HL_W5TAB + tid] = (tid & 1) ? scale : 1.0f / scale;
+  if (tid < 64) dst5[HL_W5TAB3 + tid] = (tid & 1) ? scale : 1.0f / scale;
   uint32_t* __restrict__ ox = reinterpret_cast<uint32_t*>(dstx);
-  for (int i = tid; i < (C / 8) * HC_WTAB; i += 256) {
-    const int s = i / HC_WTAB, rem = i - s * HC_WTAB;
-    const int d = rem & 3, l = (rem >> 2) & 63, h = (rem >> 8) & 1, c = rem >> 9;
+  for (int i = tid; i < (C / 8) * HC_WTAB3; i += 256) {
+    const int s = i / HC_WTAB3, rem = i - s * HC_WTAB3;
+    const int c = rem / HC_WC3, q = rem - c * HC_WC3, l = lane_of(q);
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
     const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
     const bool live = dy >= 0 && dy <= 2;
-    const int ic = 2 + s * 8 + 2 * d;
-    const float x0 = live ? w_in[(((size_t)oc * CI + ic) * 3 + dy) * 3 + dx] : 0.f;
-    const float x1 = live ? w_in[(((size_t)oc * CI + ic + 1) * 3 + dy) * 3 + dx] : 0.f;
-    ox[i] = pack(x0, x1, h);
+    float wv[8];
+    for (int ch = 0; ch < 8; ++ch) wv[ch] = live ? w_in[(((size_t)oc * CI + 2 + s * 8 + ch) * 3 + dy) * 3 + dx] * scale : 0.f;
+    ox[i] = entry(q, wv);
   }
   // the two message channels as an 8-channel chunk (channels 2..7 zero): chunk 0 of conv_in_h_kernel
   uint32_t* __restrict__ oc_ = reinterpret_cast<uint32_t*>(dstc);
-  for (int i = tid; i < HC_WTAB; i += 256) {
-    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, c = i >> 9;
+  for (int i = tid; i < HC_WTAB3; i += 256) {
+    const int c = i / HC_WC3, q = i - c * HC_WC3, l = lane_of(q);
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
     const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
-    const bool live = d == 0 && dy >= 0 && dy <= 2;
-    const float x0 = live ? w_in[(((size_t)oc * CI + 0) * 3 + dy) * 3 + dx] : 0.f;
-    const float x1 = live ? w_in[(((size_t)oc * CI + 1) * 3 + dy) * 3 + dx] : 0.f;
-    oc_[i] = pack(x0, x1, h);
+    const bool live = dy >= 0 && dy <= 2;
+    float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < 2; ++ch) wv[ch] = live ? w_in[(((size_t)oc * CI + ch) * 3 + dy) * 3 + dx] * scale : 0.f;
+    oc_[i] = entry(q, wv);
   }
 }
 
-// value of channel i at (tile row, pixel px in -2..65) of the 20-row A' tile: hi + lo
-__device__ __forceinline__ float hl_tile_value(const unsigned char* tile, int row, int px, int i) {
-  const int addr = hc_addr(row, px) + 2 * i;
-  const _Float16 h = *reinterpret_cast<const _Float16*>(tile + addr);
-  const _Float16 l = *reinterpret_cast<const _Float16*>(tile + HL_PLANE5 + addr);
-  return (float)h + (float)l;
+// Exact fp32 A' values of the image's outermost ring inside the tile, for the border correction (the tile itself holds A' as
+// hi + lo + a deferred third term): rows [0] = image row 0, [1] = image row H-1, indexed by tile pixel + 2; then columns
+// [0] = image column 0, [1] = image column W-1, indexed by tile row; 8 channels each.  Every position the correction reads
+// lies on that ring (it is an in-image neighbour of an out-of-image position).
+__device__ __forceinline__ int hl_ring_slot(int gy, int gx, int trow, int tpx, int H, int W) {
+  if (gy == 0) return tpx + 2;
+  if (gy == H - 1) return (HC_TW + 4) + tpx + 2;
+  if (gx == 0) return 2 * (HC_TW + 4) + trow;
+  return 2 * (HC_TW + 4) + HL_LH5 + trow;  // gx == W - 1
 }
-
 // Border correction of one output row strip (row gy, pixels gx..gx+3, channels oc0..oc0+3) -- the terms of the 5x5
 // composite that would pass through x0_hat positions outside the image (latent_kernels.h, phase 2b, same algebra).
-__device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const unsigned char* tile, float (&fix)[4][4], int gy, int gx,
-                                              int trow /* gy - y0 */, int px0 /* gx - x0 */, int oc0, float c1) {
+// Applied IN PLACE to the accumulators of the row pair (accp[pixel group j][channel o], accumulator units: x sc) -- a separate
+// 32-register correction array beside the 32 accumulators and the deferred third terms made the kernel spill.
+__device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const float* ring, int x0, int y0, f32x4 (&accp)[4], int gy, int gx,
+                                              int trow /* gy - y0 */, int px0 /* gx - x0 */, int oc0, float c1, float sc) {
   const int H = a.H, W = a.W;
   const bool mine = gy < H && gx < W && (gy == 0 || gy == H - 1 || gx == 0 || gx + 4 >= W);
   if (!__any(mine)) return;
@@ -115,9 +133,9 @@ __device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const unsigne
     if (!__any(anyo)) continue;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      const float b = a.bring[t1 * 8 + oc0 + o] * c1;
+      const float b = a.bring[t1 * 8 + oc0 + o] * c1 * sc;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) fix[o][p] -= outp[p] ? b : 0.f;
+      for (int p = 0; p < 4; ++p) accp[p][o] -= outp[p] ? b : 0.f;
     }
 #pragma unroll 1
     for (int t2 = 0; t2 < 9; ++t2) {
@@ -137,13 +155,15 @@ __device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const unsigne
       for (int i = 0; i < 8; ++i) {
         float av[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)  // always inside the halo-2 tile
-          av[p] = inp[p] ? hl_tile_value(tile, trow + t1y + t2y, px0 + p + t1x + t2x - 2, i) : 0.f;
+        for (int p = 0; p < 4; ++p) {  // always inside the halo-2 tile and on the image's outermost ring
+          const int tr = trow + t1y + t2y, tp = px0 + p + t1x + t2x - 2;  // tile row (0 = image row y0 - 2), tile pixel (0 = image column x0)
+          av[p] = inp[p] ? ring[hl_ring_slot(y0 - 2 + tr, x0 + tp, tr, tp, H, W) * 8 + i] : 0.f;
+        }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          const float wv = w[i * 8 + oc0 + o];
+          const float wv = w[i * 8 + oc0 + o] * sc;
 #pragma unroll
-          for (int p = 0; p < 4; ++p) fix[o][p] = fmaf(-wv, av[p], fix[o][p]);
+          for (int p = 0; p < 4; ++p) accp[p][o] = fmaf(-wv, av[p], accp[p][o]);
         }
       }
     }
@@ -160,7 +180,7 @@ __device__ __forceinline__ void hl_border_fix(const LatentArgs& a, const unsigne
 struct ConvInHArgs {
   const float* cond;    // [n][2][H][W]
   const float* x;       // [n][C][H][W]
-  const float* wch;     // message-chunk table
+  const float* wch;     // message-chunk table (three-term layout, HC_WTAB3 dwords)
   const float* wxh;     // C/8 tables of the x part
   const float* scales;  // [0] = 1 / scale, [1] = scale
   const float* bias;    // [8]
@@ -173,7 +193,7 @@ struct ConvInHArgs {
 
 __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
-  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
+  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE + HC_TPLANE];
   __shared__ float s_red[NT / 64][16];
   fp16_ovfl_clamp();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -217,8 +237,6 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
         hc.y = sp[plane + (unsigned)gy * (unsigned)W + (unsigned)gxh];
       }
     }
-    half8_t wa[3][2];
-    load_wa(wa, a.wch, lane);
     if (nchunk > 0) {  // first x chunk requested behind the message tile
       stage_load<TW, TH, NT, 8, false>(R, xp, plane, W, H, W, x0, y0, tid);
       hreg = halo_load_h<false>(xp, plane, W, H, W, x0, y0, tid);
@@ -230,25 +248,23 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
       for (int j = 0; j < 4; ++j) e[c][j] = 0.f;
     e[0][0] = Rc.v[0].x * mul; e[0][1] = Rc.v[0].y * mul; e[0][2] = Rc.v[0].z * mul; e[0][3] = Rc.v[0].w * mul;
     e[1][0] = Rc.v[1].x * mul; e[1][1] = Rc.v[1].y * mul; e[1][2] = Rc.v[1].z * mul; e[1][3] = Rc.v[1].w * mul;
-    hc_store_main<HC_PLANE>(tile, r0, qx, e);
+    hc_store_main3(tile, r0, qx, e);
     const float er[4] = {Rc.vr.x * mul, Rc.vr.y * mul, Rc.vr.z * mul, Rc.vr.w * mul};  // zero for threads whose channel (tid / 32) is not 0 or 1
-    hc_store_rem<HC_PLANE>(tile, tid, er);
-    if (tid < HC_LH * 8) hc_store_halo<HC_PLANE>(tile, tid, hc.x * mul, hc.y * mul);  // pairs 1..3: zeros
+    hc_store_rem3(tile, tid, er);
+    if (tid < HC_LH * 8) hc_store_halo3(tile, tid, hc.x * mul, hc.y * mul);  // pairs 1..3: zeros
     __syncthreads();
-    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+    if (wave_live) conv_tile_mfma3(tile, a.wch, acc, off, lane);
   }
 #pragma unroll 1
   for (int cc = 0; cc < nchunk; ++cc) {
     __syncthreads();
-    half8_t wa[3][2];
-    load_wa(wa, a.wxh + (size_t)cc * HC_WTAB, lane);
-    stage_store_h<false>(tile, R, hreg, H, W, x0, y0, nullptr, tid, mul);
+    stage_store_h<false, true>(tile, R, hreg, H, W, x0, y0, nullptr, tid, mul);
     if (cc + 1 < nchunk) {
       stage_load<TW, TH, NT, 8, false>(R, xp + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
       hreg = halo_load_h<false>(xp + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
     }
     __syncthreads();
-    if (wave_live) conv_tile_mfma_h(tile, wa, acc, off);
+    if (wave_live) conv_tile_mfma3(tile, a.wxh + (size_t)cc * HC_WTAB3, acc, off, lane);
   }
 
   float part[8];
@@ -298,30 +314,41 @@ __global__ __launch_bounds__(256) void prep_conv_out_h_kernel(const float* __res
   const float wmax = s_max[0];
   int ex = 0;
   if (wmax > 0.f) (void)frexpf(wmax, &ex);
-  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 14 - ex) : 1.0f;  // largest weight in [2^13, 2^14), see prep_conv8h_kernel
   const int nocb = (C + 15) / 16;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
-  for (int i = tid; i < nocb * HC_WTAB; i += 256) {
-    const int ob = i / HC_WTAB, rem = i - ob * HC_WTAB;
-    const int d = rem & 3, l = (rem >> 2) & 63, h = (rem >> 8) & 1, c = rem >> 9;
+  for (int i = tid; i < nocb * HC_WTAB3; i += 256) {
+    const int ob = i / HC_WTAB3, rem = i - ob * HC_WTAB3;
+    const int c = rem / HC_WC3, q = rem - c * HC_WC3;
+    const int l = q < 768 ? (q >> 2) & 63 : (q - 768) >> 1;
     const int oc = 16 * ob + (l & 15), t = 4 * c + (l >> 4);
-    uint16_t v[2];
-    for (int e = 0; e < 2; ++e) {
-      const int ic = 2 * d + e;
-      const float x = (t < 9 && oc < C) ? w[((size_t)oc * 8 + ic) * 9 + t] * scale : 0.f;
-      const _Float16 hi = (_Float16)x;
-      const _Float16 lo = (_Float16)(x - (float)hi);
-      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    float wv[8];
+    for (int ch = 0; ch < 8; ++ch) wv[ch] = (t < 9 && oc < C) ? w[((size_t)oc * 8 + ch) * 9 + t] * scale : 0.f;
+    if (q < 768) {
+      const int d = q & 3, term = q >> 8;
+      uint16_t v[2];
+      for (int e = 0; e < 2; ++e) {
+        const float x = wv[2 * d + e];
+        const _Float16 w1 = (_Float16)x;
+        const float r1 = x - (float)w1;
+        const _Float16 w2 = (_Float16)r1;
+        const _Float16 w3 = (_Float16)(r1 - (float)w2);
+        v[e] = __builtin_bit_cast(uint16_t, term == 0 ? w1 : term == 1 ? w2 : w3);
+      }
+      out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    } else {
+      const int d = (q - 768) & 1;
+      const float k = 1.0f / HC_TSCALE;
+      out[i] = bf8x4(wv[4 * d] * k, wv[4 * d + 1] * k, wv[4 * d + 2] * k, wv[4 * d + 3] * k);
     }
-    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
   }
-  if (tid < 64) tab[nocb * HC_WTAB + tid] = (tid & 1) ? scale : 1.0f / scale;
+  if (tid < 64) tab[nocb * HC_WTAB3 + tid] = (tid & 1) ? scale : 1.0f / scale;
 }
 
 template <int POST>
 __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs a) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
-  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE];
+  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE + HC_TPLANE];
   __shared__ float s_ab[8][2];
   fp16_ovfl_clamp();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -345,7 +372,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
     s_ab[tid][1] = B;
   }
   __syncthreads();
-  stage_store_h<true>(tile, R, hreg, H, W, x0, y0, s_ab, tid);
+  stage_store_h<true, true>(tile, R, hreg, H, W, x0, y0, s_ab, tid);
   __syncthreads();
   if (!wave_live) return;  // no barrier below
 
@@ -360,7 +387,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
       for (int j = 0; j < 4; ++j) off[j][c] = hc_addr(4 * wave + dy, 4 * ln + j + dx - 1);
     }
   }
-  const float inv_s = a.wh[nocb * HC_WTAB], sc = a.wh[nocb * HC_WTAB + 1];
+  const float inv_s = a.wh[nocb * HC_WTAB3], sc = a.wh[nocb * HC_WTAB3 + 1];
   const unsigned long long seed = (POST == 2 && a.seed_dev) ? *a.seed_dev : a.seed;
   float c1 = 0.f, c2 = 0.f, sg = 0.f;
   if (POST != 0) { c1 = a.sched[2]; c2 = a.sched[3]; sg = a.sched[4]; }
@@ -368,62 +395,89 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
 
 #pragma unroll 1
   for (int ob = 0; ob < nocb; ++ob) {
-    half8_t wa[3][2];
-    load_wa(wa, a.wh + (size_t)ob * HC_WTAB, lane);
+    const float* __restrict__ tab = a.wh + (size_t)ob * HC_WTAB3;
     const int oc0 = 16 * ob + 4 * g;
     f32x4 b0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) b0[i] = (oc0 + i < C) ? a.bias[oc0 + i] * sc : 0.f;
-    // one output row at a time (16 accumulator registers live; the whole 4-row block at once spilled 1.6 KB per thread)
+    // two output rows at a time (32 accumulator registers live; the whole 4-row block at once spilled 1.6 KB per thread):
+    // the bf8 third-term instructions of both rows first, then the f16 passes row by row -- instructions of different input
+    // type on the same registers are at least four matrix instructions apart (conv8h_kernels.h conv_tile_mfma3)
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-      f32x4 acc[4] = {b0, b0, b0, b0};
-      const unsigned char* trow = tile + r * HC_ROW;
+    for (int rp = 0; rp < 2; ++rp) {
+      f32x4 acc[2][4] = {{b0, b0, b0, b0}, {b0, b0, b0, b0}};
+      const unsigned char* trow = tile + 2 * rp * HC_ROW;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        half8_t bh[4], bl[4];
+        WA3 wa;
+        load_wa3(wa, tab, c, lane);
+        long bt[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bh[j] = *reinterpret_cast<const half8_t*>(trow + off[j][c]);
-          bl[j] = *reinterpret_cast<const half8_t*>(trow + HC_PLANE + off[j][c]);
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bt[r][j] = *reinterpret_cast<const long*>(tile + HC_TOFF + (((2 * rp + r) * HC_ROW + off[j][c]) >> 1));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wa.wb, bt[r][j], acc[r][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bh[j], acc[j], 0, 0, 0);
+        for (int r = 0; r < 2; ++r) {
+          half8_t bh[4], bl[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][0], bl[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c][1], bh[j], acc[j], 0, 0, 0);
-      }
-      const int gy = y0 + 4 * wave + r;
-      if (gy >= H || gx + 3 >= W) continue;
-#pragma unroll
-      for (int ip = 0; ip < 2; ++ip) {  // channel pairs (oc0 + 2 ip, oc0 + 2 ip + 1): one noise call each
-        if (oc0 + 2 * ip >= C) continue;
-        float z8[8];
-        if (POST == 2)  // canonical step-noise field, already scaled by sigma_t and rounded to fp16 (common.h)
-          noise_pair_quad((uint64_t)(((size_t)n * C + oc0 + 2 * ip) * plane + (size_t)gy * W + gx), a.stream_id, seed, bm_k2(sg), z8);
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const int i = 2 * ip + ii, oc = oc0 + i;
-          const size_t e = ((size_t)n * C + oc) * plane + (size_t)gy * W + gx;
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[j][i] * inv_s;
-          if (POST != 0) {
-            const float4 t4 = *reinterpret_cast<const float4*>(a.xt + e);
-            const float xt[4] = {t4.x, t4.y, t4.z, t4.w};
-            if (POST == 1) {
-              const float4 z4 = *reinterpret_cast<const float4*>(a.noise + e);
-              const float z[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = fmaf(sg, z[j], fmaf(c1, v[j], c2 * xt[j]));
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = z8[4 * ii + j] + fmaf(c1, v[j], c2 * xt[j]);
-            }
+          for (int j = 0; j < 4; ++j) {
+            bh[j] = *reinterpret_cast<const half8_t*>(trow + r * HC_ROW + off[j][c]);
+            bl[j] = *reinterpret_cast<const half8_t*>(trow + r * HC_ROW + HC_PLANE + off[j][c]);
           }
-          *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1], v[2], v[3]);
-          if (POST != 0) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa.w[2], bh[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa.w[1], bl[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa.w[1], bh[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa.w[0], bl[j], acc[r][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa.w[0], bh[j], acc[r][j], 0, 0, 0);
+          if (r == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int gy = y0 + 4 * wave + 2 * rp + r;
+        if (gy >= H || gx + 3 >= W) continue;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {  // channel pairs (oc0 + 2 ip, oc0 + 2 ip + 1): one noise call each
+          if (oc0 + 2 * ip >= C) continue;
+          float z8[8];
+          if (POST == 2)  // canonical step-noise field, already scaled by sigma_t and rounded to fp16 (common.h)
+            noise_pair_quad((uint64_t)(((size_t)n * C + oc0 + 2 * ip) * plane + (size_t)gy * W + gx), a.stream_id, seed, bm_k2(sg), z8);
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * ip + ii, oc = oc0 + i;
+            const size_t e = ((size_t)n * C + oc) * plane + (size_t)gy * W + gx;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[r][j][i] * inv_s;
+            if (POST != 0) {
+              const float4 t4 = *reinterpret_cast<const float4*>(a.xt + e);
+              const float xt[4] = {t4.x, t4.y, t4.z, t4.w};
+              if (POST == 1) {
+                const float4 z4 = *reinterpret_cast<const float4*>(a.noise + e);
+                const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaf(sg, z[j], fmaf(c1, v[j], c2 * xt[j]));
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = z8[4 * ii + j] + fmaf(c1, v[j], c2 * xt[j]);
+              }
+            }
+            *reinterpret_cast<float4*>(a.out + e) = make_float4(v[0], v[1], v[2], v[3]);
+            if (POST != 0) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          }
         }
       }
     }
@@ -434,7 +488,11 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
 template <int NOISE>
 __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArgs a) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
-  __shared__ __align__(16) unsigned char tile[2 * HL_PLANE5];
+  // in-kernel noise: the step noise is an fp16 number (hi plane only) and the composite's third-term plane lies in the lo
+  // region during phase 3: 2 x 23040 bytes.  Explicit noise (tests): three planes of the 18-row noise tile, 51840 bytes.
+  constexpr int TILE_BYTES = NOISE == 1 ? 2 * HC_PLANE + HC_TPLANE : 2 * HL_PLANE5;
+  __shared__ __align__(16) unsigned char tile[TILE_BYTES];
+  __shared__ float s_ring[HL_RING];
   __shared__ float s_ab[8][2];
   __shared__ float s_red[NT / 64][16];
 
@@ -452,7 +510,8 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
   const int gy0 = y0 + 4 * wave + rr;
   const bool wave_live = y0 + 4 * wave < H;
 
-  // ---------------- phase 1: A' = c1 * SiLU(GN(a)) with a 2-pixel halo -> LDS (fp16 hi / lo) ----------------
+  // ---------------- phase 1: A' = c1 * SiLU(GN(a)) with a 2-pixel halo -> LDS: hi / lo planes now, third terms kept in
+  // registers (11 dwords of bf8) until the lo region is free for them (phase 3, first chunk) ----------------
   const int af32 = !a.a_bf16;
   const size_t abase = (size_t)n * 8 * plane;
   float4 qm[8], qr[2];
@@ -492,37 +551,97 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
   }
   __syncthreads();
   auto act = [&](int c, float v, bool ok) { return ok ? c1 * silu_f(fmaf(s_ab[c][0], v, s_ab[c][1])) : 0.f; };
+  uint2 tq[4];      // third terms of the main pass: pixel j -> 8 channels
+  uint32_t tr2[2];  // rows 16..19: pixels (0, 1) and (2, 3) of the thread's channel pair, 16 bits each
+  uint32_t th2;     // halo columns: the two items' channel pairs, 16 bits each
   {
     float e[8][4];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       e[c][0] = act(c, qm[c].x, ok_m); e[c][1] = act(c, qm[c].y, ok_m); e[c][2] = act(c, qm[c].z, ok_m); e[c][3] = act(c, qm[c].w, ok_m);
     }
-    hc_store_main<HL_PLANE5>(tile, r0, qx, e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 hi, lo;
+      float t[8];
+      split3_pair(e[0][j], e[1][j], hi.x, lo.x, t[0], t[1]);
+      split3_pair(e[2][j], e[3][j], hi.y, lo.y, t[2], t[3]);
+      split3_pair(e[4][j], e[5][j], hi.z, lo.z, t[4], t[5]);
+      split3_pair(e[6][j], e[7][j], hi.w, lo.w, t[6], t[7]);
+      const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
+      *reinterpret_cast<uint4*>(tile + addr) = hi;
+      *reinterpret_cast<uint4*>(tile + HL_PLANE5 + addr) = lo;
+      tq[j] = make_uint2(bf8x4(t[0], t[1], t[2], t[3]), bf8x4(t[4], t[5], t[6], t[7]));
+    }
   }
   {
     const float e0[4] = {qr[0].x, qr[0].y, qr[0].z, qr[0].w}, e1[4] = {qr[1].x, qr[1].y, qr[1].z, qr[1].w};
+    tr2[0] = tr2[1] = 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint32_t hi, lo;
-      split_pair(act(2 * cpr, e0[j], ok_r), act(2 * cpr + 1, e1[j], ok_r), hi, lo);
+      float ta, tb;
+      const float v0 = act(2 * cpr, e0[j], ok_r), v1 = act(2 * cpr + 1, e1[j], ok_r);
+      split3_pair(v0, v1, hi, lo, ta, tb);
       const int addr = rrow * HC_ROW + j * HC_PHASE + (qx + 1) * 16 + cpr * 4;
       *reinterpret_cast<uint32_t*>(tile + addr) = hi;
       *reinterpret_cast<uint32_t*>(tile + HL_PLANE5 + addr) = lo;
+      tr2[j >> 1] |= bf8x2(ta, tb) << (16 * (j & 1));
     }
   }
+  th2 = 0u;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int idx = tid + j * NT;
     if (idx < HL_LH5 * 16) {
       const int cp = idx & 3, s = (idx >> 2) & 3, r = idx >> 4;
       uint32_t hi, lo;
-      split_pair(act(2 * cp, hh[j][0], ok_h[j]), act(2 * cp + 1, hh[j][1], ok_h[j]), hi, lo);
-      const int addr = hc_addr(r, s < 2 ? s - 2 : TW + (s - 2)) + cp * 4;
+      float ta, tb;
+      const float v0 = act(2 * cp, hh[j][0], ok_h[j]), v1 = act(2 * cp + 1, hh[j][1], ok_h[j]);
+      split3_pair(v0, v1, hi, lo, ta, tb);
+      const int tpx = s < 2 ? s - 2 : TW + (s - 2);
+      const int addr = hc_addr(r, tpx) + cp * 4;
       *reinterpret_cast<uint32_t*>(tile + addr) = hi;
       *reinterpret_cast<uint32_t*>(tile + HL_PLANE5 + addr) = lo;
+      th2 |= bf8x2(ta, tb) << (16 * j);
     }
   }
+  // exact fp32 A' of the image's outermost ring inside this tile's window, for the border correction: only tiles that meet
+  // the ring (wave-uniform test) run this, one (slot, channel) value per thread and round, recomputed from the source map
+  if (y0 - 2 <= 0 || y0 + TH + 1 >= H - 1 || x0 == 0 || x0 + TW + 1 >= W - 1) {
+    constexpr int NSLOT = 2 * (TW + 4) + 2 * HL_LH5;
+    for (int i = tid; i < NSLOT * 8; i += NT) {
+      const int slot = i >> 3, c = i & 7;
+      int gy, gxp;
+      if (slot < 2 * (TW + 4)) {
+        gy = slot < TW + 4 ? 0 : H - 1;
+        gxp = x0 - 2 + (slot < TW + 4 ? slot : slot - (TW + 4));
+      } else {
+        const int k = slot - 2 * (TW + 4);
+        gxp = k < HL_LH5 ? 0 : W - 1;
+        gy = y0 - 2 + (k < HL_LH5 ? k : k - HL_LH5);
+      }
+      const bool in_win = gy >= y0 - 2 && gy < y0 + TH + 2 && gxp >= x0 - 2 && gxp < x0 + TW + 2;
+      if (in_win && gy >= 0 && gy < H && gxp >= 0 && gxp < W)
+        s_ring[i] = act(c, ld1(a.a_src, af32, abase + (unsigned)c * plane + (unsigned)gy * (unsigned)W + (unsigned)gxp), true);
+    }
+  }
+  // the third-term plane of the 20-row tile: 8-byte records at half the byte offsets, based at `tbase`
+  auto write_t_plane = [&](unsigned char* tbase) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2*>(tbase + ((r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16) >> 1)) = tq[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint16_t*>(tbase + ((rrow * HC_ROW + j * HC_PHASE + (qx + 1) * 16 + cpr * 4) >> 1)) = (uint16_t)(tr2[j >> 1] >> (16 * (j & 1)));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + j * NT;
+      if (idx < HL_LH5 * 16) {
+        const int cp = idx & 3, s = (idx >> 2) & 3, r = idx >> 4;
+        *reinterpret_cast<uint16_t*>(tbase + ((hc_addr(r, s < 2 ? s - 2 : TW + (s - 2)) + cp * 4) >> 1)) = (uint16_t)(th2 >> (16 * j));
+      }
+    }
+  };
   // eps chunk 0 is requested now so that it arrives during the composite phase
   const float* __restrict__ np_ = NOISE == 1 ? a.noise + (size_t)n * a.C * plane : nullptr;
   TileRegs<TW, TH, NT, 8> R;
@@ -533,8 +652,8 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
   }
   __syncthreads();
 
-  // ---------------- phase 2: 5x5 composite on the f16 matrix pipe ----------------
-  const float inv_s = a.wc5h[HL_W5TAB], sc = a.wc5h[HL_W5TAB + 1];
+  // ---------------- phase 2: 5x5 composite on the f16 matrix pipe: the five f16 terms now, the bf8 term in phase 3 ----------------
+  const float inv_s = a.wc5h[HL_W5TAB3], sc = a.wc5h[HL_W5TAB3 + 1];
   f32x4 acc[2][4];
   {
     const float4 b4 = *reinterpret_cast<const float4*>(a.bsum + 4 * ch);
@@ -545,66 +664,95 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[p][j] = b0;
   }
+  // byte offset of the B operand of tap group c, row pair p, pixel group j in the 20-row tile
+  auto addr5 = [&](int c, int p, int j) {
+    const int t = min(4 * c + g, 29);  // tap slots 30, 31 carry zero weights: any valid address
+    const int dyp = t / 5, dx = t - 5 * dyp;
+    const int po = j + dx - 2;  // pixel 4*ln + po
+    return (4 * wave + dyp + 2 * p) * HC_ROW + (ln + 1) * 16 + (po & 3) * HC_PHASE + (po >> 2) * 16;
+  };
   if (wave_live) {
-    static_for<0, 8>([&](auto CC) {
-      constexpr int c = decltype(CC)::value;
-      const int t = min(4 * c + g, 29);  // tap slots 30, 31 carry zero weights: any valid address
-      const int dyp = t / 5, dx = t - 5 * dyp;
-      const uint4 w0 = *reinterpret_cast<const uint4*>(a.wc5h + ((c * 2 + 0) * 64 + lane) * 4);
-      const uint4 w1 = *reinterpret_cast<const uint4*>(a.wc5h + ((c * 2 + 1) * 64 + lane) * 4);
-      const half8_t wa0 = __builtin_bit_cast(half8_t, w0), wa1 = __builtin_bit_cast(half8_t, w1);
-      const int base = (4 * wave + dyp) * HC_ROW + (ln + 1) * 16;
+#pragma unroll 2   // fully unrolled, hipcc hoists the LDS reads of several tap groups and spills the deferred third terms
+    for (int c = 0; c < 8; ++c) {
+      half8_t w[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w[k] = __builtin_bit_cast(half8_t, *reinterpret_cast<const uint4*>(a.wc5h + c * HC_WC3 + (k * 64 + lane) * 4));
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        half8_t bh[4], bl[4];
+        // 16 operand registers in flight: the hi records feed three passes, the lo records are fetched behind them (the third
+        // terms of phase 1 are live across this phase: with 32 the kernel spills)
+        half8_t b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int po = j + dx - 2;  // pixel 4*ln + po
-          const int addr = base + p * 2 * HC_ROW + (po & 3) * HC_PHASE + (po >> 2) * 16;
-          bh[j] = *reinterpret_cast<const half8_t*>(tile + addr);
-          bl[j] = *reinterpret_cast<const half8_t*>(tile + HL_PLANE5 + addr);
-        }
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + addr5(c, p, j));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bh[j], acc[p][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2], b[j], acc[p][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bl[j], acc[p][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], b[j], acc[p][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, bh[j], acc[p][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], b[j], acc[p][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + HL_PLANE5 + addr5(c, p, j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], b[j], acc[p][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    });
+    }
   }
 
-  // ---------------- phase 2b: border fix (lanes whose strips touch the image border) ----------------
-  float fix[2][4][4];
-#pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fix[p][i][j] = 0.f;
+  // ---------------- phase 2b: border fix (lanes whose strips touch the image border), from the exact ring values ----------------
   if (wave_live) {
-    hl_border_fix(a, tile, fix[0], gy0, gx, gy0 - y0, gx - x0, 4 * ch, c1);
-    hl_border_fix(a, tile, fix[1], gy0 + 2, gx, gy0 + 2 - y0, gx - x0, 4 * ch, c1);
-    // folded into the accumulators (in accumulator units) so that the 32 registers are free during phase 3
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[p][j][i] = fmaf(fix[p][i][j], sc, acc[p][j][i]);
+    hl_border_fix(a, s_ring, x0, y0, acc[0], gy0, gx, gy0 - y0, gx - x0, 4 * ch, c1, sc);
+    hl_border_fix(a, s_ring, x0, y0, acc[1], gy0 + 2, gx, gy0 + 2 - y0, gx - x0, 4 * ch, c1, sc);
   }
+
+  // the composite's bf8 term: two fenced passes per tap group (row pair 0, row pair 1); every instruction of another input
+  // type on the same registers is a whole pass or more away (conv8h_kernels.h conv_tile_mfma3)
+  auto composite_third_term = [&](const unsigned char* tbase) {
+    static_for<0, 8>([&](auto CC) {
+      constexpr int c = decltype(CC)::value;
+      const long wb = *reinterpret_cast<const long*>(a.wc5h + c * HC_WC3 + 768 + lane * 2);
+      long bt[2][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bt[p][j] = *reinterpret_cast<const long*>(tbase + (addr5(c, p, j) >> 1));
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wb, bt[p][j], acc[p][j], 0, 0, 0);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // The third terms move into the lo region (free once phase 2 has read it) and are applied from there, before the noise
+  // chunks: inside the chunk loop (first iteration only) the 64 operand offsets of the pass are hoisted out of the loop as
+  // invariants and the kernel spills 44 registers across every iteration's noise generation.
+  __syncthreads();
+  write_t_plane(tile + HL_PLANE5);
+  __syncthreads();
+  if (wave_live) composite_third_term(tile + HL_PLANE5);
 
   // ---------------- phase 3: s * (W_x (*) eps), eps in chunks of 8 channels through LDS ----------------
   int off[4][3];
   hc_lane_offsets(off, wave, lane);
   const int nchunk = a.C / 8;
+  if (NOISE == 2) {
+    // the composite's third terms move into the lo region (free since phase 2; the noise tile is one 18-row hi plane).
+    // Outside the chunk loop: written inside it (first iteration only) the 11 registers stay live across every iteration's
+    // noise generation and the kernel spills 66 registers there.
+    __syncthreads();
+    write_t_plane(tile + HL_PLANE5);
+  }
 #pragma unroll 1
   for (int cc = 0; cc < nchunk; ++cc) {
-    __syncthreads();  // previous LDS contents (A' tile / previous chunk) are no longer read
-    half8_t wa[3][2];
-    load_wa(wa, a.wxh + (size_t)cc * HC_WTAB, lane);
+    __syncthreads();  // previous LDS contents (third-term plane / previous chunk) are no longer read
+    const float* __restrict__ wtab = a.wxh + (size_t)cc * HC_WTAB3;
     if (NOISE == 1) {
-      stage_store_h<false>(tile, R, hreg, H, W, x0, y0, nullptr, tid, sg);
+      stage_store_h<false, true>(tile, R, hreg, H, W, x0, y0, nullptr, tid, sg);
       if (cc + 1 < nchunk) {
         stage_load<TW, TH, NT, 8, false>(R, np_ + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
         hreg = halo_load_h<false>(np_ + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
@@ -612,7 +760,7 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
     } else {
       // canonical step-noise field (common.h): nu = fp16(sigma_t * z), one Philox call per (channel pair, aligned quad)
       // gives the packed (even, odd channel) dword of each of the quad's four pixel records.  Only the hi plane is
-      // written: nu IS an fp16 number, so the noise convolution needs one operand term (conv_tile_mfma_hionly).
+      // written: nu IS an fp16 number, so the noise convolution needs one operand term (conv_tile_mfma3_hionly).
       // No branch around the generator: lanes whose quad lies outside the image run it with k2 = 0 and get (+-0, +-0).
       // The remainder rows and the halo columns need only two / one of a quad's four words: Box-Muller on those only.
       const float k2 = bm_k2(sg);
@@ -656,8 +804,11 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
     }
     __syncthreads();
     if (wave_live) {
-      if (NOISE == 1) conv_tile_mfma_h(tile, wa, acc, off);
-      else conv_tile_mfma_hionly(tile, wa, acc, off);
+      if (NOISE == 1) {
+        conv_tile_mfma3(tile, wtab, acc, off, lane);
+      } else {
+        conv_tile_mfma3_hionly(tile, wtab, acc, off, lane);
+      }
     }
   }
 

@@ -114,7 +114,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         const dim3 grid(cdiv(Wl, tw), cdiv(Hl, th), c.n);
         TimedLaunch tl(KF_CONV_IN, c.st);
         if (tc == TILE_64x16 && c.m.split() && (Wl & 3) == 0) {
-          ConvInHArgs ah{cond, x_t, P + p.p_wch, P + p.p_wxh, P + p.p_wc5h + HL_W5TAB, P + p.conv_in.b, c.tensor_ptr(o.dst),
+          ConvInHArgs ah{cond, x_t, P + p.p_wch, P + p.p_wxh, P + p.p_wc5h + HL_W5TAB3, P + p.conv_in.b, c.tensor_ptr(o.dst),
                          c.stat_ptr(o.dst), p.C, Hl, Wl, c.m.xcd(), c.amax()};
           GC_KLOG("conv_in_h_kernel");
           conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
@@ -280,7 +280,7 @@ inline void kmap_enqueue(const UNetCall& c, const float* cond) {
   tile_dims(tc, &tw, &th);
   const dim3 grid(cdiv(c.W, tw), cdiv(c.H, th), c.n);
   if (tc == TILE_64x16 && c.m.split() && (c.W & 3) == 0) {
-    ConvInHArgs ah{cond, nullptr, c.prepared + p.p_wch, c.prepared + p.p_wxh, c.prepared + p.p_wc5h + HL_W5TAB, c.prepared + p.conv_in.b,
+    ConvInHArgs ah{cond, nullptr, c.prepared + p.p_wch, c.prepared + p.p_wxh, c.prepared + p.p_wc5h + HL_W5TAB3, c.prepared + p.conv_in.b,
                    reinterpret_cast<float*>(c.wsp + c.ws->kmap_off), nullptr, 0, c.H, c.W, c.m.xcd(), c.amax()};
     conv_in_h_kernel<<<grid, 256, 0, c.st>>>(ah);
   } else if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, c.st>>>(a);

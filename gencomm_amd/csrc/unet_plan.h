@@ -193,13 +193,13 @@ struct UNetPlan {
     prepared_floats = (raw_floats + 63) / 64 * 64;
     conv_in.p_w = padd(8LL * (C + 2) * 9);
     conv_out.p_w = padd((long long)((C + 15) / 16 * 16) * 8 * 9);
-    conv_out.p_wh = padd((long long)((C + 15) / 16) * 1536 + 64);
+    conv_out.p_wh = padd((long long)((C + 15) / 16) * kWtab3 + 64);
     for (int l = 0; l < L; ++l) {
       if (down[l].w >= 0) down[l].p_w = padd(8 * 8 * 9);
       if (up[l].w >= 0) { up[l].p_w = padd(8 * 8 * 9); up[l].p_wh = padd(kWtab3 + 64); up[l].p_wb = padd(768); }
     }
     p_wc5 = padd(1600); p_wc1 = padd(5184); p_bring = padd(72); p_bsum = padd(8);
-    p_wc5h = padd(4096 + 64); p_wxh = padd((long long)(C / 8) * 1536); p_wch = padd(1536);
+    p_wc5h = padd(8 * (kWtab3 / 3) + 64); p_wxh = padd((long long)(C / 8) * kWtab3); p_wch = padd(kWtab3);
     for (auto& b : blocks) {
       b.p_c1w = padd(8LL * b.cin * 9);
       b.p_c2w = padd(8 * 8 * 9);
