@@ -59,8 +59,8 @@ inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
   auto take = [&](size_t floats) { const size_t o = off; off += align_up(floats * sizeof(float), 256); return o; };
   w.colsum = take((size_t)n * p.C);
   w.gate = take((size_t)n * p.C);
-  // pconv weights: fp32 [9][dc][dcp] or the fp16 hi/lo A-operand table (oc blocks x k slices x 512 dwords + 64)
-  w.wT = take(std::max((size_t)9 * p.dc * p.dcp, (size_t)(p.dc / 16) * ((9 * p.dc + 31) / 32) * 512 + 64));
+  // pconv weights: fp32 [9][dc][dcp] or the three-term A-operand table (oc blocks x k slices x 896 dwords + 64)
+  w.wT = take(std::max((size_t)9 * p.dc * p.dcp, (size_t)(p.dc / 16) * ((9 * p.dc + 31) / 32) * 896 + 64));
   w.Y = take(M * p.C);
   w.Z = take(M * p.C);
   w.Zc = take(M * p.dc);
@@ -89,10 +89,10 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   }
   if (m.split() && (p.dc == 16 || p.dc == 32) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
     const int nslice = (9 * p.dc + 31) / 32;
-    enh_prep_pconv_h_kernel<<<(p.dc / 16) * nslice * 2, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, nslice);   // 256 table entries per workgroup
+    enh_prep_pconv_h_kernel<<<(p.dc / 16) * nslice * 4, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, nslice);   // <= 256 table entries per workgroup
     TimedLaunch tl(KF_ENH_PCONV, st);
     EnhPconvHArgs a{F(w.Zc), F(w.wT), F(w.Z), C, p.dc, H, W, nslice};
-    const size_t sh = (size_t)2 * 18 * 34 * p.dc * 2;
+    const size_t sh = (size_t)18 * 34 * p.dc * 5;   // fp16 hi + lo planes, bf8 third-term plane
     if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)enh_pconv_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     enh_pconv_h_kernel<<<dim3((W + 31) / 32, (H + 15) / 16, n), 256, sh, st>>>(a);
   } else

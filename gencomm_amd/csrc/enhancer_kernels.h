@@ -313,40 +313,68 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same GEMM on the f16 matrix pipe with exact fp16 hi/lo splits of both operands (the arithmetic of
-// conv8h_kernels.h: three v_mfma_f32_32x32x16_f16 per product block -- hi*hi, hi*lo, lo*hi -- fp32 accumulation, 22-bit
-// products).  Tokens are split while they are staged into LDS; the weights (pre-multiplied by 2^6 so that their low parts
-// stay normal fp16 numbers, undone exactly in the epilogue) likewise.  K = 64 costs 24 MFMAs of 32 cycles per wave
-// instead of 64 fp32 MFMAs of 64, beside -- not in front of -- the GELU / residual epilogue's VALU work.
-// LDS rows are 32 halves + 8 pad (80 B): the 16 lanes of a ds_read_b128 phase hit 64 distinct banks.
-// Operand maps of v_mfma_f32_32x32x16_f16: A[i = lane & 31][k = 8 * (lane >> 5) .. +7], B[k same][j = lane & 31],
+// The same GEMM on the f16 matrix pipe with EXACT THREE-TERM splits of both operands (the arithmetic of conv8h_kernels.h,
+// round 3): a token x = hi + lo + t (fp16, fp16, the last bit or two as a power of two -> bf8 after scaling by 2^20), a
+// weight w 2^12 = w1 + w2 + w3 (fp16) and its bf8 rounding wb = bf8(w 2^-8).  Per product block five
+// v_mfma_f32_32x32x16_f16 (hi w1, lo w1, hi w2, lo w2, hi w3) into the main accumulators and one
+// v_mfma_f32_32x32x16_bf8_bf8 (t wb) into accumulators OF ITS OWN, added in the epilogue: matrix instructions of different
+// input type never share registers (gfx950 does not forward SrcC between them; hipcc assumes it does --
+// tools/probes/mfma_mixed_dep_probe.hip).  Products to 2^-26; fp32 accumulation.  Tokens and weights are split while they are
+// staged into LDS; K = 64 costs 48 matrix instructions of 32 cycles per wave instead of 64 fp32 ones of 64, beside -- not in
+// front of -- the GELU / residual epilogue's VALU work.
+// LDS rows are 32 halves + 8 pad (80 B; 40 B in the bf8 planes): the 16 lanes of a read phase hit distinct banks.
+// Operand maps of v_mfma_f32_32x32x16_{f16, bf8_bf8}: A[i = lane & 31][k = 8 * (lane >> 5) .. +7], B[k same][j = lane & 31],
 // D as in the fp32 kernel.  K must be a multiple of 4 (it is C or 2C).
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 eh8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 eh2_t __attribute__((ext_vector_type(2)));
 typedef float ef2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void enh_split4(float4 v, float mul, uint2& hi, uint2& lo) {
+constexpr float ENH_TSCALE = 1048576.0f;  // 2^20: third terms are stored as bf8(t 2^20), bf8 weights as bf8(w scale 2^-20)
+constexpr float ENH_WS = 4096.0f;         // static weight scale of the Linear layers (2^12; |w| < 16 stays inside fp16)
+__device__ __forceinline__ uint32_t enh_bf8x4(float a, float b, float c, float d) {
+  int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+  return (uint32_t)v;
+}
+// exact three-term split of four values: hi / lo as packed fp16, the third terms (x 2^20) as four bf8 bytes
+__device__ __forceinline__ void enh_split4(float4 v, float mul, uint2& hi, uint2& lo, uint32_t& t8) {
   const float x[4] = {v.x * mul, v.y * mul, v.z * mul, v.w * mul};
   const eh2_t h0 = __builtin_convertvector((ef2_t){x[0], x[1]}, eh2_t), h1 = __builtin_convertvector((ef2_t){x[2], x[3]}, eh2_t);
-  const eh2_t l0 = __builtin_convertvector((ef2_t){x[0] - (float)h0[0], x[1] - (float)h0[1]}, eh2_t);
-  const eh2_t l1 = __builtin_convertvector((ef2_t){x[2] - (float)h1[0], x[3] - (float)h1[1]}, eh2_t);
+  const float r[4] = {x[0] - (float)h0[0], x[1] - (float)h0[1], x[2] - (float)h1[0], x[3] - (float)h1[1]};
+  const eh2_t l0 = __builtin_convertvector((ef2_t){r[0], r[1]}, eh2_t), l1 = __builtin_convertvector((ef2_t){r[2], r[3]}, eh2_t);
   hi = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
   lo = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+  t8 = enh_bf8x4((r[0] - (float)l0[0]) * ENH_TSCALE, (r[1] - (float)l0[1]) * ENH_TSCALE, (r[2] - (float)l1[0]) * ENH_TSCALE,
+                 (r[3] - (float)l1[1]) * ENH_TSCALE);
+}
+// a weight row segment: w1 / w2 / w3 as packed fp16 and the bf8 rounding of w scale 2^-20
+__device__ __forceinline__ void enh_split4_w(float4 v, float mul, uint2& w1, uint2& w2, uint2& w3, uint32_t& wb) {
+  const float x[4] = {v.x * mul, v.y * mul, v.z * mul, v.w * mul};
+  const eh2_t a0 = __builtin_convertvector((ef2_t){x[0], x[1]}, eh2_t), a1 = __builtin_convertvector((ef2_t){x[2], x[3]}, eh2_t);
+  const float r[4] = {x[0] - (float)a0[0], x[1] - (float)a0[1], x[2] - (float)a1[0], x[3] - (float)a1[1]};
+  const eh2_t b0 = __builtin_convertvector((ef2_t){r[0], r[1]}, eh2_t), b1 = __builtin_convertvector((ef2_t){r[2], r[3]}, eh2_t);
+  const eh2_t c0 = __builtin_convertvector((ef2_t){r[0] - (float)b0[0], r[1] - (float)b0[1]}, eh2_t);
+  const eh2_t c1 = __builtin_convertvector((ef2_t){r[2] - (float)b1[0], r[3] - (float)b1[1]}, eh2_t);
+  w1 = make_uint2(__builtin_bit_cast(uint32_t, a0), __builtin_bit_cast(uint32_t, a1));
+  w2 = make_uint2(__builtin_bit_cast(uint32_t, b0), __builtin_bit_cast(uint32_t, b1));
+  w3 = make_uint2(__builtin_bit_cast(uint32_t, c0), __builtin_bit_cast(uint32_t, c1));
+  const float k = 1.0f / ENH_TSCALE;
+  wb = enh_bf8x4(x[0] * k, x[1] * k, x[2] * k, x[3] * k);
 }
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f16s_mfma_kernel(const GemmArgs a) {
-  constexpr int BM = 128, BN = 64, KC = 32, RB = 80;  // row bytes
-  constexpr float WS = 64.0f, WSI = 1.0f / 64.0f;
-  __shared__ __align__(16) unsigned char Ah[BM * RB], Al[BM * RB], Bh[BN * RB], Bl[BN * RB];
+  constexpr int BM = 128, BN = 64, KC = 32, RB = 80, RT = 40;  // row bytes of the fp16 / bf8 planes
+  constexpr float WS = ENH_WS, WSI = 1.0f / ENH_WS;
+  __shared__ __align__(16) unsigned char Ah[BM * RB], Al[BM * RB], At[BM * RT], B1[BN * RB], B2[BN * RB], B3[BN * RB], Bb[BN * RT];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
   const int ag = blockIdx.z;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const float* __restrict__ Ap = a.A + (size_t)ag * a.M * a.K;
 
-  f32x16 acc0, acc1;
+  f32x16 acc0, acc1, act0, act1;  // act*: the bf8 third-term products, accumulators of their own (header)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; act0[i] = 0.f; act1[i] = 0.f; }
 
   // software pipeline: the next K chunk's tokens and weights travel from global memory into registers while the current chunk
   // is on the matrix cores (the unpipelined loop spent 0.89 of its wave cycles parked: profiles/r2_pmc_sq.json)
@@ -373,36 +401,48 @@ __global__ __launch_bounds__(256) void gemm_f16s_mfma_kernel(const GemmArgs a) {
       for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 3) + 32 * i;
         uint2 hi, lo;
-        enh_split4(va[i], 1.0f, hi, lo);
+        uint32_t t8;
+        enh_split4(va[i], 1.0f, hi, lo, t8);
         *reinterpret_cast<uint2*>(Ah + row * RB + 8 * kq) = hi;
         *reinterpret_cast<uint2*>(Al + row * RB + 8 * kq) = lo;
+        *reinterpret_cast<uint32_t*>(At + row * RT + 4 * kq) = t8;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = (tid >> 3) + 32 * i;
-        uint2 hi, lo;
-        enh_split4(vb[i], WS, hi, lo);
-        *reinterpret_cast<uint2*>(Bh + row * RB + 8 * kq) = hi;
-        *reinterpret_cast<uint2*>(Bl + row * RB + 8 * kq) = lo;
+        uint2 w1, w2, w3;
+        uint32_t wb;
+        enh_split4_w(vb[i], WS, w1, w2, w3, wb);
+        *reinterpret_cast<uint2*>(B1 + row * RB + 8 * kq) = w1;
+        *reinterpret_cast<uint2*>(B2 + row * RB + 8 * kq) = w2;
+        *reinterpret_cast<uint2*>(B3 + row * RB + 8 * kq) = w3;
+        *reinterpret_cast<uint32_t*>(Bb + row * RT + 4 * kq) = wb;
       }
     }
     __syncthreads();
     if (k0 + KC < a.K) fetch(k0 + KC);
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
-      const int ko = 32 * ks + 16 * h;  // byte offset of this lane's 8 halves in the row
+      const int ko = 32 * ks + 16 * h;  // byte offset of this lane's 8 halves in the row (half of it in the bf8 planes)
       const eh8_t ah = *reinterpret_cast<const eh8_t*>(Ah + (32 * w + r) * RB + ko);
       const eh8_t al = *reinterpret_cast<const eh8_t*>(Al + (32 * w + r) * RB + ko);
-      const eh8_t b0h = *reinterpret_cast<const eh8_t*>(Bh + r * RB + ko);
-      const eh8_t b0l = *reinterpret_cast<const eh8_t*>(Bl + r * RB + ko);
-      const eh8_t b1h = *reinterpret_cast<const eh8_t*>(Bh + (32 + r) * RB + ko);
-      const eh8_t b1l = *reinterpret_cast<const eh8_t*>(Bl + (32 + r) * RB + ko);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc1, 0, 0, 0);
+      const long at = *reinterpret_cast<const long*>(At + (32 * w + r) * RT + (ko >> 1));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16& acc = t == 0 ? acc0 : acc1;
+        f32x16& act = t == 0 ? act0 : act1;
+        const int row = 32 * t + r;
+        const eh8_t b1 = *reinterpret_cast<const eh8_t*>(B1 + row * RB + ko);
+        const eh8_t b2 = *reinterpret_cast<const eh8_t*>(B2 + row * RB + ko);
+        const eh8_t b3 = *reinterpret_cast<const eh8_t*>(B3 + row * RB + ko);
+        const long bb = *reinterpret_cast<const long*>(Bb + row * RT + (ko >> 1));
+        act = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(at, bb, act, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1, acc, 0, 0, 0);
+      }
     }
   }
 
@@ -417,7 +457,7 @@ __global__ __launch_bounds__(256) void gemm_f16s_mfma_kernel(const GemmArgs a) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int m = m0 + 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      float v = fmaf(t == 0 ? acc0[reg] : acc1[reg], WSI, b);
+      float v = fmaf((t == 0 ? acc0[reg] : acc1[reg]) + (t == 0 ? act0[reg] : act1[reg]), WSI, b);
       if (cok && m < a.M) {
         if (EPI == 0) v = gelu_erf_f(v);
         else { v += rp[(size_t)m * a.N + col]; cs += v; }
@@ -432,11 +472,12 @@ __global__ __launch_bounds__(256) void gemm_f16s_mfma_kernel(const GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 on the f16 matrix pipe (dc = 16 or 32): the partial 3x3 convolution as an implicit GEMM with the hi/lo split
+// K2 on the f16 matrix pipe (dc = 16 or 32): the partial 3x3 convolution as an implicit GEMM with the three-term
 // arithmetic of the GEMM above.  M = 16 output channels, N = 16 consecutive pixels of a row, K = 32 consecutive
-// (tap, input channel) pairs; the tile (32x16 pixels + halo) is staged token-major in fp16 hi / lo planes, so a B
-// operand is one 16-B read at (pixel + tap shift, channel offset).  Table: [oc block][k slice][hi/lo][lane][4 dwords],
-// then 64 floats (even 1 / scale, odd scale).
+// (tap, input channel) pairs; the tile (32x16 pixels + halo) is staged token-major in fp16 hi / lo planes and a bf8
+// third-term plane, so a B operand is one 16-B (8-B) read at (pixel + tap shift, channel offset).
+// Table: [oc block][k slice] x {[term 3][lane][4 dwords] fp16, [lane][2 dwords] bf8} = 896 dwords, then 64 floats
+// (even 1 / scale, odd scale).
 // ---------------------------------------------------------------------------------------------
 struct EnhPconvHArgs {
   const float* Zc;   // [n][H][W][dc]
@@ -460,21 +501,35 @@ __global__ __launch_bounds__(256) void enh_prep_pconv_h_kernel(const float* __re
   const float wmax = s_max[0];
   int ex = 0;
   if (wmax > 0.f) (void)frexpf(wmax, &ex);
-  const float scale = wmax > 0.f ? ldexpf(1.0f, 8 - ex) : 1.0f;
-  const int nob = dc / 16, total = nob * nslice * 512;
+  const float scale = wmax > 0.f ? ldexpf(1.0f, 14 - ex) : 1.0f;  // largest weight in [2^13, 2^14): conv8h_kernels.h
+  const int nob = dc / 16, total = nob * nslice * 896;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
   for (int i = blockIdx.x * 256 + tid; i < total; i += gridDim.x * 256) {   // every workgroup derives the same scale
-    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, sl = (i >> 9) % nslice, ob = (i >> 9) / nslice;
+    const int blk = i / 896, q = i - blk * 896, sl = blk % nslice, ob = blk / nslice;
+    const int l = q < 768 ? (q >> 2) & 63 : (q - 768) >> 1;
     const int mrow = l & 15, kg = l >> 4, oc = 16 * ob + mrow;
-    uint16_t v[2];
-    for (int e = 0; e < 2; ++e) {
-      const int kidx = 32 * sl + 8 * kg + 2 * d + e, tap = kidx / dc, ic = kidx - tap * dc;
-      const float x = tap < 9 ? w[((size_t)oc * dc + ic) * 9 + tap] * scale : 0.f;
-      const _Float16 hi = (_Float16)x;
-      const _Float16 lo = (_Float16)(x - (float)hi);
-      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    float wv[8];
+    for (int e = 0; e < 8; ++e) {
+      const int kidx = 32 * sl + 8 * kg + e, tap = kidx / dc, ic = kidx - tap * dc;
+      wv[e] = tap < 9 ? w[((size_t)oc * dc + ic) * 9 + tap] * scale : 0.f;
     }
-    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    if (q < 768) {
+      const int d = q & 3, term = q >> 8;
+      uint16_t v[2];
+      for (int e = 0; e < 2; ++e) {
+        const float x = wv[2 * d + e];
+        const _Float16 w1 = (_Float16)x;
+        const float r1 = x - (float)w1;
+        const _Float16 w2 = (_Float16)r1;
+        const _Float16 w3 = (_Float16)(r1 - (float)w2);
+        v[e] = __builtin_bit_cast(uint16_t, term == 0 ? w1 : term == 1 ? w2 : w3);
+      }
+      out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    } else {
+      const int d = (q - 768) & 1;
+      const float k = 1.0f / ENH_TSCALE;
+      out[i] = enh_bf8x4(wv[4 * d] * k, wv[4 * d + 1] * k, wv[4 * d + 2] * k, wv[4 * d + 3] * k);
+    }
   }
   if (blockIdx.x == 0 && tid < 64) tab[total + tid] = (tid & 1) ? scale : 1.0f / scale;
 }
@@ -494,26 +549,30 @@ __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a)
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(zp + ((size_t)gy * a.W + gx) * dc + 4 * q);
     uint2 hi, lo;
-    enh_split4(v, 1.0f, hi, lo);
+    uint32_t t8;
+    enh_split4(v, 1.0f, hi, lo, t8);
     *reinterpret_cast<uint2*>(pch_smem + pix * PB + 8 * q) = hi;
     *reinterpret_cast<uint2*>(pch_smem + plane + pix * PB + 8 * q) = lo;
+    *reinterpret_cast<uint32_t*>(pch_smem + 2 * plane + ((pix * PB + 8 * q) >> 1)) = t8;
   }
   __syncthreads();
   const int ln = lane & 15, kg = lane >> 4;
   const int nob = dc >> 4;
-  const float inv_s = a.tab[nob * a.nslice * 512];
+  const float inv_s = a.tab[nob * a.nslice * 896];
   for (int ob = 0; ob < nob; ++ob) {
-    ef32x4 acc[8];
+    ef32x4 acc[8], act[8];  // act: the bf8 third-term products, accumulators of their own (see the GEMM above)
 #pragma unroll
-    for (int g = 0; g < 8; ++g) acc[g] = ef32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 8; ++g) { acc[g] = ef32x4{0.f, 0.f, 0.f, 0.f}; act[g] = ef32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
     for (int sl = 0; sl < a.nslice; ++sl) {
       const int kidx0 = 32 * sl + 8 * kg;
       const int tap = min(kidx0 / dc, 8), ic0 = kidx0 - (kidx0 / dc) * dc;  // slices past tap 8 carry zero weights
       const int dy = tap / 3, dx = tap - 3 * dy;
-      const uint4 w0 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(ob * a.nslice + sl) * 2 + 0) * 64 + lane) * 4);
-      const uint4 w1 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(ob * a.nslice + sl) * 2 + 1) * 64 + lane) * 4);
-      const eh8_t wa0 = __builtin_bit_cast(eh8_t, w0), wa1 = __builtin_bit_cast(eh8_t, w1);
+      const float* __restrict__ tb = a.tab + (size_t)(ob * a.nslice + sl) * 896;
+      eh8_t wa[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wa[k] = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(tb + (k * 64 + lane) * 4));
+      const long wb = *reinterpret_cast<const long*>(tb + 768 + lane * 2);
       const int base = ((4 * wave + dy) * LW + ln + dx) * PB + ic0 * 2;
       eh8_t bh[8], bl[8];
 #pragma unroll
@@ -521,14 +580,22 @@ __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a)
         const int ad = base + ((g >> 1) * LW + 16 * (g & 1)) * PB;
         bh[g] = *reinterpret_cast<const eh8_t*>(pch_smem + ad);
         bl[g] = *reinterpret_cast<const eh8_t*>(pch_smem + plane + ad);
+        const long bt = *reinterpret_cast<const long*>(pch_smem + 2 * plane + (ad >> 1));
+        act[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wb, bt, act[g], 0, 0, 0);
       }
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bh[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2], bh[g], acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa0, bl[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], bl[g], acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa1, bh[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], bl[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], bh[g], acc[g], 0, 0, 0);
     }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[g] += act[g];
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const int gy = y0 + 4 * wave + (g >> 1), gx = x0 + 16 * (g & 1) + ln;
@@ -550,7 +617,8 @@ __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a)
 //   32 region pixels (one per wave), K = C: 4 k-steps x 3 split products of v_mfma_f32_32x32x16_f16; + bias, GELU, zero
 //   outside the image (the depthwise conv pads its INPUT with zeros) -> LDS [100][32]; then 64 pixels x 16 channels:
 //   dw3x3 + bias, GELU, times x2 at the centre -> G[pixel][16q + ch].
-// Table (prep kernel): [chunk][k-step 4][hi/lo][lane 64][4 dwords], weights pre-multiplied by 2^6.
+// Table (prep kernel): [chunk][k-step 4] x {[term 3][lane 64][4 dwords] fp16, [lane][2 dwords] bf8} = 896 dwords, weights
+// pre-multiplied by 2^12 (three-term arithmetic of the GEMM above).
 // ---------------------------------------------------------------------------------------------
 struct EnhFrontArgs {
   const float* Z;     // [n][H][W][C] tokens (LayerNorm2 output, partial conv applied)
@@ -563,35 +631,46 @@ struct EnhFrontArgs {
 };
 
 __global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __restrict__ w1 /*[2*hid][C]*/, float* __restrict__ tab, int C, int hid) {
-  const int ksteps = C / 16, total = (hid / 16) * ksteps * 512;
+  const int ksteps = C / 16, total = (hid / 16) * ksteps * 896;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int d = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, ks = (i >> 9) % ksteps, q = (i >> 9) / ksteps;
+    const int blk = i / 896, qq = i - blk * 896, ks = blk % ksteps, q = blk / ksteps;
+    const int l = qq < 768 ? (qq >> 2) & 63 : (qq - 768) >> 1;
     const int m = l & 31, kg = l >> 5;
     const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
-    uint16_t v[2];
-    for (int e = 0; e < 2; ++e) {
-      const float x = w1[(size_t)row * C + 16 * ks + 8 * kg + 2 * d + e] * 64.0f;
-      const _Float16 hi = (_Float16)x;
-      const _Float16 lo = (_Float16)(x - (float)hi);
-      v[e] = __builtin_bit_cast(uint16_t, h ? lo : hi);
+    float wv[8];
+    for (int e = 0; e < 8; ++e) wv[e] = w1[(size_t)row * C + 16 * ks + 8 * kg + e] * ENH_WS;
+    if (qq < 768) {
+      const int d = qq & 3, term = qq >> 8;
+      uint16_t v[2];
+      for (int e = 0; e < 2; ++e) {
+        const float x = wv[2 * d + e];
+        const _Float16 a1 = (_Float16)x;
+        const float r1 = x - (float)a1;
+        const _Float16 a2 = (_Float16)r1;
+        const _Float16 a3 = (_Float16)(r1 - (float)a2);
+        v[e] = __builtin_bit_cast(uint16_t, term == 0 ? a1 : term == 1 ? a2 : a3);
+      }
+      out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    } else {
+      const int d = (qq - 768) & 1;
+      const float k = 1.0f / ENH_TSCALE;
+      out[i] = enh_bf8x4(wv[4 * d] * k, wv[4 * d + 1] * k, wv[4 * d + 2] * k, wv[4 * d + 3] * k);
     }
-    out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
   }
 }
 
 __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) {
   fp16_ovfl_clamp();
-  constexpr int TP = 8, RP = TP + 2, NPX = RP * RP, C = 64, RB = C * 2 + 16, HS = 33;  // region 10x10, row bytes, hb stride
-  __shared__ __align__(16) unsigned char zh[NPX * RB], zl[NPX * RB];
+  constexpr int TP = 8, RP = TP + 2, NPX = RP * RP, C = 64, RB = C * 2 + 16, RT = C + 8, HS = 33;  // region 10x10, row bytes, hb stride
+  __shared__ __align__(16) unsigned char zh[NPX * RB], zl[NPX * RB], zt[NPX * RT];  // hi / lo fp16 planes, bf8 third-term plane
   __shared__ float hb[NPX * HS];
-  __shared__ float s_b1[4 * C], s_dww[2 * C * 9], s_dwb[2 * C];  // Linear1 bias, depthwise weights / bias: read per chunk
+  __shared__ float s_b1[4 * C];  // Linear1 bias; the depthwise weights / bias are read from global memory per chunk (a few KB, cache
+                                 // hits): with the third plane their 5 KB in LDS would cost the third resident workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
   const int x0 = blockIdx.x * TP, y0 = blockIdx.y * TP;
   const int hid = a.hid;  // == 2 * C
   for (int i = tid; i < 4 * C; i += 256) s_b1[i] = a.b1[i];
-  for (int i = tid; i < 2 * C * 9; i += 256) s_dww[i] = a.dww[i];
-  for (int i = tid; i < 2 * C; i += 256) s_dwb[i] = a.dwb[i];
   // ---- stage the region's tokens: item = (pixel, float4 of 4 channels): 100 * 16 items
   for (int i = tid; i < NPX * (C / 4); i += 256) {
     const int p = i >> 4, q4 = i & 15;
@@ -599,9 +678,11 @@ __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) 
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(a.Z + ((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * C + 4 * q4);
     uint2 hi, lo;
-    enh_split4(v, 1.0f, hi, lo);
+    uint32_t t8;
+    enh_split4(v, 1.0f, hi, lo, t8);
     *reinterpret_cast<uint2*>(zh + p * RB + 8 * q4) = hi;
     *reinterpret_cast<uint2*>(zl + p * RB + 8 * q4) = lo;
+    *reinterpret_cast<uint32_t*>(zt + p * RT + 4 * q4) = t8;
   }
   __syncthreads();
   const int r = lane & 31, h = lane >> 5;
@@ -618,20 +699,26 @@ __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) 
   const int nchunk = hid / 16;
 #pragma unroll 1
   for (int q = 0; q < nchunk; ++q) {
-    f32x16 acc;
+    f32x16 acc, act;  // act: the bf8 third-term products, accumulators of their own (see the GEMM above)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; act[i] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < C / 16; ++ks) {
-      const uint4 w0 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(q * (C / 16) + ks) * 2 + 0) * 64 + lane) * 4);
-      const uint4 w1 = *reinterpret_cast<const uint4*>(a.tab + (((size_t)(q * (C / 16) + ks) * 2 + 1) * 64 + lane) * 4);
-      const eh8_t ah = __builtin_bit_cast(eh8_t, w0), al = __builtin_bit_cast(eh8_t, w1);
+      const float* __restrict__ tb = a.tab + (size_t)(q * (C / 16) + ks) * 896;
+      eh8_t wa[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wa[k] = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(tb + (k * 64 + lane) * 4));
+      const long wb = *reinterpret_cast<const long*>(tb + 768 + lane * 2);
       const int ko = 32 * ks + 16 * h;
       const eh8_t bh = *reinterpret_cast<const eh8_t*>(zh + pb * RB + ko);
       const eh8_t bl = *reinterpret_cast<const eh8_t*>(zl + pb * RB + ko);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+      const long bt = *reinterpret_cast<const long*>(zt + pb * RT + (ko >> 1));
+      act = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(wb, bt, act, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[2], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0], bh, acc, 0, 0, 0);
     }
     if (q > 0) __syncthreads();  // the previous chunk's depthwise phase has finished reading hb
     if (pvalid) {
@@ -640,7 +727,7 @@ __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) 
         const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // row of the chunk: < 16 gate-branch x1, >= 16 x2
         const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
         const bool need = m < 16 ? inimg : centre;  // compile-time m per register: uniform branch per lane group
-        hb[pcol * HS + m] = need ? gelu_erf_f(fmaf(acc[reg], 1.0f / 64.0f, s_b1[row])) : 0.f;
+        hb[pcol * HS + m] = need ? gelu_erf_f(fmaf(acc[reg] + act[reg], 1.0f / ENH_WS, s_b1[row])) : 0.f;
       }
     }
     __syncthreads();
@@ -648,8 +735,8 @@ __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) 
       const int ch = 16 * q + dch;
       float wd[9];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wd[t] = s_dww[ch * 9 + t];
-      const float bd = s_dwb[ch];
+      for (int t = 0; t < 9; ++t) wd[t] = a.dww[ch * 9 + t];
+      const float bd = a.dwb[ch];
       const int gy = y0 + dpy;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
