@@ -240,7 +240,7 @@ def main():
         if conv:
             c_ms, c_b, c_n = sum(v["ms"] for v in conv.values()), sum(v["bytes"] for v in conv.values()), sum(v["launches"] for v in conv.values())
             traffic = None
-            pmc = os.path.join(REPO, "profiles", "r2_pmc_traffic.json")
+            pmc = os.path.join(REPO, "profiles", "r3_pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
                     tj = json.load(open(pmc))
@@ -259,7 +259,7 @@ def main():
                 "note": "achieved = ALGORITHMIC bytes (source maps + residual sources + destination of each launch, fp32, computed by the "
                         "host from the launch shape) / HIP-event time of the launches, one scene batch in flight; averages over the full- "
                         "and half-resolution levels. traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from the committed rocprofv3 --pmc "
-                        "passes of this command (profiles/r2_pmc_traffic.json, tools/pmc_pass.sh), null when none matches this workload. " + arith_note}
+                        "passes of this command (profiles/r3_pmc_traffic.json, tools/pmc_pass.sh), null when none matches this workload. " + arith_note}
         if LATENT_FAMILY in fam:
             v = fam[LATENT_FAMILY]
             fl = 2.0 * (1600.0 + 72.0 * C) * HW * N * B
@@ -320,10 +320,13 @@ def main():
                                  "variance added 8e-8 relative; q_sample's eps is unrounded fp32. The reference draws torch.randn "
                                  "(cond_diff.py:307); KS / tail / correlation tests on 1.4e8 samples of this field: tests/test_gpu_noise_stats.py; "
                                  "the field is exported (gencomm_step_noise_fwd) and replayed through the oracle: tests/test_gpu_philox_replay.py"),
-                       "arithmetic": ("fp32 tensors in HBM, fp32 accumulation; 3x3 / 5x5 / Linear products formed on the f16 matrix pipe from "
-                                      "exact two-term fp16 splits of both operands (22-bit products: slightly narrower than an fp32 FMA, same parity "
-                                      "tolerance; range-guarded, see DESIGN.md section 4); the arithmetic-identical-to-the-reference mode is "
-                                      "exact_fp32_mode") if split_default else
+                       "arithmetic": ("fp32 tensors in HBM, fp32 accumulation, fp32-EQUIVALENT products: every 3x3 / 5x5 / Linear operand is split "
+                                      "EXACTLY into three terms (activations: fp16 hi + fp16 lo + a bf8 third term holding the last bit or two; weights: three "
+                                      "fp16 terms + one bf8 copy) and a product is six matrix instructions (five v_mfma_f32_*_f16, one v_mfma_f32_*_bf8_bf8) "
+                                      "accurate to 2^-26 -- all 24 bits of both operands enter it (|x| >= 2^-3; absolute operand accuracy 2^-28 below, "
+                                      "the fp16 subnormal range of the second term). Per layer the result is closer to a float64 convolution than the "
+                                      "exact-fp32 kernel's (rms 0.60x; tests/test_gpu_conv8.py::test_f16_pipe_layer_is_at_least_as_accurate_as_the_exact_fp32_kernel). "
+                                      "Round 2's two-term / three-instruction form (22-bit products) is gone; exact_fp32_mode = the fp32 matrix-core kernels") if split_default else
                                      ("exact fp32 MFMA kernels (GENCOMM_MODE_ARITH = 1)" if arith_mode == 1 else
                                       "bf16 denoise mode (GENCOMM_MODE_ARITH = 2): the UNet's 8-channel maps stored as bf16, single bf16 MFMA products, "
                                       "fp32 accumulation, f64 GroupNorm statistics, fp32 sampler state; Enhancer / fusion as in the fp32 mode. "
