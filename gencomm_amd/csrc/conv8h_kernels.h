@@ -379,7 +379,9 @@ __device__ __forceinline__ void load_wa3(WA3& o, const float* __restrict__ tab, 
 }
 // DIAG (unit-test instantiation only): `mask` selects which of the six terms are issued -- bit 0 hi w1, 1 lo w1, 2 hi w2,
 // 3 lo w2, 4 hi w3, 5 t wb -- so that every operand plane and table is checked on its own (tests/test_gpu_conv8.py).
-template <bool DIAG = false>
+// LOWREG (kernels that hold the NEXT chunk's tile in registers during this phase): no operand prefetch of the next tap group
+// and the lo records fetched behind the hi passes -- 30 fewer live registers.
+template <bool DIAG = false, bool LOWREG = false>
 __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const float* __restrict__ tab, f32x4 (&acc)[2][4],
                                                 const int (&off)[4][3], int lane, int mask = 63) {
   // ORDER MATTERS.  On gfx950 a v_mfma_f32_16x16x32_f16 issued fewer than 6 wait states after a v_mfma_f32_16x16x32_bf8_bf8
@@ -394,7 +396,7 @@ __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const
   load_wa3(cur, tab, 0, lane);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    if (c < 2) load_wa3(nxt, tab, c + 1, lane);
+    if (!LOWREG && c < 2) load_wa3(nxt, tab, c + 1, lane);
     long bt[2][4];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -410,6 +412,26 @@ __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
+      if constexpr (LOWREG) {
+        half8_t b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c] + p * 2 * HC_ROW);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[2], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[1], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[0], b[j], acc[p][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8_t*>(tile + HC_PLANE + off[j][c] + p * 2 * HC_ROW);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[1], b[j], acc[p][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[0], b[j], acc[p][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       half8_t bh[4], bl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -435,7 +457,10 @@ __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const
         for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[0], bh[j], acc[p][j], 0, 0, 0);
       if (p == 0) __builtin_amdgcn_sched_barrier(0);   // row pair 1's f16 instructions stay behind row pair 0's
     }
-    if (c < 2) cur = nxt;
+    if (c < 2) {
+      if constexpr (LOWREG) load_wa3(cur, tab, c + 1, lane);
+      else cur = nxt;
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -628,7 +653,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   }
   __syncthreads();
   GC_STAMP(2);
-  if (wave_live) conv_tile_mfma3<DIAG>(tile, a.wh, acc, off, lane, a.term_mask);
+  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2>(tile, a.wh, acc, off, lane, a.term_mask);
   GC_STAMP(3);
   if (NSRC == 2) {
     __syncthreads();

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) {
+__global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs a) {
   fp16_ovfl_clamp();
   constexpr int TP = 8, RP = TP + 2, NPX = RP * RP, C = 64, RB = C * 2 + 16, RT = C + 8, HS = 33;  // region 10x10, row bytes, hb stride
   __shared__ __align__(16) unsigned char zh[NPX * RB], zl[NPX * RB], zt[NPX * RT];  // hi / lo fp16 planes, bf8 third-term plane
@@ -697,29 +697,47 @@ __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) 
   // second phase ownership: channel tid % 16, tile row (tid / 16) % 8, pixels 4 * (tid / 128) .. +3 of that row
   const int dch = tid & 15, dpy = (tid >> 4) & 7, dx0 = 4 * (tid >> 7);
   const int nchunk = hid / 16;
+  // The A operands of a chunk (4 k-steps x {3 fp16 terms, 1 bf8} = 56 registers) are requested one chunk AHEAD, right behind the
+  // matrix phase that consumed the previous set: they arrive during the GELU / depthwise phases.  The table (114 KB) does not
+  // fit the 32 KB L1: fetched just before use, every k-step waited for an L2 round trip (2.07 ms per 16-agent launch; 32 waits
+  // per workgroup).
+  eh8_t wa[C / 16][3];
+  long wbq[C / 16];
+  auto load_chunk_operands = [&](int q) {
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ++ks) {
+      const float* __restrict__ tb = a.tab + (size_t)(q * (C / 16) + ks) * 896;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wa[ks][k] = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(tb + (k * 64 + lane) * 4));
+      wbq[ks] = *reinterpret_cast<const long*>(tb + 768 + lane * 2);
+    }
+  };
+  load_chunk_operands(0);
 #pragma unroll 1
   for (int q = 0; q < nchunk; ++q) {
     f32x16 acc, act;  // act: the bf8 third-term products, accumulators of their own (see the GEMM above)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i] = 0.f; act[i] = 0.f; }
+    // this chunk's depthwise weights / bias: requested now, used behind the matrix phase and a barrier
+    float wd[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wd[t] = a.dww[(16 * q + dch) * 9 + t];
+    const float bd = a.dwb[16 * q + dch];
 #pragma unroll
     for (int ks = 0; ks < C / 16; ++ks) {
-      const float* __restrict__ tb = a.tab + (size_t)(q * (C / 16) + ks) * 896;
-      eh8_t wa[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) wa[k] = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(tb + (k * 64 + lane) * 4));
-      const long wb = *reinterpret_cast<const long*>(tb + 768 + lane * 2);
       const int ko = 32 * ks + 16 * h;
       const eh8_t bh = *reinterpret_cast<const eh8_t*>(zh + pb * RB + ko);
       const eh8_t bl = *reinterpret_cast<const eh8_t*>(zl + pb * RB + ko);
       const long bt = *reinterpret_cast<const long*>(zt + pb * RT + (ko >> 1));
-      act = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(wb, bt, act, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[2], bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1], bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1], bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0], bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0], bh, acc, 0, 0, 0);
+      act = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(wbq[ks], bt, act, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][2], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][1], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][1], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][0], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][0], bh, acc, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 1 < nchunk) load_chunk_operands(q + 1);
     if (q > 0) __syncthreads();  // the previous chunk's depthwise phase has finished reading hb
     if (pvalid) {
 #pragma unroll
@@ -733,10 +751,6 @@ __global__ __launch_bounds__(256) void enh_front_h_kernel(const EnhFrontArgs a) 
     __syncthreads();
     {
       const int ch = 16 * q + dch;
-      float wd[9];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wd[t] = a.dww[ch * 9 + t];
-      const float bd = a.dwb[ch];
       const int gy = y0 + dpy;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
     hc_store_rem3(tile, tid, er);
     if (tid < HC_LH * 8) hc_store_halo3(tile, tid, hc.x * mul, hc.y * mul);  // pairs 1..3: zeros
     __syncthreads();
-    if (wave_live) conv_tile_mfma3(tile, a.wch, acc, off, lane);
+    if (wave_live) conv_tile_mfma3<false, true>(tile, a.wch, acc, off, lane);
   }
 #pragma unroll 1
   for (int cc = 0; cc < nchunk; ++cc) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_in_h_kernel(const ConvInHArgs a
       hreg = halo_load_h<false>(xp + (size_t)(cc + 1) * 8 * plane, plane, W, H, W, x0, y0, tid);
     }
     __syncthreads();
-    if (wave_live) conv_tile_mfma3(tile, a.wxh + (size_t)cc * HC_WTAB3, acc, off, lane);
+    if (wave_live) conv_tile_mfma3<false, true>(tile, a.wxh + (size_t)cc * HC_WTAB3, acc, off, lane);
   }
 
   float part[8];
