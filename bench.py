@@ -46,7 +46,7 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA pe
 CONV8_FAMILIES = {1: "conv1 8->8 (GN+SiLU)", 16: "conv2 + identity residual", 17: "conv2 + 1x1 nin_shortcut", 2: "conv1 16->8 (skip concat)",
                   4: "Upsample conv (nearest x2)"}
 LATENT_FAMILY = 15
-N_FAMILIES = 18
+N_FAMILIES = 19
 
 
 def algorithmic_work(N, C, HW, T):
@@ -157,7 +157,7 @@ def main():
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the scene's launch sequence as a captured HIP graph")
     ap.add_argument("--mode", action="append", default=[], metavar="KEY=VALUE",
-                    help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd), e.g. --mode xcd=0")
+                    help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow), e.g. --mode xcd=0")
     args = ap.parse_args()
 
     from gencomm_amd import dist as gdist
@@ -175,7 +175,8 @@ def main():
     from gencomm_amd.pipeline import ScenePipeline
     lib = _lib.lib()
     mode_keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
-                 "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP}
+                 "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP,
+                 "dataflow": _lib.MODE_DATAFLOW}
     for kv in args.mode:
         k, v = kv.split("=")
         _lib.check(lib.gencomm_set_mode(mode_keys[k], int(v)), "gencomm_set_mode")

@@ -16,7 +16,7 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
 ABI_VERSION = 5
-MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP = range(6)
+MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW = range(7)
 
 _lock = threading.Lock()
 _lib = None
@@ -48,6 +48,8 @@ _SIGNATURES = {
     "gencomm_unet_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_conv8_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_denoise_workspace_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
+    "gencomm_dataflow_error": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "gencomm_dataflow_words": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_uint), _i, _p]),
     "gencomm_unet_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_denoise_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, C.c_ulonglong,
                                  _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),

@@ -52,7 +52,8 @@ enum ModeKey : int {
   MODE_ENH_FUSE = 3,     // 1: Enhancer Linear1 + depthwise stage fused at C = 64 (default); 0: separate launches
   MODE_CONV8H_MASK = 4,  // diagnostic: bit mask of conv8h variants allowed on the f16 pipe (-1: all)
   MODE_XCD_REMAP = 5,    // 1: workgroup -> tile mapping keeps neighbouring tiles on one XCD (default); 0: plain grid order
-  MODE_COUNT = 6
+  MODE_DATAFLOW = 6,     // 1: the UNet body of a call runs as ONE persistent dataflow launch (dataflow_kernels.h); 0: one launch per layer
+  MODE_COUNT = 7
 };
 struct Modes {
   long long v[MODE_COUNT];
@@ -71,7 +72,7 @@ enum KernelFamily : int {
   KF_CONV_IN = 0, KF_CONV8 = 1, KF_CONV16 = 2, KF_DOWN = 3, KF_UP = 4, KF_CONV_OUT = 5, KF_Q_SAMPLE = 6,
   KF_ENH_LN = 7, KF_ENH_PCONV = 8, KF_ENH_GEMM1 = 9, KF_ENH_DWGATE = 10, KF_ENH_GEMM2 = 11,
   KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_LATENT_STEP = 15, KF_CONV8_RES1 = 16, KF_CONV8_RES2 = 17,
-  KF_COUNT = 18
+  KF_DATAFLOW = 18, KF_COUNT = 19
 };
 inline const char* kernel_family_name(int id) {
   static const char* names[KF_COUNT] = {
@@ -81,7 +82,8 @@ inline const char* kernel_family_name(int id) {
       "enh_pconv_h_kernel | enh_pconv_kernel", "enh_front_h_kernel | gemm_*_mfma_kernel<0>", "enh_dwgate_kernel",
       "gemm_*_mfma_kernel<1>", "enh_gate_kernel", "enh_scale_transpose_kernel", "warp_attfuse_kernel | warp_attfuse_tok_kernel",
       "latent_step_h_kernel | latent_step_kernel", "conv8h_kernel<1,GN,RES=1> | conv8_kernel (ResnetBlock conv2 + identity)",
-      "conv8h_kernel<1,GN,RES=2> | conv8_kernel (ResnetBlock conv2 + nin_shortcut)"};
+      "conv8h_kernel<1,GN,RES=2> | conv8_kernel (ResnetBlock conv2 + nin_shortcut)",
+      "unet_dataflow_kernel (UNet body of one call, persistent)"};
   return (id >= 0 && id < KF_COUNT) ? names[id] : "?";
 }
 struct KernelTimer {

@@ -551,20 +551,16 @@ __device__ __forceinline__ void hc_stats_commit(float (&part)[8], float (*s_red)
   }
 }
 
+// One 64x16 output tile of one agent (bid = tile x, tile y, agent): the body of conv8h_kernel, also called per work item by
+// the persistent dataflow kernel (dataflow_kernels.h).  LDS is the caller's: tile (2 * HC_PLANE + HC_TPLANE bytes, 16-byte
+// aligned), s_ab [16][2], s_red [4][16].
+constexpr int HC_TILE_BYTES = 2 * HC_PLANE + HC_TPLANE;
 template <int NSRC, bool GN, bool UP, int RES, bool DIAG = false>
-__global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
+__device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bid, unsigned char* tile, float (*s_ab)[2], float (*s_red)[16],
+                                            size_t bias_off = 0) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
-  __shared__ __align__(16) unsigned char tile[2 * HC_PLANE + HC_TPLANE];  // hi | lo (fp16) | third term (bf8)
-  __shared__ float s_ab[16][2];
-  __shared__ float s_red[NT / 64][16];
-#ifdef HC_LDS_PAD  // diagnostic builds: inflate the LDS footprint to limit workgroups per CU
-  __shared__ float s_pad[HC_LDS_PAD / 4];
-  if (a.H < 0) s_pad[threadIdx.x] = 1.f;
-#endif
-
   fp16_ovfl_clamp();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const BlockId bid = xcd_block(a.xcd);
   const int n = bid.z;
   const int x0 = bid.x * TW, y0 = bid.y * TH;
   const size_t plane_in = (size_t)a.Hin * a.Win;
@@ -585,16 +581,18 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
     if (a.amax != nullptr) {
       bound = *a.amax;
     } else if (a.sstat[0] != nullptr) {  // max|x| <= sqrt(sum x^2) of the largest channel of this sample
-      const double* __restrict__ st = a.sstat[0] + (size_t)n * 16;
+      // vector loads at agent scope: in the dataflow kernel another workgroup of this launch wrote these sums, and a
+      // wave-uniform address would otherwise go through the scalar cache, which an acquire does not refresh
+      const double* st = a.sstat[0] + (size_t)n * 16;
       double q = 0.0;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) q = fmax(q, st[2 * c + 1]);
+      for (int c = 0; c < 8; ++c) q = fmax(q, __hip_atomic_load(st + 2 * c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       bound = sqrtf((float)q) * 1.0001f;
     }
     mul = act_scale(bound);
   }
   const float inv_s = a.wh[NSRC * HC_WTAB3] / mul;  // one scale for the whole (concatenated) weight tensor
-  const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + 4 * ch);
+  const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + bias_off + 4 * ch);
   const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
   TileRegs<TW, TH, NT, 8> R;
   float2 hreg = make_float2(0.f, 0.f);
@@ -728,6 +726,18 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   GC_STAMP(5);
   if (a.dstat != nullptr) hc_stats_commit(part, s_red, a.dstat + (size_t)n * 16, tid);
   GC_STAMP(6);
+}
+
+template <int NSRC, bool GN, bool UP, int RES, bool DIAG = false>
+__global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
+  __shared__ __align__(16) unsigned char tile[HC_TILE_BYTES];  // hi | lo (fp16) | third term (bf8)
+  __shared__ float s_ab[16][2];
+  __shared__ float s_red[HC_NT / 64][16];
+#ifdef HC_LDS_PAD  // diagnostic builds: inflate the LDS footprint to limit workgroups per CU
+  __shared__ float s_pad[HC_LDS_PAD / 4];
+  if (a.H < 0) s_pad[threadIdx.x] = 1.f;
+#endif
+  conv8h_tile<NSRC, GN, UP, RES, DIAG>(a, xcd_block(a.xcd), tile, s_ab, s_red);
 }
 
 // Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 three-term tables of HC_WTAB3 dwords + 64 floats (1 / scale, scale).

@@ -30,7 +30,7 @@ KernelTimer& kernel_timer() {
   static KernelTimer t;
   return t;
 }
-static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {1}, {-1}, {1}};  // defaults, see ModeKey
+static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {1}, {-1}, {1}, {0}};  // defaults, see ModeKey
 static std::atomic<bool> g_klog_armed{false};
 static std::mutex g_klog_mu;
 static std::map<std::string, int> g_klog;
@@ -212,6 +212,35 @@ long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels
   UNetWorkspace w;
   if (const char* e = w.build(p, n, H, W)) { fail(GC_ERR_ARG, e); return -1; }
   return (long long)w.total;
+}
+
+// Diagnostic: the dataflow kernel's error word of the LAST UNet call on this workspace (0 = every dependency wait was satisfied;
+// k + 1 = a workgroup gave up waiting for the predecessor of body op k).  Synchronises `stream`.
+int gencomm_dataflow_error(const void* workspace, int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, 1)) { fail(GC_ERR_ARG, e); return -1; }
+  UNetWorkspace w;
+  if (workspace == nullptr || n < 1) { fail(GC_ERR_ARG, "null workspace / bad n"); return -1; }
+  if (const char* e = w.build(p, n, H, W)) { fail(GC_ERR_ARG, e); return -1; }
+  unsigned v = 0;
+  const char* src = (const char*)workspace + w.df_words_off + (8 + 64 * (size_t)n) * sizeof(unsigned);
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, src, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+    fail(GC_ERR_HIP, "reading the dataflow error word failed");
+    return -1;
+  }
+  return (int)v;
+}
+// Diagnostic: the first `count` words of the dataflow kernel's block ([8] tickets, [64][n] done counters, error word) to host memory.
+int gencomm_dataflow_words(const void* workspace, int n, int C, int H, int W, int levels, int res_blocks, int attn_mask,
+                           unsigned int* host_out, int count, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, 1)) return fail(GC_ERR_ARG, e);
+  UNetWorkspace w;
+  GC_CHECK_ARG(workspace && host_out && n >= 1 && count >= 1 && count <= 8 + 64 * n + 1, "bad arguments");
+  if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
+  GC_HIP(hipStreamSynchronize((hipStream_t)stream));
+  GC_HIP(hipMemcpy(host_out, (const char*)workspace + w.df_words_off, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToHost));
+  return GC_OK;
 }
 
 // bf16 denoise mode: one kernel family (64x16 tiles, vector loads), no AttnBlock
@@ -436,7 +465,7 @@ int gencomm_denoise_fwd_dseed(const float* prepared, const float* sched,
     ConvOutArgs co{};
     co.out = out;
     // step 0 of the loop starts from x_{T-1} through conv_in (op 0); later steps start from hs0
-    if (int rc = unet_enqueue_range(c, out, cond, t, 0, co, i == 0 ? 0 : 1, t == 0 ? nops : nops - 1, i != 0)) return rc;
+    if (int rc = unet_enqueue_range(c, out, cond, t, 0, co, i == 0 ? 0 : 1, t == 0 ? nops : nops - 1, i != 0, /*df_upload=*/i == 0)) return rc;
     if (t > 0) {
       const float* nz = philox ? nullptr : step_noise + (size_t)i * n * per_agent;
       if (int rc = latent_step_enqueue(c, sched + (size_t)t * 5, nz, seed, (unsigned)t, seed_dev)) return rc;

@@ -5,6 +5,7 @@
 #include "attn_kernels.h"
 #include "conv8b_kernels.h"
 #include "conv8h_kernels.h"
+#include "dataflow_kernels.h"
 #include "latent_kernels.h"
 #include "latenth_kernels.h"
 #include "unet_kernels.h"
@@ -90,19 +91,146 @@ struct UNetCall {
   double* stat_ptr(int id) const { return reinterpret_cast<double*>(wsp) + (size_t)id * n * 16; }
 };
 
+// Launch arguments of the 8-channel layers (shared by the per-layer launches and the dataflow program)
+inline Conv8Args conv1_args(const UNetCall& c, const Op& o, int t) {
+  const ResBlockPlan& b = c.plan->blocks[o.blk];
+  const float* P = c.prepared;
+  const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level];
+  Conv8Args a{};
+  a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
+  if (o.src[1] >= 0) { a.src[1] = c.tensor_ptr(o.src[1]); a.sstat[1] = c.stat_ptr(o.src[1]); }
+  a.gamma = P + b.n1w; a.beta = P + b.n1b;
+  a.w = P + b.p_c1w; a.wh = P + b.p_c1wh; a.bias = P + b.p_bias1 + (size_t)t * 8;
+  a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
+  a.H = a.Hin = Hl; a.W = a.Win = Wl;
+  a.inv_cnt = 1.0 / ((b.cin == 8 ? 2.0 : 4.0) * Hl * Wl);
+  a.xcd = c.m.xcd();
+  return a;
+}
+inline Conv8Args conv2_args(const UNetCall& c, const Op& o) {
+  const ResBlockPlan& b = c.plan->blocks[o.blk];
+  const float* P = c.prepared;
+  const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level];
+  Conv8Args a{};
+  a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
+  a.gamma = P + b.n2w; a.beta = P + b.n2b;
+  a.w = P + b.p_c2w; a.wh = P + b.p_c2wh; a.bias = P + b.p_bias2;
+  a.res[0] = c.tensor_ptr(o.res[0]);
+  if (o.res[1] >= 0) { a.res[1] = c.tensor_ptr(o.res[1]); a.ninw = P + b.p_ninw; }
+  a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
+  a.H = a.Hin = Hl; a.W = a.Win = Wl;
+  a.inv_cnt = 1.0 / (2.0 * Hl * Wl);
+  a.xcd = c.m.xcd();
+  return a;
+}
+inline Conv8Args up_args(const UNetCall& c, const Op& o) {
+  const UNetPlan& p = *c.plan;
+  const float* P = c.prepared;
+  const int lin = o.level + 1;
+  Conv8Args a{};
+  a.src[0] = c.tensor_ptr(o.src[0]);
+  a.sstat[0] = c.stat_ptr(o.src[0]);  // raw input: range bound from its sum of squares (conv8h_kernel)
+  a.w = P + p.up[lin].p_w; a.wh = P + p.up[lin].p_wh; a.bias = P + p.up[lin].b;
+  a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
+  a.H = c.ws->Hl[o.level]; a.W = c.ws->Wl[o.level]; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin];
+  a.xcd = c.m.xcd();
+  return a;
+}
+inline DownArgs down_args(const UNetCall& c, const Op& o) {
+  const UNetPlan& p = *c.plan;
+  const float* P = c.prepared;
+  const int lin = o.level - 1;
+  return DownArgs{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst), c.stat_ptr(o.dst),
+                  c.ws->Hl[o.level], c.ws->Wl[o.level], c.ws->Hl[lin], c.ws->Wl[lin], !c.is_f32(o.src[0]), !c.is_f32(o.dst)};
+}
+
+// ---- dataflow execution of ops [f, l) (dataflow_kernels.h).  Eligible: GENCOMM_MODE_DATAFLOW on, f16-pipe arithmetic (not the
+// bf16 storage mode), every op of the range one of {ResnetBlock conv1 / conv2, Downsample, Upsample} on 64x16 tiles.
+inline bool df_eligible(const UNetCall& c, int f, int l) {
+  if (c.m.v[MODE_DATAFLOW] == 0 || !c.m.split() || c.m.bf16() || l - f < 2 || l - f > DF_MAX_OPS || c.n > 64 * 1024) return false;
+  if (c.m.v[MODE_CONV8H_MASK] != -1) return false;
+  for (int oi = f; oi < l; ++oi) {
+    const Op& o = c.plan->ops[oi];
+    if (o.kind != OP_RES_CONV1 && o.kind != OP_RES_CONV2 && o.kind != OP_DOWN && o.kind != OP_UP) return false;
+    if (o.kind == OP_DOWN) {
+      if ((c.ws->Wl[o.level - 1] & 3) != 0) return false;
+    } else if (pick_tile(c.m, c.n, c.ws->Hl[o.level], c.ws->Wl[o.level]) != TILE_64x16) return false;
+  }
+  return true;
+}
+inline int df_enqueue(const UNetCall& c, int t, int f, int l, bool upload) {
+  const UNetPlan& p = *c.plan;
+  DfProgram* dprog = reinterpret_cast<DfProgram*>(c.wsp + c.ws->df_prog_off);
+  unsigned* words = reinterpret_cast<unsigned*>(c.wsp + c.ws->df_words_off);
+  const int nops = l - f;
+  if (upload) {
+    static thread_local DfProgram hp;  // host staging (3 KB per 8 ops travel as kernel arguments)
+    hp.nops = nops; hp.n = c.n;
+    int qlen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < nops; ++k) {
+      const Op& o = p.ops[f + k];
+      DfOp& d = hp.ops[k];
+      d = DfOp{};
+      const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level];
+      if (o.kind == OP_DOWN) {
+        d.kind = DF_DOWN; d.tx = cdiv(Hl * ((Wl + 1) / 2), 256); d.ty = 1; d.down = down_args(c, o);
+      } else {
+        d.tx = cdiv(Wl, 64); d.ty = cdiv(Hl, 16);
+        if (o.kind == OP_RES_CONV1) {
+          d.kind = p.blocks[o.blk].cin == 8 ? DF_CONV1 : DF_CONV16; d.conv = conv1_args(c, o, 0); d.bias_stride = 8;
+        } else if (o.kind == OP_RES_CONV2) {
+          d.kind = p.blocks[o.blk].cin == 8 ? DF_CONV2_RES1 : DF_CONV2_RES2; d.conv = conv2_args(c, o);
+        } else {
+          d.kind = DF_UP; d.conv = up_args(c, o);
+        }
+      }
+      d.tiles = d.tx * d.ty;
+      d.items = d.tiles * c.n;
+      // contiguous eighths of the op's agent-major item order (the rule of xcd_block)
+      const int qq = d.items >> 3, rr = d.items & 7;
+      for (int x = 0; x <= 8; ++x) d.item_base[x] = x * qq + (x < rr ? x : rr);
+      for (int x = 0; x < 8; ++x) { d.ticket_base[x] = qlen[x]; qlen[x] += d.item_base[x + 1] - d.item_base[x]; }
+    }
+    for (int x = 0; x < 8; ++x) hp.queue_len[x] = qlen[x];
+    for (int k0 = 0; k0 < nops; k0 += DF_CHUNK) {
+      DfUploadArgs ua{};
+      ua.dst = dprog; ua.first = k0; ua.count = std::min(DF_CHUNK, nops - k0); ua.nops = nops; ua.n = c.n;
+      for (int x = 0; x < 8; ++x) ua.queue_len[x] = qlen[x];
+      for (int k = 0; k < ua.count; ++k) ua.ops[k] = hp.ops[k0 + k];
+      df_upload_kernel<<<1, 64, 0, c.st>>>(ua);
+    }
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  DfArgs da{dprog, words, words + 8, words + 8 + 64 * (size_t)c.n, t, c.m.v[MODE_DATAFLOW] == 2 ? 1 : 0};
+  GC_KLOG("unet_dataflow_kernel (persistent, per-agent layer dependencies)");
+  TimedLaunch tl(KF_DATAFLOW, c.st);
+  unet_dataflow_kernel<<<dim3(3 * cus), HC_NT, 0, c.st>>>(da);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 // Enqueue one UNet evaluation for integer timestep t.  The last op (conv_out) is launched with
 // `post` (0 plain x0, 1 explicit noise, 2 Philox) and the pointers in `co` (xt/noise/sched/out/seed).
 // ops [first, last) of the launch program; `keep_hs0_stats` leaves tensor 0's statistics alone
 // (they were produced by the previous latent step).
 inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* cond, int t, int post,
-                              ConvOutArgs co, int first, int last, bool keep_hs0_stats) {
+                              ConvOutArgs co, int first, int last, bool keep_hs0_stats, bool df_upload = true) {
   const UNetPlan& p = *c.plan;
   const float* P = c.prepared;
   {
     const size_t skip = keep_hs0_stats ? (size_t)c.n * 16 * sizeof(double) : 0;  // hs0 is tensor 0
     GC_HIP(hipMemsetAsync(c.wsp + skip, 0, c.ws->stats_bytes - skip, c.st));
   }
+  // the body (everything between conv_in and conv_out) as ONE persistent dataflow launch where eligible
+  const int df_f = std::max(first, 1), df_l = std::min(last, (int)p.ops.size() - 1);
+  const bool dataflow = df_eligible(c, df_f, df_l);
   for (int oi = first; oi < last; ++oi) {
+    if (dataflow && oi == df_f) {
+      if (int rc = df_enqueue(c, t, df_f, df_l, df_upload)) return rc;
+      oi = df_l - 1;
+      continue;
+    }
     const Op& o = p.ops[oi];
     const int Hl = c.ws->Hl[o.level], Wl = c.ws->Wl[o.level];
     switch (o.kind) {
@@ -139,15 +267,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
           else launch_conv8b<2, true, false, 0>(a, c.n, c.st);
           break;
         }
-        Conv8Args a{};
-        a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
-        if (o.src[1] >= 0) { a.src[1] = c.tensor_ptr(o.src[1]); a.sstat[1] = c.stat_ptr(o.src[1]); }
-        a.gamma = P + b.n1w; a.beta = P + b.n1b;
-        a.w = P + b.p_c1w; a.wh = P + b.p_c1wh; a.bias = P + b.p_bias1 + (size_t)t * 8;
-        a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
-        a.H = a.Hin = Hl; a.W = a.Win = Wl;
-        a.inv_cnt = 1.0 / ((b.cin == 8 ? 2.0 : 4.0) * Hl * Wl);
-        a.xcd = c.m.xcd();
+        const Conv8Args a = conv1_args(c, o, t);
         const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl);
         if (b.cin == 8) launch_conv8<1, true, false, 0>(c.m, tc, a, c.n, c.st);
         else launch_conv8<2, true, false, 0>(c.m, tc, a, c.n, c.st);
@@ -167,25 +287,14 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
           else launch_conv8b<1, true, false, 2>(a, c.n, c.st);
           break;
         }
-        Conv8Args a{};
-        a.src[0] = c.tensor_ptr(o.src[0]); a.sstat[0] = c.stat_ptr(o.src[0]);
-        a.gamma = P + b.n2w; a.beta = P + b.n2b;
-        a.w = P + b.p_c2w; a.wh = P + b.p_c2wh; a.bias = P + b.p_bias2;
-        a.res[0] = c.tensor_ptr(o.res[0]);
-        if (o.res[1] >= 0) { a.res[1] = c.tensor_ptr(o.res[1]); a.ninw = P + b.p_ninw; }
-        a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
-        a.H = a.Hin = Hl; a.W = a.Win = Wl;
-        a.inv_cnt = 1.0 / (2.0 * Hl * Wl);
-        a.xcd = c.m.xcd();
+        const Conv8Args a = conv2_args(c, o);
         const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl);
         if (b.cin == 8) launch_conv8<1, true, false, 1>(c.m, tc, a, c.n, c.st);
         else launch_conv8<1, true, false, 2>(c.m, tc, a, c.n, c.st);
         break;
       }
       case OP_DOWN: {
-        const int lin = o.level - 1;
-        DownArgs a{c.tensor_ptr(o.src[0]), P + p.down[lin].p_w, P + p.down[lin].b, c.tensor_ptr(o.dst),
-                   c.stat_ptr(o.dst), Hl, Wl, c.ws->Hl[lin], c.ws->Wl[lin], !c.is_f32(o.src[0]), !c.is_f32(o.dst)};
+        const DownArgs a = down_args(c, o);
         TimedLaunch tl(KF_DOWN, c.st, 4.0 * c.n * 8.0 * ((double)a.Hin * a.Win + (double)Hl * Wl));
         GC_KLOG((a.Win & 3) == 0 ? "down8x2_kernel" : "down8_kernel");
         if ((a.Win & 3) == 0) down8x2_kernel<<<dim3(cdiv(Hl * ((Wl + 1) / 2), 256), 1, c.n), 256, 0, c.st>>>(a);
@@ -203,13 +312,7 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
           launch_conv8b<1, false, true, 0>(a, c.n, c.st);
           break;
         }
-        Conv8Args a{};
-        a.src[0] = c.tensor_ptr(o.src[0]);
-        a.sstat[0] = c.stat_ptr(o.src[0]);  // raw input: range bound from its sum of squares (conv8h_kernel)
-        a.w = P + p.up[lin].p_w; a.wh = P + p.up[lin].p_wh; a.bias = P + p.up[lin].b;
-        a.dst = c.tensor_ptr(o.dst); a.dstat = c.stat_ptr(o.dst);
-        a.H = Hl; a.W = Wl; a.Hin = c.ws->Hl[lin]; a.Win = c.ws->Wl[lin];
-        a.xcd = c.m.xcd();
+        const Conv8Args a = up_args(c, o);
         launch_conv8<1, false, true, 0>(c.m, pick_tile(c.m, c.n, Hl, Wl), a, c.n, c.st);
         break;
       }

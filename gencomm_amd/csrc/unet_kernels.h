@@ -523,11 +523,11 @@ __global__ __launch_bounds__(256) void down8_kernel(const DownArgs a) {
 // Same layer, two horizontally adjacent outputs per thread: the 3x5 input window of the pair is one aligned float4 + one
 // scalar per (channel, row) -- 48 load instructions per thread instead of 72 stride-2 scalar gathers PER OUTPUT (the
 // scalar form moved 2.7 TB/s: 33 us per 16-agent launch at 200x704).  Needs Win % 4 == 0 (16-B aligned rows).
-__global__ __launch_bounds__(256) void down8x2_kernel(const DownArgs a) {
-  __shared__ float s_red[4][16];
-  const int n = blockIdx.z;
+// one workgroup's share (256 output pixel pairs of agent n, block bx): body of down8x2_kernel, also a work item of the
+// persistent dataflow kernel (dataflow_kernels.h)
+__device__ __forceinline__ void down8x2_tile(const DownArgs& a, int bx, int n, float (*s_red)[16]) {
   const int Wp = (a.W + 1) >> 1;  // output pairs per row
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = bx * 256 + threadIdx.x;
   const bool ok = i < a.H * Wp;
   const int oy = ok ? i / Wp : 0, op = ok ? i - oy * Wp : 0;
   const int ox = 2 * op, ix = 4 * op;
@@ -593,6 +593,10 @@ __global__ __launch_bounds__(256) void down8x2_kernel(const DownArgs a) {
     part[8 + o] = fmaf(v0, v0, v1 * v1);
   }
   if (a.dstat != nullptr) block_stats_commit<256>(part, s_red, a.dstat + (size_t)n * 16);
+}
+__global__ __launch_bounds__(256) void down8x2_kernel(const DownArgs a) {
+  __shared__ float s_red[4][16];
+  down8x2_tile(a, blockIdx.x, blockIdx.z, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------

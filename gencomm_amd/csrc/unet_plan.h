@@ -292,6 +292,7 @@ struct UNetWorkspace {
   std::vector<int> Hl, Wl;
   std::vector<size_t> level_base, slot_bytes;
   size_t stats_bytes = 0, total = 0, kmap_off = 0, amax_off = 0;
+  size_t df_words_off = 0, df_prog_off = 0;  // dataflow kernel: tickets / done counters / error word (inside the zeroed statistics block), program
 
   const char* build(const UNetPlan& p, int n, int H, int W) {
     Hl.assign(p.L, 0); Wl.assign(p.L, 0);
@@ -302,7 +303,9 @@ struct UNetWorkspace {
       Hl[l] = Hl[l - 1] / 2; Wl[l] = Wl[l - 1] / 2;
     }
     if (Hl[p.L - 1] < 1 || Wl[p.L - 1] < 1) return "feature map too small for the number of levels";
-    stats_bytes = align_up(p.tensors.size() * (size_t)n * 16 * sizeof(double), 256);
+    // statistics of every tensor, then the dataflow kernel's words: [8] tickets, [64 ops][n] done counters, [1] error word
+    df_words_off = align_up(p.tensors.size() * (size_t)n * 16 * sizeof(double), 256);
+    stats_bytes = align_up(df_words_off + (8 + 64 * (size_t)n + 4) * sizeof(unsigned), 256);
     size_t off = stats_bytes;
     level_base.assign(p.L, 0); slot_bytes.assign(p.L, 0);
     for (int l = 0; l < p.L; ++l) {
@@ -314,6 +317,8 @@ struct UNetWorkspace {
     off += slot_bytes[0];
     amax_off = off;  // two floats: device bounds on max|cond|, max|x_t| (range guard of conv_in on the f16 pipe)
     off += 256;
+    df_prog_off = off;  // program of the dataflow kernel (dataflow_kernels.h DfProgram)
+    off += 1 << 16;
     total = off;
     return nullptr;
   }

@@ -72,10 +72,13 @@ const char* gencomm_build_info(void);
  *                             64x16-tile kernels are used (1 forces them onto small maps: tests)
  *   GENCOMM_MODE_ENH_FUSE     1 (default): Enhancer Linear1 + depthwise stage fused at C = 64; 0: separate launches
  *   GENCOMM_MODE_CONV8H_MASK  diagnostic bit mask of 8-channel layer variants allowed on the f16 pipe (-1: all)
- *   GENCOMM_MODE_XCD_REMAP    1 (default): workgroup -> tile mapping keeps neighbouring tiles on one XCD; 0: grid order */
+ *   GENCOMM_MODE_XCD_REMAP    1 (default): workgroup -> tile mapping keeps neighbouring tiles on one XCD; 0: grid order
+ *   GENCOMM_MODE_DATAFLOW     1: the body of a UNet call (every layer between conv_in and conv_out) runs as ONE persistent launch
+ *                             whose workgroups take (layer, agent, tile) items from per-XCD queues and wait on per-(layer, agent)
+ *                             completion counters (no grid barrier); 0: one launch per layer.  Same device functions, same results */
 enum {
   GENCOMM_MODE_ARITH = 0, GENCOMM_MODE_SAMPLER = 1, GENCOMM_MODE_TILE_WANT = 2, GENCOMM_MODE_ENH_FUSE = 3,
-  GENCOMM_MODE_CONV8H_MASK = 4, GENCOMM_MODE_XCD_REMAP = 5
+  GENCOMM_MODE_CONV8H_MASK = 4, GENCOMM_MODE_XCD_REMAP = 5, GENCOMM_MODE_DATAFLOW = 6
 };
 int gencomm_set_mode(int key, long long value);
 long long gencomm_get_mode(int key);
@@ -147,6 +150,15 @@ int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, 
 
 /* Scratch for one UNet call / the denoise loop on n agents of [C, H, W]. */
 long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask);
+
+/* Diagnostic for GENCOMM_MODE_DATAFLOW: the persistent kernel's error word of the last UNet call on this workspace -- 0: every
+ * dependency wait was satisfied; k + 1: a workgroup gave up (bounded spin) waiting for the predecessor of body op k, the call's
+ * result is then invalid; -1: bad arguments.  Synchronises `stream`. */
+int gencomm_dataflow_error(const void* workspace, int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, void* stream);
+/* Diagnostic: the kernel's counter block of the last call ([8] tickets taken per XCD queue, [64][n] finished tiles per body op and
+ * agent, the error word) copied to host_out[count]. Synchronises `stream`. */
+int gencomm_dataflow_words(const void* workspace, int n, int C, int H, int W, int levels, int res_blocks, int attn_mask,
+                           unsigned int* host_out, int count, void* stream);
 
 /* x0_hat[n,C,H,W] = UNet(cat[cond[n,2,H,W], x_t[n,C,H,W]], t) for one integer timestep t. */
 int gencomm_unet_fwd(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,

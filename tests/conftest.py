@@ -20,11 +20,12 @@ def golden_dir():
 @pytest.fixture
 def modes():
     """Setter for the library modes of include/gencomm_hip.h (gencomm_set_mode), restored after the test:
-    ``modes(arith="f32", sampler="direct", tile_want=1, xcd=0, enh_fuse=0, conv8h_mask=-1)``."""
+    ``modes(arith="f32", sampler="direct", tile_want=1, xcd=0, enh_fuse=0, conv8h_mask=-1, dataflow=1)``."""
     from gencomm_amd import _lib
     l = _lib.lib()
     keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
-            "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP}
+            "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP,
+            "dataflow": _lib.MODE_DATAFLOW}
     names = {"split": 0, "f32": 1, "bf16": 2, "latent": 2, "direct": 1, "auto": 0}
     prev = {k: l.gencomm_get_mode(k) for k in keys.values()}
 
