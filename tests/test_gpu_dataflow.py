@@ -38,8 +38,8 @@ def test_dataflow_golden_path(name, sampler, modes):
             outs[df] = gen(inp["feat"], inp["cond"], inp["record_len"], noise=noise)["pred_feature"].clone()
             torch.cuda.synchronize()
         ran_df = any("unet_dataflow_kernel" in k for k in kl.counts)
-        assert ran_df == bool(df), kl.counts
-        if df:
+        assert ran_df == (bool(df) and W % 4 == 0), kl.counts   # a map width that is no multiple of 4 keeps the per-layer launches
+        if ran_df:
             assert not any(k.startswith("conv8h_kernel") or k.startswith("down8") for k in kl.counts), kl.counts
             assert _df_error(gen, n, H, W) == 0
     assert_close(sub(outs[1], st), g["pred_feature"], RTOL, ATOL, f"{name} {sampler}: dataflow vs golden")
@@ -55,7 +55,7 @@ def test_dataflow_many_agents_and_repeatability(modes):
     gen = GenComm(synth.default_gencomm_cfg(C, T)).eval()
     synth.fill_params_(gen, 3)
     gen = gen.to(DEV)
-    inp = synth.make_inputs([n], C, H, W, 5)
+    inp = synth.make_inputs([4] * (n // 4), C, H, W, 5)
     feat, cond = torch.from_numpy(inp["feat"]).to(DEV), torch.from_numpy(inp["cond"]).to(DEV)
     modes(dataflow=0)
     with torch.no_grad():

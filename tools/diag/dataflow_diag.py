@@ -8,7 +8,8 @@ DEV = torch.device("cuda:0")
 l = _lib.lib()
 C, H, W, T, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 gen = GenComm(synth.default_gencomm_cfg(C, T)).eval(); synth.fill_params_(gen, 3); gen = gen.to(DEV)
-inp = synth.make_inputs([n], C, H, W, 5)
+rl = [4] * (n // 4) + ([n % 4] if n % 4 else [])
+inp = synth.make_inputs(rl, C, H, W, 5)
 x = torch.cat([torch.from_numpy(inp["cond"]), torch.from_numpy(inp["feat"])], 1).to(DEV)
 tt = torch.full((n,), 1.0, device=DEV)
 l.gencomm_set_mode(_lib.MODE_TILE_WANT, 1)
