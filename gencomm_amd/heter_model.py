@@ -119,6 +119,11 @@ class HeterModelBaselineWGenComm(nn.Module):
         self.reg_head = HipConv2d(args["in_head"], 7 * args["anchor_number"] * self.num_class, kernel_size=1)
         self.dir_head = HipConv2d(args["in_head"], args["dir_args"]["num_bins"] * args["anchor_number"], kernel_size=1)
         if "enhancer" in args:
+            if not isinstance(args["enhancer"], dict) or "in_ch" not in args["enhancer"]:
+                # opv2v/GenComm_yamls/gencomm/stage2/m1m3_{att,v2xvit}.yaml ship `enhancer: enhancev12` (a string): the reference
+                # fails at the same place with a bare "string indices must be integers" (stage2.py:153); same exception type, a
+                # message that names the key (found by oracle/sweep_yamls.py)
+                raise TypeError(f"model.args.enhancer must be a mapping with 'in_ch' (e.g. {{in_ch: 128}}), got {args['enhancer']!r}")
             self.enhancer = Enhancer(args["enhancer"]["in_ch"], [8, 8], 4)
             if self.STAGE2:
                 self.fix_modules += ["enhancer"]

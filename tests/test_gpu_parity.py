@@ -370,3 +370,32 @@ def test_half_precision_inputs_are_accepted_and_computed_in_fp32(dtype):
     assert torch.equal(outs[0][0], outs[1][0])                                  # GenComm: same fp32 computation on the same values
     rel = float((outs[0][1] - outs[1][1]).abs().max() / outs[1][1].abs().max())
     assert rel < 2e-2, rel                                                      # Enhancer fed the ROUNDED prediction (what AMP would hand over)
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+def test_forward_single_vs_oracle(train):
+    """GenComm.forward_single (cond_diff.py:385-432): every agent denoises from its OWN feature (no ego repeat), eval branch batched
+    and train branch per agent with `stack().squeeze()` -- the same maths; against the oracle with record_len = one scene per
+    agent (ego_repeat is then the identity), explicit noise, elementwise rtol 1e-4 / atol 1e-5. Eval also returns 't1' / 't2'."""
+    from gencomm_amd import GenComm, synth
+    from oracle import torch_port as O
+    C, H, W, T, n = 16, 20, 28, 4, 3
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen = GenComm(cfg)
+    synth.fill_params_(gen, 23)
+    sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    gen = gen.to(DEV).train(train)
+    inp = synth.make_inputs([n], C, H, W, 24)
+    feat, cond = torch.from_numpy(inp["feat"]), torch.from_numpy(inp["cond"])
+    n0, sn = (torch.from_numpy(a) for a in synth.make_eval_noise(25, n, C, H, W, T))
+    with torch.no_grad():
+        want = O.gencomm_forward(sd, cfg, feat, cond, [1] * n, n0, sn)
+        out = gen.forward_single(feat.to(DEV), cond.to(DEV), noise=(n0.to(DEV), sn.to(DEV)))
+    assert set(out) == ({"pred_feature"} if train else {"pred_feature", "t1", "t2"})
+    pred = out["pred_feature"]
+    assert tuple(pred.shape) == (n, C, H, W)
+    assert_close(pred.cpu().numpy(), want.numpy(), RTOL, ATOL, f"forward_single ({'train' if train else 'eval'})")
+    # differs from forward() with one scene, where collaborators start from the EGO's feature (cond_diff.py:332-337)
+    with torch.no_grad():
+        other = gen.eval()(feat.to(DEV), cond.to(DEV), [n], noise=(n0.to(DEV), sn.to(DEV)))["pred_feature"]
+    assert float((other[1:] - pred[1:]).abs().max()) > 1e-3 and torch.allclose(other[0], pred[0], rtol=1e-4, atol=1e-5)
