@@ -7,6 +7,7 @@
 //   D  v_mfma_f32_16x16x32_f16 D, .., D           -> N wait states -> v_pk_fma_f32 E, D[2:3], S, E   (VALU read of the LAST result registers;
 //      hipcc puts `s_nop 7` = 8 wait states here.  Round 2's conv8h_kernel epilogue lost its bias behind this pair, lanes 48..63)
 //   E  the same with v_fma_f32 reading D[3]
+//   F  round 2's exact reader: v_pk_fma_f32 D[0:1], D[0:1], S, E op_sel:[0,0,1] (in place, SGPR-pair source)
 // Operands are small integers: every result is exact; the reference is the same sequence with 32 wait states everywhere.
 // Grid: 1 workgroup alone, then 1 / 4 / 12 waves per SIMD-equivalent (256 / 1024 / 3072 workgroups of 4 waves).
 //   hipcc --offload-arch=gfx950 -O3 mfma_mixed_dep_probe.hip -o mfma_mixed_dep_probe.bin && ./mfma_mixed_dep_probe.bin
@@ -23,6 +24,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define MF_F16B "v_mfma_f32_16x16x32_f16 v[100:103], %12, %13, v[100:103]\n"
 #define RD_PK "v_pk_fma_f32 v[104:105], v[102:103], %14, v[104:105]\n"
 #define RD_FMA "v_fma_f32 v104, v103, 2.0, v104\nv_fma_f32 v105, v102, 2.0, v105\n"
+// round 2's exact form: in place on the FIRST result pair, SGPR-pair multiplier, op_sel on the addend, then copied out through v[104:105]
+#define RD_PK_R2 "v_pk_fma_f32 v[100:101], v[100:101], %14, v[104:105] op_sel:[0,0,1]\nv_mov_b32 v104, v100\nv_mov_b32 v105, v101\n"
 #define OPS : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(a8), "v"(b8), "v"(a16), "v"(b16), "v"(a16b), "v"(b16b), "s"(s2) \
             : "v100", "v101", "v102", "v103", "v104", "v105"
 #define W0 ""
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(256) void probe(float* out, int rounds) {
       else RUN(MF_F16 W32 MF_BF8, STORE_D);
     } else {
       if (SEQ < 200) RUN(MF_F16 W32 RD_PK, STORE_E);
-      else RUN(MF_F16 W32 RD_FMA, STORE_E);
+      else if (SEQ < 300) RUN(MF_F16 W32 RD_FMA, STORE_E);
+      else RUN(MF_F16 W32 RD_PK_R2, STORE_E);
     }
     for (int i = 0; i < 4; ++i) q[i] = r[i];
     if (SEQ == 0) RUN(MF_BF8 W0 MF_F16, STORE_D);
@@ -83,6 +87,10 @@ __global__ __launch_bounds__(256) void probe(float* out, int rounds) {
     if (SEQ == 112) RUN(MF_F16 W12 RD_PK, STORE_E);
     if (SEQ == 204) RUN(MF_F16 W4 RD_FMA, STORE_E);
     if (SEQ == 208) RUN(MF_F16 W8 RD_FMA, STORE_E);
+    if (SEQ == 304) RUN(MF_F16 W4 RD_PK_R2, STORE_E);
+    if (SEQ == 306) RUN(MF_F16 W6 RD_PK_R2, STORE_E);
+    if (SEQ == 308) RUN(MF_F16 W8 RD_PK_R2, STORE_E);
+    if (SEQ == 310) RUN(MF_F16 W10 RD_PK_R2, STORE_E);
     for (int i = 0; i < 4; ++i) bad[i] += (r[i] != q[i]) ? 1.f : 0.f;
   }
   float* o = out + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -124,6 +132,10 @@ int main() {
     run<112>("D f16 mfma -> 12 wait states -> v_pk_fma_f32", blocks, rounds);
     run<204>("E f16 mfma -> 4 wait states -> v_fma_f32 on D[3], D[2]", blocks, rounds);
     run<208>("E f16 mfma -> 8 wait states -> v_fma_f32", blocks, rounds);
+    run<304>("F f16 mfma -> 4 wait states -> v_pk_fma_f32 in place, sgpr pair, op_sel", blocks, rounds);
+    run<306>("F f16 mfma -> 6 wait states -> the same", blocks, rounds);
+    run<308>("F f16 mfma -> 8 wait states (hipcc) -> the same", blocks, rounds);
+    run<310>("F f16 mfma -> 10 wait states -> the same", blocks, rounds);
   }
   return 0;
 }
