@@ -49,7 +49,7 @@ enum ModeKey : int {
                          // 2: bf16 denoise mode (bf16 storage of the UNet's 8-channel maps, single bf16 products: conv8b_kernels.h)
   MODE_SAMPLER = 1,      // 0: automatic (latent structure on large maps, literal on small); 1: literal conv_in .. conv_out + update per step; 2: latent
   MODE_TILE_WANT = 2,    // 0: automatic; > 0: minimum number of 64x16 workgroups before the 64x16-tile kernels are chosen
-  MODE_ENH_FUSE = 3,     // 1: Enhancer Linear1 + depthwise stage fused at C = 64 (default); 0: separate launches
+  MODE_ENH_FUSE = 3,     // Enhancer at C = 64 -- 2 (default): Linear1 + depthwise stage + Linear2 in one kernel; 1: Linear1 + depthwise; 0: separate launches
   MODE_CONV8H_MASK = 4,  // diagnostic: bit mask of conv8h variants allowed on the f16 pipe (-1: all)
   MODE_XCD_REMAP = 5,    // 1: workgroup -> tile mapping keeps neighbouring tiles on one XCD (default); 0: plain grid order
   MODE_DATAFLOW = 6,     // 1: the UNet body of a call runs as ONE persistent dataflow launch (dataflow_kernels.h); 0: one launch per layer

@@ -49,7 +49,7 @@ struct EnhancerPlan {
 };
 
 struct EnhancerWs {
-  size_t Y, Z, Zc, Hd, G, O, colsum, gate, wT, total;
+  size_t Y, Z, Zc, Hd, G, O, O2, colsum, gate, wT, tab1, tab2, total;
 };
 
 inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
@@ -66,10 +66,16 @@ inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
   w.Zc = take(M * p.dc);
   w.Hd = take(M * 2 * p.hid);
   w.G = take(M * p.hid);
-  w.O = w.Z;  // linear2's output reuses Z (dead after linear1)
+  w.O = w.Z;   // the Linear2 GEMM's output reuses Z (dead after linear1)
+  w.O2 = w.G;  // the fused front kernel's Linear2 output: NOT Z (neighbouring workgroups read their halos from it); G is unused then
+  w.tab1 = take((size_t)(p.hid / 16) * (p.C / 16) * 896);  // fused front kernel: Linear1 / Linear2 operand tables
+  w.tab2 = take((size_t)(p.hid / 16) * (p.C / 32 > 0 ? p.C / 32 : 1) * 896);
   w.total = off;
   return w;
 }
+// 0: separate launches, 1: Linear1 + depthwise stage fused, 2: + Linear2 (the token-major result then lives in ws.O2)
+inline int enh_fuse_level(const Modes& m, int C) { return (m.split() && C == 64) ? (int)m.v[MODE_ENH_FUSE] : 0; }
+inline size_t enhancer_token_output(const EnhancerWs& w, const Modes& m, int C) { return enh_fuse_level(m, C) >= 2 ? w.O2 : w.O; }
 inline size_t enhancer_workspace_bytes(const EnhancerPlan& p, int n, int H, int W) { return enhancer_ws(p, n, H, W).total; }
 
 inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float* x, float* out,
@@ -109,12 +115,16 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
       enh_pconv_kernel<16, 8><<<dim3((W + 15) / 16, (H + 7) / 8, n), 128, sh, st>>>(a);
     }
   }
-  if (m.split() && C == 64 && m.v[MODE_ENH_FUSE] != 0) {  // MODE_ENH_FUSE 0: separate Linear1 / depthwise launches (A/B runs)
-    // K3 + K4 fused: the hidden tensor never reaches HBM; its slot in the workspace holds the 64 KB operand table
-    enh_prep_front_kernel<<<32, 256, 0, st>>>(raw + p.l1w, F(w.Hd), C, p.hid);
-    EnhFrontArgs a{F(w.Z), F(w.Hd), raw + p.l1b, raw + p.dww, raw + p.dwb, F(w.G), C, p.hid, H, W};
+  const int fuse = enh_fuse_level(m, C);
+  if (fuse != 0) {
+    // K3 + K4 (+ K5) fused: the hidden tensors never reach HBM
+    enh_prep_front_kernel<<<32, 256, 0, st>>>(raw + p.l1w, F(w.tab1), C, p.hid);
+    if (fuse >= 2) enh_prep_back_kernel<<<16, 256, 0, st>>>(raw + p.l2w, F(w.tab2), C, p.hid);
+    EnhFrontArgs a{F(w.Z), F(w.tab1), raw + p.l1b, raw + p.dww, raw + p.dwb, F(w.G), C, p.hid, H, W,
+                   F(w.tab2), raw + p.l2b, F(w.Y), F(w.O2), F(w.colsum)};
     TimedLaunch tl(KF_ENH_GEMM1, st);
-    enh_front_h_kernel<<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);
+    if (fuse >= 2) enh_front_h_kernel<true><<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);
+    else enh_front_h_kernel<false><<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);
   } else {
   {  // K3: linear1 + GELU
     GemmArgs a{F(w.Z), raw + p.l1w, raw + p.l1b, nullptr, F(w.Hd), nullptr, HW, 2 * p.hid, C};
@@ -130,7 +140,8 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     enh_dwgate_kernel<SL><<<dim3((unsigned)((total + 255) / 256), n), 256, 0, st>>>(a);
   }
   }
-  {  // K5: linear2 + residual, column sums for the global average pool
+  float* const Otok = fuse >= 2 ? F(w.O2) : F(w.O);
+  if (fuse < 2) {  // K5: linear2 + residual, column sums for the global average pool
     GemmArgs a{F(w.G), raw + p.l2w, raw + p.l2b, F(w.Y), F(w.O), F(w.colsum), HW, C, p.hid};
     TimedLaunch tl(KF_ENH_GEMM2, st);
     if (m.split() && (p.hid & 3) == 0) gemm_f16s_mfma_kernel<1><<<dim3((HW + 127) / 128, (C + 63) / 64, n), 256, 0, st>>>(a);
@@ -142,7 +153,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     enh_gate_kernel<<<n, 256, (2 * C + 8) * sizeof(float), st>>>(a);
   }
   if (out != nullptr) {  // K7 (skipped when the caller consumes the token-major result + gate directly)
-    EnhOutArgs a{F(w.O), F(w.gate), out, C, HW};
+    EnhOutArgs a{Otok, F(w.gate), out, C, HW};
     const size_t sh = (size_t)32 * (C + 1) * sizeof(float);
     TimedLaunch tl(KF_ENH_OUT, st);
     enh_scale_transpose_kernel<<<dim3((HW + 31) / 32, n), 256, sh, st>>>(a);

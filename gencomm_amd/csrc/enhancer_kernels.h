@@ -626,8 +626,14 @@ struct EnhFrontArgs {
   const float* b1;    // [2*hid]
   const float* dww;   // [hid][9]
   const float* dwb;   // [hid]
-  float* G;           // [n][H][W][hid]
+  float* G;           // [n][H][W][hid]   (written when Linear2 is not fused)
   int C, hid, H, W;
+  // Linear2 fused (enh_front_h_kernel<true>): out = G W2^T + b2 + res, column sums for the global average pool
+  const float* tab2;  // prepared Linear2 B operands (enh_prep_back_kernel)
+  const float* b2;    // [C]
+  const float* res;   // [n][H][W][C]  x + LayerNorm1(x) (enhancer.py:355)
+  float* O;           // [n][H][W][C]  must not alias Z (neighbouring workgroups still read their halos)
+  float* colsum;      // [n][C]
 };
 
 __global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __restrict__ w1 /*[2*hid][C]*/, float* __restrict__ tab, int C, int hid) {
@@ -660,11 +666,52 @@ __global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __rest
   }
 }
 
+// Linear2's weights [C][hid] as B operands of v_mfma_f32_32x32x16_*: block (chunk q of 16 hidden channels, output-channel block ob
+// of 32) = {[term 3][lane 64][4 dwords] fp16, [lane][2 dwords] bf8} = 896 dwords; lane l holds W2[32 ob + (l & 31)][16 q + 8 (l >> 5) ..+7]
+__global__ __launch_bounds__(256) void enh_prep_back_kernel(const float* __restrict__ w2 /*[C][hid]*/, float* __restrict__ tab, int C, int hid) {
+  const int nob = C / 32, total = (hid / 16) * nob * 896;
+  uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int blk = i / 896, qq = i - blk * 896, ob = blk % nob, q = blk / nob;
+    const int l = qq < 768 ? (qq >> 2) & 63 : (qq - 768) >> 1;
+    const int oc = 32 * ob + (l & 31), kg = l >> 5;
+    float wv[8];
+    for (int e = 0; e < 8; ++e) wv[e] = w2[(size_t)oc * hid + 16 * q + 8 * kg + e] * ENH_WS;
+    if (qq < 768) {
+      const int d = qq & 3, term = qq >> 8;
+      uint16_t v[2];
+      for (int e = 0; e < 2; ++e) {
+        const float x = wv[2 * d + e];
+        const _Float16 a1 = (_Float16)x;
+        const float r1 = x - (float)a1;
+        const _Float16 a2 = (_Float16)r1;
+        const _Float16 a3 = (_Float16)(r1 - (float)a2);
+        v[e] = __builtin_bit_cast(uint16_t, term == 0 ? a1 : term == 1 ? a2 : a3);
+      }
+      out[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    } else {
+      const int d = (qq - 768) & 1;
+      const float k = 1.0f / ENH_TSCALE;
+      out[i] = enh_bf8x4(wv[4 * d] * k, wv[4 * d + 1] * k, wv[4 * d + 2] * k, wv[4 * d + 3] * k);
+    }
+  }
+}
+
+// L2 = true: Linear2 + bias + residual + the column sums of the global average pool run here as well.  The gated
+// hidden chunk g [64 pixels][16 channels] goes through 5 KB of LDS as fp32, is split into its three terms while it is read as the A
+// operand (M = 32 pixels per wave, K = 16 = the chunk), W2's prepared B operands give N = 32 output channels per wave: wave w owns
+// pixel block w >> 1, output-channel block w & 1, one 32x32 accumulator for the whole kernel.  The 4C-per-pixel gated tensor
+// (1.15 GB per 16 agents written in 64-byte runs, read back by the Linear2 GEMM) and that GEMM's launch disappear.
+// The bf8 third-term product shares the accumulator with the f16 products: 16 wait states stand between the two instruction types
+// (tools/probes/mfma32_mixed_dep_probe.hip; tests/test_abi.py checks the code object).
+template <bool L2>
 __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs a) {
   fp16_ovfl_clamp();
-  constexpr int TP = 8, RP = TP + 2, NPX = RP * RP, C = 64, RB = C * 2 + 16, RT = C + 8, HS = 33;  // region 10x10, row bytes, hb stride
+  constexpr int TP = 8, RP = TP + 2, NPX = RP * RP, C = 64, RB = C * 2 + 16, RT = C + 8, HS = 17, GS = 20;  // region 10x10, row bytes, strides
   __shared__ __align__(16) unsigned char zh[NPX * RB], zl[NPX * RB], zt[NPX * RT];  // hi / lo fp16 planes, bf8 third-term plane
-  __shared__ float hb[NPX * HS];
+  __shared__ float hb1[NPX * HS];       // GELU(x1) on the 10x10 region, 16 channels of the chunk
+  __shared__ float hb2[TP * TP * HS];   // GELU(x2) on the tile's own 8x8 pixels (the gate is read at the centre only)
+  __shared__ __align__(16) float gbuf[L2 ? TP * TP * GS : 4];  // the gated chunk [pixel][16] (+4 pad: conflict-free 128-bit reads)
   __shared__ float s_b1[4 * C];  // Linear1 bias; the depthwise weights / bias are read from global memory per chunk (a few KB, cache
                                  // hits): with the third plane their 5 KB in LDS would cost the third resident workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
@@ -693,7 +740,9 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
   const bool inimg = pvalid && pgy >= 0 && pgy < a.H && pgx >= 0 && pgx < a.W;
   // the gate branch x2 is only read at the tile's own 8x8 pixels: no GELU for it on the halo ring
   const int prow = pcol / RP, pcl = pcol - prow * RP;
-  const bool centre = inimg && prow >= 1 && prow <= TP && pcl >= 1 && pcl <= TP;
+  const bool ring = !(pvalid && prow >= 1 && prow <= TP && pcl >= 1 && pcl <= TP);
+  const bool centre = inimg && !ring;
+  const int cidx = ring ? 0 : (prow - 1) * TP + (pcl - 1);
   // second phase ownership: channel tid % 16, tile row (tid / 16) % 8, pixels 4 * (tid / 128) .. +3 of that row
   const int dch = tid & 15, dpy = (tid >> 4) & 7, dx0 = 4 * (tid >> 7);
   const int nchunk = hid / 16;
@@ -713,6 +762,9 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
     }
   };
   load_chunk_operands(0);
+  f32x16 acc2;  // Linear2: [32 pixels of block wave >> 1] x [32 output channels of block wave & 1]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
 #pragma unroll 1
   for (int q = 0; q < nchunk; ++q) {
     f32x16 acc, act;  // act: the bf8 third-term products, accumulators of their own (see the GEMM above)
@@ -738,17 +790,27 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
     }
     __builtin_amdgcn_sched_barrier(0);
     if (q + 1 < nchunk) load_chunk_operands(q + 1);
-    if (q > 0) __syncthreads();  // the previous chunk's depthwise phase has finished reading hb
+    if (q > 0) __syncthreads();  // the previous chunk's depthwise phase has finished reading hb1 / hb2 (and its Linear2 step gbuf)
     if (pvalid) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // row of the chunk: < 16 gate-branch x1, >= 16 x2
         const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
-        const bool need = m < 16 ? inimg : centre;  // compile-time m per register: uniform branch per lane group
-        hb[pcol * HS + m] = need ? gelu_erf_f(fmaf(acc[reg] + act[reg], 1.0f / ENH_WS, s_b1[row])) : 0.f;
+        const float v = fmaf(acc[reg] + act[reg], 1.0f / ENH_WS, s_b1[row]);
+        if (m < 16) hb1[pcol * HS + m] = inimg ? gelu_erf_f(v) : 0.f;
+        else if (!ring) hb2[cidx * HS + (m - 16)] = centre ? gelu_erf_f(v) : 0.f;
       }
     }
     __syncthreads();
+    // Linear2's operands of this chunk: requested now, they arrive during the depthwise phase
+    eh8_t w2a[3];
+    long w2b = 0;
+    if (L2) {
+      const float* __restrict__ tb = a.tab2 + (size_t)(q * 2 + (wave & 1)) * 896;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w2a[k] = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(tb + (k * 64 + lane) * 4));
+      w2b = *reinterpret_cast<const long*>(tb + 768 + lane * 2);
+    }
     {
       const int ch = 16 * q + dch;
       const int gy = y0 + dpy;
@@ -759,11 +821,51 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) s = fmaf(wd[dy * 3 + dx], hb[((dpy + dy) * RP + x + dx) * HS + dch], s);
-        const float g = gelu_erf_f(s) * hb[((dpy + 1) * RP + x + 1) * HS + 16 + dch];
-        if (gy < a.H && gx < a.W) a.G[((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * hid + ch] = g;
+          for (int dx = 0; dx < 3; ++dx) s = fmaf(wd[dy * 3 + dx], hb1[((dpy + dy) * RP + x + dx) * HS + dch], s);
+        const float g = gelu_erf_f(s) * hb2[(dpy * TP + x) * HS + dch];
+        if (L2) gbuf[(dpy * TP + x) * GS + dch] = g;
+        else if (gy < a.H && gx < a.W) a.G[((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * hid + ch] = g;
       }
     }
+    if (L2) {
+      __syncthreads();
+      const float* __restrict__ gp = gbuf + (32 * (wave >> 1) + r) * GS + 8 * h;
+      uint2 h0, l0, h1, l1;
+      uint32_t t0, t1;
+      enh_split4(*reinterpret_cast<const float4*>(gp), 1.0f, h0, l0, t0);
+      enh_split4(*reinterpret_cast<const float4*>(gp + 4), 1.0f, h1, l1, t1);
+      const eh8_t ah = __builtin_bit_cast(eh8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      const eh8_t al = __builtin_bit_cast(eh8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+      const long at = (long)(((unsigned long)t1 << 32) | (unsigned long)t0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(at, w2b, acc2, 0, 0, 0);
+      // 24 wait states between matrix instructions of different input type on one accumulator (tied to it: nothing moves across)
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc2));
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w2a[2], acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w2a[1], acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w2a[1], acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w2a[0], acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w2a[0], acc2, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (L2) {  // out[pixel][oc] = acc2 / scale + b2 + res; column sums over the tile's pixels -> one atomic per (workgroup half, oc)
+    const int oc = 32 * (wave & 1) + r;
+    const float b = a.b2[oc];
+    float cs = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int p = 32 * (wave >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      const int gy = y0 + (p >> 3), gx = x0 + (p & 7);
+      if (gy < a.H && gx < a.W) {
+        const size_t o = ((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * C + oc;
+        const float v = fmaf(acc2[reg], 1.0f / ENH_WS, b) + a.res[o];
+        a.O[o] = v;
+        cs += v;
+      }
+    }
+    cs += __shfl_xor(cs, 32, 64);
+    if (h == 0) atomicAdd(&a.colsum[(size_t)n * C + oc], cs);
   }
 }
 

@@ -287,55 +287,78 @@ struct FuseTokArgs {
   const int* scene_off;  // [B+1]
   float* out;            // [B][C][H][W]
   int C, H, W;
+  int xcd;               // 1: XCD-aware block order (MODE_XCD_REMAP)
 };
 
+// bilinear cell of one (output pixel, agent): the four corner pixels CLAMPED into the map (every corner is loaded, without a branch:
+// with a branch per corner the loads of a pass were issued one latency after the other), fractions, valid corners
+struct __align__(16) FuseGeo { int idx[4]; float tx, ty; unsigned mask, pad; };
+
 template <int N, int QPL /*float4 quads per lane*/>
-__device__ __forceinline__ void fuse_tok_body(const FuseTokArgs& a, int b, int off, float* s_out /*[64][C+1]*/) {
+__device__ __forceinline__ void fuse_tok_body(const FuseTokArgs& a, int bx, int b, int off, float* s_out /*[64][C+1]*/, FuseGeo (*s_geo)[64]) {
   const int tid = threadIdx.x;
   const int C = a.C, H = a.H, W = a.W, HW = H * W;
-  const int lp = tid >> 4, ql = tid & 15;       // 16 pixels per 256-thread block pass, 16 lanes per pixel
-  const int c0 = ql * 4 * QPL;                  // first channel of this lane
-  for (int pass = 0; pass < 4; ++pass) {        // 64 pixels per block
-    const int pl = pass * 16 + lp;              // local pixel 0..63
-    const int pix = blockIdx.x * 64 + pl;
+  // sampling geometry ONCE per (pixel, agent) -- one thread each -- instead of once per lane of the pixel's 16: the float64
+  // affine grid (as F.affine_grid evaluates the reference's float64 theta) with its two divisions was 16 x redundant
+  for (int e = tid; e < 64 * N; e += 256) {
+    const int pl = e & 63, j = e >> 6;
+    const int pix = bx * 64 + pl;
     const bool ok = pix < HW;
     const int h = ok ? pix / W : 0, w = ok ? pix - h * W : 0;
     const double xb = (2.0 * w + 1.0) / (double)W - 1.0, yb = (2.0 * h + 1.0) / (double)H - 1.0;
+    const double* __restrict__ th = a.theta + (size_t)(off + j) * 6;
+    const float gx = (float)(th[0] * xb + th[1] * yb + th[2]);
+    const float gy = (float)(th[3] * xb + th[4] * yb + th[5]);
+    const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+    const bool far = fx != (float)x0 || fy != (float)y0;
+    const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
+    const bool in = ok && !far;
+    FuseGeo g;
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1), yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    g.idx[0] = yc0 * W + xc0; g.idx[1] = yc0 * W + xc1; g.idx[2] = yc1 * W + xc0; g.idx[3] = yc1 * W + xc1;
+    g.tx = ix - fx;
+    g.ty = iy - fy;
+    g.mask = (in && xl && yt ? 1u : 0u) | (in && xr && yt ? 2u : 0u) | (in && xl && yb_ ? 4u : 0u) | (in && xr && yb_ ? 8u : 0u);
+    g.pad = 0u;
+    s_geo[j][pl] = g;
+  }
+  __syncthreads();
+  const int lp = tid >> 4, ql = tid & 15;       // 16 pixels per 256-thread block pass, 16 lanes per pixel
+  const int c0 = ql * 4 * QPL;                  // first channel of this lane
+  float4 gate[N][QPL];                          // channel gate of agent j (sigmoid output of SplitAttn), constant over pixels
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) gate[j][q] = *reinterpret_cast<const float4*>(a.gate + (size_t)(off + j) * C + c0 + 4 * q);
+  const float inv = 1.0f / sqrtf((float)C);
+  for (int pass = 0; pass < 4; ++pass) {        // 64 pixels per block
+    const int pl = pass * 16 + lp;              // local pixel 0..63
     float4 v[N][QPL];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const double* __restrict__ th = a.theta + (size_t)(off + j) * 6;
-      const float gx = (float)(th[0] * xb + th[1] * yb + th[2]);
-      const float gy = (float)(th[3] * xb + th[4] * yb + th[5]);
-      const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
-      const float fx = floorf(ix), fy = floorf(iy);
-      const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
-      const float tx = ix - fx, ty = iy - fy;
-      const bool far = fx != (float)x0 || fy != (float)y0;
-      const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W;
-      const bool yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
+      const FuseGeo g = s_geo[j][pl];
+      const float tx = g.tx, ty = g.ty;
       const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
-      const bool val[4] = {ok && xl && yt && !far, ok && xr && yt && !far, ok && xl && yb_ && !far, ok && xr && yb_ && !far};
-      const int idx[4] = {y0 * W + x0, y0 * W + x0 + 1, (y0 + 1) * W + x0, (y0 + 1) * W + x0 + 1};
       const float* __restrict__ base = a.O + (size_t)(off + j) * HW * C + c0;
 #pragma unroll
       for (int q = 0; q < QPL; ++q) v[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (val[k]) {
+        const bool on = (g.mask >> k) & 1u;   // an invalid corner contributes an exact zero whatever the clamped pixel holds
 #pragma unroll
-          for (int q = 0; q < QPL; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(base + (size_t)idx[k] * C + 4 * q);
-            v[j][q].x = fmaf(t.x, wgt[k], v[j][q].x); v[j][q].y = fmaf(t.y, wgt[k], v[j][q].y);
-            v[j][q].z = fmaf(t.z, wgt[k], v[j][q].z); v[j][q].w = fmaf(t.w, wgt[k], v[j][q].w);
-          }
+        for (int q = 0; q < QPL; ++q) {
+          float4 t = *reinterpret_cast<const float4*>(base + (size_t)g.idx[k] * C + 4 * q);
+          t.x = on ? t.x : 0.f; t.y = on ? t.y : 0.f; t.z = on ? t.z : 0.f; t.w = on ? t.w : 0.f;
+          v[j][q].x = fmaf(t.x, wgt[k], v[j][q].x); v[j][q].y = fmaf(t.y, wgt[k], v[j][q].y);
+          v[j][q].z = fmaf(t.z, wgt[k], v[j][q].z); v[j][q].w = fmaf(t.w, wgt[k], v[j][q].w);
         }
       }
-      // channel gate of agent j (sigmoid output of SplitAttn), constant over pixels
 #pragma unroll
       for (int q = 0; q < QPL; ++q) {
-        const float4 g = *reinterpret_cast<const float4*>(a.gate + (size_t)(off + j) * C + c0 + 4 * q);
-        v[j][q].x *= g.x; v[j][q].y *= g.y; v[j][q].z *= g.z; v[j][q].w *= g.w;
+        v[j][q].x *= gate[j][q].x; v[j][q].y *= gate[j][q].y; v[j][q].z *= gate[j][q].z; v[j][q].w *= gate[j][q].w;
       }
     }
     float sc[N];
@@ -349,7 +372,6 @@ __device__ __forceinline__ void fuse_tok_body(const FuseTokArgs& a, int b, int o
       for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 16);   // over the 16 lanes of this pixel
       sc[j] = d;
     }
-    const float inv = 1.0f / sqrtf((float)C);
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < N; ++j) { sc[j] *= inv; mx = fmaxf(mx, sc[j]); }
@@ -372,7 +394,7 @@ __device__ __forceinline__ void fuse_tok_body(const FuseTokArgs& a, int b, int o
   __syncthreads();
   // NCHW store: lanes over the 64 pixels of the block, waves over channels
   const int p = tid & 63;
-  const int pix = blockIdx.x * 64 + p;
+  const int pix = bx * 64 + p;
   if (pix < HW)
     for (int c = tid >> 6; c < C; c += 4) a.out[((size_t)b * C + c) * HW + pix] = s_out[p * (C + 1) + c];
 }
@@ -380,24 +402,28 @@ __device__ __forceinline__ void fuse_tok_body(const FuseTokArgs& a, int b, int o
 template <int QPL>
 __global__ __launch_bounds__(256) void warp_attfuse_tok_kernel(const FuseTokArgs a) {
   extern __shared__ float s_out[];
-  const int b = blockIdx.y;
+  __shared__ FuseGeo s_geo[8][64];
+  // XCD-aware order (common.h xcd_block): a block is 64 pixels of ONE output row and shares both source rows of its bilinear
+  // cells with the blocks of the neighbouring rows, gridDim.x ids away -- dealt round-robin those land on other XCDs' L2s
+  const BlockId bi = xcd_block(a.xcd);
+  const int b = bi.y;
   const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
   switch (N) {
-    case 1: fuse_tok_body<1, QPL>(a, b, off, s_out); break;
-    case 2: fuse_tok_body<2, QPL>(a, b, off, s_out); break;
-    case 3: fuse_tok_body<3, QPL>(a, b, off, s_out); break;
-    case 4: fuse_tok_body<4, QPL>(a, b, off, s_out); break;
-    case 5: fuse_tok_body<5, QPL>(a, b, off, s_out); break;
-    case 6: fuse_tok_body<6, QPL>(a, b, off, s_out); break;
-    case 7: fuse_tok_body<7, QPL>(a, b, off, s_out); break;
-    case 8: fuse_tok_body<8, QPL>(a, b, off, s_out); break;
+    case 1: fuse_tok_body<1, QPL>(a, bi.x, b, off, s_out, s_geo); break;
+    case 2: fuse_tok_body<2, QPL>(a, bi.x, b, off, s_out, s_geo); break;
+    case 3: fuse_tok_body<3, QPL>(a, bi.x, b, off, s_out, s_geo); break;
+    case 4: fuse_tok_body<4, QPL>(a, bi.x, b, off, s_out, s_geo); break;
+    case 5: fuse_tok_body<5, QPL>(a, bi.x, b, off, s_out, s_geo); break;
+    case 6: fuse_tok_body<6, QPL>(a, bi.x, b, off, s_out, s_geo); break;
+    case 7: fuse_tok_body<7, QPL>(a, bi.x, b, off, s_out, s_geo); break;
+    case 8: fuse_tok_body<8, QPL>(a, bi.x, b, off, s_out, s_geo); break;
     default: break;
   }
 }
 
 inline int warp_attfuse_tok_enqueue(const float* O, const float* gate, const double* theta, const int* scene_off, float* out,
-                                    int B, int C, int H, int W, hipStream_t st) {
-  FuseTokArgs a{O, gate, theta, scene_off, out, C, H, W};
+                                    int B, int C, int H, int W, int xcd, hipStream_t st) {
+  FuseTokArgs a{O, gate, theta, scene_off, out, C, H, W, xcd};
   const dim3 grid((H * W + 63) / 64, B);
   const size_t sh = (size_t)64 * (C + 1) * sizeof(float);
   TimedLaunch tl(KF_WARP_ATTFUSE, st);

@@ -30,7 +30,7 @@ KernelTimer& kernel_timer() {
   static KernelTimer t;
   return t;
 }
-static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {1}, {-1}, {1}, {0}};  // defaults, see ModeKey
+static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {2}, {-1}, {1}, {0}};  // defaults, see ModeKey
 static std::atomic<bool> g_klog_armed{false};
 static std::mutex g_klog_mu;
 static std::map<std::string, int> g_klog;
@@ -811,8 +811,9 @@ int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* t
   GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && H >= 1 && W >= 1, "bad B/n/H/W");
   const EnhancerWs w = enhancer_ws(p, n, H, W);
   const char* base = (const char*)enhancer_workspace;
-  return warp_attfuse_tok_enqueue(reinterpret_cast<const float*>(base + w.O), reinterpret_cast<const float*>(base + w.gate),
-                                  theta, scene_off, out, B, C, H, W, (hipStream_t)stream);
+  const Modes m = modes_snapshot();  // the same mode the Enhancer call saw decides where its token-major result lives
+  return warp_attfuse_tok_enqueue(reinterpret_cast<const float*>(base + enhancer_token_output(w, m, C)), reinterpret_cast<const float*>(base + w.gate),
+                                  theta, scene_off, out, B, C, H, W, m.xcd(), (hipStream_t)stream);
 }
 
 }  // extern "C"

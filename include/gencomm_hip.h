@@ -70,7 +70,8 @@ const char* gencomm_build_info(void);
  *                             kernels (x_t stays out of HBM), 1 on small, cache-resident maps (shorter dependent chain)
  *   GENCOMM_MODE_TILE_WANT    0 (default): automatic tile choice; > 0: minimum number of 64x16 workgroups before the
  *                             64x16-tile kernels are used (1 forces them onto small maps: tests)
- *   GENCOMM_MODE_ENH_FUSE     1 (default): Enhancer Linear1 + depthwise stage fused at C = 64; 0: separate launches
+ *   GENCOMM_MODE_ENH_FUSE     Enhancer at C = 64 -- 2 (default): Linear1 + depthwise stage + Linear2 in one kernel;
+ *                             1: Linear1 + depthwise stage fused; 0: separate launches
  *   GENCOMM_MODE_CONV8H_MASK  diagnostic bit mask of 8-channel layer variants allowed on the f16 pipe (-1: all)
  *   GENCOMM_MODE_XCD_REMAP    1 (default): workgroup -> tile mapping keeps neighbouring tiles on one XCD; 0: grid order
  *   GENCOMM_MODE_DATAFLOW     1: the body of a UNet call (every layer between conv_in and conv_out) runs as ONE persistent launch
