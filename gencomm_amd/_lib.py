@@ -15,8 +15,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 5
-MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW = range(7)
+ABI_VERSION = 6
+MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW, MODE_RESFUSE_EMU = range(8)
 
 _lock = threading.Lock()
 _lib = None
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "gencomm_dwconv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_dwconv3x3_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_gelu_bwd": (_i, [_p, _p, _p, _ll, _p]),
+    "gencomm_lincomb_fwd": (_i, [_p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _ll, _p]),
     "gencomm_det_workspace_bytes": (C.c_longlong, [_i, _i, _i]),
     "gencomm_nms_workspace_bytes": (C.c_longlong, []),
     "gencomm_nms_max_candidates": (_i, []),

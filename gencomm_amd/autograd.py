@@ -25,6 +25,9 @@ from typing import List, Sequence
 import torch
 import torch.nn.functional as F
 
+from . import _lib
+from .runtime import dev_ints, ptr, stream_ptr
+
 
 # ----------------------------------------------------------------------------------------- UNet + sampler
 def _silu(x):
@@ -69,20 +72,92 @@ class UNetFunction(torch.autograd.Function):
                 graw if ctx.needs_input_grad[5] else None)
 
 
-def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise):
-    """The training branch's maths (cond_diff.py:342-360, :262-264, :272-315) as a chain of `UNetFunction` calls and
-    elementwise torch ops; autograd composes the T steps. `step_noise[i]` is the noise of the i-th loop iteration."""
-    T = gen.num_timesteps
-    idx = torch.as_tensor(list(src_rows), dtype=torch.long, device=feat.device)
-    flat = gen.denoiser.flat_params()
-    x = gen.sqrt_alphas_cumprod[T - 1] * feat.index_select(0, idx) + gen.sqrt_one_minus_alphas_cumprod[T - 1] * noise0
-    for i, t in enumerate(reversed(range(T))):
-        x0 = UNetFunction.apply(gen.denoiser, t, T, x, cond, flat)
-        if t == 0:
-            return x0
-        x = gen.posterior_mean_coef1[t] * x0 + gen.posterior_mean_coef2[t] * x \
-            + (0.5 * gen.posterior_log_variance_clipped[t]).exp() * step_noise[i]
-    return x
+def _lincomb(out, x, a, y=None, b=0.0, z=None, c=0.0):
+    """out = a x + b y + c z on the HIP elementwise kernel (out may alias an input)."""
+    _lib.check(_lib.lib().gencomm_lincomb_fwd(ptr(out), ptr(x), ptr(y), ptr(z), float(a), float(b), float(c), out.numel(), stream_ptr(out.device)),
+               "gencomm_lincomb_fwd")
+    return out
+
+
+class SamplerChainFunction(torch.autograd.Function):
+    """The training branch's whole T-step chain (cond_diff.py:342-360, :262-264, :272-315) as ONE autograd node: q_sample, T HIP
+    UNet calls with every intermediate kept (`gencomm_unet_fwd_train`), the posterior-mean update between them, and in backward
+    the same walk in reverse (`gencomm_unet_bwd` per step) -- the elementwise glue and the accumulation of the T gradient blobs
+    run on HIP kernels (`gencomm_lincomb_fwd`), the noise is either the explicit tensors of the caller (tests) or the sampler's
+    own in-kernel Philox field (`gencomm_q_sample_fwd` / `gencomm_step_noise_fwd`: the field inference adds for the same seed).
+    Round 2 composed the chain from `UNetFunction` and torch tensor arithmetic: 60 framework kernels per training step."""
+
+    @staticmethod
+    def forward(ctx, gen, src_rows, noise0, step_noise, seed, feat, cond, flat):
+        T = gen.num_timesteps
+        unet = gen.denoiser
+        dev = feat.device
+        n, (C, H, W) = cond.shape[0], feat.shape[1:]
+        l = _lib.lib()
+        st = stream_ptr(dev)
+        with torch.no_grad():
+            f, cd = feat.detach().float().contiguous(), cond.detach().float().contiguous()
+            sched = gen._sched_table(dev)
+            rows = dev_ints(list(src_rows), dev)
+            x = torch.empty((n, C, H, W), dtype=torch.float32, device=dev)
+            n0 = None if noise0 is None else noise0.detach().float().contiguous()
+            _lib.check(l.gencomm_q_sample_fwd(ptr(sched[T - 1]), ptr(f), f.shape[0], ptr(rows), ptr(n0), int(seed), T, ptr(x), n, C, H, W, st),
+                       "gencomm_q_sample_fwd")
+            xs, wss = [], []
+            coef = sched.detach().cpu().tolist()   # [T][5]: sqrt_ac, sqrt_1m_ac, coef1, coef2, sigma
+            out = None
+            for i, t in enumerate(reversed(range(T))):
+                x0, ws = unet.forward_train(x, cd, t, T)
+                xs.append(x)
+                wss.append(ws)
+                if t == 0:
+                    out = x0
+                    break
+                if step_noise is None:   # nu_t = fp16(sigma_t z) of the sampler's Philox field, already scaled
+                    nu = torch.empty_like(x)
+                    _lib.check(l.gencomm_step_noise_fwd(ptr(sched[t]), int(seed), t, ptr(nu), n, C, H, W, 0, st), "gencomm_step_noise_fwd")
+                    x = _lincomb(nu, x0, coef[t][2], x, coef[t][3], nu, 1.0)
+                else:
+                    x = _lincomb(torch.empty_like(x), x0, coef[t][2], x, coef[t][3], step_noise[i].detach().float().contiguous(), coef[t][4])
+        ctx.gen, ctx.src_rows, ctx.coef = gen, list(src_rows), coef
+        ctx.xs, ctx.wss, ctx.cond = xs, wss, cd
+        ctx.feat_shape = tuple(feat.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gen, coef = ctx.gen, ctx.coef
+        unet, T = gen.denoiser, gen.num_timesteps
+        need_feat, need_cond, need_flat = ctx.needs_input_grad[5], ctx.needs_input_grad[6], ctx.needs_input_grad[7]
+        with torch.no_grad():
+            g_x0 = grad_out.float().contiguous()
+            d_prev = None            # gradient of x_{t-1}, the input of the step walked before this one
+            g_cond = g_flat = None
+            for t in range(T):       # the loop ran t = T-1 .. 0; xs[T-1-t] is the x_t the call at t saw
+                i = T - 1 - t
+                if t > 0:
+                    g_x0 = _lincomb(torch.empty_like(d_prev), d_prev, coef[t][2])
+                gx, gc, graw = unet.backward_call(ctx.xs[i], ctx.cond, t, g_x0, T, ws=ctx.wss[i])
+                ctx.wss[i] = None
+                if t > 0:
+                    _lincomb(gx, gx, 1.0, d_prev, coef[t][3])      # d x_t = UNet input gradient + c2_t d x_{t-1}
+                d_prev = gx
+                g_cond = gc if g_cond is None else _lincomb(g_cond, g_cond, 1.0, gc, 1.0)
+                g_flat = graw if g_flat is None else _lincomb(g_flat, g_flat, 1.0, graw, 1.0)
+            g_feat = None
+            if need_feat:            # x_{T-1} = sqrt_ac feat[src_rows] + ...: rows of one scene all point at its ego row
+                g_feat = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=d_prev.device)
+                for k, r in enumerate(ctx.src_rows):
+                    _lincomb(g_feat[r], g_feat[r], 1.0, d_prev[k], coef[T - 1][0])
+            ctx.xs = ctx.wss = None
+        return None, None, None, None, None, g_feat, g_cond if need_cond else None, g_flat if need_flat else None
+
+
+def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise, seed: int = 0):
+    """The training branch's maths (cond_diff.py:342-360, :262-264, :272-315): one `SamplerChainFunction` node.  `noise0` /
+    `step_noise[i]` (the noise of the i-th loop iteration) may be None: the chain then draws the sampler's in-kernel Philox field
+    of `seed`."""
+    return SamplerChainFunction.apply(gen, list(src_rows), noise0, step_noise, int(seed), feat, cond, gen.denoiser.flat_params())
 
 
 # ----------------------------------------------------------------------------------------- Enhancer

@@ -164,14 +164,10 @@ class GenComm(nn.Module):
         from .autograd import sampler_forward
         require_gpu(feat, "GenComm.forward(spatial_features)")
         require_gpu(cond, "GenComm.forward(conditions)")
-        n, (C, H, W), T = cond.shape[0], feat.shape[1:], self.num_timesteps
-        if noise is None:
-            g = None
-            if seed is not None:
-                g = torch.Generator(device=feat.device)
-                g.manual_seed(int(seed))
-            noise = (torch.randn(n, C, H, W, device=feat.device, generator=g),
-                     torch.randn(T, n, C, H, W, device=feat.device, generator=g))
+        if noise is None:   # the sampler's own in-kernel Philox field of `seed` (what inference adds for the same seed)
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            return sampler_forward(self, f32c(feat), f32c(cond), list(src_rows), None, None, seed)
         return sampler_forward(self, f32c(feat), f32c(cond), list(src_rows), f32c(noise[0]), f32c(noise[1]))
 
     def _debug_t1_t2(self, spatial_features: torch.Tensor, data_dict: dict) -> None:

@@ -53,7 +53,8 @@ enum ModeKey : int {
   MODE_CONV8H_MASK = 4,  // diagnostic: bit mask of conv8h variants allowed on the f16 pipe (-1: all)
   MODE_XCD_REMAP = 5,    // 1: workgroup -> tile mapping keeps neighbouring tiles on one XCD (default); 0: plain grid order
   MODE_DATAFLOW = 6,     // 1: the UNet body of a call runs as ONE persistent dataflow launch (dataflow_kernels.h); 0: one launch per layer
-  MODE_COUNT = 7
+  MODE_RESFUSE_EMU = 7,  // TIMING EXPERIMENT ONLY, off by default -- the results are NOT the UNet's: unet_host.h "ResnetBlock fusion, emulated"
+  MODE_COUNT = 8
 };
 struct Modes {
   long long v[MODE_COUNT];

@@ -652,6 +652,9 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
   __syncthreads();
   GC_STAMP(2);
   if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2>(tile, a.wh, acc, off, lane, a.term_mask);
+  // diagnostic instantiation, MODE_RESFUSE_EMU: the matrix work of a second convolution on the same tile (its result is added: the
+  // numbers are meaningless, the instruction count is that of a fused conv1 + conv2 workgroup)
+  if (DIAG && (a.term_mask & 128) && wave_live) conv_tile_mfma3<DIAG, NSRC == 2>(tile, a.wh, acc, off, lane, a.term_mask);
   GC_STAMP(3);
   if (NSRC == 2) {
     __syncthreads();
@@ -707,7 +710,8 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
         float* __restrict__ dp = a.dst + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
         float s = 0.f, q = 0.f;
         if (vec_ok && gy < a.H) {
-          *reinterpret_cast<float4*>(dp) = make_float4(out[p][i][0], out[p][i][1], out[p][i][2], out[p][i][3]);
+          if (!(DIAG && (a.term_mask & 64)))   // diagnostic, MODE_RESFUSE_EMU: statistics-only pass (no store)
+            *reinterpret_cast<float4*>(dp) = make_float4(out[p][i][0], out[p][i][1], out[p][i][2], out[p][i][3]);
           s = out[p][i][0] + out[p][i][1];  // no "0 + x" / "x * x + 0" instructions in the common path
           q = out[p][i][0] * out[p][i][0];
           q = fmaf(out[p][i][1], out[p][i][1], q);

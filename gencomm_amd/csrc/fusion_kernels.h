@@ -36,6 +36,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, int b, int off, int
   const double xb = (2.0 * w + 1.0) / (double)W - 1.0;
   const double yb = (2.0 * h + 1.0) / (double)H - 1.0;
   int idx[N][4];
+  unsigned ok[N];
   float wt[N][4];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -54,16 +55,20 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, int b, int off, int
     const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W;
     const bool yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
     const bool far = fx != (float)x0 || fy != (float)y0;  // clamped => everything out of range
-    idx[j][0] = (xl && yt && !far) ? y0 * W + x0 : -1;
-    idx[j][1] = (xr && yt && !far) ? y0 * W + x0 + 1 : -1;
-    idx[j][2] = (xl && yb_ && !far) ? (y0 + 1) * W + x0 : -1;
-    idx[j][3] = (xr && yb_ && !far) ? (y0 + 1) * W + x0 + 1 : -1;
+    // every tap is LOADED, from the corner clamped into the map, and an invalid one is replaced by an exact zero afterwards: with a
+    // branch per tap the loads of a channel were issued one memory latency after the other (the token-major kernel's lesson)
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1), yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    idx[j][0] = yc0 * W + xc0; idx[j][1] = yc0 * W + xc1; idx[j][2] = yc1 * W + xc0; idx[j][3] = yc1 * W + xc1;
+    ok[j] = (xl && yt && !far ? 1u : 0u) | (xr && yt && !far ? 2u : 0u) | (xl && yb_ && !far ? 4u : 0u) | (xr && yb_ && !far ? 8u : 0u);
     wt[j][0] = wnw; wt[j][1] = wne; wt[j][2] = wsw; wt[j][3] = wse;
   }
   auto sample = [&](int j, const float* __restrict__ plane) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = plane[idx[j][k]];
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v = fmaf(idx[j][k] >= 0 ? plane[idx[j][k]] : 0.f, wt[j][k], v);
+    for (int k = 0; k < 4; ++k) v = fmaf((ok[j] >> k) & 1u ? t[k] : 0.f, wt[j][k], v);
     return v;
   };
   const float* __restrict__ xs = a.x + (size_t)off * a.C * HW;
@@ -166,6 +171,7 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
   const double xb = (2.0 * w + 1.0) / (double)W - 1.0;
   const double yb = (2.0 * h + 1.0) / (double)H - 1.0;
   int idx[N][4];
+  unsigned ok[N];
   float wt[N][4];
 #pragma unroll
   for (int j = 0; j < N; ++j) {  // identical to fuse_body's tap computation
@@ -181,16 +187,20 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
     const bool xl = x0 >= 0 && x0 < W, xr = x0 + 1 >= 0 && x0 + 1 < W;
     const bool yt = y0 >= 0 && y0 < H, yb_ = y0 + 1 >= 0 && y0 + 1 < H;
     const bool far = fx != (float)x0 || fy != (float)y0;
-    idx[j][0] = (xl && yt && !far) ? y0 * W + x0 : -1;
-    idx[j][1] = (xr && yt && !far) ? y0 * W + x0 + 1 : -1;
-    idx[j][2] = (xl && yb_ && !far) ? (y0 + 1) * W + x0 : -1;
-    idx[j][3] = (xr && yb_ && !far) ? (y0 + 1) * W + x0 + 1 : -1;
+    // every tap is LOADED, from the corner clamped into the map, and an invalid one is replaced by an exact zero afterwards: with a
+    // branch per tap the loads of a channel were issued one memory latency after the other (the token-major kernel's lesson)
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1), yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    idx[j][0] = yc0 * W + xc0; idx[j][1] = yc0 * W + xc1; idx[j][2] = yc1 * W + xc0; idx[j][3] = yc1 * W + xc1;
+    ok[j] = (xl && yt && !far ? 1u : 0u) | (xr && yt && !far ? 2u : 0u) | (xl && yb_ && !far ? 4u : 0u) | (xr && yb_ && !far ? 8u : 0u);
     wt[j][0] = (1.f - tx) * (1.f - ty); wt[j][1] = tx * (1.f - ty); wt[j][2] = (1.f - tx) * ty; wt[j][3] = tx * ty;
   }
   auto sample = [&](int j, const float* __restrict__ plane) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = plane[idx[j][k]];
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v = fmaf(idx[j][k] >= 0 ? plane[idx[j][k]] : 0.f, wt[j][k], v);
+    for (int k = 0; k < 4; ++k) v = fmaf((ok[j] >> k) & 1u ? t[k] : 0.f, wt[j][k], v);
     return v;
   };
   const float* __restrict__ xs = a.x + (size_t)off * a.C * HW;
@@ -238,15 +248,15 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
       float* __restrict__ plane = gxs + ((size_t)j * a.C + c) * HW;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (idx[j][k] >= 0) atomicAdd(plane + idx[j][k], wt[j][k] * dj);
+        if ((ok[j] >> k) & 1u) atomicAdd(plane + idx[j][k], wt[j][k] * dj);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void warp_attfuse_bwd_kernel(const FuseBwdArgs a) {
+__global__ __launch_bounds__(64) void warp_attfuse_bwd_kernel(const FuseBwdArgs a) {
   const int b = blockIdx.y;
   const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int pix = blockIdx.x * 64 + threadIdx.x;   // one wave per workgroup: a single scene is 2 200 workgroups instead of 550
   if (pix >= a.H * a.W) return;
   switch (N) {
     case 1: fuse_bwd_body<1>(a, b, off, pix); break;
@@ -265,7 +275,7 @@ inline int warp_attfuse_bwd_enqueue(const float* x, const double* theta, const i
                                     int B, int n, int C, int H, int W, hipStream_t st) {
   GC_HIP(hipMemsetAsync(gx, 0, (size_t)n * C * H * W * sizeof(float), st));
   FuseBwdArgs a{x, theta, scene_off, gout, gx, C, H, W};
-  warp_attfuse_bwd_kernel<<<dim3((H * W + 255) / 256, B), 256, 0, st>>>(a);
+  warp_attfuse_bwd_kernel<<<dim3((H * W + 63) / 64, B), 64, 0, st>>>(a);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

@@ -30,7 +30,7 @@ KernelTimer& kernel_timer() {
   static KernelTimer t;
   return t;
 }
-static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {2}, {-1}, {1}, {0}};  // defaults, see ModeKey
+static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {2}, {-1}, {1}, {0}, {0}};  // defaults, see ModeKey
 static std::atomic<bool> g_klog_armed{false};
 static std::mutex g_klog_mu;
 static std::map<std::string, int> g_klog;
@@ -731,6 +731,14 @@ int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* d
 int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream) {
   GC_CHECK_ARG(v && g && out && count >= 0 && (count + 255) / 256 < (1LL << 31), "bad arguments");
   if (count > 0) gelu_bwd_kernel<<<(unsigned)((count + 255) / 256), 256, 0, (hipStream_t)stream>>>(v, g, out, count);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_lincomb_fwd(float* out, const float* x, const float* y, const float* z, float a, float b, float c, long long count, void* stream) {
+  GC_CHECK_ARG(out && x && count >= 0 && (count + 1023) / 1024 < (1LL << 31), "bad arguments");
+  GC_CHECK_ARG((((uintptr_t)out | (uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15) == 0, "pointers must be 16-byte aligned");
+  if (count > 0) lincomb_kernel<<<(unsigned)((count + 1023) / 1024), 256, 0, (hipStream_t)stream>>>(out, x, y, z, a, b, c, count);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

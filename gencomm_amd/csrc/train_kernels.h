@@ -292,6 +292,28 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   out[i] = g[i] * (0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x));
 }
 
+// out = a x + b y + c z (y, z optional; out may alias any input): the elementwise glue of the training branch's sampler chain
+// (x_{t-1} = c1 x0_hat + c2 x_t + sigma eps, cond_diff.py:272-315, and its adjoint) without framework kernels
+__global__ __launch_bounds__(256) void lincomb_kernel(float* out, const float* x, const float* y, const float* z, float a, float b, float c,
+                                                      long long count) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = q * 4;
+  if (i + 3 < count) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+    if (y != nullptr) { const float4 u = *reinterpret_cast<const float4*>(y + i); v.x = fmaf(b, u.x, v.x); v.y = fmaf(b, u.y, v.y); v.z = fmaf(b, u.z, v.z); v.w = fmaf(b, u.w, v.w); }
+    if (z != nullptr) { const float4 u = *reinterpret_cast<const float4*>(z + i); v.x = fmaf(c, u.x, v.x); v.y = fmaf(c, u.y, v.y); v.z = fmaf(c, u.z, v.z); v.w = fmaf(c, u.w, v.w); }
+    *reinterpret_cast<float4*>(out + i) = v;
+  } else {
+    for (long long k = i; k < count; ++k) {
+      float v = a * x[k];
+      if (y != nullptr) v = fmaf(b, y[k], v);
+      if (z != nullptr) v = fmaf(c, z[k], v);
+      out[k] = v;
+    }
+  }
+}
+
 // ---- deformable 3x3 convolution (DCNv1, one offset group, padding 1) for the training path of MessageExtractorv2 ------------
 // (message_extractor_v2.py:78,:108; sampling arithmetic as in dcn_kernel, msgext_kernels.h).  The convolution is split
 // into its sampling half and its GEMM half so that the backward is GEMMs on the general kernels plus one scatter kernel:

@@ -37,7 +37,7 @@ inline size_t dgrad_table_floats(const UNetPlan& p) {
 }
 
 struct UNetBwdWs {
-  size_t fwd_total, g_base, A, DA, red, wtmp, ones, zeros, total;
+  size_t fwd_total, g_base, A, DA, red, wtmp, ones, zeros, wpart, total;
   std::vector<size_t> g_level_base;
 };
 inline UNetBwdWs unet_bwd_ws(const UNetPlan& p, const UNetWorkspace& w, int n, int H, int W) {
@@ -58,6 +58,8 @@ inline UNetBwdWs unet_bwd_ws(const UNetPlan& p, const UNetWorkspace& w, int n, i
   b.wtmp = take(dgrad_table_floats(p) * sizeof(float));
   b.ones = take((size_t)(p.C + 16) * sizeof(float));
   b.zeros = take((size_t)(p.C + 16) * sizeof(float));
+  // partial sums of the weight-gradient kernels (conv_wgrad_scratch_floats): the largest layer is conv_in (C + 2 -> 8) / conv_out (8 -> C)
+  b.wpart = take(std::max(conv_wgrad_scratch_floats(8, p.C + 2, 3, H, W, n), conv_wgrad_scratch_floats(p.C, 8, 3, H, W, n)) * sizeof(float));
   b.total = off;
   return b;
 }
@@ -185,6 +187,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         // y = conv_out(SiLU(GN_out(h))) + b
         WgradArgs wa{grad_x0, nullptr, nullptr, b.graw + p.conv_out.w, b.graw + p.conv_out.b, C, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         wgrad_gn_sources(b, wa, o.src[0], -1, b.raw + p.nout_w, b.raw + p.nout_b, 2, HW);
+        wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad3x3_enqueue(b, grad_x0, b.raw + p.conv_out.w, C, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
         if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, DA, 8, 0, p.nout_w, p.nout_b)) return rc;
@@ -196,6 +199,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         const float* go = b.G(o.dst);
         WgradArgs wa{go, nullptr, nullptr, b.graw + rb.c2w, b.graw + rb.c2b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         wgrad_gn_sources(b, wa, o.src[0], -1, b.raw + rb.n2w, b.raw + rb.n2b, 2, HW);
+        wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad8_enqueue(b, go, b.raw + rb.c2w, 8, 0, DA, n, Hl, Wl)) return rc;
         if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, rb.n2w, rb.n2b)) return rc;
@@ -203,6 +207,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
           axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
         } else {
           WgradArgs wn{go, c.tensor_ptr(o.res[0]), c.tensor_ptr(o.res[1]), b.graw + rb.ninw, b.graw + rb.ninb, 8, 8, 8, Hl, Wl, Hl, Wl, 1, 1, 0, 0};
+          wn.part = b.F(b.bw->wpart);
           if (int rc = conv_wgrad_enqueue(wn, n, st)) return rc;
           nin_dgrad_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW);
         }
@@ -215,6 +220,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         const int nsrc = rb.cin / 8, gs = rb.cin == 8 ? 2 : 4;
         WgradArgs wa{gt, nullptr, nullptr, b.graw + rb.c1w, b.graw + rb.c1b, 8, 8, nsrc == 2 ? 8 : 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         wgrad_gn_sources(b, wa, o.src[0], nsrc == 2 ? o.src[1] : -1, b.raw + rb.n1w, b.raw + rb.n1b, gs, HW);
+        wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         for (int s = 0; s < nsrc; ++s)   // one 8-channel input gradient per source, DA = [source][n][8][HW]
           if (int rc = dgrad8_enqueue(b, gt, b.raw + rb.c1w, rb.cin, 8 * s, DA + (size_t)s * n * 8 * HW, n, Hl, Wl)) return rc;
@@ -227,6 +233,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         const int lin = o.level - 1, Hi = c.ws->Hl[lin], Wi = c.ws->Wl[lin];
         const float* gd = b.G(o.dst);
         WgradArgs wa{gd, c.tensor_ptr(o.src[0]), nullptr, b.graw + p.down[lin].w, b.graw + p.down[lin].b, 8, 8, 0, Hl, Wl, Hi, Wi, 3, 2, 0, 0};
+        wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         DownDgradArgs da{gd, b.raw + p.down[lin].w, b.G(o.src[0]), Hl, Wl, Hi, Wi};
         down_dgrad_kernel<<<dim3(cdiv(Hi * Wi, 256), 1, n), 256, 0, st>>>(da);
@@ -236,6 +243,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         const int lin = o.level + 1, Hs = c.ws->Hl[lin], Ws = c.ws->Wl[lin];
         const float* gu = b.G(o.dst);
         WgradArgs wa{gu, c.tensor_ptr(o.src[0]), nullptr, b.graw + p.up[lin].w, b.graw + p.up[lin].b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 1};
+        wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad8_enqueue(b, gu, b.raw + p.up[lin].w, 8, 0, DA, n, Hl, Wl)) return rc;
         sum2x2_add_kernel<<<cdiv(n * 8 * Hs * Ws, 256), 256, 0, st>>>(DA, b.G(o.src[0]), n * 8, Hs, Ws);
@@ -244,6 +252,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
       case OP_CONV_IN: {
         const float* gh = b.G(o.dst);
         WgradArgs wa{gh, cond, x_t, b.graw + p.conv_in.w, b.graw + p.conv_in.b, 8, 2, C, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
+        wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad3x3_enqueue(b, gh, b.raw + p.conv_in.w, 8, C + 2, 0, 2, grad_cond, 2, 0, n, Hl, Wl)) return rc;
         if (int rc = dgrad3x3_enqueue(b, gh, b.raw + p.conv_in.w, 8, C + 2, 2, C, grad_xt, C, 0, n, Hl, Wl)) return rc;

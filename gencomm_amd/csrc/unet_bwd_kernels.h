@@ -186,6 +186,9 @@ struct WgradArgs {
   const float* gn_beta = nullptr;
   double gn_inv_cnt = 0.0;
   int gn_gs = 0;
+  // optional scratch of conv_wgrad_scratch_floats(...) floats: the workgroups' partial sums are written there and summed by a second
+  // kernel instead of one float atomic per (workgroup, weight) on the same few hundred addresses (31 of 80 us per 8 -> 8 layer)
+  float* part = nullptr;
 };
 
 template <int K, int STRIDE>
@@ -254,8 +257,178 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// The same gradient on the fp32 matrix cores (round 3), stride 1 and "same" padding (every 3x3 and 1x1 layer of
+// the UNet but the stride-2 Downsample): a GEMM with the PIXELS as the reduction dimension,
+//     dW[oc][(ic, tap)] = sum_pixels dY[oc][pixel] X[ic][pixel + tap],
+// on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation): M = 16 rows = the chunk's 8 output channels + 8 zero rows,
+// N = 8 input channels x K*K taps + ONE column of ones (its row sums are the bias gradient) in tiles of 16, K = 4 consecutive
+// pixels of a row per instruction.  A workgroup stages a 32x16-pixel tile of dY (8 planes + a zero plane for the padding rows) and
+// the haloed tile of X (8 planes + a plane of ones; SiLU(GroupNorm(x)) and the nearest-x2 index are applied while staging, as in
+// the VALU kernel above); wave w walks rows 4w..4w+3: per 4 pixels one A read, NT B reads (ds_read_b32 each) and NT matrix
+// instructions.  The four waves' accumulators meet in LDS; one atomic per (oc, ic, tap) and workgroup.
+// VALU kernel: 82.6 us per 8 -> 8 layer at 4 x 200 x 704 (10 LDS reads per 9 FMAs); this one: see DESIGN.md section 4 "Backward".
+template <int K>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs a) {
+  constexpr int TW = 32, TH = 16, PAD = K / 2, PW = TW + 2 * PAD, PHt = TH + 2 * PAD, KK = K * K;
+  constexpr int NC = 8 * KK + 1, NT = (NC + 15) / 16;          // columns: (ic, tap) pairs + the ones column
+  constexpr int DPS = TH * TW + 4;                             // dY plane stride: +4 words puts the 8 channels of a pixel on 8 x 4 distinct banks
+  constexpr int PWS = (PW + 3) & ~3, XPS = PHt * PWS + 4;      // X row / plane stride
+  constexpr int RED = 4 * NT * 16 * 8;                         // reduction buffer of the four waves (aliases the tiles)
+  constexpr int TILE_WORDS = 9 * DPS + 9 * XPS;
+  __shared__ float smem[TILE_WORDS > RED ? TILE_WORDS : RED];
+  __shared__ float s_gn[8][2];
+  float* const sdy = smem;                // [9][DPS], plane 8 = zeros (rows 8..15 of the A operand)
+  float* const sx = smem + 9 * DPS;       // [9][XPS], plane 8 = ones
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
+  const int Cin = a.c0 + a.c1, icc = (Cin + 7) / 8;
+  const int occ = blockIdx.y / icc, ich = blockIdx.y - occ * icc;
+  const int tiles_x = (a.Wo + TW - 1) / TW;
+  const int oy0 = (blockIdx.x / tiles_x) * TH, ox0 = (blockIdx.x % tiles_x) * TW;
+  const int Hs = a.up ? a.Hi / 2 : a.Hi, Ws = a.up ? a.Wi / 2 : a.Wi;
+  const bool gn = a.gn_stat[0] != nullptr;   // 8-channel sources: chunk ich is source ich
+  // every global load of the workgroup is issued before the first barrier (one memory round trip instead of three): the dY tile
+  // (18 values per thread), the X tile (<= NX values per thread), and -- eight threads -- the GroupNorm coefficients
+  constexpr int ND = 9 * TH * TW / 256, NX = (9 * PHt * PW + 255) / 256;
+  float vd[ND], vx[NX];
+#pragma unroll
+  for (int k = 0; k < ND; ++k) {
+    const int i = tid + 256 * k;
+    const int o = i / (TH * TW), r = i - o * (TH * TW), py = r / TW, px = r - py * TW;
+    const int oc = occ * 8 + o, oy = oy0 + py, ox = ox0 + px;
+    vd[k] = (o < 8 && oc < a.Cout && oy < a.Ho && ox < a.Wo) ? a.dy[(((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const int i = tid + 256 * k;
+    const int c = i / (PHt * PW), r = i - c * (PHt * PW), py = r / PW, px = r - py * PW;
+    const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - PAD + px;
+    float v = 0.f;
+    if (c < 8 && ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+      const float* __restrict__ sp = ic < a.c0 ? a.x0 + ((size_t)n * a.c0 + ic) * Hs * Ws : a.x1 + ((size_t)n * a.c1 + (ic - a.c0)) * Hs * Ws;
+      v = a.up ? sp[(size_t)(iy >> 1) * Ws + (ix >> 1)] : sp[(size_t)iy * Ws + ix];
+    }
+    vx[k] = v;
+  }
+  if (gn && tid < 8) {
+    const int ic = ich * 8 + tid;
+    float A = 0.f, B = 0.f;
+    if (ic < Cin) gn_coeff(a.gn_stat[ic < a.c0 ? 0 : 1] + (size_t)n * 16, tid, a.gn_gs, a.gn_inv_cnt, a.gn_gamma[ic], a.gn_beta[ic], &A, &B);
+    s_gn[tid][0] = A; s_gn[tid][1] = B;
+  }
+#pragma unroll
+  for (int k = 0; k < ND; ++k) {
+    const int i = tid + 256 * k;
+    const int o = i / (TH * TW), r = i - o * (TH * TW);
+    sdy[o * DPS + r] = vd[k];
+  }
+  __syncthreads();   // s_gn
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const int i = tid + 256 * k;
+    if (i < 9 * PHt * PW) {
+      const int c = i / (PHt * PW), r = i - c * (PHt * PW), py = r / PW, px = r - py * PW;
+      const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - PAD + px;
+      float v = vx[k];
+      if (c == 8) v = 1.0f;
+      else if (gn && ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = silu_f(fmaf(s_gn[c][0], v, s_gn[c][1]));   // zero padding stays zero
+      sx[c * XPS + py * PWS + px] = v;
+    }
+  }
+  __syncthreads();
+  const int j = lane & 15, kq = lane >> 4;
+  const int aoff = (j < 8 ? j : 8) * DPS + kq;
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = 16 * t + j;
+    const int ic = c < 8 * KK ? c / KK : 8, tap = c < 8 * KK ? c - ic * KK : 0;
+    boff[t] = ic * XPS + (tap / K) * PWS + (tap % K) + kq;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int y = 4 * wave; y < 4 * wave + 4; ++y) {
+#pragma unroll
+    for (int s4 = 0; s4 < TW / 4; ++s4) {
+      const float av = sdy[aoff + y * TW + 4 * s4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sx[boff[t] + y * PWS + 4 * s4], acc[t], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // the tiles are dead: the reduction buffer aliases them
+  if (kq < 2) {      // rows 0..7 = output channels 4 kq + reg live in lanes 0..31
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) smem[((wave * NT + t) * 16 + j) * 8 + 4 * kq + reg] = acc[t][reg];
+  }
+  __syncthreads();
+  for (int i = tid; i < NT * 16 * 8; i += 256) {
+    const int c = i >> 3, o = i & 7, oc = occ * 8 + o;
+    const float v = smem[i] + smem[NT * 128 + i] + smem[2 * NT * 128 + i] + smem[3 * NT * 128 + i];
+    if (a.part != nullptr) {   // [pair][workgroup of the pair][NT * 128]: coalesced, summed by conv_wgrad_reduce_kernel
+      const size_t wg = blockIdx.x + (size_t)gridDim.x * blockIdx.z;
+      a.part[((size_t)blockIdx.y * gridDim.x * gridDim.z + wg) * (NT * 128) + i] = v;
+      continue;
+    }
+    if (oc >= a.Cout) continue;
+    if (c < 8 * KK) {
+      const int icl = c / KK, tap = c - icl * KK, ic = ich * 8 + icl;
+      if (ic < Cin) atomicAdd(&a.dw[((size_t)oc * Cin + ic) * KK + tap], v);
+    } else if (c == 8 * KK && a.db != nullptr && ich == 0) {
+      atomicAdd(&a.db[oc], v);
+    }
+  }
+}
+
+// second stage: column i of pair (occ, ich) summed over the pair's workgroups in `slices` slices (blockIdx.z), one atomic per slice
+template <int K>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradArgs a, int nwg, int per_slice) {
+  constexpr int KK = K * K, NT = (8 * KK + 1 + 15) / 16, NW = NT * 128;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= NW) return;
+  const int Cin = a.c0 + a.c1, icc = (Cin + 7) / 8;
+  const int occ = blockIdx.y / icc, ich = blockIdx.y - occ * icc;
+  const int w0 = blockIdx.z * per_slice, w1 = min(w0 + per_slice, nwg);
+  const float* __restrict__ p = a.part + ((size_t)blockIdx.y * nwg + w0) * NW + i;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = w0;
+  for (; w + 3 < w1; w += 4, p += 4 * (size_t)NW) { s0 += p[0]; s1 += p[NW]; s2 += p[2 * (size_t)NW]; s3 += p[3 * (size_t)NW]; }
+  for (; w < w1; ++w, p += NW) s0 += p[0];
+  const float v = (s0 + s1) + (s2 + s3);
+  const int c = i >> 3, o = i & 7, oc = occ * 8 + o;
+  if (oc >= a.Cout) return;
+  if (c < 8 * KK) {
+    const int icl = c / KK, tap = c - icl * KK, ic = ich * 8 + icl;
+    if (ic < Cin) atomicAdd(&a.dw[((size_t)oc * Cin + ic) * KK + tap], v);
+  } else if (c == 8 * KK && a.db != nullptr && ich == 0) {
+    atomicAdd(&a.db[oc], v);
+  }
+}
+
+// floats of WgradArgs::part for a layer (stride-1 "same" layers only; 0 otherwise)
+inline size_t conv_wgrad_scratch_floats(int Cout, int Cin, int K, int H, int W, int n) {
+  const size_t NT = (size_t)(8 * K * K + 1 + 15) / 16;
+  return (size_t)((H + 15) / 16) * ((W + 31) / 32) * n * ((Cout + 7) / 8) * ((Cin + 7) / 8) * NT * 128;
+}
+
 inline int conv_wgrad_enqueue(const WgradArgs& a, int n, hipStream_t st) {
   const int Cin = a.c0 + a.c1;
+  if (a.stride == 1 && (a.K == 3 || a.K == 1) && a.pad == a.K / 2 && a.Ho == a.Hi && a.Wo == a.Wi) {   // fp32 matrix cores
+    const dim3 grid(((a.Ho + 15) / 16) * ((a.Wo + 31) / 32), ((a.Cout + 7) / 8) * ((Cin + 7) / 8), n);
+    if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv_wgrad: too many channel chunks / samples");
+    if (a.K == 3) conv_wgrad_mfma_kernel<3><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_mfma_kernel<1><<<grid, 256, 0, st>>>(a);
+    if (a.part != nullptr) {
+      const int nwg = (int)(grid.x * grid.z), slices = std::min(nwg, 16), per = (nwg + slices - 1) / slices;
+      const int NW = ((8 * a.K * a.K + 1 + 15) / 16) * 128;
+      const dim3 rg((NW + 255) / 256, grid.y, (nwg + per - 1) / per);
+      if (a.K == 3) conv_wgrad_reduce_kernel<3><<<rg, 256, 0, st>>>(a, nwg, per);
+      else conv_wgrad_reduce_kernel<1><<<rg, 256, 0, st>>>(a, nwg, per);
+    }
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   const dim3 grid(((a.Ho + 15) / 16) * ((a.Wo + 15) / 16), ((a.Cout + 7) / 8) * ((Cin + 7) / 8), n);
   if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv_wgrad: too many channel chunks / samples");
   if (a.K == 3 && a.stride == 1) conv_wgrad_kernel<3, 1><<<grid, 256, 0, st>>>(a);

@@ -144,6 +144,18 @@ inline DownArgs down_args(const UNetCall& c, const Op& o) {
                   c.ws->Hl[o.level], c.ws->Wl[o.level], c.ws->Hl[lin], c.ws->Wl[lin], !c.is_f32(o.src[0]), !c.is_f32(o.dst)};
 }
 
+// ---- ResnetBlock fusion, emulated (GENCOMM_MODE_RESFUSE_EMU = 1).  TIMING EXPERIMENT, never a product path: the
+// outputs are not the UNet's.  A fused 8 -> 8 ResnetBlock (unet.py:119-138) would be (A) a statistics-only pass of conv1 -- GroupNorm2
+// needs the sums over the whole map before conv2 can start -- and (B) one kernel that stages the block input, recomputes conv1 on the
+// tile + ring, applies GroupNorm2 + SiLU in registers and runs conv2 with the residual epilogue: 72 + 144 MB instead of 144 + 216 MB per
+// 16-agent launch pair.  The emulation launches exactly that traffic and at least that matrix work with the existing tile function:
+// (A) = conv1 without its store; (B) = the conv2 variant reading the block input as its source (its residual is the same tensor) with
+// the matrix phase run twice.  It leaves out what the real kernel adds on top (a 20 x 68 instead of 18 x 66 input tile, the 1.3x
+// ring, one LDS round trip of the intermediate tile and two barriers), so it is an UPPER bound of the fusion's gain.
+inline bool resfuse_emulated(const UNetCall& c, const ResBlockPlan& b, TileCfg tc, bool wvec) {
+  return c.m.v[MODE_RESFUSE_EMU] != 0 && b.cin == 8 && tc == TILE_64x16 && c.m.split() && !c.m.bf16() && wvec;
+}
+
 // ---- dataflow execution of ops [f, l) (dataflow_kernels.h).  Eligible: GENCOMM_MODE_DATAFLOW on, f16-pipe arithmetic (not the
 // bf16 storage mode), every op of the range one of {ResnetBlock conv1 / conv2, Downsample, Upsample} on 64x16 tiles.
 inline bool df_eligible(const UNetCall& c, int f, int l) {
@@ -269,6 +281,14 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         }
         const Conv8Args a = conv1_args(c, o, t);
         const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl);
+        if (resfuse_emulated(c, b, tc, (Wl & 3) == 0)) {   // "ResnetBlock fusion, emulated" (above): the statistics-only pass of conv1
+          Conv8Args e = a;
+          e.term_mask = 63 | 64;
+          TimedLaunch tl(KF_CONV8, c.st, 4.0 * c.n * 8.0 * Hl * Wl);
+          GC_KLOG("conv8h_kernel<1,GN,0,0,DIAG> (MODE_RESFUSE_EMU: statistics only)");
+          conv8h_kernel<1, true, false, 0, true><<<dim3(cdiv(Wl, 64), cdiv(Hl, 16), c.n), 256, 0, c.st>>>(e);
+          break;
+        }
         if (b.cin == 8) launch_conv8<1, true, false, 0>(c.m, tc, a, c.n, c.st);
         else launch_conv8<2, true, false, 0>(c.m, tc, a, c.n, c.st);
         break;
@@ -289,6 +309,15 @@ inline int unet_enqueue_range(const UNetCall& c, const float* x_t, const float* 
         }
         const Conv8Args a = conv2_args(c, o);
         const TileCfg tc = pick_tile(c.m, c.n, Hl, Wl);
+        if (resfuse_emulated(c, b, tc, (Wl & 3) == 0)) {   // the fused pass: reads the BLOCK INPUT (not conv1's output), two convolutions of matrix work
+          Conv8Args e = a;
+          e.src[0] = a.res[0]; e.sstat[0] = c.stat_ptr(o.res[0]); e.gamma = P + b.n1w; e.beta = P + b.n1b;
+          e.term_mask = 63 | 128;
+          TimedLaunch tl(KF_CONV8_RES1, c.st, 4.0 * c.n * 16.0 * Hl * Wl);
+          GC_KLOG("conv8h_kernel<1,GN,0,1,DIAG> (MODE_RESFUSE_EMU: block input, double matrix work)");
+          conv8h_kernel<1, true, false, 1, true><<<dim3(cdiv(Wl, 64), cdiv(Hl, 16), c.n), 256, 0, c.st>>>(e);
+          break;
+        }
         if (b.cin == 8) launch_conv8<1, true, false, 1>(c.m, tc, a, c.n, c.st);
         else launch_conv8<1, true, false, 2>(c.m, tc, a, c.n, c.st);
         break;

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 5
+#define GENCOMM_ABI_VERSION 6
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -76,10 +76,13 @@ const char* gencomm_build_info(void);
  *   GENCOMM_MODE_XCD_REMAP    1 (default): workgroup -> tile mapping keeps neighbouring tiles on one XCD; 0: grid order
  *   GENCOMM_MODE_DATAFLOW     1: the body of a UNet call (every layer between conv_in and conv_out) runs as ONE persistent launch
  *                             whose workgroups take (layer, agent, tile) items from per-XCD queues and wait on per-(layer, agent)
- *                             completion counters (no grid barrier); 0: one launch per layer.  Same device functions, same results */
+ *                             completion counters (no grid barrier); 0: one launch per layer.  Same device functions, same results
+ *   GENCOMM_MODE_RESFUSE_EMU  0 (default).  1: TIMING EXPERIMENT ONLY -- the 8 -> 8 ResnetBlocks run the launch pattern a fused
+ *                             conv1 + conv2 block would have (statistics-only conv1 pass; conv2 pass reading the block input with twice
+ *                             the matrix work), an upper bound of that fusion's gain; the outputs are NOT the UNet's */
 enum {
   GENCOMM_MODE_ARITH = 0, GENCOMM_MODE_SAMPLER = 1, GENCOMM_MODE_TILE_WANT = 2, GENCOMM_MODE_ENH_FUSE = 3,
-  GENCOMM_MODE_CONV8H_MASK = 4, GENCOMM_MODE_XCD_REMAP = 5, GENCOMM_MODE_DATAFLOW = 6
+  GENCOMM_MODE_CONV8H_MASK = 4, GENCOMM_MODE_XCD_REMAP = 5, GENCOMM_MODE_DATAFLOW = 6, GENCOMM_MODE_RESFUSE_EMU = 7
 };
 int gencomm_set_mode(int key, long long value);
 long long gencomm_get_mode(int key);
@@ -338,6 +341,8 @@ int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* t
  *   gencomm_dwconv3x3_fwd    depthwise 3x3 pad 1 (+ bias); flip != 0: correlation with the flipped taps = input gradient
  *   gencomm_dwconv3x3_wgrad  dw[C][3][3] +=, db[C] += (db may be NULL)
  *   gencomm_gelu_bwd         out = g * GELU'(v), erf form
+ *   gencomm_lincomb_fwd      out = a x + b y + c z (y, z may be NULL; out may alias an input; 16-byte aligned pointers): the
+ *                            sampler chain's x_{t-1} = c1 x0_hat + c2 x_t + sigma eps (cond_diff.py:272-315) and its adjoint
  * -------------------------------------------------------------------------------------------- */
 int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
                          int K, int stride, int pad, void* stream);
@@ -347,6 +352,7 @@ int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, flo
 int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream);
 int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream);
 int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream);
+int gencomm_lincomb_fwd(float* out, const float* x, const float* y, const float* z, float a, float b, float c, long long count, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * iou3d_nms with the reference extension's own semantics (opencood/pcdet_utils/iou3d_nms: src/iou3d_nms_kernel.cu:104-372,

@@ -90,6 +90,29 @@ def test_sampler_chain_backward_vs_oracle_autograd():
     print(f"sampler chain backward (T={T}): worst relative error {worst:.2e}")
 
 
+def test_training_chain_with_in_kernel_noise_is_the_inference_chain_of_the_same_seed():
+    """noise=None in the training branch: q_sample and the T - 1 step noises come from the sampler's Philox field (no framework
+    generator, no noise tensors from the caller) -- the same field inference adds for that seed, so the differentiable chain
+    (per-step HIP UNet calls) and the fused inference loop must agree, and the gradients must flow."""
+    from gencomm_amd import GenComm, synth
+    C, H, W, T, rl = 16, 16, 24, 3, [2, 1]
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen = GenComm(cfg).train().to(DEV)
+    synth.fill_params_(gen, 77)
+    inp = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_inputs(rl, C, H, W, 78).items()}
+    with torch.no_grad():
+        ref = gen(inp["feat"], inp["cond"], inp["record_len"], seed=1234)["pred_feature"]
+    cond = inp["cond"].clone().requires_grad_(True)
+    pred = gen(inp["feat"], cond, inp["record_len"], seed=1234)["pred_feature"]
+    assert pred.requires_grad
+    err = (pred - ref).abs()
+    assert (err <= 2e-5 + 1e-4 * ref.abs()).all(), err.max().item()
+    (pred ** 2).mean().backward()
+    assert float(cond.grad.abs().max()) > 0 and all(p.grad is not None for p in gen.denoiser.parameters() if p.requires_grad)
+    other = gen(inp["feat"], cond, inp["record_len"], seed=1235)["pred_feature"]
+    assert float((other - pred).abs().max()) > 1e-3
+
+
 DDP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])

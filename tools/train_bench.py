@@ -10,8 +10,11 @@ from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, sy
 
 DEV = "cuda:0"
 OPTIMIZER = "--no-optimizer" not in sys.argv
-for name, (N, C, H, W, T) in {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128, 64, 128, 3),
-                               "4 agents, C=64, 200x704, T=3": (4, 64, 200, 704, 3)}.items():
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""   # "shipped" / "large": one shape (profiling runs)
+SHAPES = {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128, 64, 128, 3), "large: 4 agents, C=64, 200x704, T=3": (4, 64, 200, 704, 3)}
+for name, (N, C, H, W, T) in SHAPES.items():
+    if ONLY and not name.startswith(ONLY):
+        continue
     gen, enh, fus = GenComm(synth.default_gencomm_cfg(C, T)).train().to(DEV), Enhancer(C, [8, 8], 4).train().to(DEV), AttFusion(C)
     g = torch.Generator(device=DEV).manual_seed(1)
     feat = torch.randn(N, C, H, W, generator=g, device=DEV).clamp_(min=0)
