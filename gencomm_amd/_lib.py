@@ -85,6 +85,9 @@ _SIGNATURES = {
     "gencomm_dwconv3x3_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_gelu_bwd": (_i, [_p, _p, _p, _ll, _p]),
     "gencomm_lincomb_fwd": (_i, [_p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _ll, _p]),
+    "gencomm_ew_slice_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
+    "gencomm_nc_scale_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "gencomm_nc_dot_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "gencomm_det_workspace_bytes": (C.c_longlong, [_i, _i, _i]),
     "gencomm_nms_workspace_bytes": (C.c_longlong, []),
     "gencomm_nms_max_candidates": (_i, []),

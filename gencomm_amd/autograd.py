@@ -104,7 +104,7 @@ class SamplerChainFunction(torch.autograd.Function):
             _lib.check(l.gencomm_q_sample_fwd(ptr(sched[T - 1]), ptr(f), f.shape[0], ptr(rows), ptr(n0), int(seed), T, ptr(x), n, C, H, W, st),
                        "gencomm_q_sample_fwd")
             xs, wss = [], []
-            coef = sched.detach().cpu().tolist()   # [T][5]: sqrt_ac, sqrt_1m_ac, coef1, coef2, sigma
+            coef = gen._sched_host(dev)            # [T][5]: sqrt_ac, sqrt_1m_ac, coef1, coef2, sigma (cached host copy: no sync)
             out = None
             for i, t in enumerate(reversed(range(T))):
                 x0, ws = unet.forward_train(x, cd, t, T)
@@ -183,54 +183,57 @@ class EnhancerFunction(torch.autograd.Function):
         b1, sa, m = enh.block_1, enh.split_attn, enh.block_1.mlp
         n, C, H, W = x.shape
         dc, hid, HW = C // 4, m.dwconv[0].weight.shape[0], H * W
+        f32 = dict(dtype=torch.float32, device=x.device)
         with torch.no_grad():
-            # ---- forward recompute, every intermediate kept
+            # ---- forward recompute, every intermediate kept; slices / concatenations / activations on the library's own kernels
             y = T.ln_fwd(x, b1.norm1.weight, b1.norm1.bias, 1e-5, True)            # x + LN1(x)       enhancer.py:351-352
             z = T.ln_fwd(y, b1.norm2.weight, b1.norm2.bias, 1e-5, False)           # LN2              :354
-            z1 = z[:, :dc].contiguous()
-            zi = torch.cat([T.conv2d(z1, m.partial_conv3.weight, None, 1), z[:, dc:]], dim=1)                    # :229-232
+            z1 = T.copy_slice(z, 0, dc)
+            zi = torch.empty_like(z)                                                # cat[pconv(z[:, :dc]), z[:, dc:]]   :229-232
+            T.copy_slice(z, dc, C - dc, zi, dc)
+            T.conv2d(z1, m.partial_conv3.weight, None, 1, out=zi, out_coff=0)
             w1 = m.linear1[0].weight.detach()[:, :, None, None]
             v = T.conv2d(zi, w1, m.linear1[0].bias, 0)                                # Linear1          :235
-            hdn = F.gelu(v)
-            h1, h2 = hdn[:, :hid].contiguous(), hdn[:, hid:].contiguous()
+            h1, h2 = torch.empty(n, hid, H, W, **f32), torch.empty(n, hid, H, W, **f32)
+            T.ew_slice(T.EW_GELU_SPLIT, v, o0=h1, o1=h2, n=n, nch=hid, HW=HW)         # GELU, chunk      :236-240
             u = T.dwconv3x3(h1, m.dwconv[0].weight, m.dwconv[0].bias)                  # depthwise        :241-243
-            h1p = F.gelu(u)
-            g = h1p * h2
+            g = torch.empty_like(u)
+            T.ew_slice(T.EW_GELU_GATE, u, h2, o0=g, n=n, nch=hid, HW=HW)               # GELU(u) * x2     :244-246
             w2 = m.linear2[0].weight.detach()[:, :, None, None]
-            y2 = y + T.conv2d(g, w2, m.linear2[0].bias, 0)                             # Linear2 + residual :247, :354
+            y2 = T.conv2d(g, w2, m.linear2[0].bias, 0, residual=y)                     # Linear2 + residual :247, :354
+            go = grad_out.float().contiguous()
+            gap0 = T.nc_dot(y2, None)                                                  # global average pool x HW   :325
+            da = T.nc_dot(go, y2)
         # ---- channel gate on [n, C] vectors (split_attn, :315-333): torch autograd on a few hundred numbers
         gate_params = [sa.fc1.weight, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight]
         with torch.enable_grad():
-            gap = y2.mean((2, 3)).requires_grad_(True)
+            gap = (gap0 / HW).requires_grad_(True)
             local = [p.detach().requires_grad_(True) for p in gate_params]
             a = torch.sigmoid(F.linear(F.relu(F.layer_norm(F.linear(gap, local[0]), (local[0].shape[0],), local[1], local[2], 1e-5)), local[3]))
-            go = grad_out.float()
-            da = (go * y2).sum((2, 3))
             dgap, *dgate = torch.autograd.grad(a, [gap] + local, da)
         with torch.no_grad():
-            a = a.detach()
-            dy2 = go * a[:, :, None, None] + dgap[:, :, None, None] / HW
+            dy2 = T.nc_scale(go, a.detach(), dgap / HW)
             # ---- Linear2
             dg = T.conv2d(dy2, w2.transpose(0, 1).contiguous(), None, 0)
             dW2, db2 = T.conv2d_wgrad(dy2, g, 1, 0, True)
-            dh1p, dh2 = dg * h2, dg * h1p
-            # ---- depthwise + GELU
-            du = T.gelu_bwd(u, dh1p)
+            # ---- gate, depthwise + GELU, Linear1's GELU: d u and the x2 half of d v in one pass, the x1 half behind the depthwise dgrad
+            du, dv = torch.empty_like(u), torch.empty_like(v)
+            T.ew_slice(T.EW_GATE_BWD, u, h2, dg, v, o0=du, o1=dv, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
             dh1 = T.dwconv3x3(du, m.dwconv[0].weight, None, flip=True)
             dWd, dbd = T.dwconv3x3_wgrad(h1, du)
-            # ---- Linear1 + GELU
-            dv = T.gelu_bwd(v, torch.cat([dh1, dh2], dim=1))
+            T.ew_slice(T.EW_GELU_BWD, v, dh1, o0=dv, n=n, nch=hid, HW=HW, o0_ct=2 * hid, o0_c0=0)
+            # ---- Linear1
             dzi = T.conv2d(dv, w1.transpose(0, 1).contiguous(), None, 0)
             dW1, db1l = T.conv2d_wgrad(dv, zi, 1, 0, True)
-            # ---- partial conv
-            dzi1 = dzi[:, :dc].contiguous()
-            dz = torch.cat([T.conv2d_dgrad(dzi1, m.partial_conv3.weight, 1), dzi[:, dc:]], dim=1)
+            # ---- partial conv: its input gradient overwrites the first dc channels of d zi (= d z)
+            dzi1 = T.copy_slice(dzi, 0, dc)
+            T.conv2d(dzi1, m.partial_conv3.weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, 1, out=dzi, out_coff=0)
+            dz = dzi
             dWp, _ = T.conv2d_wgrad(dzi1, z1, 3, 1, False)
             # ---- LayerNorms and residuals
-            dy_ln, dg2, db2n = T.ln_bwd(y, b1.norm2.weight, dz, 1e-5)
-            dy = dy2 + dy_ln
-            dx_ln, dg1, db1n = T.ln_bwd(x, b1.norm1.weight, dy, 1e-5)
-            dx = dy + dx_ln
+            dy, dg2, db2n = T.ln_bwd(y, b1.norm2.weight, dz, 1e-5, accumulate_into=dy2)       # d y = d y2 + LN2 backward
+            dx, dg1, db1n = T.ln_bwd(x, b1.norm1.weight, dy, 1e-5)
+            _lincomb(dx, dx, 1.0, dy, 1.0)                                                 # d x = d y + LN1 backward
         grads = {id(b1.norm1.weight): dg1, id(b1.norm1.bias): db1n, id(b1.norm2.weight): dg2, id(b1.norm2.bias): db2n,
                  id(m.partial_conv3.weight): dWp, id(m.linear1[0].weight): dW1[:, :, 0, 0], id(m.linear1[0].bias): db1l,
                  id(m.dwconv[0].weight): dWd, id(m.dwconv[0].bias): dbd, id(m.linear2[0].weight): dW2[:, :, 0, 0], id(m.linear2[0].bias): db2}

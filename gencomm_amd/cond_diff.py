@@ -77,6 +77,7 @@ class GenComm(nn.Module):
             lvlb_weights[0] = lvlb_weights[1]
         self.register_buffer("lvlb_weights", lvlb_weights, persistent=False)
         self._sched_dev = None
+        self._sched_rows = None
         self._sched_key = None
 
     # ------------------------------------------------------------------ helpers
@@ -91,8 +92,14 @@ class GenComm(nn.Module):
                 cols = [b.detach().float().to(device) for b in bufs]
                 cols[4] = (0.5 * cols[4]).exp()  # (0.5 * model_log_variance).exp(), cond_diff.py:311
                 self._sched_dev = torch.stack(cols, dim=1).contiguous()
+                self._sched_rows = self._sched_dev.cpu().tolist()   # host copy of the same rows (one sync per schedule change, not per step)
             self._sched_key = key
         return self._sched_dev
+
+    def _sched_host(self, device: torch.device):
+        """The rows of `_sched_table` as Python floats, for host-side kernel arguments (no device-to-host copy per call)."""
+        self._sched_table(device)
+        return self._sched_rows
 
     def q_sample(self, x_start, t, noise=None):
         """cond_diff.py:262-264 (torch elementwise; only used for the eval branch's two debug

@@ -716,14 +716,14 @@ int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, flo
 
 int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream) {
   GC_CHECK_ARG(x && w && y && n >= 1 && C >= 1 && (long long)n * C <= 65535 && H >= 1 && W >= 1, "bad arguments");
-  dwconv3x3_kernel<<<dim3((H * W + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
+  dwconv3x3_kernel<<<dim3((H * ((W + 3) / 4) + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
 
 int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream) {
   GC_CHECK_ARG(x && dy && dw && n >= 1 && C >= 1 && C <= 65535 && H >= 1 && W >= 1, "bad arguments");
-  dwconv3x3_wgrad_kernel<<<dim3(C, (unsigned)std::min<long long>(((long long)n * H * W + 4095) / 4096, 128)), 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
+  dwconv3x3_wgrad_kernel<<<dim3(C, (unsigned)std::min<long long>(((long long)n * H * ((W + 3) / 4) + 1023) / 1024, 128)), 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -731,6 +731,36 @@ int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* d
 int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream) {
   GC_CHECK_ARG(v && g && out && count >= 0 && (count + 255) / 256 < (1LL << 31), "bad arguments");
   if (count > 0) gelu_bwd_kernel<<<(unsigned)((count + 255) / 256), 256, 0, (hipStream_t)stream>>>(v, g, out, count);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+int gencomm_ew_slice_fwd(int op, const float* a, const float* b, const float* c, const float* d, float* o0, float* o1, int n, int nch, int HW,
+                         int a_ct, int a_c0, int o0_ct, int o0_c0, int o1_ct, int o1_c0, void* stream) {
+  GC_CHECK_ARG(a && o0 && n >= 1 && n <= 65535 && nch >= 1 && nch <= 65535 && HW >= 1 && op >= 0 && op <= 4, "bad arguments");
+  SliceArgs s{a, b, c, d, o0, o1, n, nch, HW, a_ct, a_c0, 0, 0, o0_ct, o0_c0, o1_ct, o1_c0};
+  const dim3 grid((HW + 255) / 256, nch, n);
+  hipStream_t st = (hipStream_t)stream;
+  switch (op) {
+    case EW_COPY: ew_slice_kernel<EW_COPY><<<grid, 256, 0, st>>>(s); break;
+    case EW_GELU_SPLIT: GC_CHECK_ARG(o1, "null pointer"); ew_slice_kernel<EW_GELU_SPLIT><<<grid, 256, 0, st>>>(s); break;
+    case EW_GELU_GATE: GC_CHECK_ARG(b, "null pointer"); ew_slice_kernel<EW_GELU_GATE><<<grid, 256, 0, st>>>(s); break;
+    case EW_GATE_BWD: GC_CHECK_ARG(b && c && d && o1, "null pointer"); ew_slice_kernel<EW_GATE_BWD><<<grid, 256, 0, st>>>(s); break;
+    default: GC_CHECK_ARG(b, "null pointer"); ew_slice_kernel<EW_GELU_BWD><<<grid, 256, 0, st>>>(s); break;
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_nc_scale_fwd(const float* x, const float* a, const float* b, float* out, int n, int C, int HW, void* stream) {
+  GC_CHECK_ARG(x && a && out && n >= 1 && C >= 1 && (long long)n * C <= 65535 && HW >= 1, "bad arguments");
+  nc_scale_kernel<<<dim3((HW + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, a, b, out, HW);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+int gencomm_nc_dot_fwd(const float* x, const float* y, float* out, int n, int C, int HW, void* stream) {
+  GC_CHECK_ARG(x && out && n >= 1 && C >= 1 && (long long)n * C <= 65535 && HW >= 1, "bad arguments");
+  GC_HIP(hipMemsetAsync(out, 0, (size_t)n * C * sizeof(float), (hipStream_t)stream));
+  nc_dot_kernel<<<dim3(std::min((HW + 255) / 256, 64), n * C), 256, 0, (hipStream_t)stream>>>(x, y, out, HW);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

@@ -136,43 +136,71 @@ __global__ __launch_bounds__(256) void ln_nchw_param_grad_kernel(const float* __
 
 // depthwise 3x3, padding 1: y[n][c] = conv(x[n][c], w[c][3][3]) + b[c].  flip = 1 computes the input gradient
 // (correlation with the flipped taps, no bias).
+// Round 3: four consecutive pixels of a row per thread, every tap LOADED (rows / columns clamped into the map, the out-of-range taps
+// replaced by exact zeros afterwards) -- with one branch per tap the nine loads of a pixel were issued one memory latency after the
+// other (1 TB/s at 4 x 128 x 200 x 704).
+__device__ __forceinline__ void dw_load_row6(const float* __restrict__ row, int x0, int W, bool row_ok, float v[6]) {
+  // v[0..5] = row[x0 - 1 .. x0 + 4], zero outside [0, W) or when the row itself is outside the map
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int xx = x0 - 1 + j;
+    const float t = row[min(max(xx, 0), W - 1)];
+    v[j] = (row_ok && xx >= 0 && xx < W) ? t : 0.f;
+  }
+}
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                         float* __restrict__ y, int C, int H, int W, int flip) {
-  const int nc = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= H * W) return;
-  const int c = nc % C, h = p / W, x0 = p - h * W;
+  const int nc = blockIdx.y, W4 = (W + 3) >> 2, q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= H * W4) return;
+  const int c = nc % C, h = q / W4, x0 = 4 * (q - h * W4);
   const float* __restrict__ xp = x + (size_t)nc * H * W;
-  float acc = (b != nullptr && !flip) ? b[c] : 0.f;
+  float wk[9];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + (flip ? 8 - t : t)];
+  const float b0 = (b != nullptr && !flip) ? b[c] : 0.f;
+  float acc[4] = {b0, b0, b0, b0};
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int yy = h + ky - 1, xx = x0 + kx - 1;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc = fmaf(w[c * 9 + (flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx)], xp[(size_t)yy * W + xx], acc);
-    }
-  y[(size_t)nc * H * W + p] = acc;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = h + ky - 1;
+    float v[6];
+    dw_load_row6(xp + (size_t)min(max(yy, 0), H - 1) * W, x0, W, yy >= 0 && yy < H, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[j] = fmaf(wk[ky * 3 + kx], v[j + kx], acc[j]);
+  }
+  float* __restrict__ yp = y + (size_t)nc * H * W + (size_t)h * W + x0;
+  if ((W & 3) == 0) *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  else
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (x0 + j < W) yp[j] = acc[j];
 }
 // dw[c][tap] += sum_{n,p} dy[n][c](p) x[n][c](p + tap), db[c] += sum dy: grid (channel, pixel chunk), one f32 atomic per
-// output and workgroup
+// output and workgroup; the same four-pixel, branch-free loads
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                                               float* __restrict__ db, int n, int C, int H, int W) {
   __shared__ float s_red[4][10];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, tid = threadIdx.x, W4 = (W + 3) >> 2;
   float acc[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = 0.f;
-  for (long long i = (long long)blockIdx.y * 256 + tid; i < (long long)n * H * W; i += (long long)gridDim.y * 256) {
-    const int s = (int)(i / (H * W)), p = (int)(i - (long long)s * H * W), h = p / W, x0 = p - h * W;
+  for (long long i = (long long)blockIdx.y * 256 + tid; i < (long long)n * H * W4; i += (long long)gridDim.y * 256) {
+    const int s = (int)(i / (H * W4)), q = (int)(i - (long long)s * H * W4), h = q / W4, x0 = 4 * (q - h * W4);
     const size_t base = ((size_t)s * C + c) * H * W;
-    const float d = dy[base + p];
-    acc[9] += d;
+    float d[4];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int j = 0; j < 4; ++j) { const float t = dy[base + (size_t)h * W + min(x0 + j, W - 1)]; d[j] = x0 + j < W ? t : 0.f; }
+    acc[9] += (d[0] + d[1]) + (d[2] + d[3]);
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int yy = h + ky - 1, xx = x0 + kx - 1;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[ky * 3 + kx] = fmaf(d, x[base + (size_t)yy * W + xx], acc[ky * 3 + kx]);
-      }
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = h + ky - 1;
+      float v[6];
+      dw_load_row6(x + base + (size_t)min(max(yy, 0), H - 1) * W, x0, W, yy >= 0 && yy < H, v);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ky * 3 + kx] = fmaf(d[j], v[j + kx], acc[ky * 3 + kx]);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 10; ++t) {
@@ -290,6 +318,64 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   if (i >= count) return;
   const float x = v[i];
   out[i] = g[i] * (0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x));
+}
+
+// ---- elementwise / per-(sample, channel) pieces of the Enhancer's backward (enhancer.py:222-250, :315-333, :346-357), so that the
+// training step's own arithmetic runs on this library's kernels only (round 2 composed them from framework tensor operations).
+// All tensors NCHW fp32; a "slice" is channels [c0, c0 + nch) of a tensor with ctotal channels.
+__device__ __forceinline__ float gelu_grad_f(float x) {   // d/dx GELU(x), erf form
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+struct SliceArgs {
+  const float* a; const float* b; const float* c; const float* d;
+  float* o0; float* o1;
+  int n, nch, HW;
+  int a_ct, a_c0, b_ct, b_c0, o0_ct, o0_c0, o1_ct, o1_c0;
+};
+enum EwOp : int {
+  EW_COPY = 0,        // o0 = a                                   (slice -> slice: replaces cat / contiguous)
+  EW_GELU_SPLIT = 1,  // o0 = GELU(a[:, :nch]), o1 = GELU(a[:, nch:2 nch])      (a has 2 nch channels)
+  EW_GELU_GATE = 2,   // o0 = GELU(a) * b                         (g = GELU(u) x2)
+  EW_GATE_BWD = 3,    // o0 = GELU'(a) * c * b  (du);  o1 slice = GELU'(d slice) * c * GELU(a)   (a = u, b = h2, c = dg, d = v)
+  EW_GELU_BWD = 4,    // o0 slice = GELU'(a slice) * b            (dv[:, :hid] = GELU'(v1) dh1)
+};
+template <int OP>
+__global__ __launch_bounds__(256) void ew_slice_kernel(const SliceArgs s) {
+  const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, n = blockIdx.z;
+  if (p >= s.HW) return;
+  auto at = [&](const float* t, int ct, int c0) { return t[((size_t)n * ct + c0 + c) * s.HW + p]; };
+  auto to = [&](float* t, int ct, int c0) -> float& { return t[((size_t)n * ct + c0 + c) * s.HW + p]; };
+  if (OP == EW_COPY) {
+    to(s.o0, s.o0_ct, s.o0_c0) = at(s.a, s.a_ct, s.a_c0);
+  } else if (OP == EW_GELU_SPLIT) {
+    to(s.o0, s.nch, 0) = gelu_erf_f(at(s.a, 2 * s.nch, 0));
+    to(s.o1, s.nch, 0) = gelu_erf_f(at(s.a, 2 * s.nch, s.nch));
+  } else if (OP == EW_GELU_GATE) {
+    to(s.o0, s.nch, 0) = gelu_erf_f(at(s.a, s.nch, 0)) * at(s.b, s.nch, 0);
+  } else if (OP == EW_GATE_BWD) {
+    const float u = at(s.a, s.nch, 0), h2 = at(s.b, s.nch, 0), dg = at(s.c, s.nch, 0);
+    to(s.o0, s.nch, 0) = gelu_grad_f(u) * (dg * h2);
+    to(s.o1, s.o1_ct, s.o1_c0) = gelu_grad_f(at(s.d, s.o1_ct, s.o1_c0)) * (dg * gelu_erf_f(u));
+  } else {
+    to(s.o0, s.o0_ct, s.o0_c0) = gelu_grad_f(at(s.a, s.o0_ct, s.o0_c0)) * at(s.b, s.nch, 0);
+  }
+}
+// out[n][c][p] = x[n][c][p] * a[n][c] + b[n][c]       (d y2 = grad_out * gate + d gap / HW, enhancer.py:325-333)
+__global__ __launch_bounds__(256) void nc_scale_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ out, int HW) {
+  const int p = blockIdx.x * 256 + threadIdx.x, nc = blockIdx.y;
+  if (p < HW) out[(size_t)nc * HW + p] = fmaf(x[(size_t)nc * HW + p], a[nc], b != nullptr ? b[nc] : 0.f);
+}
+// out[n][c] = sum_p x[n][c][p] * (y ? y[n][c][p] : 1)   (global average pool and d gate), f64 accumulation; out zeroed by the caller
+__global__ __launch_bounds__(256) void nc_dot_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int HW) {
+  __shared__ double s_red[4];
+  const int nc = blockIdx.y, tid = threadIdx.x;
+  double acc = 0.0;
+  for (int p = blockIdx.x * 256 + tid; p < HW; p += gridDim.x * 256) acc += (double)x[(size_t)nc * HW + p] * (y != nullptr ? (double)y[(size_t)nc * HW + p] : 1.0);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&out[nc], (float)(s_red[0] + s_red[1] + s_red[2] + s_red[3]));
 }
 
 // out = a x + b y + c z (y, z optional; out may alias any input): the elementwise glue of the training branch's sampler chain

@@ -18,8 +18,10 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().float().contiguous()
 
 
-def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad: int, stride: int = 1) -> torch.Tensor:
-    """y = conv(x, w [Cout, Cin, K, K]) + b, K in {1, 3} (exact-fp32 implicit GEMM, csrc/conv_kernels.h)."""
+def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad: int, stride: int = 1, residual: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+    """y = conv(x, w [Cout, Cin, K, K]) + b (+ residual), K in {1, 3} (csrc/conv_kernels.h). `out` / `out_coff`: write the result into
+    channels [out_coff, out_coff + Cout) of an existing [n, ctotal, Ho, Wo] tensor (replaces a torch.cat)."""
     x, w = _c(x), _c(w)
     n, cin, H, W = x.shape
     cout, _, kh, kw = w.shape
@@ -30,9 +32,15 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad: int
     bb = _c(b) if b is not None else None
     _lib.check(l.gencomm_conv2d_fold(None, None, None, None, ptr(bb), 0.0, cout, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-    y = torch.empty(n, cout, Ho, Wo, dtype=torch.float32, device=dev)
+    if residual is not None:
+        assert out is None
+        y = torch.empty(n, cout, Ho, Wo, dtype=torch.float32, device=dev)
+        _lib.check(l.gencomm_conv2d_act_res_fwd(ptr(x), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(_c(residual)), ptr(y), n, cin, H, W, cout, kh, kw,
+                                                stride, pad, 0, st), "gencomm_conv2d_act_res_fwd")
+        return y
+    y = out if out is not None else torch.empty(n, cout, Ho, Wo, dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_conv2d_fwd(ptr(x), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(y), n, cin, H, W, cout, kh, kw, stride, pad, 0, 1,
-                                    cout, 0, st), "gencomm_conv2d_fwd")
+                                    y.shape[1], int(out_coff), st), "gencomm_conv2d_fwd")
     return y
 
 
@@ -107,16 +115,53 @@ def ln_fwd(x: torch.Tensor, gamma, beta, eps: float, residual: bool) -> torch.Te
     return out
 
 
-def ln_bwd(x: torch.Tensor, gamma, dy: torch.Tensor, eps: float):
+def ln_bwd(x: torch.Tensor, gamma, dy: torch.Tensor, eps: float, accumulate_into: Optional[torch.Tensor] = None):
+    """(dx, dgamma, dbeta); `accumulate_into`: dx is ADDED to that tensor (which is returned) instead of a fresh one."""
     x, dy = _c(x), _c(dy)
     n, C, H, W = x.shape
-    dx = torch.empty_like(x)
+    dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
     dg = torch.zeros(C, dtype=torch.float32, device=x.device)
     db = torch.zeros(C, dtype=torch.float32, device=x.device)
     scratch = torch.empty(n * H * W * 2, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().gencomm_ln_nchw_bwd(ptr(x), ptr(_c(gamma)), ptr(dy), ptr(dx), ptr(dg), ptr(db), ptr(scratch), float(eps), 0,
-                                              n, C, H * W, stream_ptr(x.device)), "gencomm_ln_nchw_bwd")
+    _lib.check(_lib.lib().gencomm_ln_nchw_bwd(ptr(x), ptr(_c(gamma)), ptr(dy), ptr(dx), ptr(dg), ptr(db), ptr(scratch), float(eps),
+                                              int(accumulate_into is not None), n, C, H * W, stream_ptr(x.device)), "gencomm_ln_nchw_bwd")
     return dx, dg, db
+
+
+EW_COPY, EW_GELU_SPLIT, EW_GELU_GATE, EW_GATE_BWD, EW_GELU_BWD = range(5)
+
+
+def ew_slice(op: int, a, b=None, c=None, d=None, o0=None, o1=None, *, n: int, nch: int, HW: int, a_ct: int = 0, a_c0: int = 0,
+             o0_ct: int = 0, o0_c0: int = 0, o1_ct: int = 0, o1_c0: int = 0) -> None:
+    """gencomm_ew_slice_fwd (include/gencomm_hip.h): the elementwise pieces of the Enhancer's backward on channel slices."""
+    _lib.check(_lib.lib().gencomm_ew_slice_fwd(int(op), ptr(a), ptr(b), ptr(c), ptr(d), ptr(o0), ptr(o1), n, nch, HW, a_ct, a_c0, o0_ct, o0_c0,
+                                               o1_ct, o1_c0, stream_ptr(a.device)), "gencomm_ew_slice_fwd")
+
+
+def copy_slice(src: torch.Tensor, c0: int, nch: int, dst: Optional[torch.Tensor] = None, dst_c0: int = 0) -> torch.Tensor:
+    """dst[:, dst_c0:dst_c0 + nch] = src[:, c0:c0 + nch] (dst: a fresh [n, nch, H, W] tensor when None)."""
+    n, C, H, W = src.shape
+    if dst is None:
+        dst = torch.empty(n, nch, H, W, dtype=torch.float32, device=src.device)
+    ew_slice(EW_COPY, src, o0=dst, n=n, nch=nch, HW=H * W, a_ct=C, a_c0=c0, o0_ct=dst.shape[1], o0_c0=dst_c0)
+    return dst
+
+
+def nc_scale(x: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """out[n, c] = x[n, c] * a[n, c] + b[n, c] over the pixels."""
+    n, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().gencomm_nc_scale_fwd(ptr(x), ptr(_c(a)), ptr(_c(b)) if b is not None else None, ptr(out), n, C, H * W, stream_ptr(x.device)),
+               "gencomm_nc_scale_fwd")
+    return out
+
+
+def nc_dot(x: torch.Tensor, y: Optional[torch.Tensor]) -> torch.Tensor:
+    """[n, C]: sum over the pixels of x (* y), float64 accumulation."""
+    n, C, H, W = x.shape
+    out = torch.empty(n, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gencomm_nc_dot_fwd(ptr(x), ptr(y), ptr(out), n, C, H * W, stream_ptr(x.device)), "gencomm_nc_dot_fwd")
+    return out
 
 
 def dwconv3x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], flip: bool = False) -> torch.Tensor:

@@ -353,6 +353,17 @@ int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float*
 int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream);
 int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream);
 int gencomm_lincomb_fwd(float* out, const float* x, const float* y, const float* z, float a, float b, float c, long long count, void* stream);
+/* Elementwise pieces of the Enhancer's backward on channel slices (slice = channels [c0, c0 + nch) of an [n][ct][HW] tensor), op:
+ *   0 copy: o0 slice = a slice                                    (replaces cat / contiguous)
+ *   1 o0 = GELU(a[:, :nch]), o1 = GELU(a[:, nch:])                (a has 2 nch channels; o0, o1 have nch)
+ *   2 o0 = GELU(a) * b                                            (gated product, enhancer.py:241-246)
+ *   3 o0 = GELU'(a) c b, o1 slice = GELU'(d slice) c GELU(a)      (a = u, b = x2, c = d gated, d = Linear1 output; o1 / d share ct, c0)
+ *   4 o0 slice = GELU'(a slice) b                                 (a, o0 share ct, c0; b has nch channels)
+ * nc_scale: out = x * a[n][c] + b[n][c] (b may be NULL);  nc_dot: out[n][c] = sum_p x (* y) with f64 accumulation (out is zeroed). */
+int gencomm_ew_slice_fwd(int op, const float* a, const float* b, const float* c, const float* d, float* o0, float* o1, int n, int nch, int HW,
+                         int a_ct, int a_c0, int o0_ct, int o0_c0, int o1_ct, int o1_c0, void* stream);
+int gencomm_nc_scale_fwd(const float* x, const float* a, const float* b, float* out, int n, int C, int HW, void* stream);
+int gencomm_nc_dot_fwd(const float* x, const float* y, float* out, int n, int C, int HW, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * iou3d_nms with the reference extension's own semantics (opencood/pcdet_utils/iou3d_nms: src/iou3d_nms_kernel.cu:104-372,
