@@ -248,7 +248,7 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
       float* __restrict__ plane = gxs + ((size_t)j * a.C + c) * HW;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if ((ok[j] >> k) & 1u) atomicAdd(plane + idx[j][k], wt[j][k] * dj);
+        if (((ok[j] >> k) & 1u) && wt[j][k] != 0.f) atomicAdd(plane + idx[j][k], wt[j][k] * dj);   // the ego agent's identity warp: 3 of 4 weights are exact zeros
     }
   }
 }

@@ -94,7 +94,10 @@ inline int dgrad3x3_enqueue(const UNetBwdCall& b, const float* dy, const float* 
 // The same for an 8 -> 8 channel layer (forward output channels 8, forward input channels [ic0, ic0 + 8)) through the UNet's
 // own exact-fp32 8-channel kernel (conv8_kernel on v_mfma_f32_4x4x1, unet_kernels.h): the table entry for nic = 8,
 // [(oc * 9 + flipped tap)][8], IS that kernel's weight layout [ic][tap][oc].  out = [n][8][H][W].
-inline int dgrad8_enqueue(const UNetBwdCall& b, const float* dy, const float* w_fwd, int Cin_f, int ic0, float* out, int n, int H, int W) {
+// gn_src >= 0: the layer's input was SiLU(GroupNorm(tensor gn_src)) -- the epilogue (conv8_kernel RES = 3) turns d A into
+// d z = d A SiLU'(.) and accumulates GroupNorm backward's two sums into the reduction slot gn_bwd_enqueue(..., fused) will use.
+inline int dgrad8_enqueue(const UNetBwdCall& b, const float* dy, const float* w_fwd, int Cin_f, int ic0, float* out, int n, int H, int W,
+                          int gn_src = -1, const float* gamma = nullptr, const float* beta = nullptr, int gs = 0) {
   const DgradEntry& e = (*b.dg)[b.dg_next++];
   if (b.raw + e.w_off != w_fwd || e.cout != 8 || e.cin != Cin_f || e.ic0 != ic0 || e.nic != 8)
     return fail(GC_ERR_ARG, "gencomm_unet_bwd: dgrad weight table out of step with the backward walk");
@@ -104,7 +107,35 @@ inline int dgrad8_enqueue(const UNetBwdCall& b, const float* dy, const float* w_
   a.xcd = b.c.m.xcd();
   Modes mf = b.c.m;
   mf.v[MODE_ARITH] = 1;   // exact fp32: gradients span many orders of magnitude
+  if (gn_src >= 0) {
+    if (b.gp.uses >= kMaxGnUses) return fail(GC_ERR_ARG, "gencomm_unet_bwd: too many GroupNorm uses");
+    a.res[0] = b.c.tensor_ptr(gn_src); a.sstat[1] = b.c.stat_ptr(gn_src); a.gamma = gamma; a.beta = beta; a.gn_gs = gs;
+    a.inv_cnt = 1.0 / ((double)gs * H * W);
+    a.dstat = reinterpret_cast<double*>(b.c.wsp + b.bw->red) + (size_t)b.gp.uses * b.c.n * 16;   // the slot the next gn_bwd_enqueue takes
+    launch_conv8<1, false, false, 3>(mf, pick_tile(mf, n, H, W), a, n, b.c.st);
+    return GC_OK;
+  }
   launch_conv8<1, false, false, 0>(mf, pick_tile(mf, n, H, W), a, n, b.c.st);
+  return GC_OK;
+}
+
+// The input gradient of conv_out (forward 8 -> C, so C -> 8 here) through the UNet's own exact-fp32 C -> 8 kernel (conv_in_kernel
+// without its message chunk): the table entry [(oc * 9 + flipped tap)][8] is that kernel's [ic][tap][oc] layout over C channels.  The
+// general implicit-GEMM kernel pads the 8 outputs to 64: 248 us per call at 4 x 64 x 200 x 704.
+inline int dgradC8_enqueue(const UNetBwdCall& b, const float* dy, const float* w_fwd, int C, float* out, int n, int H, int W) {
+  const DgradEntry& e = (*b.dg)[b.dg_next++];
+  if (b.raw + e.w_off != w_fwd || e.cout != C || e.cin != 8 || e.ic0 != 0 || e.nic != 8)
+    return fail(GC_ERR_ARG, "gencomm_unet_bwd: dgrad weight table out of step with the backward walk");
+  ConvInArgs a{nullptr, dy, b.F(b.bw->wtmp) + e.p_off, b.F(b.bw->zeros), out, nullptr, C, H, W, b.c.m.xcd()};
+  Modes mf = b.c.m;
+  mf.v[MODE_ARITH] = 1;
+  const TileCfg tc = pick_tile(mf, n, H, W);
+  int tw, th;
+  tile_dims(tc, &tw, &th);
+  const dim3 grid(cdiv(W, tw), cdiv(H, th), n);
+  if (tc == TILE_64x16) conv_in_kernel<64, 16, 4><<<grid, 256, 0, b.c.st>>>(a);
+  else if (tc == TILE_32x16) conv_in_kernel<32, 16, 4><<<grid, 128, 0, b.c.st>>>(a);
+  else conv_in_kernel<32, 8, 1><<<grid, 256, 0, b.c.st>>>(a);
   return GC_OK;
 }
 
@@ -125,7 +156,7 @@ inline void gn_fwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma,
 }
 // G[src] += backward of SiLU(GN(src)) given dA (channels coff.. of a ctotal-channel tensor); d gamma / d beta accumulated
 inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, const float* beta, int gs, int HW, const float* dA, int ctotal,
-                          int coff, long long dgamma_off, long long dbeta_off) {
+                          int coff, long long dgamma_off, long long dbeta_off, bool fused = false) {
   hipStream_t st = b.c.st;
   const int u = b.gp.uses;
   if (u >= kMaxGnUses) return fail(GC_ERR_ARG, "gencomm_unet_bwd: too many GroupNorm uses");
@@ -134,7 +165,8 @@ inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, 
   GnArgs g{};
   g.x = b.c.tensor_ptr(src_id); g.stat = b.c.stat_ptr(src_id); g.gamma = gamma; g.beta = beta; g.da = dA; g.out = b.G(src_id); g.red = red;
   g.inv_cnt = 1.0 / ((double)gs * HW); g.gs = gs; g.HW = HW; g.da_ctotal = ctotal; g.da_coff = coff;
-  gn_silu_bwd_reduce_kernel<<<dim3(std::min(cdiv(HW, 256), 64), 8, b.c.n), 256, 0, st>>>(g);
+  g.da_is_dz = fused ? 1 : 0;   // fused: dgrad8_enqueue's epilogue wrote d z and this slot's sums
+  if (!fused) gn_silu_bwd_reduce_kernel<<<dim3(std::min(cdiv(HW, 256), 64), 8, b.c.n), 256, 0, st>>>(g);
   gn_silu_bwd_apply_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, st>>>(g);
   return GC_OK;
 }
@@ -189,7 +221,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         wgrad_gn_sources(b, wa, o.src[0], -1, b.raw + p.nout_w, b.raw + p.nout_b, 2, HW);
         wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        if (int rc = dgrad3x3_enqueue(b, grad_x0, b.raw + p.conv_out.w, C, 8, 0, 8, DA, 8, 0, n, Hl, Wl)) return rc;
+        if (int rc = dgradC8_enqueue(b, grad_x0, b.raw + p.conv_out.w, C, DA, n, Hl, Wl)) return rc;
         if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + p.nout_w, b.raw + p.nout_b, 2, HW, DA, 8, 0, p.nout_w, p.nout_b)) return rc;
         break;
       }
@@ -201,8 +233,8 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         wgrad_gn_sources(b, wa, o.src[0], -1, b.raw + rb.n2w, b.raw + rb.n2b, 2, HW);
         wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        if (int rc = dgrad8_enqueue(b, go, b.raw + rb.c2w, 8, 0, DA, n, Hl, Wl)) return rc;
-        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, rb.n2w, rb.n2b)) return rc;
+        if (int rc = dgrad8_enqueue(b, go, b.raw + rb.c2w, 8, 0, DA, n, Hl, Wl, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2)) return rc;
+        if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, rb.n2w, rb.n2b, true)) return rc;
         if (rb.cin == 8) {
           axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
         } else {
@@ -222,11 +254,12 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         wgrad_gn_sources(b, wa, o.src[0], nsrc == 2 ? o.src[1] : -1, b.raw + rb.n1w, b.raw + rb.n1b, gs, HW);
         wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        for (int s = 0; s < nsrc; ++s)   // one 8-channel input gradient per source, DA = [source][n][8][HW]
-          if (int rc = dgrad8_enqueue(b, gt, b.raw + rb.c1w, rb.cin, 8 * s, DA + (size_t)s * n * 8 * HW, n, Hl, Wl)) return rc;
-        for (int s = 0; s < nsrc; ++s)
+        for (int s = 0; s < nsrc; ++s) {   // one 8-channel input gradient per source (its epilogue = GroupNorm backward's reductions), then the apply
+          if (int rc = dgrad8_enqueue(b, gt, b.raw + rb.c1w, rb.cin, 8 * s, DA + (size_t)s * n * 8 * HW, n, Hl, Wl, o.src[s], b.raw + rb.n1w + 8 * s,
+                                      b.raw + rb.n1b + 8 * s, gs)) return rc;
           if (int rc = gn_bwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, DA + (size_t)s * n * 8 * HW, 8, 0,
-                                      rb.n1w + 8 * s, rb.n1b + 8 * s)) return rc;
+                                      rb.n1w + 8 * s, rb.n1b + 8 * s, true)) return rc;
+        }
         break;
       }
       case OP_DOWN: {

@@ -15,17 +15,6 @@
 
 namespace gc {
 
-// mean / rstd / scale of channel c from the f64 statistics, exactly as gn_coeff (unet_kernels.h) forms them
-__device__ __forceinline__ void gn_mean_rstd(const double* __restrict__ stat, int c, int gs, double inv_cnt, float* mean, float* rstd) {
-  const int g0 = c & ~(gs - 1);
-  double s = 0.0, q = 0.0;
-  for (int j = 0; j < gs; ++j) { s += stat[(g0 + j) * 2 + 0]; q += stat[(g0 + j) * 2 + 1]; }
-  const double m = s * inv_cnt;
-  const float var = fmaxf((float)(q * inv_cnt - m * m), 0.f);
-  *mean = (float)m;
-  *rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
-}
-
 struct GnArgs {
   const float* x;        // [n][8][HW] one 8-channel source
   const double* stat;    // [n][8][2]
@@ -36,6 +25,7 @@ struct GnArgs {
   double* red;           // [n][8][2] f64: sum dz, sum dz*xhat (backward)
   double inv_cnt;        // 1 / (gs * HW)
   int gs, HW, out_ctotal, out_coff, da_ctotal, da_coff;
+  int da_is_dz;          // backward apply: `da` already holds dz = dA * SiLU'(.) (written by the input-gradient convolution's epilogue)
 };
 
 __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const GnArgs a) {
@@ -43,11 +33,6 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const GnArgs a) {
   float A, B;
   gn_coeff(a.stat + (size_t)n * 16, c, a.gs, a.inv_cnt, a.gamma[c], a.beta[c], &A, &B);
   if (p < a.HW) a.out[((size_t)n * a.out_ctotal + a.out_coff + c) * a.HW + p] = silu_f(fmaf(A, a.x[((size_t)n * 8 + c) * a.HW + p], B));
-}
-
-__device__ __forceinline__ float silu_grad_f(float z) {
-  const float s = sigmoid_f(z);
-  return s * fmaf(z, 1.0f - s, 1.0f);
 }
 
 __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const GnArgs a) {
@@ -83,7 +68,8 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const GnArgs a) 
   if (p < a.HW) {
     const size_t e = ((size_t)n * 8 + c) * a.HW + p;
     const float g = a.gamma[c], xh = (a.x[e] - mean) * rstd;
-    const float dz = a.da[((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p] * silu_grad_f(fmaf(g, xh, a.beta[c]));
+    const float d0 = a.da[((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p];
+    const float dz = a.da_is_dz ? d0 : d0 * silu_grad_f(fmaf(g, xh, a.beta[c]));
     a.out[e] += rstd * (g * dz - f1 - xh * f2);
   }
 }

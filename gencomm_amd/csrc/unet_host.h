@@ -50,6 +50,7 @@ inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, h
   tile_dims(t, &tw, &th);
   const dim3 grid(cdiv(a.W, tw), cdiv(a.H, th), n);
   const int variant = UP ? 16 : (RES == 2 ? 8 : (RES == 1 ? 4 : (NSRC == 2 ? 2 : 1)));  // MODE_CONV8H_MASK: diagnostic
+  if constexpr (RES != 3)   // RES 3 = the backward's GroupNorm epilogue: exact-fp32 kernel only
   if (t == TILE_64x16 && a.wh != nullptr && m.split() && (m.v[MODE_CONV8H_MASK] & variant)) {
     GC_KLOG(UP ? "conv8h_kernel<1,0,UP,0>" : NSRC == 2 ? "conv8h_kernel<2,GN,0,0>" : RES == 2 ? "conv8h_kernel<1,GN,0,2>" : RES == 1 ? "conv8h_kernel<1,GN,0,1>" : GN ? "conv8h_kernel<1,GN,0,0>" : "conv8h_kernel<1,0,0,0>");
     conv8h_kernel<NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a);

@@ -300,6 +300,23 @@ __device__ __forceinline__ void conv_tile_mfma(const float (*tile)[LH][LS], cons
 // ---------------------------------------------------------------------------------------------
 // 3x3 convolution, 8 (or 8+8) input channels -> 8 output channels, stride 1, zero padding 1.
 // ---------------------------------------------------------------------------------------------
+// mean / rstd / scale of channel c from the f64 statistics, exactly as gn_coeff (unet_kernels.h) forms them
+__device__ __forceinline__ void gn_mean_rstd(const double* __restrict__ stat, int c, int gs, double inv_cnt, float* mean, float* rstd) {
+  const int g0 = c & ~(gs - 1);
+  double s = 0.0, q = 0.0;
+  for (int j = 0; j < gs; ++j) { s += stat[(g0 + j) * 2 + 0]; q += stat[(g0 + j) * 2 + 1]; }
+  const double m = s * inv_cnt;
+  const float var = fmaxf((float)(q * inv_cnt - m * m), 0.f);
+  *mean = (float)m;
+  *rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
+}
+
+__device__ __forceinline__ float silu_grad_f(float z) {
+  const float s = sigmoid_f(z);
+  return s * fmaf(z, 1.0f - s, 1.0f);
+}
+
+
 struct Conv8Args {
   const float* src[2];    // [n][8][Hin][Win]
   const double* sstat[2]; // statistics of src (sum, sumsq per channel) [n][8][2]
@@ -317,6 +334,7 @@ struct Conv8Args {
   int xcd;                // 1: XCD-aware workgroup -> tile mapping (common.h xcd_block)
   const float* amax;      // !GN on the f16 pipe: device bound on max|src| (or null: bound from sstat[0], or none)
   int term_mask;          // diagnostic instantiation of conv8h_kernel only (gencomm_conv8_fwd): which of the six terms run
+  int gn_gs;              // RES == 3 (backward): channels per GroupNorm group of the tensor in res[0]
 };
 
 template <int TW, int TH, int PPL, int NSRC, bool GN, bool UP, int RES>
@@ -360,8 +378,12 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
   TileRegs<TW, TH, NT, 8> R;
   if (GC_EXP & 16) R = TileRegs<TW, TH, NT, 8>{};
   else if (wvec) stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
-  float resv[RES == 1 ? 8 : 1][PPL];
-  if (RES == 1) {
+  // RES == 3 (backward, unet_bwd_host.h): this convolution is an input gradient d A, res[0] is the forward tensor x whose
+  // SiLU(GroupNorm(x)) the forward layer consumed: the epilogue turns d A into d z = d A * SiLU'(gamma xhat + beta), stores d z and
+  // accumulates sum d z / sum d z xhat where the forward accumulates sum / sum of squares (GroupNorm backward's two reductions: the
+  // separate reduce pass over x and d A disappears)
+  float resv[(RES == 1 || RES == 3) ? 8 : 1][PPL];
+  if (RES == 1 || RES == 3) {
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + o) * plane + pix;
@@ -382,6 +404,16 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
       gn_coeff(a.sstat[s] + (size_t)n * 16, c, 2 * NSRC, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
       s_ab[tid][0] = A;
       s_ab[tid][1] = B;
+    }
+    __syncthreads();
+  }
+
+  if (RES == 3) {   // xhat = rstd x - mean rstd of the tensor in res[0] (statistics in sstat[1])
+    if (tid < 8) {
+      float mean, rstd;
+      gn_mean_rstd(a.sstat[1] + (size_t)n * 16, tid, a.gn_gs, a.inv_cnt, &mean, &rstd);
+      s_ab[8 + tid][0] = rstd;
+      s_ab[8 + tid][1] = -mean * rstd;
     }
     __syncthreads();
   }
@@ -421,6 +453,19 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
   #pragma unroll
       for (int p = 0; p < PPL; ++p) out[o][p] = acc[o >> 2][p][o & 3] + bias[o] + (RES == 1 ? resv[o][p] : 0.f);
 
+    float xh[RES == 3 ? 8 : 1][PPL];
+    if (RES == 3) {
+  #pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const float g = as_const(a.gamma)[o], b = as_const(a.beta)[o];
+  #pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+          xh[o][p] = fmaf(s_ab[8 + o][0], resv[o][p], s_ab[8 + o][1]);
+          out[o][p] *= silu_grad_f(fmaf(g, xh[o][p], b));
+        }
+      }
+    }
+
     if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
   #pragma unroll 4
       for (int c = 0; c < 16; ++c) {
@@ -457,7 +502,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
       for (int p = 0; p < PPL; ++p) {
         const float m = ok[p] ? out[o][p] : 0.f;
         s += m;
-        q = fmaf(m, m, q);
+        q = fmaf(m, RES == 3 ? xh[RES == 3 ? o : 0][p] : m, q);
       }
       part[o] = s;
       part[8 + o] = q;
@@ -604,7 +649,7 @@ __global__ __launch_bounds__(256) void down8x2_kernel(const DownArgs a) {
 // first, cond_diff.py:318). Input channels are streamed through LDS in chunks of 8.
 // ---------------------------------------------------------------------------------------------
 struct ConvInArgs {
-  const float* cond;  // [n][2][H][W]
+  const float* cond;  // [n][2][H][W], or null: no message chunk, the weights are [C][9][8]
   const float* x;     // [n][C][H][W]
   const float* w;     // prepared [(C+2)][9][8]
   const float* bias;  // [8]
@@ -639,7 +684,9 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_in_kernel(const ConvInAr
     for (int p = 0; p < PPL; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- chunk 0: the two message channels (channel order: cond first, cond_diff.py:318) ----
-  {
+  // cond == nullptr: a plain C -> 8 convolution whose weights start at a.w (the backward uses it for conv_out's input gradient)
+  const float* __restrict__ xw = a.cond != nullptr ? a.w + 144 : a.w;
+  if (a.cond != nullptr) {
     const float* __restrict__ sp = a.cond + (size_t)n * 2 * plane;
     float wc[3];
     load_wregs<3>(wc, a.w, 144, lane);
@@ -661,7 +708,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_in_kernel(const ConvInAr
   float wn[9];
   if (nchunk > 0) {  // C == 0: message channels only (the sampler's constant map k = W_cond (*) cond + b_in)
     if (wvec) stage_load<TW, TH, NT, 8, false>(R, xp, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
-    load_wregs<9>(wn, a.w + 144, 576, lane);
+    load_wregs<9>(wn, xw, 576, lane);
   }
 #pragma unroll 1
   for (int ch = 0; ch < nchunk; ++ch) {
@@ -673,7 +720,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_in_kernel(const ConvInAr
     for (int g = 0; g < 9; ++g) wcur[g] = wn[g];
     if (ch + 1 < nchunk) {
       if (wvec) stage_load<TW, TH, NT, 8, false>(R, xp + (size_t)(ch + 1) * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
-      load_wregs<9>(wn, a.w + 144 + (size_t)(ch + 1) * 576, 576, lane);
+      load_wregs<9>(wn, xw + (size_t)(ch + 1) * 576, 576, lane);
     }
     __syncthreads();
     conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wcur, acc, tx, ty);
