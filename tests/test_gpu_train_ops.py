@@ -1,0 +1,130 @@
+"""Direct tests of the training-path kernels added in round 3, each against float64 torch on the same inputs:
+weight gradients on the fp32 matrix cores (conv_wgrad_mfma_kernel through gencomm_conv2d_wgrad: what torch autograd's
+convolution_backward computes in the reference's training runs), the elementwise glue of the sampler chain and of the Enhancer's
+backward (gencomm_lincomb_fwd, gencomm_ew_slice_fwd, gencomm_nc_scale_fwd, gencomm_nc_dot_fwd), the depthwise kernels, and the
+module-level workspaces under two concurrent HIP streams."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 37, 50, 3), (1, 16, 8, 16, 24, 3), (2, 16, 8, 20, 36, 1), (1, 66, 8, 18, 26, 3), (1, 8, 64, 18, 26, 3),
+                                   (3, 8, 8, 200, 64, 3)])
+def test_weight_gradient_on_the_matrix_cores_vs_float64(shape):
+    from gencomm_amd import train_ops as T
+    N, Cin, Cout, H, W, K = shape
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g) * torch.logspace(-3, 0, Cout).view(1, Cout, 1, 1)   # gradients of very different size per channel
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, K, K), dy.double(), padding=K // 2)
+    ref_b = dy.double().sum((0, 2, 3))
+    dw, db = T.conv2d_wgrad(dy.to(DEV), x.to(DEV), K, K // 2, True)
+    for o in range(Cout):   # per output channel: the scale differs by 1e3
+        err = (dw[o].double().cpu() - ref_w[o]).abs().max().item()
+        assert err <= 3e-6 * ref_w[o].abs().max().item() + 1e-9, (shape, o, err)
+    # the bias gradient is a cancelling sum: its error is judged against the sum of magnitudes
+    assert ((db.double().cpu() - ref_b).abs() <= 1e-6 * dy.double().abs().sum((0, 2, 3))).all()
+
+
+def test_sampler_and_enhancer_glue_kernels_vs_torch():
+    from gencomm_amd import train_ops as T
+    from gencomm_amd.autograd import _lincomb
+    g = torch.Generator(device=DEV).manual_seed(5)
+    n, hid, H, W = 2, 24, 9, 13
+    HW = H * W
+    x, y, z = (torch.randn(n, hid, H, W, device=DEV, generator=g) for _ in range(3))
+    out = _lincomb(torch.empty_like(x), x, 0.3, y, -1.7, z, 2.5)
+    assert torch.allclose(out, 0.3 * x - 1.7 * y + 2.5 * z, rtol=1e-6, atol=1e-6)
+    assert torch.equal(_lincomb(x.clone(), x, 1.0), x)
+    odd = torch.randn(1027, device=DEV, generator=g)          # tail that is not a multiple of four
+    assert torch.allclose(_lincomb(torch.empty_like(odd), odd, 2.0, odd, 1.0), 3.0 * odd, rtol=1e-6)
+    v = torch.randn(n, 2 * hid, H, W, device=DEV, generator=g)
+    h1, h2 = torch.empty_like(x), torch.empty_like(x)
+    T.ew_slice(T.EW_GELU_SPLIT, v, o0=h1, o1=h2, n=n, nch=hid, HW=HW)
+    ref = F.gelu(v.double())
+    assert torch.allclose(h1.double(), ref[:, :hid], atol=5e-7) and torch.allclose(h2.double(), ref[:, hid:], atol=5e-7)
+    gt = torch.empty_like(x)
+    T.ew_slice(T.EW_GELU_GATE, x, y, o0=gt, n=n, nch=hid, HW=HW)
+    assert torch.allclose(gt.double(), F.gelu(x.double()) * y.double(), atol=2e-6)
+    # gate backward against autograd: g = GELU(u) * GELU(v2) with upstream dg
+    u, dg = x, z
+    ud, vd = u.double().requires_grad_(True), v.double().requires_grad_(True)
+    hd = F.gelu(vd)
+    (F.gelu(ud) * hd[:, hid:] * dg.double()).sum().backward()
+    du, dv = torch.empty_like(u), torch.zeros_like(v)
+    T.ew_slice(T.EW_GATE_BWD, u, h2, dg, v, o0=du, o1=dv, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
+    assert torch.allclose(du.double(), ud.grad, atol=3e-6) and torch.allclose(dv[:, hid:].double(), vd.grad[:, hid:], atol=3e-6)
+    assert float(dv[:, :hid].abs().max()) == 0.0                 # the other half is not touched
+    T.ew_slice(T.EW_GELU_BWD, v, y, o0=dv, n=n, nch=hid, HW=HW, o0_ct=2 * hid, o0_c0=0)
+    vd2 = v.double().requires_grad_(True)
+    (F.gelu(vd2)[:, :hid] * y.double()).sum().backward()
+    assert torch.allclose(dv[:, :hid].double(), vd2.grad[:, :hid], atol=3e-6)
+    part = T.copy_slice(v, 5, 7)
+    assert torch.equal(part, v[:, 5:12])
+    big = torch.zeros(n, 40, H, W, device=DEV)
+    T.copy_slice(v, 0, 10, big, 30)
+    assert torch.equal(big[:, 30:], v[:, :10]) and float(big[:, :30].abs().max()) == 0.0
+    a, b = torch.randn(n, hid, device=DEV, generator=g), torch.randn(n, hid, device=DEV, generator=g)
+    assert torch.allclose(T.nc_scale(x, a, b), x * a[:, :, None, None] + b[:, :, None, None], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(T.nc_dot(x, y).double(), (x.double() * y.double()).sum((2, 3)), rtol=1e-6, atol=1e-5)
+    assert torch.allclose(T.nc_dot(x, None).double(), x.double().sum((2, 3)), rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 9, 13), (1, 8, 16, 24), (2, 4, 7, 5)])
+def test_depthwise_kernels_vs_torch(shape):
+    from gencomm_amd import train_ops as T
+    n, C, H, W = shape
+    g = torch.Generator().manual_seed(W)
+    x, dy = torch.randn(n, C, H, W, generator=g), torch.randn(n, C, H, W, generator=g)
+    w, b = torch.randn(C, 1, 3, 3, generator=g), torch.randn(C, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, b.double(), padding=1, groups=C)
+    (yd * dy.double()).sum().backward()
+    y = T.dwconv3x3(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert torch.allclose(y.double().cpu(), yd.detach(), atol=2e-6)
+    dx = T.dwconv3x3(dy.to(DEV), w.to(DEV), None, flip=True)
+    assert torch.allclose(dx.double().cpu(), xd.grad, atol=2e-6)
+    dw, db = T.dwconv3x3_wgrad(x.to(DEV), dy.to(DEV))
+    assert torch.allclose(dw.double().cpu(), wd.grad, rtol=1e-5, atol=2e-5) and torch.allclose(db.double().cpu(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
+
+
+def test_modules_on_two_concurrent_streams_match_sequential_runs():
+    """The module-level API keeps one scratch workspace per (device, HIP stream): two streams running GenComm -> Enhancer -> AttFusion
+    at the same time on different scenes must not see each other."""
+    from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, synth
+    C, H, W, T, rl = 64, 24, 40, 3, [2, 1]
+    gen, enh, fus = GenComm(synth.default_gencomm_cfg(C, T)).eval().to(DEV), Enhancer(C, [8, 8], 4).eval().to(DEV), AttFusion(C)
+    synth.fill_params_(gen, 3)
+    synth.fill_params_(enh, 4)
+    scenes = []
+    for s in range(2):
+        inp = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_inputs(rl, C, H, W, 50 + s, max_shift=8.0).items()}
+        scenes.append((inp, normalize_pairwise_tfm(inp["pairwise_t_matrix"], H * 0.8, W * 0.8, 1)))
+
+    def run(inp, aff, seed):
+        pred = gen(inp["feat"], inp["cond"], inp["record_len"], seed=seed)["pred_feature"]
+        return fus(enh(pred, aff, rl), rl, aff)
+
+    with torch.no_grad():
+        ref = [run(inp, aff, 7 + i).clone() for i, (inp, aff) in enumerate(scenes)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=DEV) for _ in scenes]
+        outs = [None, None]
+        for rep in range(3):
+            for i, (inp, aff) in enumerate(scenes):
+                with torch.cuda.stream(streams[i]):
+                    outs[i] = run(inp, aff, 7 + i)
+        torch.cuda.synchronize()
+        again = [run(inp, aff, 7 + i) for i, (inp, aff) in enumerate(scenes)]
+        torch.cuda.synchronize()
+    for i in range(2):
+        # not bit-identical by construction: the Enhancer's global average pool is a float atomic sum (enh_front_h_kernel epilogue), whose
+        # order changes from run to run -- also between two sequential runs; a workspace shared by the streams would be wrong by O(1)
+        d_conc, d_seq = float((outs[i] - ref[i]).abs().max()), float((again[i] - ref[i]).abs().max())
+        print(f"scene {i}: max |concurrent - sequential| {d_conc:.2e}, max |sequential - sequential| {d_seq:.2e}, max |ref| {float(ref[i].abs().max()):.2f}")
+        assert d_conc <= 2e-5 * float(ref[i].abs().max())
