@@ -767,9 +767,11 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
   for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
 #pragma unroll 1
   for (int q = 0; q < nchunk; ++q) {
-    f32x16 acc, act;  // act: the bf8 third-term products, accumulators of their own (see the GEMM above)
+    // one accumulator for the f16 and the bf8 products: the 32x32x16 forms do not show the stale-accumulator behaviour of the
+    // 16x16x32 pair (tools/probes/mfma32_mixed_dep_probe.hip); the bf8 instruction of a k-step goes first, five f16 ones follow
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; act[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     // this chunk's depthwise weights / bias: requested now, used behind the matrix phase and a barrier
     float wd[9];
 #pragma unroll
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
       const eh8_t bh = *reinterpret_cast<const eh8_t*>(zh + pb * RB + ko);
       const eh8_t bl = *reinterpret_cast<const eh8_t*>(zl + pb * RB + ko);
       const long bt = *reinterpret_cast<const long*>(zt + pb * RT + (ko >> 1));
-      act = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(wbq[ks], bt, act, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(wbq[ks], bt, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][2], bh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][1], bl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][1], bh, acc, 0, 0, 0);
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
       for (int reg = 0; reg < 16; ++reg) {
         const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // row of the chunk: < 16 gate-branch x1, >= 16 x2
         const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
-        const float v = fmaf(acc[reg] + act[reg], 1.0f / ENH_WS, s_b1[row]);
+        const float v = fmaf(acc[reg], 1.0f / ENH_WS, s_b1[row]);
         if (m < 16) hb1[pcol * HS + m] = inimg ? gelu_erf_f(v) : 0.f;
         else if (!ring) hb2[cidx * HS + (m - 16)] = centre ? gelu_erf_f(v) : 0.f;
       }
