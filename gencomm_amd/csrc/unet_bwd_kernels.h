@@ -272,8 +272,72 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
   const int oy0 = (blockIdx.x / tiles_x) * TH, ox0 = (blockIdx.x % tiles_x) * TW;
   const int Hs = a.up ? a.Hi / 2 : a.Hi, Ws = a.up ? a.Wi / 2 : a.Wi;
   const bool gn = a.gn_stat[0] != nullptr;   // 8-channel sources: chunk ich is source ich
-  // every global load of the workgroup is issued before the first barrier (one memory round trip instead of three): the dY tile
-  // (18 values per thread), the X tile (<= NX values per thread), and -- eight threads -- the GroupNorm coefficients
+  // every global load of the workgroup is issued before the first barrier (one memory round trip instead of three): the dY tile,
+  // the X tile and -- eight threads -- the GroupNorm coefficients.  Fast path (image width a multiple of 4, no nearest-x2 source):
+  // 128-bit loads -- 4 per thread for dY, <= 6 for X (aligned quads covering columns ox0 - 4 .. ox0 + 35 of the 34-column haloed row) --
+  // instead of 18 + 22 scalar ones (the kernel was staging-bound: 35 of its 48 us without the atomics)
+  const bool vec = !a.up && (a.Wo & 3) == 0 && (a.Wi & 3) == 0;
+  if (gn && tid < 8) {
+    const int ic = ich * 8 + tid;
+    float A = 0.f, B = 0.f;
+    if (ic < Cin) gn_coeff(a.gn_stat[ic < a.c0 ? 0 : 1] + (size_t)n * 16, tid, a.gn_gs, a.gn_inv_cnt, a.gn_gamma[ic], a.gn_beta[ic], &A, &B);
+    s_gn[tid][0] = A; s_gn[tid][1] = B;
+  }
+  if (vec) {
+    constexpr int QD = 8 * TH * (TW / 4) / 256;                 // dY quads per thread: 4
+    constexpr int XQ = (PW + (4 - PAD) + 3) / 4;                // aligned quads per haloed row: 10 for K = 3 (columns -4 .. 35), 9 for K = 1 (the first unused)
+    constexpr int QX = (8 * PHt * XQ + 255) / 256;              // X quads per thread: 6
+    float4 qd[QD], qx[QX];
+#pragma unroll
+    for (int k = 0; k < QD; ++k) {
+      const int i = tid + 256 * k;
+      const int o = i / (TH * (TW / 4)), r = i - o * (TH * (TW / 4)), py = r / (TW / 4), q4 = r - py * (TW / 4);
+      const int oc = occ * 8 + o, oy = oy0 + py, ox = ox0 + 4 * q4;
+      qd[k] = (oc < a.Cout && oy < a.Ho && ox < a.Wo) ? *reinterpret_cast<const float4*>(a.dy + (((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < QX; ++k) {
+      const int i = tid + 256 * k;
+      const int c = i / (PHt * XQ), r = i - c * (PHt * XQ), py = r / XQ, q4 = r - py * XQ;
+      const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - 4 + 4 * q4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < 8 && ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+        const float* __restrict__ sp = ic < a.c0 ? a.x0 + ((size_t)n * a.c0 + ic) * Hs * Ws : a.x1 + ((size_t)n * a.c1 + (ic - a.c0)) * Hs * Ws;
+        v = *reinterpret_cast<const float4*>(sp + (size_t)iy * Ws + ix);
+      }
+      qx[k] = v;
+    }
+    for (int i = tid; i < DPS; i += 256) sdy[8 * DPS + i] = 0.f;                 // the zero plane (rows 8..15 of the A operand)
+    for (int i = tid; i < PHt * PWS; i += 256) sx[8 * XPS + i] = 1.0f;             // the plane of ones (bias column)
+#pragma unroll
+    for (int k = 0; k < QD; ++k) {
+      const int i = tid + 256 * k;
+      const int o = i / (TH * (TW / 4)), r = i - o * (TH * (TW / 4));
+      *reinterpret_cast<float4*>(sdy + o * DPS + 4 * r) = qd[k];
+    }
+    __syncthreads();   // s_gn
+#pragma unroll
+    for (int k = 0; k < QX; ++k) {
+      const int i = tid + 256 * k;
+      const int c = i / (PHt * XQ), r = i - c * (PHt * XQ), py = r / XQ, q4 = r - py * XQ;
+      if (c < 8) {
+        const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - 4 + 4 * q4;
+        const bool inside = ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;   // a quad is inside or outside as a whole (W % 4 == 0)
+        const float e[4] = {qx[k].x, qx[k].y, qx[k].z, qx[k].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int px = 4 * q4 + u - (4 - PAD);      // column inside the haloed tile row
+          if (px >= 0 && px < PW) {
+            float v = e[u];
+            if (gn && inside) v = silu_f(fmaf(s_gn[c][0], v, s_gn[c][1]));   // zero padding stays zero
+            sx[c * XPS + py * PWS + px] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  } else {
   constexpr int ND = 9 * TH * TW / 256, NX = (9 * PHt * PW + 255) / 256;
   float vd[ND], vx[NX];
 #pragma unroll
@@ -295,12 +359,6 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
     }
     vx[k] = v;
   }
-  if (gn && tid < 8) {
-    const int ic = ich * 8 + tid;
-    float A = 0.f, B = 0.f;
-    if (ic < Cin) gn_coeff(a.gn_stat[ic < a.c0 ? 0 : 1] + (size_t)n * 16, tid, a.gn_gs, a.gn_inv_cnt, a.gn_gamma[ic], a.gn_beta[ic], &A, &B);
-    s_gn[tid][0] = A; s_gn[tid][1] = B;
-  }
 #pragma unroll
   for (int k = 0; k < ND; ++k) {
     const int i = tid + 256 * k;
@@ -321,6 +379,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
     }
   }
   __syncthreads();
+  }
   const int j = lane & 15, kq = lane >> 4;
   const int aoff = (j < 8 ? j : 8) * DPS + kq;
   int boff[NT];
