@@ -5,6 +5,7 @@
 //   R  round 2's form: v_pk_fma_f32 D[0:1], D[0:1], s[n:n+1], v[104:105] op_sel:[0,0,1]    (in place, SGPR pair, op_sel)
 //   P  the same without op_sel          Q  not in place (dst v[106:107])          V  VGPR-pair multiplier instead of the SGPR pair
 //   N  form R with no MFMA in front     O  form R behind an MFMA that writes other registers
+//   W X Y Z  VGPR-only forms without op_sel (pk_mul in place, pk_fma, pk_add, pk_fma in place)
 //   hipcc --offload-arch=gfx950 -O3 pk_fma_after_mfma_probe.hip -o pk_fma_probe.bin && ./pk_fma_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,6 +22,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define RD_P "v_pk_fma_f32 v[100:101], v[100:101], %10, v[104:105]\n"
 #define RD_Q "v_pk_fma_f32 v[106:107], v[100:101], %10, v[104:105] op_sel:[0,0,1]\n"
 #define RD_V "v_pk_fma_f32 v[100:101], v[100:101], v[108:109], v[104:105] op_sel:[0,0,1]\n"
+// the VGPR-only forms without op_sel that hand-placed packed arithmetic would use (scale in place, sum of squares, sum)
+#define RD_W "v_pk_mul_f32 v[100:101], v[100:101], v[108:109]\n"
+#define RD_X "v_pk_fma_f32 v[106:107], v[100:101], v[100:101], v[104:105]\n"
+#define RD_Y "v_pk_add_f32 v[106:107], v[100:101], v[104:105]\n"
+#define RD_Z "v_pk_fma_f32 v[100:101], v[100:101], v[108:109], v[104:105]\n"
+
 #define OPS : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(a), "v"(b), "s"(s2) \
             : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113"
 #define NOP(n) "s_nop " #n "\n"
@@ -43,6 +50,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int rounds) {
     CASE(3, "s_nop 15\ns_nop 7\n", RD_R, "v100", "v101")
     CASE(4, NOP(7), RD_P, "v100", "v101") CASE(5, NOP(7), RD_Q, "v106", "v107") CASE(6, NOP(7), RD_V, "v100", "v101")
     CASEM(7, "", NOP(7), RD_R, "v100", "v101") CASEM(8, MFMA_OTHER, NOP(7), RD_R, "v100", "v101")
+    CASE(9, NOP(7), RD_W, "v100", "v101") CASE(10, NOP(7), RD_X, "v106", "v107") CASE(11, NOP(7), RD_Y, "v106", "v107") CASE(12, NOP(7), RD_Z, "v100", "v101")
     for (int i = 0; i < 2; ++i) bad[i] += (r[i] != q[i]) ? 1.f : 0.f;
   }
   float* o = out + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
@@ -77,6 +85,10 @@ int main() {
     run<6>("V vgpr-pair multiplier, 8 wait states", blocks, 1000);
     run<7>("N form R with NO mfma in front", blocks, 1000);
     run<8>("O form R behind an mfma on other registers", blocks, 1000);
+    run<9>("W v_pk_mul_f32 in place, vgpr pair, no op_sel", blocks, 1000);
+    run<10>("X v_pk_fma_f32 d = a * a + c, vgprs only", blocks, 1000);
+    run<11>("Y v_pk_add_f32 vgprs only", blocks, 1000);
+    run<12>("Z v_pk_fma_f32 in place, vgpr pairs, no op_sel", blocks, 1000);
   }
   return 0;
 }
