@@ -71,13 +71,14 @@ __device__ __forceinline__ void split_one(float a, uint16_t& hi, uint16_t& lo) {
   lo = __builtin_bit_cast(uint16_t, l);
 }
 
-// exact three-term split of a pair: hi / lo packed fp16 pairs, ta / tb = the third terms scaled by 2^20 (see the header)
+// exact three-term split of a pair: hi / lo packed fp16 pairs, ta / tb = the third terms, UNSCALED: the 2^20 rides inside the
+// conversion to bf8 (bf8x2s / bf8x4s: v_cvt_scalef32_pk_bf8_f32 divides by its scale operand 2^-20 -- one multiply per element less)
 __device__ __forceinline__ void split3_pair(float a, float b, uint32_t& hi, uint32_t& lo, float& ta, float& tb) {
   const half2_t h = __builtin_convertvector((float2_t){a, b}, half2_t);
   const float ra = a - (float)h[0], rb = b - (float)h[1];
   const half2_t l = __builtin_convertvector((float2_t){ra, rb}, half2_t);
-  ta = (ra - (float)l[0]) * HC_TSCALE;
-  tb = (rb - (float)l[1]) * HC_TSCALE;
+  ta = ra - (float)l[0];
+  tb = rb - (float)l[1];
   hi = __builtin_bit_cast(uint32_t, h);
   lo = __builtin_bit_cast(uint32_t, l);
 }
@@ -89,6 +90,19 @@ __device__ __forceinline__ uint32_t bf8x4(float a, float b, float c, float d) {
   int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
   v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
   return (uint32_t)v;
+}
+
+// the same for UNSCALED third terms: bf8(t 2^20) through the scaled conversion of gfx950 (value / scale, scale = 2^-20; checked
+// bit for bit against multiply + convert on hardware)
+typedef short hc_s2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf8x2s(float a, float b) {
+  const hc_s2_t v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32((hc_s2_t){0, 0}, a, b, 1.0f / HC_TSCALE, false);
+  return (uint32_t)(uint16_t)v[0];
+}
+__device__ __forceinline__ uint32_t bf8x4s(float a, float b, float c, float d) {
+  hc_s2_t v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32((hc_s2_t){0, 0}, a, b, 1.0f / HC_TSCALE, false);
+  v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(v, c, d, 1.0f / HC_TSCALE, true);
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ int hc_addr(int row, int px /* -1 .. 64 */) {
@@ -158,7 +172,7 @@ __device__ __forceinline__ void hc_store_main3(unsigned char* tile, int r0, int 
     const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
     *reinterpret_cast<uint4*>(tile + addr) = hi;
     *reinterpret_cast<uint4*>(tile + HC_PLANE + addr) = lo;
-    *reinterpret_cast<uint2*>(tile + HC_TOFF + (addr >> 1)) = make_uint2(bf8x4(t[0], t[1], t[2], t[3]), bf8x4(t[4], t[5], t[6], t[7]));
+    *reinterpret_cast<uint2*>(tile + HC_TOFF + (addr >> 1)) = make_uint2(bf8x4s(t[0], t[1], t[2], t[3]), bf8x4s(t[4], t[5], t[6], t[7]));
   }
 }
 // rows 16, 17 (thread = one channel's quad, lane ^ 32 = the other channel of the pair; see hc_store_rem): the pair's two
@@ -179,7 +193,7 @@ __device__ __forceinline__ void hc_store_rem3(unsigned char* tile, int tid, cons
     const int addr = rr * HC_ROW + (jb + k) * HC_PHASE + (qx + 1) * 16 + (cr >> 1) * 4;
     *reinterpret_cast<uint32_t*>(tile + addr) = hi;
     *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
-    *reinterpret_cast<uint16_t*>(tile + HC_TOFF + (addr >> 1)) = (uint16_t)bf8x2(ta, tb);
+    *reinterpret_cast<uint16_t*>(tile + HC_TOFF + (addr >> 1)) = (uint16_t)bf8x2s(ta, tb);
   }
 }
 __device__ __forceinline__ void hc_store_halo3(unsigned char* tile, int tid, float e0, float e1) {
@@ -190,7 +204,7 @@ __device__ __forceinline__ void hc_store_halo3(unsigned char* tile, int tid, flo
   const int addr = hc_addr(r, side ? HC_TW : -1) + cp * 4;
   *reinterpret_cast<uint32_t*>(tile + addr) = hi;
   *reinterpret_cast<uint32_t*>(tile + HC_PLANE + addr) = lo;
-  *reinterpret_cast<uint16_t*>(tile + HC_TOFF + (addr >> 1)) = (uint16_t)bf8x2(ta, tb);
+  *reinterpret_cast<uint16_t*>(tile + HC_TOFF + (addr >> 1)) = (uint16_t)bf8x2s(ta, tb);
 }
 
 // GroupNorm+SiLU (GN) or a plain scale (!GN), split, and write this thread's share of the tile (registers filled by
@@ -295,8 +309,8 @@ __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ til
     *reinterpret_cast<uint16_t*>(tile + addr) = hi;
     *reinterpret_cast<uint16_t*>(tile + HC_PLANE + addr) = lo;
     if constexpr (T3) {
-      const float t = ((e - (float)__builtin_bit_cast(_Float16, hi)) - (float)__builtin_bit_cast(_Float16, lo)) * HC_TSCALE;
-      tile[HC_TOFF + (addr >> 1)] = (unsigned char)(bf8x2(t, 0.f) & 0xffu);
+      const float t = (e - (float)__builtin_bit_cast(_Float16, hi)) - (float)__builtin_bit_cast(_Float16, lo);
+      tile[HC_TOFF + (addr >> 1)] = (unsigned char)(bf8x2s(t, 0.f) & 0xffu);
     }
   }
 }

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
       const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
       *reinterpret_cast<uint4*>(tile + addr) = hi;
       *reinterpret_cast<uint4*>(tile + HL_PLANE5 + addr) = lo;
-      tq[j] = make_uint2(bf8x4(t[0], t[1], t[2], t[3]), bf8x4(t[4], t[5], t[6], t[7]));
+      tq[j] = make_uint2(bf8x4s(t[0], t[1], t[2], t[3]), bf8x4s(t[4], t[5], t[6], t[7]));
     }
   }
   {
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
       const int addr = rrow * HC_ROW + j * HC_PHASE + (qx + 1) * 16 + cpr * 4;
       *reinterpret_cast<uint32_t*>(tile + addr) = hi;
       *reinterpret_cast<uint32_t*>(tile + HL_PLANE5 + addr) = lo;
-      tr2[j >> 1] |= bf8x2(ta, tb) << (16 * (j & 1));
+      tr2[j >> 1] |= bf8x2s(ta, tb) << (16 * (j & 1));
     }
   }
   th2 = 0u;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
       const int addr = hc_addr(r, tpx) + cp * 4;
       *reinterpret_cast<uint32_t*>(tile + addr) = hi;
       *reinterpret_cast<uint32_t*>(tile + HL_PLANE5 + addr) = lo;
-      th2 |= bf8x2(ta, tb) << (16 * j);
+      th2 |= bf8x2s(ta, tb) << (16 * j);
     }
   }
   // exact fp32 A' of the image's outermost ring inside this tile's window, for the border correction: only tiles that meet
