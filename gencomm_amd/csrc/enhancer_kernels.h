@@ -792,7 +792,10 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
     }
     __builtin_amdgcn_sched_barrier(0);
     if (q + 1 < nchunk) load_chunk_operands(q + 1);
-    if (q > 0) __syncthreads();  // the previous chunk's depthwise phase has finished reading hb1 / hb2 (and its Linear2 step gbuf)
+    // !L2: the previous chunk's depthwise phase must have finished reading hb1 / hb2.  L2: the barrier in front of the Linear2 step
+    // (below) already separates every wave's depthwise reads of chunk q from these writes of chunk q + 1, and the barrier behind
+    // them separates the Linear2 reads of gbuf from the next depthwise phase's writes: two barriers per chunk, not three
+    if (!L2 && q > 0) __syncthreads();
     if (pvalid) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
