@@ -49,7 +49,7 @@ struct EnhancerPlan {
 };
 
 struct EnhancerWs {
-  size_t Y, Z, Zc, Hd, G, O, O2, colsum, gate, wT, tab1, tab2, total;
+  size_t Y, Z, Zc, Hd, G, O, colsum, gate, wT, tab1, tab2, total;
 };
 
 inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
@@ -66,16 +66,17 @@ inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
   w.Zc = take(M * p.dc);
   w.Hd = take(M * 2 * p.hid);
   w.G = take(M * p.hid);
-  w.O = w.Z;   // the Linear2 GEMM's output reuses Z (dead after linear1)
-  w.O2 = w.G;  // the fused front kernel's Linear2 output: NOT Z (neighbouring workgroups read their halos from it); G is unused then
+  // the token-major result of every launch structure lives in the hidden tensor's slot: dead by the time Linear2 runs in the separate /
+  // half-fused structures, never used by the fully fused one -- and never Z, whose halos neighbouring workgroups of the fused kernel
+  // still read.  One place for all modes: gencomm_warp_attfuse_tok_fwd does not have to know which structure ran.
+  w.O = w.Hd;
   w.tab1 = take((size_t)(p.hid / 16) * (p.C / 16) * 896);  // fused front kernel: Linear1 / Linear2 operand tables
   w.tab2 = take((size_t)(p.hid / 16) * (p.C / 32 > 0 ? p.C / 32 : 1) * 896);
   w.total = off;
   return w;
 }
-// 0: separate launches, 1: Linear1 + depthwise stage fused, 2: + Linear2 (the token-major result then lives in ws.O2)
+// 0: separate launches, 1: Linear1 + depthwise stage fused, 2: + Linear2
 inline int enh_fuse_level(const Modes& m, int C) { return (m.split() && C == 64) ? (int)m.v[MODE_ENH_FUSE] : 0; }
-inline size_t enhancer_token_output(const EnhancerWs& w, const Modes& m, int C) { return enh_fuse_level(m, C) >= 2 ? w.O2 : w.O; }
 inline size_t enhancer_workspace_bytes(const EnhancerPlan& p, int n, int H, int W) { return enhancer_ws(p, n, H, W).total; }
 
 inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float* x, float* out,
@@ -121,7 +122,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     enh_prep_front_kernel<<<32, 256, 0, st>>>(raw + p.l1w, F(w.tab1), C, p.hid);
     if (fuse >= 2) enh_prep_back_kernel<<<16, 256, 0, st>>>(raw + p.l2w, F(w.tab2), C, p.hid);
     EnhFrontArgs a{F(w.Z), F(w.tab1), raw + p.l1b, raw + p.dww, raw + p.dwb, F(w.G), C, p.hid, H, W,
-                   F(w.tab2), raw + p.l2b, F(w.Y), F(w.O2), F(w.colsum)};
+                   F(w.tab2), raw + p.l2b, F(w.Y), F(w.O), F(w.colsum)};
     TimedLaunch tl(KF_ENH_GEMM1, st);
     if (fuse >= 2) enh_front_h_kernel<true><<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);
     else enh_front_h_kernel<false><<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);
@@ -140,7 +141,7 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     enh_dwgate_kernel<SL><<<dim3((unsigned)((total + 255) / 256), n), 256, 0, st>>>(a);
   }
   }
-  float* const Otok = fuse >= 2 ? F(w.O2) : F(w.O);
+  float* const Otok = F(w.O);
   if (fuse < 2) {  // K5: linear2 + residual, column sums for the global average pool
     GemmArgs a{F(w.G), raw + p.l2w, raw + p.l2b, F(w.Y), F(w.O), F(w.colsum), HW, C, p.hid};
     TimedLaunch tl(KF_ENH_GEMM2, st);

@@ -849,9 +849,8 @@ int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* t
   GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && H >= 1 && W >= 1, "bad B/n/H/W");
   const EnhancerWs w = enhancer_ws(p, n, H, W);
   const char* base = (const char*)enhancer_workspace;
-  const Modes m = modes_snapshot();  // the same mode the Enhancer call saw decides where its token-major result lives
-  return warp_attfuse_tok_enqueue(reinterpret_cast<const float*>(base + enhancer_token_output(w, m, C)), reinterpret_cast<const float*>(base + w.gate),
-                                  theta, scene_off, out, B, C, H, W, m.xcd(), (hipStream_t)stream);
+  return warp_attfuse_tok_enqueue(reinterpret_cast<const float*>(base + w.O), reinterpret_cast<const float*>(base + w.gate),
+                                  theta, scene_off, out, B, C, H, W, modes_snapshot().xcd(), (hipStream_t)stream);
 }
 
 }  // extern "C"
