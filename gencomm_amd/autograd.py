@@ -161,31 +161,27 @@ def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise
 
 
 # ----------------------------------------------------------------------------------------- Enhancer
+def _gate_mlp(sa, gap, params):
+    """split_attn's channel gate on [n, C] vectors (enhancer.py:315-333): fc1 -> LayerNorm -> ReLU -> fc2 -> sigmoid."""
+    return torch.sigmoid(F.linear(F.relu(F.layer_norm(F.linear(gap, params[0]), (params[0].shape[0],), params[1], params[2], 1e-5)), params[3]))
+
+
 class EnhancerFunction(torch.autograd.Function):
-    """HIP forward (gencomm_enhancer_fwd, the fused inference kernels) and a backward composed of HIP primitives
-    (gencomm_amd/train_ops.py): the stage is recomputed layer by layer in NCHW with the exact-fp32 general convolution
-    (1x1 = Linear, 3x3 partial conv), LayerNorm and depthwise kernels, then walked backwards with their gradient kernels.
-    Elementwise products / sums and the channel gate's MLP on [n, C] vectors are plain torch tensor arithmetic."""
+    """The Enhancer for a call that will be differentiated.  The forward runs the stage layer by layer in NCHW on HIP primitives
+    (gencomm_amd/train_ops.py: LayerNorm, the partial 3x3 and the Linear layers as convolutions, depthwise 3x3, fused GELU / gate
+    kernels) and KEEPS every intermediate; the backward walks them with the matching gradient kernels -- nothing is recomputed
+    (round 2 ran the fused inference kernels forward and recomputed this chain in backward: 0.75 ms per 4-agent scene more).
+    The channel gate's MLP on [n, C] vectors is plain torch tensor arithmetic."""
 
     @staticmethod
     def forward(ctx, enh, x, *params):
-        with torch.no_grad():
-            out = enh._forward_hip(x)
-        ctx.enh = enh
-        ctx.save_for_backward(x)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
         from . import train_ops as T
-        (x,) = ctx.saved_tensors
-        enh = ctx.enh
         b1, sa, m = enh.block_1, enh.split_attn, enh.block_1.mlp
+        x = x.detach().float().contiguous()
         n, C, H, W = x.shape
         dc, hid, HW = C // 4, m.dwconv[0].weight.shape[0], H * W
         f32 = dict(dtype=torch.float32, device=x.device)
         with torch.no_grad():
-            # ---- forward recompute, every intermediate kept; slices / concatenations / activations on the library's own kernels
             y = T.ln_fwd(x, b1.norm1.weight, b1.norm1.bias, 1e-5, True)            # x + LN1(x)       enhancer.py:351-352
             z = T.ln_fwd(y, b1.norm2.weight, b1.norm2.bias, 1e-5, False)           # LN2              :354
             z1 = T.copy_slice(z, 0, dc)
@@ -201,15 +197,32 @@ class EnhancerFunction(torch.autograd.Function):
             T.ew_slice(T.EW_GELU_GATE, u, h2, o0=g, n=n, nch=hid, HW=HW)               # GELU(u) * x2     :244-246
             w2 = m.linear2[0].weight.detach()[:, :, None, None]
             y2 = T.conv2d(g, w2, m.linear2[0].bias, 0, residual=y)                     # Linear2 + residual :247, :354
+            gap = T.nc_dot(y2, None) / HW                                              # global average pool   :325
+            a = _gate_mlp(sa, gap, [sa.fc1.weight, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight])
+            out = T.nc_scale(y2, a, None)                                              # x * gate         :333
+        ctx.enh = enh
+        ctx.save_for_backward(x, y, z1, zi, v, h1, h2, u, g, y2, gap)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import train_ops as T
+        x, y, z1, zi, v, h1, h2, u, g, y2, gap0 = ctx.saved_tensors
+        enh = ctx.enh
+        b1, sa, m = enh.block_1, enh.split_attn, enh.block_1.mlp
+        n, C, H, W = x.shape
+        dc, hid, HW = C // 4, m.dwconv[0].weight.shape[0], H * W
+        w1 = m.linear1[0].weight.detach()[:, :, None, None]
+        w2 = m.linear2[0].weight.detach()[:, :, None, None]
+        with torch.no_grad():
             go = grad_out.float().contiguous()
-            gap0 = T.nc_dot(y2, None)                                                  # global average pool x HW   :325
             da = T.nc_dot(go, y2)
         # ---- channel gate on [n, C] vectors (split_attn, :315-333): torch autograd on a few hundred numbers
         gate_params = [sa.fc1.weight, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight]
         with torch.enable_grad():
-            gap = (gap0 / HW).requires_grad_(True)
+            gap = gap0.detach().clone().requires_grad_(True)
             local = [p.detach().requires_grad_(True) for p in gate_params]
-            a = torch.sigmoid(F.linear(F.relu(F.layer_norm(F.linear(gap, local[0]), (local[0].shape[0],), local[1], local[2], 1e-5)), local[3]))
+            a = _gate_mlp(sa, gap, local)
             dgap, *dgate = torch.autograd.grad(a, [gap] + local, da)
         with torch.no_grad():
             dy2 = T.nc_scale(go, a.detach(), dgap / HW)
