@@ -11,15 +11,17 @@ from gencomm_amd import AttFusion, Enhancer, GenComm, normalize_pairwise_tfm, sy
 DEV = "cuda:0"
 OPTIMIZER = "--no-optimizer" not in sys.argv
 ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""   # "shipped" / "large": one shape (profiling runs)
+BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1   # scenes per step (the shipped yamls train with batch_size 1, 2 or 4)
 SHAPES = {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128, 64, 128, 3), "large: 4 agents, C=64, 200x704, T=3": (4, 64, 200, 704, 3)}
 for name, (N, C, H, W, T) in SHAPES.items():
     if ONLY and not name.startswith(ONLY):
         continue
     gen, enh, fus = GenComm(synth.default_gencomm_cfg(C, T)).train().to(DEV), Enhancer(C, [8, 8], 4).train().to(DEV), AttFusion(C)
     g = torch.Generator(device=DEV).manual_seed(1)
-    feat = torch.randn(N, C, H, W, generator=g, device=DEV).clamp_(min=0)
-    cond = torch.randn(N, 2, H, W, generator=g, device=DEV).requires_grad_(True)
-    ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N], 5, 7, 10.0))
+    rl = [N] * BATCH
+    feat = torch.randn(N * BATCH, C, H, W, generator=g, device=DEV).clamp_(min=0)
+    cond = torch.randn(N * BATCH, 2, H, W, generator=g, device=DEV).requires_grad_(True)
+    ptm = torch.from_numpy(synth.make_pairwise_t_matrix(rl, 5, 7, 10.0))
     affine = normalize_pairwise_tfm(ptm, H * 0.4, W * 0.4, 1)
     params = [p for p in list(gen.parameters()) + list(enh.parameters()) if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-5, fused=True) if OPTIMIZER else None   # train.py uses Adam (hypes_yaml optimizer block)
@@ -27,10 +29,10 @@ for name, (N, C, H, W, T) in SHAPES.items():
     def step():
         for p in params:
             p.grad = None
-        pred = gen(feat, cond, [N], seed=3)["pred_feature"]
+        pred = gen(feat, cond, rl, seed=3)["pred_feature"]
         if pred.dim() == 3:
             pred = pred.unsqueeze(0)
-        out = fus(enh(pred, affine, [N]), [N], affine)
+        out = fus(enh(pred, affine, rl), rl, affine)
         out.square().mean().backward()
         if opt is not None:
             opt.step()          # the weights change: the next forward re-packs and re-prepares them (gencomm_unet_prepare)
@@ -42,5 +44,5 @@ for name, (N, C, H, W, T) in SHAPES.items():
     for _ in range(K):
         step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / K
-    print(f"train step [{name}]: {1e3 * dt:.1f} ms per scene (forward + backward{' + Adam step' if OPTIMIZER else ''}) = {1.0 / dt:.2f} scenes/s", flush=True)
+    dt = (time.perf_counter() - t0) / K / BATCH
+    print(f"train step [{name}, {BATCH} scene(s) per step]: {1e3 * dt:.1f} ms per scene (forward + backward{' + Adam step' if OPTIMIZER else ''}) = {1.0 / dt:.2f} scenes/s", flush=True)
