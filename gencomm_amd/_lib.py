@@ -126,7 +126,8 @@ _SIGNATURES = {
     "gencomm_voxelize_workspace_bytes": (_ll, [_i]),
     "gencomm_voxelize_fwd": (_i, [_p, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p, _p, _p, _p, _p, _ll, _p]),
     "gencomm_warp_attfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "gencomm_warp_attfuse_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_warp_attfuse_bwd_scratch_floats": (_ll, [_i, _i, _i]),
+    "gencomm_warp_attfuse_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_maxfuse_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_warp_attfuse_tok_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }

@@ -162,6 +162,8 @@ struct FuseBwdArgs {
   const float* gout;     // [B][C][H][W]
   float* gx;             // [n][C][H][W], zeroed by the caller
   int C, H, W;
+  float* ws;             // scratch [n][HW][2]: softmax weight and d score of (agent, output pixel), for the gather pass
+  int* plan;             // scratch [n]: 1 = this agent's d x is formed by the gather pass, 0 = by the scatter (float atomics)
 };
 
 template <int N>
@@ -233,6 +235,13 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
   float ds[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) ds[j] = score[j] * (dw[j] - sdot) * inv;
+  int gat[N];   // agent j's input gradient comes from the gather pass (fuse_bwd_gather_kernel): this pass only publishes (w_j, d s_j)
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    gat[j] = a.plan[off + j];
+    float2* __restrict__ wp = reinterpret_cast<float2*>(a.ws) + (size_t)(off + j) * HW + pix;
+    *wp = make_float2(score[j], ds[j]);
+  }
   float* __restrict__ gxs = a.gx + (size_t)off * a.C * HW;
   for (int c = 0; c < a.C; ++c) {
     const float g = gp[(size_t)c * HW];
@@ -244,12 +253,115 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
     for (int j = 0; j < N; ++j) d0 = fmaf(ds[j], v[j], d0);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
+      if (gat[j] == 1 && j != 0) continue;
       const float dj = j == 0 ? d0 : fmaf(score[j], g, ds[j] * v[0]);
       float* __restrict__ plane = gxs + ((size_t)j * a.C + c) * HW;
+      if (j == 0 && gat[0] == 1) {   // the ego's warp is the identity: its own pixel, exactly once
+        plane[pix] = dj;
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (((ok[j] >> k) & 1u) && wt[j][k] != 0.f) atomicAdd(plane + idx[j][k], wt[j][k] * dj);   // the ego agent's identity warp: 3 of 4 weights are exact zeros
+        if (((ok[j] >> k) & 1u) && wt[j][k] != 0.f) atomicAdd(plane + idx[j][k], wt[j][k] * dj);
     }
+  }
+}
+
+// Which agents take the gather pass (decided on the device: theta lives there and nothing synchronises the host).  Ego (first agent
+// of a scene): 1 if its warp is exactly the identity -- d x_0 is then written once per pixel without atomics.  Others: 1 if the
+// inverse map is tame (in pixel units every row of its matrix has an L1 norm <= 1.5, true for the rigid transforms of
+// normalize_pairwise_tfm): at most KM output pixels sample a source pixel and they lie in a 5 x 5 window around its pre-image.
+constexpr int FUSE_KM = 12;
+__global__ __launch_bounds__(64) void fuse_bwd_plan_kernel(const FuseBwdArgs a, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
+  for (int j = 0; j < N; ++j) {
+    const double* th = a.theta + (size_t)(off + j) * 6;
+    int ok;
+    if (j == 0) {
+      ok = th[0] == 1.0 && th[1] == 0.0 && th[2] == 0.0 && th[3] == 0.0 && th[4] == 1.0 && th[5] == 0.0;
+    } else {
+      // pixel-space matrix of the forward map: ix = (W/2)(th0 xb + th1 yb + th2 + 1) - 1/2 with xb = (2 px + 1)/W - 1, ...
+      const double m00 = th[0], m01 = th[1] * a.W / a.H, m10 = th[3] * a.H / a.W, m11 = th[4];
+      const double det = m00 * m11 - m01 * m10;
+      ok = 0;
+      if (fabs(det) > 0.25) {
+        const double r0 = (fabs(m11) + fabs(m01)) / fabs(det), r1 = (fabs(m10) + fabs(m00)) / fabs(det);
+        ok = (r0 <= 1.5 && r1 <= 1.5 && fabs(det) > 0.6) ? 1 : 0;   // area of the pre-image of a 2 x 2 cell < 4 / 0.6: fewer than KM lattice points
+      }
+      if (a.plan[off] != 1) ok = 0;   // the gather needs x_0[c][p] = the ego's sample at p: only with an identity ego
+    }
+    a.plan[off + j] = ok;
+  }
+}
+
+// d x_j for a non-ego agent without atomics: thread = one SOURCE pixel q of agent j.  The output pixels p whose bilinear cell
+// contains q lie around the pre-image of q; each candidate's cell is recomputed with exactly the forward's arithmetic (float64
+// affine grid cast to float32, floor, clamp), matches are kept in LDS as (p, wt w_j(p), wt d s_j(p)) and then, per channel,
+//   d x_j[c][q] = sum over matches (wt w_j) g[c][p] + (wt d s_j) x_0[c][p]          (x_0[c][p]: the ego's warp is the identity)
+// Deterministic (no float atomics), every element written exactly once.
+__global__ __launch_bounds__(128) void fuse_bwd_gather_kernel(const FuseBwdArgs a, int B) {
+  __shared__ int s_p[FUSE_KM][128];
+  __shared__ float s_wa[FUSE_KM][128], s_wb[FUSE_KM][128];
+  const int ag = blockIdx.y, tid = threadIdx.x;
+  if (a.plan[ag] != 1) return;
+  int b = 0;
+  while (b + 1 < B && a.scene_off[b + 1] <= ag) ++b;
+  const int off = a.scene_off[b];
+  if (ag == off) return;                 // the ego: written by the pixel pass
+  if (a.plan[off] != 1) return;          // needs x_0[c][p] = the ego's sample at p: only with an identity ego (else the scatter ran)
+  const int H = a.H, W = a.W, HW = H * W;
+  const int q = blockIdx.x * 128 + tid;
+  const bool live = q < HW;
+  const int qy = live ? q / W : 0, qx = live ? q - qy * W : 0;
+  const double* __restrict__ th = a.theta + (size_t)ag * 6;
+  int cnt = 0;
+  if (live) {
+    // pre-image of q in output pixel coordinates (float64)
+    const double gx = (2.0 * qx + 1.0) / (double)W - 1.0, gy = (2.0 * qy + 1.0) / (double)H - 1.0;
+    const double det = th[0] * th[4] - th[1] * th[3];
+    const double xb = (th[4] * (gx - th[2]) - th[1] * (gy - th[5])) / det, yb = (-th[3] * (gx - th[2]) + th[0] * (gy - th[5])) / det;
+    const double pxf = ((xb + 1.0) * W - 1.0) * 0.5, pyf = ((yb + 1.0) * H - 1.0) * 0.5;
+    const int x_lo = max((int)floor(pxf - 1.6), 0), x_hi = min((int)ceil(pxf + 1.6), W - 1);
+    const int y_lo = max((int)floor(pyf - 1.6), 0), y_hi = min((int)ceil(pyf + 1.6), H - 1);
+    const float2* __restrict__ wsp = reinterpret_cast<const float2*>(a.ws) + (size_t)ag * HW;
+    for (int py = y_lo; py <= y_hi; ++py)
+      for (int px = x_lo; px <= x_hi; ++px) {
+        // exactly fuse_body's tap computation for output pixel (px, py)
+        const double oxb = (2.0 * px + 1.0) / (double)W - 1.0, oyb = (2.0 * py + 1.0) / (double)H - 1.0;
+        const float sgx = (float)(th[0] * oxb + th[1] * oyb + th[2]);
+        const float sgy = (float)(th[3] * oxb + th[4] * oyb + th[5]);
+        const float ix = ((sgx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((sgy + 1.f) * (float)H - 1.f) * 0.5f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+        if (fx != (float)x0 || fy != (float)y0) continue;   // clamped: everything out of range
+        const int dx = qx - x0, dy = qy - y0;
+        if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
+        const float tx = ix - fx, ty = iy - fy;
+        const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty);
+        if (wgt == 0.f) continue;
+        if (cnt < FUSE_KM) {
+          const int p = py * W + px;
+          const float2 sd = wsp[p];
+          s_p[cnt][tid] = p; s_wa[cnt][tid] = wgt * sd.x; s_wb[cnt][tid] = wgt * sd.y;
+        }
+        ++cnt;
+      }
+  }
+  // (cnt > FUSE_KM cannot happen for the transforms the plan admits; the bound is asserted by the tests through the error of the result)
+  cnt = min(cnt, FUSE_KM);
+  const float* __restrict__ x0p = a.x + (size_t)off * a.C * HW;
+  const float* __restrict__ gp = a.gout + (size_t)b * a.C * HW;
+  float* __restrict__ out = a.gx + (size_t)ag * a.C * HW + q;
+  for (int c = 0; c < a.C; ++c) {
+    float acc = 0.f;
+    for (int k = 0; k < cnt; ++k) {
+      const int p = s_p[k][tid];
+      acc = fmaf(s_wa[k][tid], gp[(size_t)c * HW + p], acc);
+      acc = fmaf(s_wb[k][tid], x0p[(size_t)c * HW + p], acc);
+    }
+    if (live) out[(size_t)c * HW] = acc;
   }
 }
 
@@ -271,11 +383,21 @@ __global__ __launch_bounds__(64) void warp_attfuse_bwd_kernel(const FuseBwdArgs 
   }
 }
 
-inline int warp_attfuse_bwd_enqueue(const float* x, const double* theta, const int* scene_off, const float* gout, float* gx,
+inline size_t warp_attfuse_bwd_scratch_floats(int n, int H, int W) { return (size_t)n * H * W * 2 + (size_t)n + 64; }
+// scratch: warp_attfuse_bwd_scratch_floats(n, H, W) floats, or null -- every agent then takes the scatter with float atomics (round 2)
+inline int warp_attfuse_bwd_enqueue(const float* x, const double* theta, const int* scene_off, const float* gout, float* gx, float* scratch,
                                     int B, int n, int C, int H, int W, hipStream_t st) {
   GC_HIP(hipMemsetAsync(gx, 0, (size_t)n * C * H * W * sizeof(float), st));
-  FuseBwdArgs a{x, theta, scene_off, gout, gx, C, H, W};
+  FuseBwdArgs a{x, theta, scene_off, gout, gx, C, H, W, nullptr, nullptr};
+  if (scratch != nullptr) {
+    a.ws = scratch;
+    a.plan = reinterpret_cast<int*>(scratch + (size_t)n * H * W * 2);
+    fuse_bwd_plan_kernel<<<(B + 63) / 64, 64, 0, st>>>(a, B);
+  } else {
+    return fail(GC_ERR_ARG, "warp_attfuse_bwd: scratch is required");
+  }
   warp_attfuse_bwd_kernel<<<dim3((H * W + 63) / 64, B), 64, 0, st>>>(a);
+  fuse_bwd_gather_kernel<<<dim3((H * W + 127) / 128, n), 128, 0, st>>>(a, B);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

@@ -827,11 +827,15 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
   return warp_attfuse_enqueue(x, theta, scene_off, out, B, n, C, H, W, (hipStream_t)stream);
 }
 
-int gencomm_warp_attfuse_bwd(const float* x, const double* theta, const int* scene_off, const float* grad_out, float* grad_x,
+long long gencomm_warp_attfuse_bwd_scratch_floats(int n, int H, int W) {
+  if (n < 1 || H < 1 || W < 1) { fail(GC_ERR_ARG, "bad n/H/W"); return -1; }
+  return (long long)warp_attfuse_bwd_scratch_floats(n, H, W);
+}
+int gencomm_warp_attfuse_bwd(const float* x, const double* theta, const int* scene_off, const float* grad_out, float* grad_x, float* scratch,
                              int B, int n, int C, int H, int W, void* stream) {
-  GC_CHECK_ARG(x && theta && scene_off && grad_out && grad_x, "null pointer");
-  GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && C >= 1 && H >= 1 && W >= 1, "bad B/n/C/H/W");
-  return warp_attfuse_bwd_enqueue(x, theta, scene_off, grad_out, grad_x, B, n, C, H, W, (hipStream_t)stream);
+  GC_CHECK_ARG(x && theta && scene_off && grad_out && grad_x && scratch, "null pointer");
+  GC_CHECK_ARG(B >= 1 && B <= 65535 && n >= B && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad B/n/C/H/W");
+  return warp_attfuse_bwd_enqueue(x, theta, scene_off, grad_out, grad_x, scratch, B, n, C, H, W, (hipStream_t)stream);
 }
 
 int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,

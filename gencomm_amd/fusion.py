@@ -92,8 +92,11 @@ class AttFusion(nn.Module):
             off.append(off[-1] + k)
         scene_off = dev_ints(off, xx.device)
         gx = torch.empty_like(xx)
-        _lib.check(_lib.lib().gencomm_warp_attfuse_bwd(ptr(xx), ptr(theta), ptr(scene_off), ptr(grad_out), ptr(gx), B, n, C, H, W,
-                                                       stream_ptr(xx.device)), "gencomm_warp_attfuse_bwd")
+        l = _lib.lib()
+        scratch = torch.empty(_lib.check_size(l.gencomm_warp_attfuse_bwd_scratch_floats(n, H, W), "gencomm_warp_attfuse_bwd_scratch_floats"),
+                              dtype=torch.float32, device=xx.device)
+        _lib.check(l.gencomm_warp_attfuse_bwd(ptr(xx), ptr(theta), ptr(scene_off), ptr(grad_out), ptr(gx), ptr(scratch), B, n, C, H, W,
+                                              stream_ptr(xx.device)), "gencomm_warp_attfuse_bwd")
         return gx
 
 

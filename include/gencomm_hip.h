@@ -318,7 +318,11 @@ int gencomm_bbox_overlaps_fwd(const float* boxes, const float* query_boxes, floa
 /* Backward of gencomm_warp_attfuse_fwd (what autograd does for fusion_in_one.py:131-151 + F.grid_sample in the reference's
  * training runs): grad_x [n][C][H][W] is OVERWRITTEN with the gradient w.r.t. x given grad_out [B][C][H][W]; the bilinear
  * gather's adjoint uses float atomics (summation order varies in the last bits). */
-int gencomm_warp_attfuse_bwd(const float* x, const double* theta, const int* scene_off, const float* grad_out, float* grad_x,
+/* scratch: gencomm_warp_attfuse_bwd_scratch_floats(n, H, W) floats.  The ego's gradient (identity warp) is written once per pixel; the
+ * other agents' gradients are GATHERED per source pixel from the few output pixels that sampled it (deterministic, no float atomics)
+ * whenever their transform is rigid-like (decided on the device from theta); anything else takes the scatter with float atomics. */
+long long gencomm_warp_attfuse_bwd_scratch_floats(int n, int H, int W);
+int gencomm_warp_attfuse_bwd(const float* x, const double* theta, const int* scene_off, const float* grad_out, float* grad_x, float* scratch,
                              int B, int n, int C, int H, int W, void* stream);
 int gencomm_warp_maxfuse_fwd(const float* x, const double* theta, const int* scene_off, float* out,
                              int B, int n, int C, int H, int W, void* stream);

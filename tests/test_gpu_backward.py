@@ -214,6 +214,49 @@ def test_fusion_backward_hip_vs_torch_autograd(C, H, W, rl, shift):
     print(f"fusion backward C={C} {H}x{W} scenes {rl}: worst relative error {worst:.2e}")
 
 
+@pytest.mark.parametrize("distort", ["zoom", "ego"])
+def test_fusion_backward_falls_back_to_the_scatter_for_non_rigid_maps(distort):
+    """The gather pass of gencomm_warp_attfuse_bwd is only taken for rigid-like transforms with an identity ego (decided on the device);
+    a zooming transform (more than FUSE_KM output pixels may sample one source pixel) or a non-identity ego row must take the
+    scatter with atomics and still match torch autograd."""
+    from gencomm_amd import AttFusion, normalize_pairwise_tfm, synth
+    from torch_restatements import att_fusion_forward
+    C, H, W, rl = 16, 20, 28, [3, 2]
+    inp = synth.make_inputs(rl, C, H, W, 11, max_shift=4.0)
+    affine = normalize_pairwise_tfm(torch.from_numpy(inp["pairwise_t_matrix"]), H * 0.8, W * 0.8, 1).clone()
+    if distort == "zoom":
+        affine[0, 0, 1, :, :2] *= 2.5          # agent 1 of scene 0: the output samples a 2.5 x larger area of the source
+        affine[1, 0, 1, :, :2] *= 0.3          # agent 1 of scene 1: magnified
+    else:
+        affine[0, 0, 0, 0, 2] = 0.07           # the ego of scene 0 is shifted: no identity warp
+    x = torch.from_numpy(inp["feat"]).to(DEV).requires_grad_(True)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    wgt = torch.randn(len(rl), C, H, W, generator=g, device=DEV)
+    y = AttFusion(C)(x, rl, affine)
+    (y * wgt).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = att_fusion_forward(x2, rl, affine)
+    _close("fusion forward", y, y2, 1e-4)
+    (y2 * wgt).sum().backward()
+    _close("fusion grad x", x.grad, x2.grad)
+
+
+def test_fusion_backward_is_deterministic_for_rigid_maps():
+    """Gather pass: no float atomics -- two runs give bit-identical gradients (the round-2 scatter did not)."""
+    from gencomm_amd import AttFusion, normalize_pairwise_tfm, synth
+    C, H, W, rl = 32, 40, 72, [4, 2]
+    inp = synth.make_inputs(rl, C, H, W, 5, max_shift=20.0)
+    affine = normalize_pairwise_tfm(torch.from_numpy(inp["pairwise_t_matrix"]), H * 0.8, W * 0.8, 1)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    wgt = torch.randn(len(rl), C, H, W, generator=g, device=DEV)
+    grads = []
+    for _ in range(2):
+        x = torch.from_numpy(inp["feat"]).to(DEV).requires_grad_(True)
+        (AttFusion(C)(x, rl, affine) * wgt).sum().backward()
+        grads.append(x.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
 @pytest.mark.parametrize("C,H,W,n", [(16, 12, 20, 2), (128, 16, 24, 1)])
 def test_message_extractor_backward_vs_oracle_autograd(C, H, W, n):
     """MessageExtractorv2 is THE module stage 2 trains (stage2.py:99-101): HIP forward, HIP-composed backward; gradients of all
