@@ -3,6 +3,7 @@
 // program in reverse.  Attention blocks are not differentiated here (no shipped config has one): attn_mask must be 0.
 #pragma once
 #include "conv_kernels.h"
+#include "train_kernels.h"
 #include "unet_bwd_kernels.h"
 #include "unet_host.h"
 
@@ -25,7 +26,8 @@ inline std::vector<DgradEntry> dgrad_entries(const UNetPlan& p) {
       case OP_RES_CONV2: add(p.blocks[o.blk].c2w, 8, 8, 0, 8); break;
       case OP_RES_CONV1: for (int s0 = 0; s0 < p.blocks[o.blk].cin; s0 += 8) add(p.blocks[o.blk].c1w, 8, p.blocks[o.blk].cin, s0, 8); break;
       case OP_UP: add(p.up[o.level + 1].w, 8, 8, 0, 8); break;
-      case OP_CONV_IN: add(p.conv_in.w, 8, p.C + 2, 0, 2); add(p.conv_in.w, 8, p.C + 2, 2, p.C); break;
+      // conv_in's message-channel gradient through the 8 -> 8 kernel: input channels 0..7 (the 2 message channels + 6 of x_t, discarded)
+      case OP_CONV_IN: add(p.conv_in.w, 8, p.C + 2, 0, 8); add(p.conv_in.w, 8, p.C + 2, 2, p.C); break;
       default: break;
     }
   }
@@ -287,7 +289,11 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
         WgradArgs wa{gh, cond, x_t, b.graw + p.conv_in.w, b.graw + p.conv_in.b, 8, 2, C, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        if (int rc = dgrad3x3_enqueue(b, gh, b.raw + p.conv_in.w, 8, C + 2, 0, 2, grad_cond, 2, 0, n, Hl, Wl)) return rc;
+        {  // d cond: the general kernel pads 2 output channels to 64 (124 us at 4 x 200 x 704); the 8 -> 8 kernel computes channels 0..7, two are kept
+          if (int rc = dgrad8_enqueue(b, gh, b.raw + p.conv_in.w, C + 2, 0, DA, n, Hl, Wl)) return rc;
+          SliceArgs sa{DA, nullptr, nullptr, nullptr, grad_cond, nullptr, n, 2, Hl * Wl, 8, 0, 0, 0, 2, 0, 0, 0};
+          ew_slice_kernel<EW_COPY><<<dim3(cdiv(Hl * Wl, 256), 2, n), 256, 0, st>>>(sa);
+        }
         if (int rc = dgrad3x3_enqueue(b, gh, b.raw + p.conv_in.w, 8, C + 2, 2, C, grad_xt, C, 0, n, Hl, Wl)) return rc;
         break;
       }
