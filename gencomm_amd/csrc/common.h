@@ -58,7 +58,8 @@ enum ModeKey : int {
 };
 struct Modes {
   long long v[MODE_COUNT];
-  bool split() const { return v[MODE_ARITH] != 1; }  // f16-pipe kernel family (fp16 split or bf16 mode)
+  bool split() const { return v[MODE_ARITH] != 1; }  // f16-pipe kernel family of the hot path (three-term fp16 split, or bf16 mode)
+  bool split2() const { return v[MODE_ARITH] == 3; } // opt-in: the general convolutions AROUND the path on the two-term split (22-bit products)
   bool bf16() const { return v[MODE_ARITH] == 2; }
   int xcd() const { return v[MODE_XCD_REMAP] != 0 ? 1 : 0; }
 };

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16s_kernel(const Conv2dArgs a) {
 }
 
 inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_t st) {
-  if (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2) && a.ups == 1 && a.Cin % 8 == 0 && a.CoutP >= 32 && modes_snapshot().split()) {
+  if (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2) && a.ups == 1 && a.Cin % 8 == 0 && a.CoutP >= 32 && modes_snapshot().split2()) {
     const int tiles3 = ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
     const dim3 g3(tiles3, (a.CoutP + 63) / 64, N);
     if (g3.y > 65535 || g3.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");
@@ -524,7 +524,7 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
   // measured on MI355X (V2X-ViT / Where2comm Linear layers, 2-5 agents, 64x128 .. 96x352): against the exact-fp32 kernel below the
   // split kernel wins clearly from 256 output channels up (qkv 384 / 768: 71 -> 44 us, 544 -> 315 us); at 128 it is level on the
   // smallest shape and ahead on the larger ones (V2X-ViT forward, 4 agents x 96x352: 10.1 -> 9.6 ms) since it got two chunks in flight
-  if (KH == 1 && KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin >= 16 && a.CoutP >= 128 && modes_snapshot().split()) {  // ups > 1: ConvTranspose2d deblocks
+  if (KH == 1 && KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin >= 16 && a.CoutP >= 128 && modes_snapshot().split2()) {  // ups > 1: ConvTranspose2d deblocks
     const int HW = a.H * a.W, mb = (a.CoutP + 127) / 128;
     const bool narrow = (long long)((HW + 63) / 64) * mb * N < 1024;  // fewer than 4 workgroups per CU: halve the pixel tile
     const dim3 g1(narrow ? (HW + 31) / 32 : (HW + 63) / 64, mb, N);

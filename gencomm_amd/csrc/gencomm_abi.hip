@@ -60,7 +60,7 @@ const char* gencomm_last_error(void) { return last_error_buf(); }
 // ------------------------------------------------------------------------------------ modes
 int gencomm_set_mode(int key, long long value) {
   GC_CHECK_ARG(key >= 0 && key < MODE_COUNT, "unknown mode key");
-  GC_CHECK_ARG(key != MODE_ARITH || (value >= 0 && value <= 2), "GENCOMM_MODE_ARITH: 0 (f16-pipe split), 1 (exact fp32) or 2 (bf16 denoise)");
+  GC_CHECK_ARG(key != MODE_ARITH || (value >= 0 && value <= 3), "GENCOMM_MODE_ARITH: 0 (three-term f16-pipe path), 1 (exact fp32), 2 (bf16 denoise) or 3 (0 + two-term general convolutions)");
   GC_CHECK_ARG(key != MODE_SAMPLER || (value >= 0 && value <= 2), "GENCOMM_MODE_SAMPLER: 0 (automatic), 1 (direct) or 2 (latent)");
   GC_CHECK_ARG(key != MODE_TILE_WANT || value >= 0, "GENCOMM_MODE_TILE_WANT: 0 (automatic) or a positive workgroup count");
   g_modes[key].store(value, std::memory_order_relaxed);

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void sp_conv_f16s_kernel(const SpConvArgs a) {
 inline int sp_conv_enqueue(const SpConvArgs& a, hipStream_t st) {
   if (a.K > 32) return fail(GC_ERR_ARG, "sparse conv: at most 32 kernel offsets (3 x 3 x 3)");
   const dim3 grid((a.n_out + 63) / 64, (a.CoutP + 63) / 64);
-  if (modes_snapshot().split() && (a.Cin == 32 || a.Cin == 64)) {
+  if (modes_snapshot().split2() && (a.Cin == 32 || a.Cin == 64)) {
     if (a.Cin == 32) sp_conv_f16s_kernel<32><<<grid, 256, 0, st>>>(a);
     else sp_conv_f16s_kernel<64><<<grid, 256, 0, st>>>(a);
     GC_HIP(hipGetLastError());

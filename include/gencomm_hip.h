@@ -58,8 +58,12 @@ const char* gencomm_build_info(void);
 /* Library modes.  Explicit, atomic process-wide settings that every entry point reads ONCE when it is called (they
  * travel with the call from there on); the library reads no environment variable.  gencomm_set_mode returns 0 or 1
  * (unknown key / value out of range); gencomm_get_mode returns the value, -1 for an unknown key.
- *   GENCOMM_MODE_ARITH        0 (default): 3x3 / 5x5 / Linear products on the f16 matrix pipe from exact two-term fp16
- *                             splits of the fp32 operands (22-bit products, fp32 accumulation); 1: exact-fp32 kernels;
+ *   GENCOMM_MODE_ARITH        0 (default): the hot path's 3x3 / 5x5 / Linear products on the f16 matrix pipe from exact THREE-term
+ *                             splits of both fp32 operands (fp16 + fp16 + a bf8 third term: products to 2^-26, fp32 accumulation --
+ *                             not narrower than an fp32 FMA); the general convolutions around the path (gencomm_conv2d_fwd, the
+ *                             sparse convolutions) on exact-fp32 MFMA kernels; 1: exact-fp32 instruction kernels everywhere;
+ *                             3: as 0, plus the general convolutions on the two-term fp16 split of round 2 (22-bit products: faster,
+ *                             narrower than fp32 -- opt-in);
  *                             2: bf16 denoise mode (the reference's --half / autocast analogue, train_ddp.py:139-141): the
  *                             UNet's 8-channel intermediates are stored as bf16 and multiplied by single bf16 MFMAs
  *                             (fp32 accumulation, GroupNorm statistics in f64, the sampler's carried state in fp32);
@@ -269,9 +273,9 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  * fwd:     y[:, out_coff:out_coff+Cout] = act(conv(x) * scale + shift); supported: 3x3 stride 1|2 any pad, 1x1 stride 1;
  *          ups = s > 1 runs ConvTranspose2d(kernel = stride = s) (KH = KW = 1 on the prepared matrix, output H*s x W*s).
  *          y has out_ctotal channels (write into a slice of a concat buffer without a copy).
- *          Arithmetic follows GENCOMM_MODE_ARITH: 1 = exact fp32 MFMA for every shape; 0 (default) = 3x3 with Cin % 16 == 0 and
- *          1x1 / ConvTranspose2d with >= 128 GEMM rows on the f16 matrix pipe from exact fp16 hi/lo operand splits (22-bit
- *          products, fp32 accumulation) with a running power-of-two activation scale: any finite fp32 input is safe. */
+ *          Arithmetic follows GENCOMM_MODE_ARITH: 0 (default) and 1 = exact fp32 MFMA for every shape; 3 (opt-in) = 3x3 with
+ *          Cin % 8 == 0 and 1x1 / ConvTranspose2d with >= 128 GEMM rows on the f16 matrix pipe from exact fp16 hi/lo operand splits
+ *          (22-bit products, fp32 accumulation) with a running power-of-two activation scale: any finite fp32 input is safe. */
 int gencomm_conv2d_prepare(const float* weight, float* prepared, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
 int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const float* bn_running_mean, const float* bn_running_var,
                         const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream);

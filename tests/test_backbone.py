@@ -240,12 +240,12 @@ def test_split_conv_kernels_hold_fp32_grade_accuracy_over_the_whole_input_range(
     with torch.no_grad():
         ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=stride, padding=k // 2)
         mag = torch.nn.functional.conv2d(x.abs().double(), conv.weight.abs().double(), None, stride=stride, padding=k // 2) + conv.bias.abs().double().view(1, -1, 1, 1)
-        for mode in (0, 1):
+        for mode in (3, 1, 0):   # 3: the two-term split kernels (opt-in); 1, 0: exact fp32 (the default for these layers since round 3)
             with _lib.mode(_lib.MODE_ARITH, mode):
                 got = conv2d_hip(x.cuda(), conv.cuda(), None, relu=False).cpu().double()
             assert torch.isfinite(got).all(), (case, mode)
             worst = float(((got - ref).abs() / mag).max())
-            assert worst <= 4e-6, (case, "split" if mode == 0 else "exact fp32", worst)
+            assert worst <= 4e-6, (case, "split" if mode == 3 else "exact fp32", worst)
 
 
 @pytest.mark.gpu

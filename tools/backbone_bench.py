@@ -12,6 +12,8 @@ import torch
 
 from gencomm_amd import synth
 from gencomm_amd.bev_backbone import BaseBEVBackbone, DownsampleConv, HipConv2d
+import _mode
+_mode.apply_env_modes()   # GENCOMM_TOOL_ARITH=3: the opt-in two-term general convolutions
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=2)

@@ -9,6 +9,8 @@ import numpy as np
 import torch
 from gencomm_amd import second
 from gencomm_amd.second import SECOND
+import _mode
+_mode.apply_env_modes()   # GENCOMM_TOOL_ARITH=3: the opt-in two-term general convolutions
 
 NX, NY, NZ = 2048, 1024, 40
 args = {"voxel_size": [0.1, 0.1, 0.1], "lidar_range": [-102.4, -51.2, -3, 102.4, 51.2, 1], "mean_vfe": {"num_point_features": 4},

@@ -11,6 +11,8 @@ import numpy as np
 import torch
 from gencomm_amd import synth
 from gencomm_amd.heter_model_baseline_w_gencomm_stage1 import HeterModelBaselineWGenCommStage1
+import _mode
+_mode.apply_env_modes()   # GENCOMM_TOOL_ARITH=3: the opt-in two-term general convolutions
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--agents", type=int, default=2)

@@ -8,6 +8,8 @@ import numpy as np
 import torch
 from gencomm_amd import normalize_pairwise_tfm, synth
 from gencomm_amd.v2xvit import V2XViTFusion
+import _mode
+_mode.apply_env_modes()   # GENCOMM_TOOL_ARITH=3: the opt-in two-term general convolutions
 
 args = json.loads(str(np.load(os.path.join(REPO, "tests", "golden", "v2xvit.npz"))["args"]))
 net = V2XViTFusion(args).eval()
