@@ -282,7 +282,7 @@ def main():
         elapsed = timed_region(args.steps, 2000)
     timed = rank == 0 and not args.graph and not args.no_timer  # event pairs cannot be recorded into a replayed graph
     arith_mode = lib.gencomm_get_mode(_lib.MODE_ARITH)
-    split_default = arith_mode == 0
+    split_default = arith_mode in (0, 3)   # 3 = 0 on this path (the opt-in two-term kernels are the general convolutions AROUND it)
     roofs = rooflines(family_pass(), "Arithmetic: see config.arithmetic.") if timed else {}
     instantiations = getattr(family_pass, "instantiations", None)
     # the same workload with the exact-fp32 MFMA kernels everywhere, the arithmetic that is identical to the reference's:
