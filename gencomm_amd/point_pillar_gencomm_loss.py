@@ -1,0 +1,114 @@
+"""``PointPillarGencommLoss`` -- the training criterion of the GenComm stage-1 / stage-2 recipes
+(``opencood/loss/point_pillar_gencomm_loss.py:16-58`` on top of ``point_pillar_depth_loss.py:11-59`` and
+``point_pillar_loss.py:15-126``), resolved by the reference's ``create_loss`` from
+``loss.core_method: point_pillar_gencomm_loss`` (``train_utils.py:304-323``: module name, lower-cased class name).
+
+    total = cls (sigmoid focal, positives weighted ``pos_cls_weight``, / #positives / batch)
+          + reg (smooth-L1 with the sin-difference yaw encoding, positives only)
+          + dir (2-bin softmax cross entropy of the heading, positives only)
+          + generate_weight * MSE(gt_feature, pred_feature)            <- the term that trains the hot path
+
+The maps are the head outputs ([B, 2 | 14 | 4, H, W] at the fused resolution): kilobytes, so the arithmetic stays in
+framework elementwise ops (the boundary's plumbing); what differs from the reference is that nothing here synchronises the
+host -- the reference calls ``.item()`` six times per step (``point_pillar_loss.py:93,121-123``,
+``point_pillar_gencomm_loss.py:50-55``), here ``loss_dict`` holds detached device scalars that ``logging`` converts when
+it prints.  Camera depth supervision (``depth_items*`` keys) and the IoU head are outside this build: their keys raise.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def limit_period(val, offset=0.5, period=math.pi):  # opencood/utils/common_utils.py (limit_period)
+    return val - torch.floor(val / period + offset) * period
+
+
+def sigmoid_focal_loss(preds, targets, weights, gamma, alpha):  # point_pillar_loss.py:230-245
+    ce = torch.clamp(preds, min=0) - preds * targets + torch.log1p(torch.exp(-torch.abs(preds)))
+    p = torch.sigmoid(preds)
+    p_t = targets * p + (1 - targets) * (1 - p)
+    return torch.pow(1.0 - p_t, gamma) * (targets * alpha + (1 - targets) * (1 - alpha)) * ce * weights
+
+
+def weighted_smooth_l1_loss(preds, targets, sigma, weights):  # point_pillar_loss.py:216-226
+    a = torch.abs(preds - targets)
+    lt = (a <= 1.0 / sigma ** 2).to(a.dtype)
+    return (lt * 0.5 * (a * sigma) ** 2 + (a - 0.5 / sigma ** 2) * (1.0 - lt)) * weights
+
+
+def add_sin_difference(b1, b2, dim=6):  # point_pillar_loss.py:129-140
+    s = torch.sin(b1[..., dim:dim + 1]) * torch.cos(b2[..., dim:dim + 1])
+    t = torch.cos(b1[..., dim:dim + 1]) * torch.sin(b2[..., dim:dim + 1])
+    return torch.cat([b1[..., :dim], s, b1[..., dim + 1:]], -1), torch.cat([b2[..., :dim], t, b2[..., dim + 1:]], -1)
+
+
+class PointPillarGencommLoss(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if "iou" in args:
+            raise NotImplementedError("loss.args.iou (IoU head supervision) is outside this build")
+        self.pos_cls_weight = args["pos_cls_weight"]
+        self.cls, self.reg, self.dir = args["cls"], args["reg"], args.get("dir")
+        self.depth = args.get("depth")                      # parsed like the reference; only camera agents produce depth items
+        self.generate_weight = args["generate_weight"]
+        self.loss_dict = {}
+
+    def direction_target(self, reg_targets):  # point_pillar_loss.py:142-170 -> class index per anchor [N, H*W*A]
+        a = self.dir["args"]
+        anchor_yaw = torch.as_tensor(np.deg2rad(np.array(a["anchor_yaw"])), device=reg_targets.device, dtype=torch.float64)
+        A = anchor_yaw.numel()
+        rot_gt = reg_targets[..., -1] + anchor_yaw.repeat(reg_targets.shape[1] // A).view(1, -1)   # float64 like the reference's numpy map
+        off = limit_period(rot_gt - a["dir_offset"], 0, 2 * math.pi)
+        return torch.clamp(torch.floor(off / (2 * math.pi / a["num_bins"])).long(), 0, a["num_bins"] - 1), A
+
+    def forward(self, output_dict, target_dict, suffix=""):
+        if any(k.startswith(f"depth_items{suffix}") for k in output_dict):
+            raise NotImplementedError("depth supervision of camera agents is outside this build")
+        if "record_len" in output_dict:
+            bs = int(output_dict["record_len"].sum())
+        elif "batch_size" in output_dict:
+            bs = output_dict["batch_size"]
+        else:
+            bs = target_dict["pos_equal_one"].shape[0]
+        cls_labels = target_dict["pos_equal_one"].view(bs, -1, 1)
+        positives = cls_labels > 0
+        negatives = target_dict["neg_equal_one"].view(bs, -1, 1) > 0
+        pos_norm = torch.clamp(positives.sum(1, keepdim=True).float(), min=1.0)
+
+        cls_preds = output_dict[f"cls_preds{suffix}"].permute(0, 2, 3, 1).contiguous().view(bs, -1, 1)
+        cls_w = (positives * self.pos_cls_weight + negatives * 1.0) / pos_norm
+        cls_loss = sigmoid_focal_loss(cls_preds, cls_labels.type_as(cls_preds), cls_w, self.cls["gamma"], self.cls["alpha"]).sum() * self.cls["weight"] / bs
+
+        reg_w = positives / pos_norm
+        reg_preds = output_dict[f"reg_preds{suffix}"].permute(0, 2, 3, 1).contiguous().view(bs, -1, 7)
+        reg_targets = target_dict["targets"].view(bs, -1, 7)
+        rp, rt = add_sin_difference(reg_preds, reg_targets)
+        reg_loss = weighted_smooth_l1_loss(rp, rt, self.reg["sigma"], reg_w).sum() * self.reg["weight"] / bs
+
+        total = reg_loss + cls_loss
+        self.loss_dict = {"reg_loss": reg_loss.detach(), "cls_loss": cls_loss.detach()}
+        if self.dir:
+            tgt, A = self.direction_target(reg_targets)
+            logits = output_dict[f"dir_preds{suffix}"].permute(0, 2, 3, 1).contiguous().view(-1, A)
+            dir_loss = (F.cross_entropy(logits, tgt.view(-1), reduction="none") * reg_w.flatten()).sum() * self.dir["weight"] / bs
+            total = total + dir_loss
+            self.loss_dict["dir_loss"] = dir_loss.detach()
+        gen_loss = F.mse_loss(output_dict["gt_feature"], output_dict["pred_feature"])   # point_pillar_gencomm_loss.py:46-52
+        total = total + self.generate_weight * gen_loss
+        self.loss_dict.update({"generate_loss": gen_loss.detach(), "total_loss": total.detach()})
+        return total
+
+    def logging(self, epoch, batch_id, batch_len, writer=None, suffix="", iter=None):  # point_pillar_gencomm_loss.py:61-104 (no wandb)
+        d = {k: float(v) for k, v in self.loss_dict.items()}   # the only host synchronisation of the criterion
+        print("[epoch %d][%d/%d]%s || Loss: %.4f || Conf Loss: %.4f || Loc Loss: %.4f || Dir Loss: %.4f || Gen Loss: %.4f" % (
+            epoch, batch_id + 1, batch_len, suffix, d.get("total_loss", 0), d.get("cls_loss", 0), d.get("reg_loss", 0),
+            d.get("dir_loss", 0), d.get("generate_loss", 0)))
+        if writer is not None:
+            for tag, key in (("Regression_loss", "reg_loss"), ("Confidence_loss", "cls_loss"), ("Dir_loss", "dir_loss"), ("Gen_loss", "generate_loss")):
+                writer.add_scalar(tag + suffix, d.get(key, 0), epoch * batch_len + batch_id)
+        return d

@@ -207,3 +207,22 @@ def make_detection_maps(H: int, W: int, A: int, seed: int, n_obj: int = 60, num_
     reg = r.normal(0, 0.15, (1, 7 * A, H, W)).astype(np.float32)
     dirp = r.normal(0, 1.0, (1, A * num_bins, H, W)).astype(np.float32)
     return cls, reg, dirp
+
+
+def make_loss_inputs(seed: int, B: int, H: int, W: int, A: int, C: int, pos_frac: float = 0.02):
+    """Synthetic head maps and anchor labels for the training criterion (PointPillarGencommLoss): cls / reg / dir predictions
+    [B, A | 7A | 2A, H, W], labels `pos_equal_one` / `neg_equal_one` [B, H, W, A] (a few percent positives, a "don't care" band
+    that is neither), regression `targets` [B, H, W, 7A] (yaw residuals across the whole circle, some inside the smooth-L1
+    quadratic zone), and a `gt_feature` / `pred_feature` pair [B, C, H, W]. float32, numpy-deterministic."""
+    r = np.random.RandomState(seed)
+    f = np.float32
+    u = r.rand(B, H, W, A)
+    pos = (u < pos_frac).astype(f)
+    neg = (u > 3 * pos_frac).astype(f)
+    targets = r.normal(0, 0.4, (B, H, W, 7 * A)).astype(f)
+    targets[..., 6::7] = r.uniform(-np.pi, np.pi, (B, H, W, A)).astype(f)
+    reg = (targets.transpose(0, 3, 1, 2) + r.normal(0, 0.2, (B, 7 * A, H, W)) * (r.rand(B, 7 * A, H, W) < 0.7)).astype(f)
+    gt = np.maximum(r.normal(0, 1, (B, C, H, W)), 0).astype(f)
+    return {"cls_preds": r.normal(-2, 1.5, (B, A, H, W)).astype(f), "reg_preds": reg, "dir_preds": r.normal(0, 1, (B, 2 * A, H, W)).astype(f),
+            "pos_equal_one": pos, "neg_equal_one": neg, "targets": targets, "gt_feature": gt,
+            "pred_feature": (gt + r.normal(0, 0.3, gt.shape)).astype(f)}

@@ -606,6 +606,39 @@ def run_where2comm_case() -> None:
           f"mean |dx| {float(x.grad.abs().mean()):.5f}")
 
 
+LOSS_ARGS = {  # opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml:168-189
+    "pos_cls_weight": 2.0, "cls": {"type": "SigmoidFocalLoss", "alpha": 0.25, "gamma": 2.0, "weight": 2.0},
+    "reg": {"type": "WeightedSmoothL1Loss", "sigma": 3.0, "codewise": True, "weight": 2.0},
+    "dir": {"type": "WeightedSoftmaxClassificationLoss", "weight": 0.2,
+            "args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}},
+    "depth": {"weight": 1.0}, "generate_weight": 1, "gmatch_weight": 1}
+
+
+def run_loss_case() -> None:
+    """The reference's own PointPillarGencommLoss (opencood/loss/point_pillar_gencomm_loss.py) on seeded synthetic head
+    maps and labels: the total, its components and the gradients with respect to every input that carries one."""
+    import build_ref
+    import json
+    assert build_ref.build(), "oracle/_ref/box_overlaps could not be built"   # the loss module imports the post-processor (unused by it)
+    import opencood.utils as ou
+    sys.modules["opencood.utils.box_overlaps"] = ou.box_overlaps = build_ref.load_box_overlaps()
+    from opencood.loss.point_pillar_gencomm_loss import PointPillarGencommLoss
+    B, H, W, A, C = 3, 12, 20, 2, 16
+    inp = synth.make_loss_inputs(DATA_SEED + 90, B, H, W, A, C)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    for k in ("cls_preds", "reg_preds", "dir_preds", "pred_feature"):
+        t[k].requires_grad_(True)
+    crit = PointPillarGencommLoss(LOSS_ARGS)
+    out = {k: t[k] for k in ("cls_preds", "reg_preds", "dir_preds", "gt_feature", "pred_feature")}
+    total = crit(out, {k: t[k] for k in ("pos_equal_one", "neg_equal_one", "targets")})
+    total.backward()
+    rec = {"args": json.dumps(LOSS_ARGS), "data_seed": DATA_SEED + 90, "dims": np.array([B, H, W, A, C]), "total": total.detach().numpy(),
+           **{k: np.float64(v) for k, v in crit.loss_dict.items()},
+           **{"grad_" + k: t[k].grad.numpy() for k in ("cls_preds", "reg_preds", "dir_preds", "pred_feature")}}
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **rec)
+    print("loss:", {k: float(v) for k, v in crit.loss_dict.items()})
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -633,7 +666,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()

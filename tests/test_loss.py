@@ -1,0 +1,52 @@
+"""PointPillarGencommLoss (the caller on the training side of the path) against the reference's own criterion:
+tests/golden/loss.npz was written by oracle/make_golden.py from opencood/loss/point_pillar_gencomm_loss.py on the
+seeded synthetic maps of gencomm_amd.synth.make_loss_inputs -- total, components and every gradient."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gencomm_amd import synth
+from gencomm_amd.point_pillar_gencomm_loss import PointPillarGencommLoss
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss.npz")
+
+
+def _run(device):
+    g = np.load(GOLD)
+    B, H, W, A, C = (int(v) for v in g["dims"])
+    t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_loss_inputs(int(g["data_seed"]), B, H, W, A, C).items()}
+    for k in ("cls_preds", "reg_preds", "dir_preds", "pred_feature"):
+        t[k].requires_grad_(True)
+    crit = PointPillarGencommLoss(json.loads(str(g["args"])))
+    total = crit({k: t[k] for k in ("cls_preds", "reg_preds", "dir_preds", "gt_feature", "pred_feature")},
+                 {k: t[k] for k in ("pos_equal_one", "neg_equal_one", "targets")})
+    total.backward()
+    assert all(isinstance(v, torch.Tensor) for v in crit.loss_dict.values())   # no host synchronisation inside forward
+    for k in ("total_loss", "reg_loss", "cls_loss", "dir_loss", "generate_loss"):
+        assert float(crit.loss_dict[k]) == pytest.approx(float(g[k]), rel=2e-6, abs=1e-7), k
+    assert float(total.detach()) == pytest.approx(float(g["total"]), rel=2e-6)
+    for k in ("cls_preds", "reg_preds", "dir_preds", "pred_feature"):
+        np.testing.assert_allclose(t[k].grad.cpu().numpy(), g["grad_" + k], rtol=1e-5, atol=1e-8, err_msg=k)
+    d = crit.logging(0, 0, 1)
+    assert d["total_loss"] == pytest.approx(float(g["total"]), rel=2e-6)
+
+
+def test_loss_matches_the_reference_criterion_cpu():
+    _run("cpu")
+
+
+@pytest.mark.gpu
+def test_loss_matches_the_reference_criterion_gpu():
+    _run("cuda:0")
+
+
+def test_resolver_name_and_unsupported_keys():
+    import gencomm_amd.point_pillar_gencomm_loss as m
+    # train_utils.create_loss: module `point_pillar_gencomm_loss`, class whose lower-cased name is the module name without underscores
+    assert [n for n in dir(m) if n.lower() == "pointpillargencommloss"] == ["PointPillarGencommLoss"]
+    args = json.loads(str(np.load(GOLD)["args"]))
+    with pytest.raises(NotImplementedError):
+        PointPillarGencommLoss(dict(args, iou={"sigma": 3.0, "weight": 1.0}))
