@@ -11,6 +11,14 @@ Workload = BASELINE.json's metric configuration: 4 agents, C=64, 200x704 BEV, T=
 
 Scenes are independent, so N GPUs = N replicas each running its own scenes (no data-path
 collective; weak scaling). Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` without torch.distributed.run starts its own N ranks (gencomm_amd/launch.py) before the parent
+makes any GPU call; under torch.distributed.run the environment it set is used as is. `--share-device` puts every rank on
+cuda:0 with a gloo process group (rehearsal on a 1-GPU box; RCCL refuses two ranks on one device).
+
+`--workload train` is BASELINE.json configs[3]: one optimiser step of the stage-1 recipe (PointPillars -> backbone -> message
+extractor -> GenComm training branch -> Enhancer -> AttFusion -> heads, PointPillarGencommLoss, Adam) per step and rank,
+DistributedDataParallel(find_unused_parameters=True) over RCCL (train_ddp.py:121-125), scenes sharded over the ranks.
 """
 from __future__ import annotations
 
@@ -142,12 +150,131 @@ def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, timed_steps=5):
             "scene_seconds": scene_s}
 
 
+def selftest_main(args, rank, world):
+    """`--workload launch_selftest`: the launcher, the rank environment, the process group (gloo, CPU only -- no GPU call anywhere),
+    the barrier-bracketed timed region and the aggregation of bench.py with a stand-in step (rank r "processes" `--batch` scenes
+    per step in 10 ms * (1 + r)). tests/test_launch.py runs this through `python bench.py --gpus 2 --workload launch_selftest`."""
+    from gencomm_amd import dist as gdist
+    if os.environ.get("GENCOMM_SELFTEST_FAIL_RANK") == str(rank):
+        print(f"rank {rank}: failing on request", file=sys.stderr)
+        raise SystemExit(3)
+    dist = gdist.init_process_group("gloo")
+    cpu = torch.device("cpu")
+    B = max(1, args.batch)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    busy = time.perf_counter() - t0          # this rank's own work; the closing barrier makes every rank wait for the slowest
+    if dist is not None:
+        dist.barrier()
+    elapsed_here = time.perf_counter() - t0
+    per_rank = [None] * world
+    if dist is not None:
+        dist.all_gather_object(per_rank, {"rank": rank, "scenes": args.steps * B, "elapsed": elapsed_here, "busy": busy, "pid": os.getpid(),
+                                          "env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "GENCOMM_LAUNCHED")}})
+    else:
+        per_rank = [{"rank": 0, "scenes": args.steps * B, "elapsed": elapsed_here, "busy": busy, "pid": os.getpid(), "env": {}}]
+    value, elapsed, total = gdist.aggregate_throughput(args.steps * B, elapsed_here, dist, cpu)
+    if rank == 0:
+        print(json.dumps({"metric": "scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "total_scenes": total, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "launch_selftest: stand-in steps on the CPU (gloo); exercises launcher + aggregation only"},
+                          "ranks": per_rank}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_main(args, rank, world, device, backend):
+    """`--workload train` (BASELINE.json configs[3]): the stage-1 recipe's optimiser step under DistributedDataParallel.
+
+    Model = HeterModelBaselineWGenCommStage1 built from the model block of opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml
+    (512 x 256 pillars of 0.4 m -> BaseBEVBackbone [3,5,8] -> 128 x 64 x 128 -> message extractor -> GenComm T = 3 training branch
+    -> Enhancer -> AttFusion -> heads), criterion PointPillarGencommLoss with the yaml's weights, Adam(lr 2e-3, eps 1e-10,
+    weight_decay 1e-4). Every rank runs `--train-batch` scenes of `--train-agents` agents per step on its own synthetic shard
+    (train_ddp.py:62-66 DistributedSampler); gradients are averaged by DDP's bucketed all-reduce over RCCL (train_ddp.py:121-125,
+    find_unused_parameters=True: Enhancer blocks 2/3 and the attention tables never receive gradients). The process group is
+    created at world size 1 too, so the N = 1 line exercises the same RCCL communicator + DDP reducer code."""
+    from gencomm_amd import dist as gdist
+    from gencomm_amd import synth
+    from gencomm_amd.heter_model_baseline_w_gencomm_stage1 import HeterModelBaselineWGenCommStage1
+    from gencomm_amd.point_pillar_gencomm_loss import PointPillarGencommLoss
+    dist = gdist.init_process_group(backend, device, force=True)
+    red_dev = device if backend == "nccl" else torch.device("cpu")
+    B, N, T = max(1, args.train_batch), max(1, args.train_agents), 3
+    margs = synth.stage1_model_args(T=T)
+    torch.manual_seed(0)                       # identical initial weights on every rank (DDP also broadcasts rank 0's)
+    model = HeterModelBaselineWGenCommStage1(margs)
+    synth.fill_params_(model, 3)
+    synth.fill_bn_stats_(model, 4)
+    model = model.to(device).train()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True)
+    crit = PointPillarGencommLoss(synth.STAGE1_LOSS_ARGS)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=2e-3, eps=1e-10, weight_decay=1e-4, fused=True)   # m1_att.yaml:191-196
+    rng = margs["lidar_range"]
+    n = B * N
+    pil = synth.make_pillars(12000 * n, n, 512, 256, 9 + 31 * rank, voxel_size=[0.4, 0.4, 4.0], pc_range=rng)
+    ptm = synth.make_pairwise_t_matrix([N] * B, 5, 10 + rank, max_shift=20.0)
+    data = {"agent_modality_list": ["m1"] * n, "record_len": torch.tensor([N] * B), "pairwise_t_matrix": torch.from_numpy(ptm).to(device),
+            "inputs_m1": {k: torch.from_numpy(pil[k]).to(device) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}}
+    labels = None
+
+    def step():
+        nonlocal labels
+        opt.zero_grad(set_to_none=True)
+        out = ddp(data)
+        if labels is None:                     # anchor labels of the head geometry, once
+            _, A, Hh, Wh = out["cls_preds"].shape
+            li = synth.make_loss_inputs(50 + rank, B, Hh, Wh, A, 1)
+            labels = {k: torch.from_numpy(li[k]).to(device) for k in ("pos_equal_one", "neg_equal_one", "targets")}
+        loss = crit(out, labels)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed_here = time.perf_counter() - t0
+    assert torch.isfinite(loss.detach()).all(), "non-finite training loss"
+    value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed_here, dist, red_dev)
+    grad_bytes = sum(p.numel() * p.element_size() for p in params)
+    if rank == 0:
+        d = crit.logging(0, args.steps - 1, args.steps)
+        print(json.dumps({
+            "metric": "train scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_scene_per_gpu": 1e3 * elapsed / args.steps / B, "total_scenes": total_scenes,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train: stage-1 recipe (opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml), {N} agents/scene, {B} scene(s)/step/GPU, "
+                                   f"512x256 pillars -> 128x64x128 BEV, GenComm T={T}, forward + backward + Adam",
+                       "parallelism": f"dp{world} (DistributedDataParallel, find_unused_parameters=True)", "process_group": backend,
+                       "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "share_device": backend != "nccl",
+                       "grad_bytes_allreduced_per_step": grad_bytes, "trainable_parameters": sum(p.numel() for p in params),
+                       "ddp_bucket_cap_mb": 25, "pillars_per_agent": 12000},
+            "loss": d, "roofline": None, "cpu_baseline": None}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS) + ["train", "launch_selftest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-enhancer", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 pass (profiling runs)")
@@ -158,18 +285,33 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the scene's launch sequence as a captured HIP graph")
     ap.add_argument("--mode", action="append", default=[], metavar="KEY=VALUE",
                     help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow), e.g. --mode xcd=0")
+    ap.add_argument("--share-device", action="store_true",
+                    help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
+    ap.add_argument("--train-batch", type=int, default=2, help="--workload train: scenes per rank and step (m1_att.yaml batch_size: 2)")
+    ap.add_argument("--train-agents", type=int, default=2, help="--workload train: agents per scene")
+    ap.add_argument("--launch-timeout", type=float, default=None, help="seconds before the self-launcher stops its ranks")
     args = ap.parse_args()
 
     from gencomm_amd import dist as gdist
+    from gencomm_amd import launch
+    if launch.needs_launch(args.gpus):
+        # N fresh ranks of this very command line, started before this process has made any GPU call; it never makes one
+        argv = [a for a in sys.argv[1:] if a != "--share-device"]
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), argv, args.gpus, share_device=args.share_device, timeout=args.launch_timeout))
     rank, world, local_rank = gdist.env_rank_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if args.workload == "launch_selftest":
+        return selftest_main(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = gdist.init_process_group("nccl", device)  # RCCL; only the timing barrier/reduction use it
+    dev_index = launch.device_index(local_rank)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = launch.backend()
+    if args.workload == "train":
+        return train_main(args, rank, world, device, backend)
+    dist = gdist.init_process_group(backend, device)  # RCCL; only the timing barrier/reduction use it
+    red_dev = device if backend == "nccl" else torch.device("cpu")   # gloo reduces host scalars
 
     from gencomm_amd import _lib, normalize_pairwise_tfm
     from gencomm_amd.pipeline import ScenePipeline
@@ -240,19 +382,25 @@ def main():
         conv = {f: fam[f] for f in CONV8_FAMILIES if f in fam}
         if conv:
             c_ms, c_b, c_n = sum(v["ms"] for v in conv.values()), sum(v["bytes"] for v in conv.values()), sum(v["launches"] for v in conv.values())
-            traffic = None
-            pmc = os.path.join(REPO, "profiles", "r3_pmc_traffic.json")
-            if os.path.exists(pmc):
+            # counter traffic is a committed measurement, valid only for the kernels it was taken on: the JSON carries the source
+            # stamp of the library it ran (gencomm_build_info() " src=..."); any other library -> null
+            traffic, traffic_src = None, None
+            for pmc in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):
+                pmc = os.path.join(REPO, "profiles", pmc)
+                if not os.path.exists(pmc):
+                    continue
                 try:
                     tj = json.load(open(pmc))
-                    if tj.get("workload") == args.workload and tj.get("scenes_per_launch") == B:
-                        traffic = tj["conv8h_family"]["hbm_bytes_per_launch"]
+                    if (tj.get("workload") == args.workload and tj.get("scenes_per_launch") == B
+                            and tj.get("library_src") and tj.get("library_src") == _lib.library_src_hash()):
+                        traffic, traffic_src = tj["conv8h_family"]["hbm_bytes_per_launch"], os.path.basename(pmc)
+                        break
                 except Exception:
                     traffic = None
             out["roofline"] = {
                 "kernel": "conv8h_kernel<NSRC, GN, UP, RES> (8-channel 3x3 layers of the UNet: ResnetBlock conv1 / conv2, Upsample; all levels)",
                 "bound": "hbm", "achieved": c_b / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": c_b / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": c_b / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": c_n, "avg_launch_ms": c_ms / c_n, "algorithmic_bytes_per_launch": c_b / c_n,
                 "share_of_kernel_time": c_ms / tot_ms,
                 "variants": [{"variant": CONV8_FAMILIES[f], "launches": v["launches"], "avg_launch_ms": v["ms"] / v["launches"],
@@ -260,7 +408,8 @@ def main():
                 "note": "achieved = ALGORITHMIC bytes (source maps + residual sources + destination of each launch, fp32, computed by the "
                         "host from the launch shape) / HIP-event time of the launches, one scene batch in flight; averages over the full- "
                         "and half-resolution levels. traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from the committed rocprofv3 --pmc "
-                        "passes of this command (profiles/r3_pmc_traffic.json, tools/pmc_pass.sh), null when none matches this workload. " + arith_note}
+                        "passes of this command (profiles/r4_pmc_traffic.json, tools/pmc_pass.sh), null unless that file was measured on this workload "
+                        "AND on a library with this library's source stamp (library_src). " + arith_note}
         if LATENT_FAMILY in fam:
             v = fam[LATENT_FAMILY]
             fl = 2.0 * (1600.0 + 72.0 * C) * HW * N * B
@@ -280,6 +429,28 @@ def main():
         for i in range(args.warmup):
             run_scene(i, 1000 + i)
         elapsed = timed_region(args.steps, 2000)
+        # the K-step region above is the reported number; when it is shorter than a second (20 steps = 0.4 s: too short for a
+        # 5 s-period utilisation sampler to see), the same loop is repeated to >= 1.2 s in ONE bracket and reported beside it
+        sustained = None
+        if elapsed < 1.0:
+            reps = int(np.ceil(1.2 / max(elapsed, 1e-3)))
+            ts = timed_region(args.steps * reps, 2500)
+            sustained = {"steps": args.steps * reps, "seconds": ts, "value_this_rank": args.steps * reps * B / ts, "unit": "scenes/sec"}
+        # latency of ONE scene alone (one stream, batch 1): throughput above needs S x B scenes in flight
+        latency = None
+        if rank == 0:
+            f1, c1, p1 = make_scene(N, C, H, W, 77, device, 1)
+            pipe1 = ScenePipeline(gen, None if args.no_enhancer else enh, [N], C, H, W, device)
+            pipe1.set_affine(normalize_pairwise_tfm(p1, H * PX_M, W * PX_M, 1))
+            for i in range(3):
+                pipe1.run(f1, c1, seed=5000 + i)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(10):
+                pipe1.run(f1, c1, seed=5100 + i)
+            torch.cuda.synchronize(device)
+            latency = 1e3 * (time.perf_counter() - t0) / 10
+            del pipe1, f1, c1
     timed = rank == 0 and not args.graph and not args.no_timer  # event pairs cannot be recorded into a replayed graph
     arith_mode = lib.gencomm_get_mode(_lib.MODE_ARITH)
     split_default = arith_mode in (0, 3)   # 3 = 0 on this path (the opt-in two-term kernels are the general convolutions AROUND it)
@@ -303,13 +474,14 @@ def main():
         assert torch.isfinite(pipe.fused).all(), "non-finite output"
 
     # every rank ran `steps` steps of B scenes of its own; whole-job rate = all scenes / slowest rank
-    value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed, dist, device)
+    value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed, dist, red_dev)
 
     if rank == 0:
         flops, byts = algorithmic_work(N, C, HW, T)
         out = {
             "metric": "scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "total_scenes": total_scenes,
+            "latency_ms_one_scene": latency, "sustained": sustained,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if arith_mode == 2 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: GenComm->Enhancer->AttFusion, {N} agents, C={C}, {H}x{W} BEV, "
@@ -335,7 +507,8 @@ def main():
                        "streams_per_gpu": S, "scenes_per_step": B, "hip_graph": bool(args.graph),
                        "modes": {k: lib.gencomm_get_mode(v) for k, v in mode_keys.items()},
                        "parallelism": f"replicas x{world} (scene-sharded, no collective)",
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                       "process_group": backend if dist is not None else None, "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0) if dist is not None else 1,
+                       "share_device": backend != "nccl",
                        "instantiations_per_scene_batch": instantiations},
             "scene_algorithmic": {"gflop": flops / 1e9, "gbyte": byts / 1e9,
                                   "achieved_tflops": flops * args.steps * B / elapsed / 1e12,

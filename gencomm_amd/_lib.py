@@ -142,6 +142,25 @@ def hip_sources() -> List[str]:
     return [os.path.join(CSRC_DIR, "gencomm_abi.hip"), os.path.join(CSRC_DIR, "gencomm_abi_aux.hip")]
 
 
+def source_hash() -> str:
+    """16 hex digits over the HIP sources and the C header: compiled into the library (`gencomm_build_info()` ends in
+    ` src=<hash>`) so that committed measurements (profiles/*_pmc_traffic.json) can say which kernels they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC_DIR)) + [os.path.join(REPO_DIR, "include", "gencomm_hip.h")]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC_DIR, f)
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_src_hash() -> str:
+    """The `src=` stamp of the LOADED library ("" for a library built before the stamp existed)."""
+    info = lib().gencomm_build_info().decode()
+    return info.rsplit(" src=", 1)[1] if " src=" in info else ""
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library in-tree for gfx950 (cross-compiles without a GPU)."""
     srcs = hip_sources()
@@ -155,7 +174,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # without packed ops is exact in every run (tools/conv8_unit.py), and the hot kernels are not slower for it.
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
              "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-    define = '-DGENCOMM_BUILD_FLAGS="' + " ".join(flags) + '"'
+    define = '-DGENCOMM_BUILD_FLAGS="' + " ".join(flags) + " src=" + source_hash() + '"'
     obj_dir = os.path.join(PKG_DIR, "_build")
     os.makedirs(obj_dir, exist_ok=True)
     # one object per translation unit, compiled concurrently (the hot path's unit takes ~2 min, the rocPRIM one ~1 min)

@@ -93,6 +93,15 @@ class SamplerChainFunction(torch.autograd.Function):
         unet = gen.denoiser
         dev = feat.device
         n, (C, H, W) = cond.shape[0], feat.shape[1:]
+        # raw pointers from here on: GenComm._checked has validated feat / cond / src_rows; the noise tensors once more, because this
+        # node is also reachable through autograd.sampler_forward directly
+        if tuple(cond.shape) != (n, 2, H, W) or len(src_rows) != n or C != unet.feature_channels:
+            raise ValueError(f"sampler chain: cond {tuple(cond.shape)} / feat {tuple(feat.shape)} / {len(src_rows)} source rows do not fit a {unet.feature_channels}-channel denoiser")
+        if (noise0 is None) != (step_noise is None):
+            raise ValueError("sampler chain: give both noise0 and step_noise, or neither")
+        if noise0 is not None and (tuple(noise0.shape) != (n, C, H, W) or tuple(step_noise.shape) != (T, n, C, H, W) or not (noise0.is_cuda and step_noise.is_cuda)):
+            raise ValueError(f"sampler chain: noise must be device tensors (noise0 [{n},{C},{H},{W}], step_noise [{T},{n},{C},{H},{W}]), "
+                             f"got {tuple(noise0.shape)} and {tuple(step_noise.shape)}")
         l = _lib.lib()
         st = stream_ptr(dev)
         with torch.no_grad():
@@ -128,6 +137,9 @@ class SamplerChainFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         gen, coef = ctx.gen, ctx.coef
         unet, T = gen.denoiser, gen.num_timesteps
+        if ctx.xs is None:   # the T saved x_t maps and UNet workspaces were released by the first backward
+            raise RuntimeError("GenComm's sampler chain was already differentiated once: its saved activations (T UNet workspaces) are "
+                               "freed after the first backward; run the forward again (retain_graph=True is not supported here)")
         need_feat, need_cond, need_flat = ctx.needs_input_grad[5], ctx.needs_input_grad[6], ctx.needs_input_grad[7]
         with torch.no_grad():
             g_x0 = grad_out.float().contiguous()

@@ -28,18 +28,6 @@ def _versions(*tensors):
     return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
 
 
-def _torch_expr(x, conv, bn, relu, pad):
-    """The same layer as differentiable torch ops (backward of ``_Conv2dHipFn`` only -- never the forward result)."""
-    import torch.nn.functional as F
-    if isinstance(conv, nn.ConvTranspose2d):
-        y = F.conv_transpose2d(x, conv.weight, conv.bias, stride=conv.stride)
-    else:
-        y = F.conv2d(x, conv.weight, conv.bias, stride=conv.stride, padding=conv.padding[0] if pad is None else pad)
-    if bn is not None:
-        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
-    return F.relu(y) if relu else y
-
-
 def _conv_backward(x, g, conv, pad, need_x):
     """(dx, {parameter: gradient}) of the bare convolution given d(conv output) on the HIP primitives: nn.Conv2d 1x1 / 3x3 with stride
     1 or 2 (stride 2: dy spread onto the stride-1 grid, then the stride-1 input-gradient kernel), nn.ConvTranspose2d with kernel ==

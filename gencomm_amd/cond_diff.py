@@ -122,16 +122,37 @@ class GenComm(nn.Module):
             o += k
         return rows
 
-    def _denoise(self, feat: torch.Tensor, cond: torch.Tensor, src_rows: Sequence[int],
-                 noise: Optional[Tuple[torch.Tensor, torch.Tensor]], seed: Optional[int]) -> torch.Tensor:
+    def _checked(self, feat, cond, src_rows, noise):
+        """Every shape / device / channel check of a GenComm call, BEFORE any raw pointer is taken -- shared by the HIP-only path
+        (`_denoise`) and the autograd path (`SamplerChainFunction` hands raw device pointers to gencomm_q_sample_fwd,
+        gencomm_unet_fwd_train, gencomm_step_noise_fwd and gencomm_lincomb_fwd: a wrong shape there is an out-of-bounds read, not
+        an exception). Returns the float32-contiguous (feat, cond, noise)."""
         require_gpu(feat, "GenComm.forward(spatial_features)")
         require_gpu(cond, "GenComm.forward(conditions)")
+        if feat.dim() != 4 or cond.dim() != 4:
+            raise ValueError(f"spatial_features and conditions must be 4-D [n, C, H, W], got {tuple(feat.shape)} and {tuple(cond.shape)}")
         feat, cond = f32c(feat), f32c(cond)
         n, C, H, W = cond.shape[0], feat.shape[1], feat.shape[2], feat.shape[3]
         if cond.shape[1] != 2 or tuple(cond.shape[2:]) != (H, W):
             raise ValueError(f"conditions must be [n, 2, {H}, {W}], got {tuple(cond.shape)}")
         if C != self.denoiser.feature_channels:
             raise ValueError(f"spatial_features has {C} channels, the denoiser was built for {self.denoiser.feature_channels}")
+        if len(src_rows) != n or (n and not (0 <= min(src_rows) and max(src_rows) < feat.shape[0])):
+            raise ValueError(f"{n} agents need {n} source rows inside spatial_features' {feat.shape[0]} rows")
+        if noise is not None:
+            T = self.num_timesteps
+            require_gpu(noise[0], "GenComm.forward(noise[0])")
+            require_gpu(noise[1], "GenComm.forward(noise[1])")
+            n0, sn = f32c(noise[0]), f32c(noise[1])
+            if tuple(n0.shape) != (n, C, H, W) or tuple(sn.shape) != (T, n, C, H, W):
+                raise ValueError(f"noise must be (noise0 [{n},{C},{H},{W}], step_noise [{T},{n},{C},{H},{W}]), got {tuple(n0.shape)} and {tuple(sn.shape)}")
+            noise = (n0, sn)
+        return feat, cond, noise
+
+    def _denoise(self, feat: torch.Tensor, cond: torch.Tensor, src_rows: Sequence[int],
+                 noise: Optional[Tuple[torch.Tensor, torch.Tensor]], seed: Optional[int]) -> torch.Tensor:
+        feat, cond, noise = self._checked(feat, cond, src_rows, noise)
+        n, C, H, W = cond.shape[0], feat.shape[1], feat.shape[2], feat.shape[3]
         T = self.num_timesteps
         dev = feat.device
         den = self.denoiser
@@ -140,11 +161,7 @@ class GenComm(nn.Module):
         sched = self._sched_table(dev)
         rows = dev_ints(src_rows, dev)
         out = torch.empty((n, C, H, W), dtype=torch.float32, device=dev)
-        n0 = sn = None
-        if noise is not None:
-            n0, sn = f32c(noise[0]), f32c(noise[1])
-            if tuple(n0.shape) != (n, C, H, W) or tuple(sn.shape) != (T, n, C, H, W):
-                raise ValueError("noise must be (noise0 [n,C,H,W], step_noise [T,n,C,H,W])")
+        n0, sn = noise if noise is not None else (None, None)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         _lib.check(_lib.lib().gencomm_denoise_fwd(
@@ -169,13 +186,12 @@ class GenComm(nn.Module):
         if not self._needs_grad(feat, cond):
             return self._denoise(feat, cond, src_rows, noise, seed)
         from .autograd import sampler_forward
-        require_gpu(feat, "GenComm.forward(spatial_features)")
-        require_gpu(cond, "GenComm.forward(conditions)")
+        feat, cond, noise = self._checked(feat, cond, src_rows, noise)
         if noise is None:   # the sampler's own in-kernel Philox field of `seed` (what inference adds for the same seed)
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            return sampler_forward(self, f32c(feat), f32c(cond), list(src_rows), None, None, seed)
-        return sampler_forward(self, f32c(feat), f32c(cond), list(src_rows), f32c(noise[0]), f32c(noise[1]))
+            return sampler_forward(self, feat, cond, list(src_rows), None, None, seed)
+        return sampler_forward(self, feat, cond, list(src_rows), noise[0], noise[1])
 
     def _debug_t1_t2(self, spatial_features: torch.Tensor, data_dict: dict) -> None:
         """'t1' / 't2': the eval branch's two unused q_samples of the first ego map

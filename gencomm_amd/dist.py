@@ -23,15 +23,19 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_process_group(backend: str, device: Optional[torch.device] = None):
+def init_process_group(backend: str, device: Optional[torch.device] = None, force: bool = False):
     """Initialise torch.distributed from the environment; returns the module (or None when
-    WORLD_SIZE == 1). 127.0.0.1 is the default rendezvous address (container hostnames may not resolve)."""
+    WORLD_SIZE == 1 and not ``force`` -- the training leg creates a one-rank group so that DDP and the RCCL
+    communicator run the same code at every N). 127.0.0.1 is the default rendezvous address (container hostnames
+    may not resolve)."""
     rank, world, _ = env_rank_world()
-    if world == 1:
+    if world == 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29500")
+    if "MASTER_PORT" not in os.environ:
+        from .launch import free_port
+        os.environ["MASTER_PORT"] = str(free_port()) if world == 1 else "29500"
     kw = {}
     if backend == "nccl" and device is not None:
         kw["device_id"] = device

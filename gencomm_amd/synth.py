@@ -226,3 +226,33 @@ def make_loss_inputs(seed: int, B: int, H: int, W: int, A: int, C: int, pos_frac
     return {"cls_preds": r.normal(-2, 1.5, (B, A, H, W)).astype(f), "reg_preds": reg, "dir_preds": r.normal(0, 1, (B, 2 * A, H, W)).astype(f),
             "pos_equal_one": pos, "neg_equal_one": neg, "targets": targets, "gt_feature": gt,
             "pred_feature": (gt + r.normal(0, 0.3, gt.shape)).astype(f)}
+
+
+def stage1_model_args(T: int = 3, lidar_range=(-102.4, -51.2, -3, 102.4, 51.2, 1), layer_nums=(3, 5, 8), C: int = 128) -> dict:
+    """The `model.args` block of opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml (:93-166) as a dict: one lidar modality
+    (PointPillars, 0.4 m pillars over `lidar_range` -> 512 x 256 grid by default), BaseBEVBackbone `layer_nums`, shrink to
+    C = 128 channels at 1/4 resolution (64 x 128), message extractor, GenComm (T steps), Enhancer, AttFusion, heads with two
+    anchors. Used by the training leg of bench.py and tools/shell_bench.py; tests use the reduced geometry of
+    tests/golden/shell_state_dict_keys.json."""
+    rng_ = [float(v) for v in lidar_range]
+    return {
+        "ego_modality": "m1", "lidar_range": rng_,
+        "m1": {"core_method": "point_pillar", "sensor_type": "lidar",
+               "encoder_args": {"voxel_size": [0.4, 0.4, 4], "lidar_range": rng_,
+                                "pillar_vfe": {"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+                                "point_pillar_scatter": {"num_features": 64}},
+               "backbone_args": {"layer_nums": list(layer_nums), "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+                                 "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128]},
+               "shrink_header": {"kernal_size": [3], "stride": [2], "padding": [1], "dim": [C], "input_dim": 384}},
+        "enhancer": {"in_ch": C}, "message_extractor": {"in_ch": C, "out_ch": 2},
+        "fusion_method": "att", "att": {"feat_dim": C}, "in_head": C, "anchor_number": 2,
+        "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}, "gmatch": True,
+        "gencomm": default_gencomm_cfg(C, T),
+    }
+
+
+STAGE1_LOSS_ARGS = {  # opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml:168-189
+    "pos_cls_weight": 2.0, "cls": {"type": "SigmoidFocalLoss", "alpha": 0.25, "gamma": 2.0, "weight": 2.0},
+    "reg": {"type": "WeightedSmoothL1Loss", "sigma": 3.0, "codewise": True, "weight": 2.0},
+    "dir": {"type": "WeightedSoftmaxClassificationLoss", "weight": 0.2, "args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}},
+    "depth": {"weight": 1.0}, "generate_weight": 1, "gmatch_weight": 1}

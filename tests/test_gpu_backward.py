@@ -432,3 +432,33 @@ def test_training_loop_reduces_the_generation_loss():
         losses.append(float(loss.detach()))
     print("generation loss over 20 Adam steps:", " ".join(f"{v:.4f}" for v in losses[::3]))
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
+
+
+def test_gradient_path_validates_shapes_before_taking_pointers_and_refuses_a_second_backward():
+    """with gradients enabled GenComm runs `SamplerChainFunction`, which hands raw device pointers to the library --
+    the same ValueErrors as the no-grad path must come first (a wrong cond / noise shape was an out-of-bounds read)."""
+    from gencomm_amd import GenComm, synth
+    C, H, W, T, rl = 16, 16, 24, 3, [2]
+    gen = GenComm(synth.default_gencomm_cfg(C, T)).train().to(DEV)
+    inp = {k: torch.from_numpy(v).to(DEV) for k, v in synth.make_inputs(rl, C, H, W, 5).items()}
+    n0, sn = (torch.from_numpy(a).to(DEV) for a in synth.make_train_noise(6, 2, C, H, W, T))
+    feat, cond = inp["feat"], inp["cond"].clone().requires_grad_(True)
+    with pytest.raises(ValueError, match="conditions must be"):
+        gen(feat, cond[:, :1], rl, noise=(n0, sn))
+    with pytest.raises(ValueError, match="conditions must be"):
+        gen(feat, cond[:, :, :-1], rl, noise=(n0, sn))
+    with pytest.raises(ValueError, match="channels"):
+        gen(feat[:, :8], cond, rl, noise=(n0, sn))
+    with pytest.raises(ValueError, match="noise must be"):
+        gen(feat, cond, rl, noise=(n0[:1], sn))
+    with pytest.raises(ValueError, match="noise must be"):
+        gen(feat, cond, rl, noise=(n0, sn[:-1]))
+    with pytest.raises(Exception, match="CPU|device|cuda|GPU"):
+        gen(feat, cond, rl, noise=(n0.cpu(), sn))
+    with pytest.raises(ValueError):
+        gen(feat, cond, [3], noise=(n0, sn))
+    pred = gen(feat, cond, rl, noise=(n0, sn))["pred_feature"]
+    loss = pred.square().mean()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already differentiated"):
+        loss.backward()

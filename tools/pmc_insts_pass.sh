@@ -4,11 +4,11 @@ set -o pipefail
 WL=${1:-metric}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rm -rf gpurun_out/r3_pmc_INSTS
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT --output-format csv -d gpurun_out/r3_pmc_INSTS -o pmc -- python3 bench.py --workload $WL --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-exact --no-timer > gpurun_out/r3_pmc_INSTS.log 2>&1 || { tail -n 20 gpurun_out/r3_pmc_INSTS.log; exit 1; }
+rm -rf gpurun_out/r4_pmc_INSTS
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT --output-format csv -d gpurun_out/r4_pmc_INSTS -o pmc -- python3 bench.py --workload $WL --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-exact --no-timer > gpurun_out/r4_pmc_INSTS.log 2>&1 || { tail -n 20 gpurun_out/r4_pmc_INSTS.log; exit 1; }
 python - <<'PY'
 import csv, collections, json, re
-rows = csv.DictReader(open('gpurun_out/r3_pmc_INSTS/pmc_counter_collection.csv'))
+rows = csv.DictReader(open('gpurun_out/r4_pmc_INSTS/pmc_counter_collection.csv'))
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for r in rows:
     k = re.sub(r'^void ', '', r['Kernel_Name'])
@@ -26,7 +26,7 @@ for k, d in acc.items():
               "per_wave": {c[len('SQ_INSTS_'):].lower(): round(v / w, 1) for c, v in m.items() if c != 'SQ_WAVES'}}
 res = {"_about": "dynamic instructions per wave (one SQ PMC pass, tools/pmc_insts_pass.sh): VALU includes MFMA, transcendental and conversion instructions",
        "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]['waves_per_launch'] * kv[1]['launches'] * kv[1]['per_wave'].get('valu', 0)))}
-json.dump(res, open('gpurun_out/r3_pmc_insts.json', 'w'), indent=1)
+json.dump(res, open('gpurun_out/r4_pmc_insts.json', 'w'), indent=1)
 for k, v in list(res['kernels'].items())[:10]:
     print(k[:60].ljust(60), v['launches'], v['waves_per_launch'], v['per_wave'])
 PY
