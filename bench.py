@@ -55,6 +55,7 @@ CONV8_FAMILIES = {1: "conv1 8->8 (GN+SiLU)", 16: "conv2 + identity residual", 17
                   4: "Upsample conv (nearest x2)"}
 LATENT_FAMILY = 15
 N_FAMILIES = 19
+RESULT_OUT = sys.stdout   # main() replaces it by a private copy of the original stdout
 
 
 def algorithmic_work(N, C, HW, T):
@@ -182,7 +183,7 @@ def selftest_main(args, rank, world):
                           "ms_per_step": 1e3 * elapsed / args.steps, "total_scenes": total, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "synthetic",
                           "config": {"workload": "launch_selftest: stand-in steps on the CPU (gloo); exercises launcher + aggregation only"},
-                          "ranks": per_rank}))
+                          "ranks": per_rank}), file=RESULT_OUT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -264,7 +265,7 @@ def train_main(args, rank, world, device, backend):
                        "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "share_device": backend != "nccl",
                        "grad_bytes_allreduced_per_step": grad_bytes, "trainable_parameters": sum(p.numel() for p in params),
                        "ddp_bucket_cap_mb": 25, "pillars_per_agent": 12000},
-            "loss": d, "roofline": None, "cpu_baseline": None}))
+            "loss": d, "roofline": None, "cpu_baseline": None}), file=RESULT_OUT, flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -301,6 +302,12 @@ def main():
     rank, world, local_rank = gdist.env_rank_world()
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    # stdout carries exactly ONE line, the result: native libraries (RCCL's version banner, gloo's connection notes) write to file
+    # descriptor 1 behind Python's back, so fd 1 is pointed at stderr for the rest of the run and the result goes to a saved copy
+    global RESULT_OUT
+    sys.stdout.flush()
+    RESULT_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.workload == "launch_selftest":
         return selftest_main(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
@@ -522,7 +529,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, N, C, H, W, T, gen, enh, ptm)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), file=RESULT_OUT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
