@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW, MODE_RESFUSE_EMU = range(8)
 
 _lock = threading.Lock()
@@ -79,6 +79,8 @@ _SIGNATURES = {
     "gencomm_win_attn_bwd_scratch_floats": (_ll, [_i, _i, _i, _i, _i]),
     "gencomm_win_attn_bwd": (_i, [_p] * 7 + [_i] * 6 + [_p]),
     "gencomm_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "gencomm_conv2d_wgrad_scratch_floats": (_ll, [_i] * 8),
+    "gencomm_conv2d_wgrad_ws": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_ln_nchw_fwd": (_i, [_p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
     "gencomm_ln_nchw_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
     "gencomm_dwconv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -619,16 +619,36 @@ int gencomm_conv2d_act_res_fwd(const float* x, const float* prepared, const floa
 }
 
 // ------------------------------------------------------------------------------------ training building blocks (NCHW fp32)
-int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
-                         int K, int stride, int pad, void* stream) {
+long long gencomm_conv2d_wgrad_scratch_floats(int N, int Cin, int Hi, int Wi, int Cout, int K, int stride, int pad) {
+  if (!(N >= 1 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && (K == 1 || K == 3) && (stride == 1 || stride == 2) && pad >= 0)) {
+    fail(GC_ERR_ARG, "gencomm_conv2d_wgrad_scratch_floats: bad dims");
+    return -1;
+  }
+  const int Ho = (Hi + 2 * pad - K) / stride + 1, Wo = (Wi + 2 * pad - K) / stride + 1;
+  if (K == 3 && Cin >= 32 && Cout >= 32 && Ho >= 1 && Wo >= 1) return (long long)wgrad3x3_wide_scratch_floats(N, Cin, Cout, Ho, Wo, stride);
+  return 0;
+}
+int gencomm_conv2d_wgrad_ws(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
+                            int K, int stride, int pad, float* scratch, long long scratch_floats, void* stream) {
   GC_CHECK_ARG(dy && x && dw, "null pointer");
   GC_CHECK_ARG(N >= 1 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && (K == 1 || K == 3) && (stride == 1 || stride == 2) && pad >= 0, "bad dims");
   const int Ho = (Hi + 2 * pad - K) / stride + 1, Wo = (Wi + 2 * pad - K) / stride + 1;
   GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
-  if (K == 1 && stride == 1 && pad == 0 && Cin >= 32 && Cout >= 32)   // Linear layers: split-K GEMM on the matrix cores
+  // Linear layers: split-K GEMM on the matrix cores -- also narrow ones over many pixels (PillarVFE's Linear 10 -> 64 over 1.5 M points: the
+  // 8 x 8-channel-chunk kernel below spent 8.2 ms there, 131 k workgroups each committing 640 atomics to the same 640 weights)
+  if (K == 1 && stride == 1 && pad == 0 && ((Cin >= 32 && Cout >= 32) || ((long long)N * Hi * Wi >= (1 << 16) && std::max(Cin, Cout) >= 32)))
     return wgrad1x1_enqueue(dy, x, dw, db, N, Cin, Cout, Hi * Wi, (hipStream_t)stream);
+  if (K == 3 && Cin >= 32 && Cout >= 32) {   // wide layers (BEV backbone): 64 x 64-channel implicit GEMM, nine tap accumulators per wave
+    const long long need = (long long)wgrad3x3_wide_scratch_floats(N, Cin, Cout, Ho, Wo, stride);
+    GC_CHECK_ARG(scratch == nullptr || scratch_floats >= need, "scratch smaller than gencomm_conv2d_wgrad_scratch_floats");
+    return wgrad3x3_wide_enqueue(dy, x, dw, db, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, pad, scratch, (hipStream_t)stream);
+  }
   WgradArgs a{dy, x, nullptr, dw, db, Cout, Cin, 0, Ho, Wo, Hi, Wi, K, stride, pad, 0};
   return conv_wgrad_enqueue(a, N, (hipStream_t)stream);
+}
+int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
+                         int K, int stride, int pad, void* stream) {
+  return gencomm_conv2d_wgrad_ws(dy, x, dw, db, N, Cin, Hi, Wi, Cout, K, stride, pad, nullptr, 0, stream);
 }
 
 // BatchNorm2d with batch statistics (training mode) around the HIP convolutions: scratch >= 2 C doubles (zeroed here)
@@ -662,7 +682,9 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
 int gencomm_slot_max_fwd(const float* x, float* out, unsigned char* arg, int C, int M, int P, void* stream) {
   GC_CHECK_ARG(x && out && arg && C >= 1 && M >= 0 && P >= 1 && P <= 255, "bad arguments");
   if (M == 0) return GC_OK;
-  const long long total = (long long)C * M;
+  const bool grouped = (P & 3) == 0 && P <= 64 && ((P / 4) & (P / 4 - 1)) == 0;   // P / 4 lanes per row (train_kernels.h)
+  const long long total = (long long)C * M * (grouped ? P / 4 : 1);
+  GC_CHECK_ARG((total + 255) / 256 < (1ll << 31), "too many pillars");
   slot_max_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, out, arg, C, M, P);
   GC_HIP(hipGetLastError());
   return GC_OK;

@@ -312,6 +312,199 @@ inline int wgrad1x1_enqueue(const float* dy, const float* x, float* dw, float* d
   return GC_OK;
 }
 
+// Weight gradient of a WIDE 3x3 convolution (backbone layers: 64..256 channels, stride 1 or 2) as a split-K implicit GEMM on the matrix
+// cores (exact fp32, v_mfma_f32_32x32x2_f32):
+//   dW[co][ci][ky][kx] += sum_{n,y,x} dY[n][co][y][x] X[n][ci][S y + ky - pad][S x + kx - pad],   dB[co] += sum dY.
+// A workgroup owns 64 output x 64 input channels (wave = one 32 x 32 block) and NINE accumulators per wave, one per tap (144 registers);
+// it walks `chunk` pixel tiles of one sample (TR rows x 32 columns of dY; the haloed X tile beside it in LDS, rows padded to an odd
+// word count so that the 32 channel rows of an operand read land in distinct banks), reads the dY operand once per pixel pair and the
+// X operand once per tap at the tap's shift, and commits its partial sums with f32 atomics.  grid = (tile chunks x samples, Cout / 64, Cin / 64).
+// The 8 x 8-channel-chunk kernels of unet_bwd_kernels.h (made for the UNet's 8-channel layers) re-staged every tile (Cout / 8)(Cin / 8)
+// times for these layers: 10.5 ms per stage-1 training step (profiles/r4_train_leg.txt) against 176 GFLOP of useful work.
+struct Wgrad3x3Args {
+  const float* dy;   // [n][Cout][Ho][Wo]
+  const float* x;    // [n][Cin][Hi][Wi]
+  float* dw;         // [Cout][Cin][3][3] (+=)
+  float* db;         // [Cout] (+=) or null
+  int Cout, Cin, Ho, Wo, Hi, Wi, pad, tiles_x, tiles, chunk, chunks;
+  // scratch of wgrad3x3_wide_scratch_floats(...) floats, or null.  With it every workgroup STORES its partial sums, coalesced, at
+  // part[group = blockIdx.x][co][tap][ci] (channel counts padded to 64) and wgrad3x3_wide_reduce_kernel adds the groups up in a fixed order:
+  // the f32 atomics of the null form (144 x 64 per wave onto Cout Cin 9 addresses shared by every group, resolved beyond the XCDs' L2s)
+  // cost 13x the matrix work on the 256-channel layers (790 us per layer against 61 us of MFMA time)
+  float* part;
+};
+inline size_t wgrad3x3_wide_groups(int N, int Cin, int Cout, int Ho, int Wo, int stride, int* chunk_out = nullptr) {
+  const int TR = stride == 1 ? 2 : 1;
+  const long long tiles = (long long)((Wo + 31) / 32) * ((Ho + TR - 1) / TR);
+  const long long cblocks = (long long)((Cout + 63) / 64) * ((Cin + 63) / 64);
+  // ~1 workgroup per CU over the whole launch (the kernel's residency), at least 4 tiles per workgroup
+  long long chunk = std::max<long long>(4, (tiles * N * cblocks + 255) / 256);
+  chunk = std::min(chunk, tiles);
+  if (chunk_out) *chunk_out = (int)chunk;
+  return (size_t)N * (size_t)((tiles + chunk - 1) / chunk);
+}
+inline size_t wgrad3x3_wide_scratch_floats(int N, int Cin, int Cout, int Ho, int Wo, int stride) {
+  const size_t cop = (size_t)((Cout + 63) / 64) * 64, cip = (size_t)((Cin + 63) / 64) * 64;
+  return wgrad3x3_wide_groups(N, Cin, Cout, Ho, Wo, stride) * cop * (9 * cip + 1);   // + one bias partial per (group, co)
+}
+template <int S, int TR>
+// One workgroup per CU by registers (144 accumulators + the prefetched tile + its addresses: ~250 VGPRs; capping them at two per CU spills
+// 560 B per thread): the nine independent accumulator chains and the prefetch keep a single wave per SIMD on the matrix pipe.
+__global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const Wgrad3x3Args a) {
+  constexpr int TC = 32, PX = TR * TC;                       // output pixels per tile
+  constexpr int XR = (TR - 1) * S + 3, XC = (TC - 1) * S + 3;  // haloed input tile
+  constexpr int LDA = PX + 1, LDB = (XR * XC) | 1;           // odd row strides (words)
+  __shared__ float sA[64 * LDA];   // dY tile [co][pixel]
+  __shared__ float sB[64 * LDB];   // X tile  [ci][row][col]
+  using f32x16t = __attribute__((ext_vector_type(16))) float;
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int n = blockIdx.x / a.chunks, ck = blockIdx.x - n * a.chunks;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int mh = wv & 1, nh = wv >> 1;
+  const float* __restrict__ dyn = a.dy + (size_t)n * a.Cout * a.Ho * a.Wo;
+  const float* __restrict__ xn = a.x + (size_t)n * a.Cin * a.Hi * a.Wi;
+  f32x16t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  const int t_end = min((ck + 1) * a.chunk, a.tiles);
+  // staging registers: the NEXT tile's global loads are issued right after this tile's LDS image is complete, so they fly during its
+  // matrix phase.  dY: thread -> (channel row tid / 4, PER consecutive pixels of one image row); X: element i = tid + 256 k of the
+  // [64][XR][XC] tile, columns fastest (a wave covers ~2 tile rows: coalesced)
+  constexpr int PER = PX / 4;
+  constexpr int NXE = 64 * XR * XC, XPT = (NXE + 255) / 256;
+  float va[PER], vx[XPT];
+  const int srow = tid >> 2, sq = (tid & 3) * PER;
+  auto load_tile = [&](int tile) {
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+    {
+      const int tr = sq / TC, col = sq - tr * TC;
+      const int co = co0 + srow, oy = oy0 + tr, ox = ox0 + col;
+      const bool row_ok = co < a.Cout && oy < a.Ho;
+      const float* __restrict__ pa = dyn + ((size_t)co * a.Ho + oy) * a.Wo + ox;
+      if (row_ok && ox + PER <= a.Wo && (a.Wo & 3) == 0) {
+#pragma unroll
+        for (int e = 0; e < PER; e += 4) {
+          const float4 u = *reinterpret_cast<const float4*>(pa + e);
+          va[e] = u.x; va[e + 1] = u.y; va[e + 2] = u.z; va[e + 3] = u.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) va[e] = (row_ok && ox + e < a.Wo) ? pa[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int i = tid + 256 * k;
+      const int c = i / (XR * XC), rem = i - c * (XR * XC), ry = rem / XC, e = rem - ry * XC;
+      const int ci = ci0 + c, iy = iy0 + ry, ix = ix0 + e;
+      vx[k] = (i < NXE && ci < a.Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) ? xn[((size_t)ci * a.Hi + iy) * a.Wi + ix] : 0.f;
+    }
+  };
+  int tile = ck * a.chunk;
+  if (tile < t_end) load_tile(tile);
+  for (; tile < t_end; ++tile) {
+    __syncthreads();   // the previous tile's matrix instructions are done
+#pragma unroll
+    for (int e = 0; e < PER; ++e) sA[srow * LDA + sq + e] = va[e];
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int i = tid + 256 * k;
+      const int c = i / (XR * XC), rem = i - c * (XR * XC);
+      if (i < NXE) sB[c * LDB + rem] = vx[k];
+    }
+    __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);
+    if (a.db != nullptr && blockIdx.z == 0 && tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < PX; ++k) s += sA[tid * LDA + k];
+      bsum += s;
+    }
+    const float* __restrict__ pA = sA + (mh * 32 + r) * LDA + h;
+    const float* __restrict__ pB = sB + (nh * 32 + r) * LDB + h * S;
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr) {
+#pragma unroll 4
+      for (int k2 = 0; k2 < TC / 2; ++k2) {
+        const float av = pA[tr * TC + 2 * k2];
+        const float* __restrict__ q = pB + (tr * S) * XC + 2 * k2 * S;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, q[(t / 3) * XC + (t % 3)], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // acc[t][reg]: row (co) = (reg & 3) + 8 (reg >> 2) + 4 h, column (ci) = r
+  const int ci = ci0 + nh * 32 + r;
+  if (a.part != nullptr) {
+    const size_t cop = (size_t)gridDim.y * 64, cip = (size_t)gridDim.z * 64;
+    float* __restrict__ pg = a.part + (size_t)blockIdx.x * cop * (9 * cip + 1);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = co0 + mh * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) pg[((size_t)co * 9 + t) * cip + ci] = acc[t][reg];   // 32 lanes = 128 contiguous bytes
+    }
+    if (blockIdx.z == 0 && tid < 64) pg[cop * 9 * cip + co0 + tid] = bsum;
+    return;
+  }
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = co0 + mh * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (co < a.Cout) {
+        float* __restrict__ d = a.dw + ((size_t)co * a.Cin + ci) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) atomicAdd(d + t, acc[t][reg]);
+      }
+    }
+  }
+  if (a.db != nullptr && blockIdx.z == 0 && tid < 64 && co0 + tid < a.Cout) atomicAdd(&a.db[co0 + tid], bsum);
+}
+// dw[co][ci][tap] += sum_g part[g][co][tap][ci], db[co] += sum_g part_b[g][co]: thread = one (co, tap, ci) of the padded table
+__global__ __launch_bounds__(256) void wgrad3x3_wide_reduce_kernel(const Wgrad3x3Args a, int groups, int cop, int cip) {
+  const size_t per = (size_t)cop * (9 * (size_t)cip + 1);
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per) return;
+  const float* __restrict__ p = a.part + i;
+  float s0 = 0.f, s1 = 0.f;
+  int g = 0;
+  for (; g + 1 < groups; g += 2) { s0 += p[(size_t)g * per]; s1 += p[(size_t)(g + 1) * per]; }
+  if (g < groups) s0 += p[(size_t)g * per];
+  const float v = s0 + s1;
+  if (i < (size_t)cop * 9 * cip) {
+    const int ci = (int)(i % cip), t = (int)((i / cip) % 9), co = (int)(i / ((size_t)9 * cip));
+    if (co < a.Cout && ci < a.Cin) a.dw[((size_t)co * a.Cin + ci) * 9 + t] += v;
+  } else if (a.db != nullptr) {
+    const int co = (int)(i - (size_t)cop * 9 * cip);
+    if (co < a.Cout) a.db[co] += v;
+  }
+}
+inline int wgrad3x3_wide_enqueue(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo,
+                                 int stride, int pad, float* scratch, hipStream_t st) {
+  Wgrad3x3Args a{dy, x, dw, db, Cout, Cin, Ho, Wo, Hi, Wi, pad, 0, 0, 0, 0, scratch};
+  const int TR = stride == 1 ? 2 : 1;
+  a.tiles_x = (Wo + 31) / 32;
+  a.tiles = a.tiles_x * ((Ho + TR - 1) / TR);
+  const size_t groups = wgrad3x3_wide_groups(N, Cin, Cout, Ho, Wo, stride, &a.chunk);
+  a.chunks = (int)(groups / N);
+  const dim3 grid((unsigned)groups, (Cout + 63) / 64, (Cin + 63) / 64);
+  if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "wgrad 3x3: too many channel blocks");
+  if (stride == 1) wgrad3x3_wide_kernel<1, 2><<<grid, 256, 0, st>>>(a);
+  else wgrad3x3_wide_kernel<2, 1><<<grid, 256, 0, st>>>(a);
+  if (scratch != nullptr) {
+    const int cop = (int)grid.y * 64, cip = (int)grid.z * 64;
+    const size_t per = (size_t)cop * (9 * (size_t)cip + 1);
+    wgrad3x3_wide_reduce_kernel<<<(unsigned)((per + 255) / 256), 256, 0, st>>>(a, (int)groups, cop, cip);
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 // out = g * d/dv GELU(v)   (erf form, nn.GELU default):  0.5 (1 + erf(v / sqrt 2)) + v exp(-v^2 / 2) / sqrt(2 pi)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ out, long long count) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -550,9 +743,40 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
 // ---- max over the point slots of a pillar (PFNLayer, pillar_vfe.py:49-52) for the training path of the PointPillars encoder -----
 // x [C][M][P] (channel-major rows of the 1x1-conv layout [1, C, 1, M P]) -> out [M][C] and the arg-max slot; backward routes the
 // gradient to that slot (ties: the first maximal slot, as torch.max).
+// A (c, m) row of P slots is read by P / 4 adjacent lanes as float4s (one 128-byte line per row for P = 32: the earlier form, one thread
+// per row, had every lane of a wave on its own line -- 1.67 ms for 64 x 48 000 x 32, 4 % of HBM), reduced with lane shuffles inside the group
+// (value, then the LOWEST slot among equal maxima = torch.max's first-occurrence rule).  P % 4 != 0 or P > 64 take the scalar form.
 __global__ __launch_bounds__(256) void slot_max_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, unsigned char* __restrict__ arg, int C, int M, int P) {
+  const long long rows = (long long)C * M;
+  if ((P & 3) == 0 && P <= 64 && ((P / 4) & (P / 4 - 1)) == 0) {
+    const int G = P / 4;                                    // lanes per row: a power of two <= 16
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = t / G;
+    const int q = (int)(t - row * G);
+    const bool live = row < rows;
+    float best = -INFINITY;
+    int bi = 0;
+    if (live) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * P + 4 * q);
+      best = v.x; bi = 4 * q;
+      if (v.y > best) { best = v.y; bi = 4 * q + 1; }
+      if (v.z > best) { best = v.z; bi = 4 * q + 2; }
+      if (v.w > best) { best = v.w; bi = 4 * q + 3; }
+    }
+    for (int o = 1; o < G; o <<= 1) {                       // butterfly inside the aligned group of G lanes
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (live && q == 0) {
+      const int c = (int)(row / M), m = (int)(row - (long long)c * M);
+      out[(size_t)m * C + c] = best;
+      arg[(size_t)m * C + c] = (unsigned char)bi;
+    }
+    return;
+  }
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)C * M) return;
+  if (i >= rows) return;
   const int c = (int)(i / M), m = (int)(i - (long long)c * M);
   const float* __restrict__ p = x + ((size_t)c * M + m) * P;
   float best = p[0];

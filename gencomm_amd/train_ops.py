@@ -54,10 +54,15 @@ def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, k: int, pad: int, bias: bool
     dy, x = _c(dy), _c(x)
     n, cout = dy.shape[:2]
     cin, H, W = x.shape[1:]
-    dw = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=x.device)
-    db = torch.zeros(cout, dtype=torch.float32, device=x.device) if bias else None
-    _lib.check(_lib.lib().gencomm_conv2d_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), n, cin, H, W, cout, k, int(stride), pad, stream_ptr(x.device)),
-               "gencomm_conv2d_wgrad")
+    l = _lib.lib()
+    # one zero-filled blob for both gradients (one fill launch instead of two)
+    blob = torch.zeros(cout * cin * k * k + (cout if bias else 0), dtype=torch.float32, device=x.device)
+    dw = blob[:cout * cin * k * k].view(cout, cin, k, k)
+    db = blob[cout * cin * k * k:] if bias else None
+    need = _lib.check_size(l.gencomm_conv2d_wgrad_scratch_floats(n, cin, H, W, cout, k, int(stride), pad), "gencomm_conv2d_wgrad_scratch_floats")
+    scratch = torch.empty(need, dtype=torch.float32, device=x.device) if need else None   # wide 3x3 layers: per-workgroup partial sums
+    _lib.check(l.gencomm_conv2d_wgrad_ws(ptr(dy), ptr(x), ptr(dw), ptr(db), n, cin, H, W, cout, k, int(stride), pad, ptr(scratch), need,
+                                         stream_ptr(x.device)), "gencomm_conv2d_wgrad_ws")
     return dw, db
 
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 6
+#define GENCOMM_ABI_VERSION 7
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -354,6 +354,12 @@ int gencomm_warp_attfuse_tok_fwd(const void* enhancer_workspace, const double* t
  * -------------------------------------------------------------------------------------------- */
 int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
                          int K, int stride, int pad, void* stream);
+/* The same with caller-owned scratch of gencomm_conv2d_wgrad_scratch_floats(...) floats (0 = the shape needs none). Wide 3x3 layers
+ * (Cin, Cout >= 32: the BEV backbone, opencood/models/sub_modules/base_bev_backbone.py:40-92) then store per-workgroup partial sums and
+ * add them in a fixed order -- deterministic, and 10x faster than the f32 atomics of the scratch-less form on 256-channel layers. */
+long long gencomm_conv2d_wgrad_scratch_floats(int N, int Cin, int Hi, int Wi, int Cout, int K, int stride, int pad);
+int gencomm_conv2d_wgrad_ws(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
+                            int K, int stride, int pad, float* scratch, long long scratch_floats, void* stream);
 int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream);
 int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* scratch,
                         float eps, int accumulate, int n, int C, int HW, void* stream);

@@ -31,6 +31,53 @@ def test_weight_gradient_on_the_matrix_cores_vs_float64(shape):
     assert ((db.double().cpu() - ref_b).abs() <= 1e-6 * dy.double().abs().sum((0, 2, 3))).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 22, 40, 1, 1), (1, 128, 64, 17, 70, 1, 1), (2, 40, 72, 12, 33, 1, 1),      # stride 1, "same" padding
+                                   (2, 64, 64, 32, 48, 2, 1), (1, 64, 128, 19, 37, 2, 1), (2, 128, 256, 16, 24, 2, 0)])   # stride 2 (ZeroPad2d(1) folded / pad 0)
+def test_wide_3x3_weight_gradient_vs_float64(shape):
+    """The backbone's 64..256-channel 3x3 layers: 64 x 64-channel implicit-GEMM weight gradient (wgrad3x3_wide_kernel), stride 1 and 2,
+    channel counts that are not multiples of 64, maps that are not multiples of the 32-column tile."""
+    from gencomm_amd import train_ops as T
+    N, Cin, Cout, H, W, st, pad = shape
+    g = torch.Generator().manual_seed(H * W + Cin + st)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    Ho, Wo = (H + 2 * pad - 3) // st + 1, (W + 2 * pad - 3) // st + 1
+    dy = torch.randn(N, Cout, Ho, Wo, generator=g) * torch.logspace(-2, 0, Cout).view(1, Cout, 1, 1)
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), stride=st, padding=pad)
+    ref_b = dy.double().sum((0, 2, 3))
+    dw, db = T.conv2d_wgrad(dy.to(DEV), x.to(DEV), 3, pad, True, st)
+    for o in range(Cout):
+        err = (dw[o].double().cpu() - ref_w[o]).abs().max().item()
+        assert err <= 3e-6 * ref_w[o].abs().max().item() + 1e-9, (shape, o, err)
+    assert ((db.double().cpu() - ref_b).abs() <= 1e-6 * dy.double().abs().sum((0, 2, 3))).all()
+
+
+def test_narrow_linear_weight_gradient_over_many_points_vs_float64():
+    """PillarVFE's Linear 10 -> 64 over (pillars x 32 points) as a 1x1 convolution: routed to the split-K GEMM kernel."""
+    from gencomm_amd import train_ops as T
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 10, 2300, 32, generator=g)
+    dy = torch.randn(1, 64, 2300, 32, generator=g)
+    ref = torch.einsum("nohw,nihw->oi", dy.double(), x.double())
+    dw, _ = T.conv2d_wgrad(dy.to(DEV), x.to(DEV), 1, 0, False)
+    err = (dw[:, :, 0, 0].double().cpu() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("C,M,P", [(64, 1500, 32), (5, 77, 32), (3, 40, 20), (4, 33, 7)])
+def test_slot_max_matches_torch_max_first_occurrence(C, M, P):
+    from gencomm_amd import _lib
+    from gencomm_amd.runtime import ptr, stream_ptr
+    g = torch.Generator().manual_seed(C + M)
+    x = torch.randint(-3, 4, (C, M, P), generator=g).float()          # many ties: the first maximal slot must win
+    xd = x.to(DEV)
+    out, arg = torch.empty(M, C, device=DEV), torch.empty(M, C, dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib().gencomm_slot_max_fwd(ptr(xd), ptr(out), ptr(arg), C, M, P, stream_ptr(xd.device)), "gencomm_slot_max_fwd")
+    ref = x.max(dim=2)
+    assert torch.equal(out.cpu(), ref.values.t().contiguous())
+    first = (x == ref.values.unsqueeze(2)).float().argmax(dim=2)
+    assert torch.equal(arg.cpu().long(), first.t().contiguous())
+
+
 def test_sampler_and_enhancer_glue_kernels_vs_torch():
     from gencomm_amd import train_ops as T
     from gencomm_amd.autograd import _lincomb
