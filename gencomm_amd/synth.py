@@ -256,3 +256,18 @@ STAGE1_LOSS_ARGS = {  # opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml:168-189
     "reg": {"type": "WeightedSmoothL1Loss", "sigma": 3.0, "codewise": True, "weight": 2.0},
     "dir": {"type": "WeightedSoftmaxClassificationLoss", "weight": 0.2, "args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}},
     "depth": {"weight": 1.0}, "generate_weight": 1, "gmatch_weight": 1}
+
+
+def trained_looking_heads_(model, weight_seed: int) -> None:
+    """Deterministic 'trained-looking' detection heads for the synthetic AP chain (tests/golden/apchain.npz): synthetic weights
+    everywhere, then the classification head's bias is lowered so that a few percent of the anchors pass the 0.2 score threshold and
+    the regression head is damped so that decoded boxes stay car-sized -- applied identically to the reference's shell by
+    oracle/make_golden.py and to this package's shell by tests/test_ap_chain.py."""
+    import torch
+    fill_params_(model, weight_seed)
+    fill_bn_stats_(model, weight_seed + 1)
+    with torch.no_grad():
+        model.cls_head.weight.mul_(4.0)
+        model.cls_head.bias.fill_(-2.2)
+        model.reg_head.weight.mul_(0.5)
+        model.reg_head.bias.zero_()

@@ -639,6 +639,114 @@ def run_loss_case() -> None:
     print("loss:", {k: float(v) for k, v in crit.loss_dict.items()})
 
 
+APCHAIN_PP = {  # the post-processor block of the stage-1 yamls at the reduced shell geometry (128 x 64 pillars, feature stride 4 -> 32 x 16 anchors x 2)
+    "core_method": "VoxelPostprocessor", "gt_range": [-25.6, -12.8, -3, 25.6, 12.8, 1],
+    "anchor_args": {"cav_lidar_range": [-25.6, -12.8, -3, 25.6, 12.8, 1], "l": 3.9, "w": 1.6, "h": 1.56, "r": [0, 90],
+                    "feature_stride": 4, "num": 2, "vw": 0.4, "vh": 0.4, "vd": 4, "W": 128, "H": 64, "D": 1},
+    "target_args": {"pos_threshold": 0.6, "neg_threshold": 0.45, "score_threshold": 0.2},
+    "order": "hwl", "max_num": 150, "nms_thresh": 0.15,
+    "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]},
+}
+APCHAIN_FRAMES = [[2], [3], [1], [2], [4], [2], [3], [2], [5], [2]]   # agents per frame (one scene per frame: inference.py runs batch size 1)
+
+
+def run_apchain_case() -> None:
+    """north_star's end-to-end criterion on synthetic frames: the reference's own stage-1 shell (CPU) -> the
+    reference's VoxelPostprocessor.post_process -> the reference's eval_utils AP@0.3/0.5/0.7, chained on 10 frames, plus a variant with
+    the reference's pose noise (pose_utils.generate_noise: std 0.2 m / 0.2 deg) on the agents' poses.  Ground truth = a jittered subset of
+    the reference's own detections (so that AP lands strictly inside (0, 1) and matches straddle the IoU thresholds).  Third-party
+    arithmetic absent here, as in the shell / postproc / eval cases: DeformConv2d and the shapely IoU run the oracle's restatements."""
+    import build_ref
+    import copy
+    import json
+    import detect_port as D
+    assert build_ref.build(), "oracle/_ref/box_overlaps could not be built"
+    import opencood.utils as ou
+    sys.modules["opencood.utils.box_overlaps"] = ou.box_overlaps = build_ref.load_box_overlaps()
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    from opencood.models.heter_model_baseline_w_gencomm_stage1 import HeterModelBaselineWGenComm
+    from opencood.utils import common_utils, eval_utils, pose_utils
+    from opencood.utils.transformation_utils import x_to_world
+    common_utils.convert_format = lambda boxes: np.asarray(boxes, dtype=np.float64)[:, :4, :2]
+    common_utils.compute_iou = lambda box, boxes: D.quad_iou_one_to_many(box, np.asarray(boxes).reshape(-1, 4, 2))
+    args = shell_args()
+    model = HeterModelBaselineWGenComm(copy.deepcopy(args)).eval()
+    synth.trained_looking_heads_(model, WEIGHT_SEED + 100)
+    pp = VoxelPostprocessor(json.loads(json.dumps(APCHAIN_PP)), train=False)
+    anchors = pp.generate_anchor_box()
+    nx, ny, L = 128, 64, 5
+    rec = dict(weight_seed=WEIGHT_SEED + 100, params=json.dumps(APCHAIN_PP), frames=json.dumps(APCHAIN_FRAMES), nx=nx, ny=ny, M=1500,
+               data_seed=DATA_SEED + 100, noise_seed=NOISE_SEED + 100, pos_std=0.2, rot_std=0.2)
+    r = np.random.RandomState(DATA_SEED + 101)
+
+    def corners_of(center, size, yaw, z0=-1.0, z1=0.6):
+        l, w = size
+        loc = np.array([[l / 2, w / 2], [l / 2, -w / 2], [-l / 2, -w / 2], [-l / 2, w / 2]])
+        R = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        xy = loc @ R.T + center
+        return np.concatenate([np.concatenate([xy, np.full((4, 1), z0)], 1), np.concatenate([xy, np.full((4, 1), z1)], 1)], 0).astype(np.float32)
+
+    gts = []
+    for variant in ("clean", "posenoise"):
+        stat = {t: {"tp": [], "fp": [], "gt": 0, "score": []} for t in (0.3, 0.5, 0.7)}
+        nboxes = []
+        for f, rl in enumerate(APCHAIN_FRAMES):
+            n = sum(rl)
+            pil = synth.make_pillars(1500 * n, n, nx, ny, DATA_SEED + 110 + f, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
+            # 6-dof lidar poses [x, y, z, roll, yaw, pitch] (degrees) of the frame's agents; the pairwise matrices come from the reference's
+            # own x_to_world exactly as get_pairwise_transformation builds them (transformation_utils.py:21-66)
+            rp = np.random.RandomState(DATA_SEED + 130 + f)
+            poses = np.zeros((n, 6))
+            poses[:, 0], poses[:, 1], poses[:, 4] = rp.uniform(-6, 6, n), rp.uniform(-3, 3, n), rp.uniform(-25, 25, n)
+            if variant == "posenoise":
+                np.random.seed(DATA_SEED + 150 + f)
+                for i in range(n):
+                    poses[i] = poses[i] + pose_utils.generate_noise(0.2, 0.2)      # pose_utils.py:41-74 (numpy global RNG, seeded above)
+            tl = [x_to_world(list(pz)) for pz in poses]
+            ptm = np.tile(np.eye(4), (1, L, L, 1, 1))
+            for i in range(n):
+                for j in range(n):
+                    if i != j:
+                        ptm[0, i, j] = np.linalg.solve(tl[j], tl[i])
+            rec[f"ptm_{variant}_{f}"] = ptm
+            data = {"agent_modality_list": ["m1"] * n, "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm),
+                    "inputs_m1": {k: torch.from_numpy(pil[k]) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}}
+            with torch.no_grad(), PatchedNoise(NOISE_SEED + 100 + f):
+                out = model(data)
+            boxes, scores = pp.post_process({"ego": {"transformation_matrix": torch.eye(4), "anchor_box": torch.from_numpy(anchors)}}, {"ego": out})
+            nb = 0 if boxes is None else int(boxes.shape[0])
+            nboxes.append(nb)
+            if variant == "clean":
+                # ground truth of the frame (shared by both variants): two thirds of the clean detections, jittered by 5 / 25 / 60 cm
+                g = []
+                if nb:
+                    b = boxes.numpy()
+                    for k in range(nb):
+                        if k % 3 == 2:
+                            continue
+                        xy = b[k, :4, :2]
+                        c = xy.mean(0)
+                        e0, e1 = xy[1] - xy[0], xy[2] - xy[1]
+                        size = (float(np.hypot(*e1)), float(np.hypot(*e0)))
+                        yaw = float(np.arctan2(e1[1], e1[0]))
+                        g.append(corners_of(c + r.normal(0, [0.05, 0.25, 0.6][k % 3 if k % 3 < 2 else 0] if k % 5 else 0.6, 2), size, yaw + r.normal(0, 0.03)))
+                for _ in range(2):   # objects nobody detects
+                    g.append(corners_of(r.uniform([-22, -10], [22, 10]), (4.2, 1.8), r.uniform(-np.pi, np.pi)))
+                gts.append(np.stack(g))
+                rec[f"gt_{f}"] = gts[f]
+            rec[f"boxes_{variant}_{f}"] = np.zeros((0, 8, 3), np.float32) if boxes is None else boxes.numpy()
+            rec[f"scores_{variant}_{f}"] = np.zeros((0,), np.float32) if boxes is None else scores.numpy()
+            for t in (0.3, 0.5, 0.7):
+                eval_utils.caluclate_tp_fp(boxes, scores, torch.from_numpy(gts[f]), stat, t)
+        for t in (0.3, 0.5, 0.7):
+            ap, _, _ = eval_utils.calculate_ap(copy.deepcopy(stat), t, True)
+            rec[f"ap_{variant}_{t}"] = ap
+        rec[f"nboxes_{variant}"] = np.array(nboxes)
+        print(f"apchain [{variant}]: boxes per frame {nboxes}, AP@0.3/0.5/0.7 = " + " / ".join(f"{rec[f'ap_{variant}_{t}']:.4f}" for t in (0.3, 0.5, 0.7)))
+    np.savez_compressed(os.path.join(OUT, "apchain.npz"), **rec)
+    print(f"apchain: wrote apchain.npz ({os.path.getsize(os.path.join(OUT, 'apchain.npz')) / 1024:.0f} KiB)")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -666,7 +774,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "apchain": run_apchain_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()
