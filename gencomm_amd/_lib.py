@@ -176,8 +176,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # without packed ops is exact in every run (tools/conv8_unit.py), and the hot kernels are not slower for it.
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
              "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+    # diagnostic builds (A/B variants under tools/): GENCOMM_HIP_LIB names the output, GENCOMM_EXTRA_FLAGS adds -D switches; such a
+    # library carries its switches in gencomm_build_info() and a different source stamp is not needed (the flags differ)
+    extra = os.environ.get("GENCOMM_EXTRA_FLAGS", "").split()
+    flags += extra
     define = '-DGENCOMM_BUILD_FLAGS="' + " ".join(flags) + " src=" + source_hash() + '"'
-    obj_dir = os.path.join(PKG_DIR, "_build")
+    obj_dir = os.path.join(PKG_DIR, "_build") if LIB_PATH == os.path.join(PKG_DIR, "libgencomm_hip.so") else LIB_PATH + ".obj"
     os.makedirs(obj_dir, exist_ok=True)
     # one object per translation unit, compiled concurrently (the hot path's unit takes ~2 min, the rocPRIM one ~1 min)
     procs, objs = [], []

@@ -335,8 +335,20 @@ __device__ __forceinline__ void wave_reduce16(const float (&part)[16], float (&t
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // v_bitop3_b32, truth table of a ^ b ^ c: one instruction instead of two v_xor
 }
+// Diagnostic builds only (-DGC_NOISE_DIAG=bits, tools/diag/noise_ab.sh: the VALU budget of the in-kernel noise by subtraction; the field
+// such a build produces is NOT the canonical one): 1 = Philox rounds replaced by one xor, 2 = Box-Muller without transcendentals,
+// 4 = no tail refinement, 8 = no generator at all (words = counter)
+#ifdef GC_NOISE_DIAG
+constexpr int kNoiseDiag = GC_NOISE_DIAG;
+#else
+constexpr int kNoiseDiag = 0;
+#endif
 __device__ __forceinline__ void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  if (kNoiseDiag & 1) {
+    out[0] = c0 ^ k0; out[1] = c1 + 0x9E3779B9u; out[2] = c2 ^ k1; out[3] = (c3 + c0) ^ 0xBB67AE85u;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     // one v_mad_u64_u32 per 32x32->64 product (integer multiplies are quarter-rate on CDNA:
@@ -366,7 +378,7 @@ __device__ __forceinline__ void noise_words(uint64_t ctr, uint32_t stream, uint6
     k[j] = q.w[j] & 0xffffu;
     q.ur[j] = fmaf((float)k[j], k16, 0.5f * k16);
   }
-  if (min(min(k[0], k[1]), min(k[2], k[3])) < kNoiseRefineBelow) {
+  if (!(kNoiseDiag & 4) && min(min(k[0], k[1]), min(k[2], k[3])) < kNoiseRefineBelow) {
     uint32_t f[4];
     philox4x32_7((uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 1u, (uint32_t)seed, (uint32_t)(seed >> 32), f);
 #pragma unroll
@@ -382,6 +394,13 @@ __device__ __forceinline__ void noise_words(uint64_t ctr, uint32_t stream, uint6
 __device__ __forceinline__ float bm_k2(float sg) { return -1.3862943611198906f * sg * sg; }
 __device__ __forceinline__ void bm_pair(float ur, uint32_t w, float k2, float& zc, float& zs) {
   const float ut = (float)(w >> 16) * 1.52587890625e-5f;
+  if (kNoiseDiag & 2) {   // same non-transcendental instructions, no v_log / v_sqrt / v_cos / v_sin
+    const float m = k2 * ur;
+    zc = m * ut;
+    zs = m * (ut - 0.5f);
+    asm("" : "+v"(zc), "+v"(zs));
+    return;
+  }
   const float m = __builtin_amdgcn_sqrtf(k2 * __builtin_amdgcn_logf(ur));
   zc = m * __builtin_amdgcn_cosf(ut);
   zs = m * __builtin_amdgcn_sinf(ut);

@@ -665,6 +665,9 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
   }
   __syncthreads();
   GC_STAMP(2);
+#ifdef HC_PRIO_MFMA   // diagnostic builds (tools/diag/prio_ab.sh): static wave priority from the matrix phase on
+  __builtin_amdgcn_s_setprio(HC_PRIO_MFMA);
+#endif
   if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2>(tile, a.wh, acc, off, lane, a.term_mask);
   // diagnostic instantiation, MODE_RESFUSE_EMU: the matrix work of a second convolution on the same tile (its result is added: the
   // numbers are meaningless, the instruction count is that of a fused conv1 + conv2 workgroup)
@@ -679,6 +682,9 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
   }
 
   GC_STAMP(4);
+#ifdef HC_PRIO_EPI    // diagnostic builds: static wave priority for the epilogue (the workgroup's last phase)
+  __builtin_amdgcn_s_setprio(HC_PRIO_EPI);
+#endif
   float part[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) part[i] = 0.f;

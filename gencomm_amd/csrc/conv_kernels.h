@@ -540,6 +540,7 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
   if (KH == 3 && KW == 3 && a.stride == 1) conv2d_igemm_kernel<3, 3, 8, 1><<<grid, 256, 0, st>>>(a);
   else if (KH == 3 && KW == 3 && a.stride == 2) conv2d_igemm_kernel<3, 3, 8, 2><<<grid, 256, 0, st>>>(a);
   else if (KH == 1 && KW == 1 && a.stride == 1) conv2d_igemm_kernel<1, 1, 32, 1><<<grid, 256, 0, st>>>(a);
+  else if (KH == 2 && KW == 2 && a.stride == 1) conv2d_igemm_kernel<2, 2, 8, 1><<<grid, 256, 0, st>>>(a);   // sub-pixel form of a transposed 3x3 stride-2 conv
   else return fail(GC_ERR_ARG, "conv2d: supported shapes are 3x3 stride 1/2 and 1x1 stride 1 (ConvTranspose2d with kernel == stride runs as 1x1)");
   GC_HIP(hipGetLastError());
   return GC_OK;

@@ -599,9 +599,14 @@ int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale
                        int ups, int out_ctotal, int out_coff, void* stream) {
   GC_CHECK_ARG(x && prepared && scale && shift && y, "null pointer");
   GC_CHECK_ARG(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && stride >= 1 && pad >= 0 && ups >= 1, "bad dims");
-  GC_CHECK_ARG(ups == 1 || (KH == 1 && KW == 1 && stride == 1 && pad == 0), "ups > 1 (ConvTranspose2d, kernel == stride) runs as a 1x1 GEMM");
+  // KH = KW = 2 with ups = 2: the sub-pixel form of a transposed 3x3 stride-2 pad-1 convolution (the input gradient of the backbone's
+  // stride-2 layers): output pixel (2u + a, 2v + b) of channel c is GEMM row c * 4 + a * 2 + b of a 2x2 window over input rows u, u + 1
+  // and columns v, v + 1 (zero beyond the last row / column) -- 16 instead of the 36 tap-products per output quad of a zero-stuffed input
+  const bool subpixel = KH == 2 && KW == 2 && ups == 2 && stride == 1 && pad == 0;
+  GC_CHECK_ARG(ups == 1 || subpixel || (KH == 1 && KW == 1 && stride == 1 && pad == 0),
+               "ups > 1 runs as a 1x1 GEMM (ConvTranspose2d, kernel == stride) or as the 2x2 sub-pixel form of a transposed 3x3 stride-2 convolution");
   GC_CHECK_ARG(out_coff >= 0 && out_coff + Cout <= out_ctotal, "output channel slice out of range");
-  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const int Ho = subpixel ? H : (H + 2 * pad - KH) / stride + 1, Wo = subpixel ? W : (W + 2 * pad - KW) / stride + 1;
   GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
   Conv2dArgs a{x, prepared, scale, shift, y, Cin, H, W, Cout * ups * ups, Ho, Wo, stride, pad, relu, ups, out_ctotal, out_coff};
   return conv2d_enqueue(a, N, KH, KW, (hipStream_t)stream);

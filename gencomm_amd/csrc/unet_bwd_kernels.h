@@ -175,6 +175,7 @@ struct WgradArgs {
   // optional scratch of conv_wgrad_scratch_floats(...) floats: the workgroups' partial sums are written there and summed by a second
   // kernel instead of one float atomic per (workgroup, weight) on the same few hundred addresses (31 of 80 us per 8 -> 8 layer)
   float* part = nullptr;
+  int tpc = 1;   // tiles per workgroup of conv_wgrad_mfma_kernel (set by conv_wgrad_enqueue)
 };
 
 template <int K, int STRIDE>
@@ -258,7 +259,18 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
   constexpr int TW = 32, TH = 16, PAD = K / 2, PW = TW + 2 * PAD, PHt = TH + 2 * PAD, KK = K * K;
   constexpr int NC = 8 * KK + 1, NT = (NC + 15) / 16;          // columns: (ic, tap) pairs + the ones column
   constexpr int DPS = TH * TW + 4;                             // dY plane stride: +4 words puts the 8 channels of a pixel on 8 x 4 distinct banks
-  constexpr int PWS = (PW + 3) & ~3, XPS = PHt * PWS + 4;      // X row / plane stride
+#ifdef WG_DIAG   // diagnostic builds (tools/diag/wgrad_ab.sh; results are wrong by construction): 1 = no matrix phase, 2 = no B-operand LDS reads,
+                 // 4 = LDS reads without matrix instructions, 8 = no SiLU in the staging, 16 = no LDS stores of the X tile, 32 = no global loads
+  constexpr int WGD = WG_DIAG;
+#else
+  constexpr int WGD = 0;
+#endif
+  // X tile rows start LEAD columns left of the output tile so that the aligned 128-bit quads of the image land on aligned 128-bit LDS
+  // stores (one ds_write_b128 per quad instead of four predicated scalar stores); plane stride = 4 mod 32 words: the (channel, tap row)
+  // bases of the 16 columns of an operand read then fall on distinct banks
+  constexpr int LEAD = PAD ? 4 : 0;
+  constexpr int XQ = (LEAD + TW + PAD + 3) / 4;                // aligned quads per haloed row: 10 for K = 3 (columns -4 .. 35), 8 for K = 1
+  constexpr int PWS = 4 * XQ, XPS = PHt * PWS + (K == 3 ? 20 : 4);   // X row / plane stride
   constexpr int RED = 4 * NT * 16 * 8;                         // reduction buffer of the four waves (aliases the tiles)
   constexpr int TILE_WORDS = 9 * DPS + 9 * XPS;
   __shared__ float smem[TILE_WORDS > RED ? TILE_WORDS : RED];
@@ -268,26 +280,44 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
   const int Cin = a.c0 + a.c1, icc = (Cin + 7) / 8;
   const int occ = blockIdx.y / icc, ich = blockIdx.y - occ * icc;
-  const int tiles_x = (a.Wo + TW - 1) / TW;
-  const int oy0 = (blockIdx.x / tiles_x) * TH, ox0 = (blockIdx.x % tiles_x) * TW;
+  const int tiles_x = (a.Wo + TW - 1) / TW, tiles = tiles_x * ((a.Ho + TH - 1) / TH);
   const int Hs = a.up ? a.Hi / 2 : a.Hi, Ws = a.up ? a.Wi / 2 : a.Wi;
   const bool gn = a.gn_stat[0] != nullptr;   // 8-channel sources: chunk ich is source ich
-  // every global load of the workgroup is issued before the first barrier (one memory round trip instead of three): the dY tile,
-  // the X tile and -- eight threads -- the GroupNorm coefficients.  Fast path (image width a multiple of 4, no nearest-x2 source):
-  // 128-bit loads -- 4 per thread for dY, <= 6 for X (aligned quads covering columns ox0 - 4 .. ox0 + 35 of the 34-column haloed row) --
-  // instead of 18 + 22 scalar ones (the kernel was staging-bound: 35 of its 48 us without the atomics)
+  // Round 4: a workgroup walks a.tpc consecutive tiles of its sample with the accumulators kept in registers (one cross-wave reduction
+  // and one partial-sum record per workgroup instead of per tile) and -- fast path -- the NEXT tile's global loads in flight during
+  // this tile's matrix phase: a tile cost one full load -> stage -> MFMA -> reduce chain (~14 us, three workgroup rounds per launch).
+  // Fast path (image width a multiple of 4, no nearest-x2 source): 128-bit loads -- 4 per thread for dY, <= 6 for X (aligned quads
+  // covering columns ox0 - 4 .. ox0 + 35 of the 34-column haloed row) -- instead of 18 + 22 scalar ones.
   const bool vec = !a.up && (a.Wo & 3) == 0 && (a.Wi & 3) == 0;
+  const int tpc = a.tpc > 0 ? a.tpc : 1;
+  const int t_begin = blockIdx.x * tpc, t_end = min(t_begin + tpc, tiles);
   if (gn && tid < 8) {
     const int ic = ich * 8 + tid;
     float A = 0.f, B = 0.f;
     if (ic < Cin) gn_coeff(a.gn_stat[ic < a.c0 ? 0 : 1] + (size_t)n * 16, tid, a.gn_gs, a.gn_inv_cnt, a.gn_gamma[ic], a.gn_beta[ic], &A, &B);
     s_gn[tid][0] = A; s_gn[tid][1] = B;
   }
-  if (vec) {
-    constexpr int QD = 8 * TH * (TW / 4) / 256;                 // dY quads per thread: 4
-    constexpr int XQ = (PW + (4 - PAD) + 3) / 4;                // aligned quads per haloed row: 10 for K = 3 (columns -4 .. 35), 9 for K = 1 (the first unused)
-    constexpr int QX = (8 * PHt * XQ + 255) / 256;              // X quads per thread: 6
-    float4 qd[QD], qx[QX];
+  for (int i = tid; i < DPS; i += 256) sdy[8 * DPS + i] = 0.f;                 // the zero plane (rows 8..15 of the A operand)
+  for (int i = tid; i < PHt * PWS; i += 256) sx[8 * XPS + i] = 1.0f;             // the plane of ones (bias column)
+
+  const int j = lane & 15, kq = lane >> 4;
+  const int aoff = (j < 8 ? j : 8) * DPS + kq;
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = 16 * t + j;
+    const int ic = c < 8 * KK ? c / KK : 8, tap = c < 8 * KK ? c - ic * KK : 0;
+    boff[t] = ic * XPS + (tap / K) * PWS + (tap % K) + kq + (LEAD - PAD);
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int QD = 8 * TH * (TW / 4) / 256;                 // dY quads per thread: 4
+  constexpr int QX = (8 * PHt * XQ + 255) / 256;              // X quads per thread: 6 (K = 3) / 4 (K = 1)
+  float4 qd[QD], qx[QX];
+  auto load_vec = [&](int tile) {
+    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
 #pragma unroll
     for (int k = 0; k < QD; ++k) {
       const int i = tid + 256 * k;
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
     for (int k = 0; k < QX; ++k) {
       const int i = tid + 256 * k;
       const int c = i / (PHt * XQ), r = i - c * (PHt * XQ), py = r / XQ, q4 = r - py * XQ;
-      const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - 4 + 4 * q4;
+      const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - LEAD + 4 * q4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < 8 && ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
         const float* __restrict__ sp = ic < a.c0 ? a.x0 + ((size_t)n * a.c0 + ic) * Hs * Ws : a.x1 + ((size_t)n * a.c1 + (ic - a.c0)) * Hs * Ws;
@@ -308,96 +338,81 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
       }
       qx[k] = v;
     }
-    for (int i = tid; i < DPS; i += 256) sdy[8 * DPS + i] = 0.f;                 // the zero plane (rows 8..15 of the A operand)
-    for (int i = tid; i < PHt * PWS; i += 256) sx[8 * XPS + i] = 1.0f;             // the plane of ones (bias column)
+  };
+  if (WGD & 32) {
 #pragma unroll
-    for (int k = 0; k < QD; ++k) {
-      const int i = tid + 256 * k;
-      const int o = i / (TH * (TW / 4)), r = i - o * (TH * (TW / 4));
-      *reinterpret_cast<float4*>(sdy + o * DPS + 4 * r) = qd[k];
-    }
-    __syncthreads();   // s_gn
+    for (int k = 0; k < QD; ++k) qd[k] = make_float4(1.f, 2.f, 3.f, 4.f);
 #pragma unroll
-    for (int k = 0; k < QX; ++k) {
-      const int i = tid + 256 * k;
-      const int c = i / (PHt * XQ), r = i - c * (PHt * XQ), py = r / XQ, q4 = r - py * XQ;
-      if (c < 8) {
-        const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - 4 + 4 * q4;
-        const bool inside = ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;   // a quad is inside or outside as a whole (W % 4 == 0)
-        const float e[4] = {qx[k].x, qx[k].y, qx[k].z, qx[k].w};
+    for (int k = 0; k < QX; ++k) qx[k] = make_float4(1.f, 2.f, 3.f, 4.f);
+  }
+  if (vec && t_begin < t_end && !(WGD & 32)) load_vec(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+    __syncthreads();   // s_gn / the constant planes (first tile); the previous tile's matrix instructions are done
+    if (vec) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int px = 4 * q4 + u - (4 - PAD);      // column inside the haloed tile row
-          if (px >= 0 && px < PW) {
-            float v = e[u];
-            if (gn && inside) v = silu_f(fmaf(s_gn[c][0], v, s_gn[c][1]));   // zero padding stays zero
-            sx[c * XPS + py * PWS + px] = v;
+      for (int k = 0; k < QD; ++k) {
+        const int i = tid + 256 * k;
+        const int o = i / (TH * (TW / 4)), r = i - o * (TH * (TW / 4));
+        *reinterpret_cast<float4*>(sdy + o * DPS + 4 * r) = qd[k];
+      }
+#pragma unroll
+      for (int k = 0; k < QX; ++k) {
+        const int i = tid + 256 * k;
+        const int c = i / (PHt * XQ), r = i - c * (PHt * XQ), py = r / XQ, q4 = r - py * XQ;
+        if (c < 8) {
+          const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - LEAD + 4 * q4;
+          const bool inside = ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;   // a quad is inside or outside as a whole (W % 4 == 0)
+          float4 v = qx[k];
+          if (gn && inside && !(WGD & 8)) {   // zero padding stays zero
+            v.x = silu_f(fmaf(s_gn[c][0], v.x, s_gn[c][1])); v.y = silu_f(fmaf(s_gn[c][0], v.y, s_gn[c][1]));
+            v.z = silu_f(fmaf(s_gn[c][0], v.z, s_gn[c][1])); v.w = silu_f(fmaf(s_gn[c][0], v.w, s_gn[c][1]));
           }
+          if (!(WGD & 16) || v.x == 12345.f) *reinterpret_cast<float4*>(sx + c * XPS + py * PWS + 4 * q4) = v;
+        }
+      }
+      __syncthreads();
+      if (tile + 1 < t_end && !(WGD & 32)) load_vec(tile + 1);   // in flight during this tile's matrix phase
+    } else {
+      constexpr int ND = 8 * TH * TW / 256, NX = (8 * PHt * PW + 255) / 256;
+#pragma unroll 1
+      for (int k = 0; k < ND; ++k) {
+        const int i = tid + 256 * k;
+        const int o = i / (TH * TW), r = i - o * (TH * TW), py = r / TW, px = r - py * TW;
+        const int oc = occ * 8 + o, oy = oy0 + py, ox = ox0 + px;
+        sdy[o * DPS + r] = (oc < a.Cout && oy < a.Ho && ox < a.Wo) ? a.dy[(((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox] : 0.f;
+      }
+#pragma unroll 1
+      for (int k = 0; k < NX; ++k) {
+        const int i = tid + 256 * k;
+        if (i < 8 * PHt * PW) {
+          const int c = i / (PHt * PW), r = i - c * (PHt * PW), py = r / PW, px = r - py * PW;
+          const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - PAD + px;
+          float v = 0.f;
+          if (ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+            const float* __restrict__ sp = ic < a.c0 ? a.x0 + ((size_t)n * a.c0 + ic) * Hs * Ws : a.x1 + ((size_t)n * a.c1 + (ic - a.c0)) * Hs * Ws;
+            v = a.up ? sp[(size_t)(iy >> 1) * Ws + (ix >> 1)] : sp[(size_t)iy * Ws + ix];
+            if (gn) v = silu_f(fmaf(s_gn[c][0], v, s_gn[c][1]));   // zero padding stays zero
+          }
+          sx[c * XPS + py * PWS + px + (LEAD - PAD)] = v;
+        }
+      }
+      __syncthreads();
+    }
+    if (!(WGD & 1)) {
+#pragma unroll 1
+    for (int y = 4 * wave; y < 4 * wave + 4; ++y) {
+#pragma unroll 4
+      for (int s4 = 0; s4 < TW / 4; ++s4) {
+        const float av = sdy[aoff + y * TW + 4 * s4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float bv = (WGD & 2) ? av : sx[boff[t] + y * PWS + 4 * s4];
+          if (WGD & 4) acc[t][0] += av * bv;
+          else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
         }
       }
     }
-    __syncthreads();
-  } else {
-  constexpr int ND = 9 * TH * TW / 256, NX = (9 * PHt * PW + 255) / 256;
-  float vd[ND], vx[NX];
-#pragma unroll
-  for (int k = 0; k < ND; ++k) {
-    const int i = tid + 256 * k;
-    const int o = i / (TH * TW), r = i - o * (TH * TW), py = r / TW, px = r - py * TW;
-    const int oc = occ * 8 + o, oy = oy0 + py, ox = ox0 + px;
-    vd[k] = (o < 8 && oc < a.Cout && oy < a.Ho && ox < a.Wo) ? a.dy[(((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox] : 0.f;
-  }
-#pragma unroll
-  for (int k = 0; k < NX; ++k) {
-    const int i = tid + 256 * k;
-    const int c = i / (PHt * PW), r = i - c * (PHt * PW), py = r / PW, px = r - py * PW;
-    const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - PAD + px;
-    float v = 0.f;
-    if (c < 8 && ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
-      const float* __restrict__ sp = ic < a.c0 ? a.x0 + ((size_t)n * a.c0 + ic) * Hs * Ws : a.x1 + ((size_t)n * a.c1 + (ic - a.c0)) * Hs * Ws;
-      v = a.up ? sp[(size_t)(iy >> 1) * Ws + (ix >> 1)] : sp[(size_t)iy * Ws + ix];
-    }
-    vx[k] = v;
-  }
-#pragma unroll
-  for (int k = 0; k < ND; ++k) {
-    const int i = tid + 256 * k;
-    const int o = i / (TH * TW), r = i - o * (TH * TW);
-    sdy[o * DPS + r] = vd[k];
-  }
-  __syncthreads();   // s_gn
-#pragma unroll
-  for (int k = 0; k < NX; ++k) {
-    const int i = tid + 256 * k;
-    if (i < 9 * PHt * PW) {
-      const int c = i / (PHt * PW), r = i - c * (PHt * PW), py = r / PW, px = r - py * PW;
-      const int ic = ich * 8 + c, iy = oy0 - PAD + py, ix = ox0 - PAD + px;
-      float v = vx[k];
-      if (c == 8) v = 1.0f;
-      else if (gn && ic < Cin && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = silu_f(fmaf(s_gn[c][0], v, s_gn[c][1]));   // zero padding stays zero
-      sx[c * XPS + py * PWS + px] = v;
-    }
-  }
-  __syncthreads();
-  }
-  const int j = lane & 15, kq = lane >> 4;
-  const int aoff = (j < 8 ? j : 8) * DPS + kq;
-  int boff[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int c = 16 * t + j;
-    const int ic = c < 8 * KK ? c / KK : 8, tap = c < 8 * KK ? c - ic * KK : 0;
-    boff[t] = ic * XPS + (tap / K) * PWS + (tap % K) + kq;
-  }
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int y = 4 * wave; y < 4 * wave + 4; ++y) {
-#pragma unroll
-    for (int s4 = 0; s4 < TW / 4; ++s4) {
-      const float av = sdy[aoff + y * TW + 4 * s4];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sx[boff[t] + y * PWS + 4 * s4], acc[t], 0, 0, 0);
     }
   }
   __syncthreads();   // the tiles are dead: the reduction buffer aliases them
@@ -460,10 +475,15 @@ inline size_t conv_wgrad_scratch_floats(int Cout, int Cin, int K, int H, int W, 
 inline int conv_wgrad_enqueue(const WgradArgs& a, int n, hipStream_t st) {
   const int Cin = a.c0 + a.c1;
   if (a.stride == 1 && (a.K == 3 || a.K == 1) && a.pad == a.K / 2 && a.Ho == a.Hi && a.Wo == a.Wi) {   // fp32 matrix cores
-    const dim3 grid(((a.Ho + 15) / 16) * ((a.Wo + 31) / 32), ((a.Cout + 7) / 8) * ((Cin + 7) / 8), n);
+    const int tiles = ((a.Ho + 15) / 16) * ((a.Wo + 31) / 32);
+    const long long pairs = (long long)((a.Cout + 7) / 8) * ((Cin + 7) / 8);
+    // tiles per workgroup: the fewest that make the whole launch resident at once (3 workgroups per CU = 768), at most 8
+    WgradArgs b = a;
+    b.tpc = (int)std::min<long long>(8, std::max<long long>(1, ((long long)tiles * pairs * n + 767) / 768));
+    const dim3 grid((tiles + b.tpc - 1) / b.tpc, (unsigned)pairs, n);
     if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv_wgrad: too many channel chunks / samples");
-    if (a.K == 3) conv_wgrad_mfma_kernel<3><<<grid, 256, 0, st>>>(a);
-    else conv_wgrad_mfma_kernel<1><<<grid, 256, 0, st>>>(a);
+    if (a.K == 3) conv_wgrad_mfma_kernel<3><<<grid, 256, 0, st>>>(b);
+    else conv_wgrad_mfma_kernel<1><<<grid, 256, 0, st>>>(b);
     if (a.part != nullptr) {
       const int nwg = (int)(grid.x * grid.z), slices = std::min(nwg, 16), per = (nwg + slices - 1) / slices;
       const int NW = ((8 * a.K * a.K + 1 + 15) / 16) * 128;

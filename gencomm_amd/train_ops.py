@@ -73,9 +73,42 @@ def conv2d_dgrad_strided(dy: torch.Tensor, w: torch.Tensor, pad: int, stride: in
         return conv2d_dgrad(dy, w, pad)
     k = w.shape[2]
     H, W = in_hw
+    if stride == 2 and k == 3 and pad == 1 and H % 2 == 0 and W % 2 == 0 and dy.shape[2] == H // 2 and dy.shape[3] == W // 2:
+        return _conv3x3_s2_dgrad_subpixel(dy, w)
     up = torch.zeros(dy.shape[0], dy.shape[1], H + 2 * pad - k + 1, W + 2 * pad - k + 1, dtype=torch.float32, device=dy.device)
     up[:, :, ::stride, ::stride] = dy
     return conv2d_dgrad(up, w, pad)
+
+
+def _conv3x3_s2_dgrad_subpixel(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """dx of a 3x3 stride-2 pad-1 convolution over an even-sized input as ONE 2x2 sub-pixel convolution over dy
+    (gencomm_conv2d_fwd, KH = KW = 2, ups = 2): dx[ci][2u + a][2v + b] = sum_{co, ty, tx} W[co][ci][a + 1 - 2 ty][b + 1 - 2 tx] dy[co][u + ty][v + tx]
+    (taps outside 0..2 are zero).  16 tap-products per output quad instead of the 36 of the zero-stuffed form below."""
+    dy, w = _c(dy), _c(w)
+    n, cout, Ho, Wo = dy.shape
+    cin = w.shape[1]
+    dev = dy.device
+    wp = torch.zeros(cin, 2, 2, cout, 2, 2, dtype=torch.float32, device=dev)      # rows (ci, a, b), reduction (co, ty, tx)
+    wt = w.permute(1, 0, 2, 3)                                                       # [ci, co, ky, kx]
+    for a in (0, 1):
+        for ty in (0, 1):
+            ky = a + 1 - 2 * ty
+            if not 0 <= ky <= 2:
+                continue
+            for b in (0, 1):
+                for tx in (0, 1):
+                    kx = b + 1 - 2 * tx
+                    if 0 <= kx <= 2:
+                        wp[:, a, b, :, ty, tx] = wt[:, :, ky, kx]
+    l, st = _lib.lib(), stream_ptr(dev)
+    prepared = torch.empty(wp.numel(), dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_conv2d_prepare(ptr(wp), ptr(prepared), cout, cin * 4, 2, 2, 0, st), "gencomm_conv2d_prepare")
+    ss = torch.empty(2, cin, dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_conv2d_fold(None, None, None, None, None, 0.0, cin, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
+    dx = torch.empty(n, cin, 2 * Ho, 2 * Wo, dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_conv2d_fwd(ptr(dy), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(dx), n, cout, Ho, Wo, cin, 2, 2, 1, 0, 0, 2, cin, 0, st),
+               "gencomm_conv2d_fwd")
+    return dx
 
 
 def bn2d_train_fwd(x: torch.Tensor, bn, relu: bool):

@@ -272,6 +272,9 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  *          (and/or conv_bias) when absent.
  * fwd:     y[:, out_coff:out_coff+Cout] = act(conv(x) * scale + shift); supported: 3x3 stride 1|2 any pad, 1x1 stride 1;
  *          ups = s > 1 runs ConvTranspose2d(kernel = stride = s) (KH = KW = 1 on the prepared matrix, output H*s x W*s).
+ *          KH = KW = 2 with ups = 2 (stride 1, pad 0; output 2H x 2W): the sub-pixel form of a TRANSPOSED 3x3 stride-2 pad-1 convolution,
+ *          i.e. the input gradient of base_bev_backbone.py:57-63's stride-2 layers: GEMM row c*4 + a*2 + b = output channel c at
+ *          pixel (2u + a, 2v + b), window = input rows u, u + 1 x columns v, v + 1 (zero beyond the map).
  *          y has out_ctotal channels (write into a slice of a concat buffer without a copy).
  *          Arithmetic follows GENCOMM_MODE_ARITH: 0 (default) and 1 = exact fp32 MFMA for every shape; 3 (opt-in) = 3x3 with
  *          Cin % 8 == 0 and 1x1 / ConvTranspose2d with >= 128 GEMM rows on the f16 matrix pipe from exact fp16 hi/lo operand splits

@@ -175,3 +175,21 @@ def test_modules_on_two_concurrent_streams_match_sequential_runs():
         d_conc, d_seq = float((outs[i] - ref[i]).abs().max()), float((again[i] - ref[i]).abs().max())
         print(f"scene {i}: max |concurrent - sequential| {d_conc:.2e}, max |sequential - sequential| {d_seq:.2e}, max |ref| {float(ref[i].abs().max()):.2f}")
         assert d_conc <= 2e-5 * float(ref[i].abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 48), (1, 40, 72, 12, 20), (2, 128, 32, 16, 36)])
+def test_stride2_input_gradient_subpixel_form_vs_float64(shape):
+    """dx of a 3x3 stride-2 pad-1 convolution through the 2x2 sub-pixel convolution over dy (one launch, 16 tap-products per output
+    quad) against float64 autograd; even input sizes take this path, odd ones the zero-stuffed one."""
+    from gencomm_amd import train_ops as T
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(H + W + Cin)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    for (h, wd) in ((H, W), (H - 1, W - 1)):
+        x = torch.randn(N, Cin, h, wd, generator=g, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x, w.double(), None, stride=2, padding=1)
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        y.backward(dy)
+        dx = T.conv2d_dgrad_strided(dy.float().to(DEV), w.to(DEV), 1, 2, (h, wd))
+        err = (dx.double().cpu() - x.grad).abs().max().item()
+        assert dx.shape == x.grad.shape and err <= 3e-6 * x.grad.abs().max().item(), (shape, h, wd, err)
