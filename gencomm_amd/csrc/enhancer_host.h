@@ -49,7 +49,7 @@ struct EnhancerPlan {
 };
 
 struct EnhancerWs {
-  size_t Y, Z, Zc, Hd, G, O, colsum, gate, wT, tab1, tab2, total;
+  size_t Y, Z, Zc, Hd, G, O, colsum, gate, wT, tab1, tab2, wsc, total;
 };
 
 inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
@@ -72,6 +72,7 @@ inline EnhancerWs enhancer_ws(const EnhancerPlan& p, int n, int H, int W) {
   w.O = w.Hd;
   w.tab1 = take((size_t)(p.hid / 16) * (p.C / 16) * 896);  // fused front kernel: Linear1 / Linear2 operand tables
   w.tab2 = take((size_t)(p.hid / 16) * (p.C / 32 > 0 ? p.C / 32 : 1) * 896);
+  w.wsc = take(64);   // per-tensor weight scales of the two tables
   w.total = off;
   return w;
 }
@@ -119,10 +120,11 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
   const int fuse = enh_fuse_level(m, C);
   if (fuse != 0) {
     // K3 + K4 (+ K5) fused: the hidden tensors never reach HBM
-    enh_prep_front_kernel<<<32, 256, 0, st>>>(raw + p.l1w, F(w.tab1), C, p.hid);
-    if (fuse >= 2) enh_prep_back_kernel<<<16, 256, 0, st>>>(raw + p.l2w, F(w.tab2), C, p.hid);
+    enh_wscale_kernel<<<2, 256, 0, st>>>(raw + p.l1w, (long long)2 * p.hid * C, raw + p.l2w, (long long)C * p.hid, F(w.wsc));
+    enh_prep_front_kernel<<<32, 256, 0, st>>>(raw + p.l1w, F(w.tab1), C, p.hid, F(w.wsc));
+    if (fuse >= 2) enh_prep_back_kernel<<<16, 256, 0, st>>>(raw + p.l2w, F(w.tab2), C, p.hid, F(w.wsc));
     EnhFrontArgs a{F(w.Z), F(w.tab1), raw + p.l1b, raw + p.dww, raw + p.dwb, F(w.G), C, p.hid, H, W,
-                   F(w.tab2), raw + p.l2b, F(w.Y), F(w.O), F(w.colsum)};
+                   F(w.tab2), raw + p.l2b, F(w.Y), F(w.O), F(w.colsum), F(w.wsc)};
     TimedLaunch tl(KF_ENH_GEMM1, st);
     if (fuse >= 2) enh_front_h_kernel<true><<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);
     else enh_front_h_kernel<false><<<dim3((W + 7) / 8, (H + 7) / 8, n), 256, 0, st>>>(a);

@@ -634,9 +634,42 @@ struct EnhFrontArgs {
   const float* res;   // [n][H][W][C]  x + LayerNorm1(x) (enhancer.py:355)
   float* O;           // [n][H][W][C]  must not alias Z (neighbouring workgroups still read their halos)
   float* colsum;      // [n][C]
+  const float* wsc;   // {scale of W1, 1 / it, scale of W2, 1 / it} (enh_wscale_kernel)
 };
 
-__global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __restrict__ w1 /*[2*hid][C]*/, float* __restrict__ tab, int C, int hid) {
+// Per-tensor power-of-two scales of the two Linear weight matrices for the f16 operand tables: ENH_WS = 2^12 for ordinary weights
+// (max |w| < 4: bit-identical to the static scale of round 3), smaller -- the largest power of two that keeps max |w| scale below 2^14 --
+// for larger ones: round 3 cast w * 4096 to fp16 unchecked, so a weight of magnitude >= 16 became inf in the table.
+// out = {s1, 1 / s1, s2, 1 / s2}; all-zero or non-finite maxima keep ENH_WS.  grid = 2 (one workgroup per tensor).
+__global__ __launch_bounds__(256) void enh_wscale_kernel(const float* __restrict__ w1, long long n1, const float* __restrict__ w2, long long n2,
+                                                         float* __restrict__ out) {
+  __shared__ float s_max[256];
+  const float* __restrict__ w = blockIdx.x == 0 ? w1 : w2;
+  const long long cnt = blockIdx.x == 0 ? n1 : n2;
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < cnt; i += 256) m = fmaxf(m, fabsf(w[i]));
+  s_max[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float scale = ENH_WS;
+    const float wmax = s_max[0];
+    if (wmax > 0.f && wmax < INFINITY) {
+      int ex = 0;
+      (void)frexpf(wmax, &ex);                       // wmax = f 2^ex, f in [0.5, 1)
+      scale = fminf(ENH_WS, ldexpf(1.0f, 14 - ex));  // max |w| scale < 2^14
+    }
+    out[2 * blockIdx.x] = scale;
+    out[2 * blockIdx.x + 1] = 1.0f / scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __restrict__ w1 /*[2*hid][C]*/, float* __restrict__ tab, int C, int hid,
+                                                             const float* __restrict__ wsc) {
+  const float WS1 = wsc[0];
   const int ksteps = C / 16, total = (hid / 16) * ksteps * 896;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -645,7 +678,7 @@ __global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __rest
     const int m = l & 31, kg = l >> 5;
     const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
     float wv[8];
-    for (int e = 0; e < 8; ++e) wv[e] = w1[(size_t)row * C + 16 * ks + 8 * kg + e] * ENH_WS;
+    for (int e = 0; e < 8; ++e) wv[e] = w1[(size_t)row * C + 16 * ks + 8 * kg + e] * WS1;
     if (qq < 768) {
       const int d = qq & 3, term = qq >> 8;
       uint16_t v[2];
@@ -668,7 +701,9 @@ __global__ __launch_bounds__(256) void enh_prep_front_kernel(const float* __rest
 
 // Linear2's weights [C][hid] as B operands of v_mfma_f32_32x32x16_*: block (chunk q of 16 hidden channels, output-channel block ob
 // of 32) = {[term 3][lane 64][4 dwords] fp16, [lane][2 dwords] bf8} = 896 dwords; lane l holds W2[32 ob + (l & 31)][16 q + 8 (l >> 5) ..+7]
-__global__ __launch_bounds__(256) void enh_prep_back_kernel(const float* __restrict__ w2 /*[C][hid]*/, float* __restrict__ tab, int C, int hid) {
+__global__ __launch_bounds__(256) void enh_prep_back_kernel(const float* __restrict__ w2 /*[C][hid]*/, float* __restrict__ tab, int C, int hid,
+                                                            const float* __restrict__ wsc) {
+  const float WS2 = wsc[2];
   const int nob = C / 32, total = (hid / 16) * nob * 896;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(tab);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -676,7 +711,7 @@ __global__ __launch_bounds__(256) void enh_prep_back_kernel(const float* __restr
     const int l = qq < 768 ? (qq >> 2) & 63 : (qq - 768) >> 1;
     const int oc = 32 * ob + (l & 31), kg = l >> 5;
     float wv[8];
-    for (int e = 0; e < 8; ++e) wv[e] = w2[(size_t)oc * hid + 16 * q + 8 * kg + e] * ENH_WS;
+    for (int e = 0; e < 8; ++e) wv[e] = w2[(size_t)oc * hid + 16 * q + 8 * kg + e] * WS2;
     if (qq < 768) {
       const int d = qq & 3, term = qq >> 8;
       uint16_t v[2];
@@ -717,6 +752,7 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
   const int x0 = blockIdx.x * TP, y0 = blockIdx.y * TP;
   const int hid = a.hid;  // == 2 * C
+  const float inv_ws1 = a.wsc[1], inv_ws2 = a.wsc[3];   // 1 / the tables' weight scales (enh_wscale_kernel)
   for (int i = tid; i < 4 * C; i += 256) s_b1[i] = a.b1[i];
   // ---- stage the region's tokens: item = (pixel, float4 of 4 channels): 100 * 16 items
   for (int i = tid; i < NPX * (C / 4); i += 256) {
@@ -801,7 +837,7 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
       for (int reg = 0; reg < 16; ++reg) {
         const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // row of the chunk: < 16 gate-branch x1, >= 16 x2
         const int row = m < 16 ? 16 * q + m : hid + 16 * q + (m - 16);
-        const float v = fmaf(acc[reg], 1.0f / ENH_WS, s_b1[row]);
+        const float v = fmaf(acc[reg], inv_ws1, s_b1[row]);
         if (m < 16) hb1[pcol * HS + m] = inimg ? gelu_erf_f(v) : 0.f;
         else if (!ring) hb2[cidx * HS + (m - 16)] = centre ? gelu_erf_f(v) : 0.f;
       }
@@ -864,7 +900,7 @@ __global__ __launch_bounds__(256, 3) void enh_front_h_kernel(const EnhFrontArgs 
       const int gy = y0 + (p >> 3), gx = x0 + (p & 7);
       if (gy < a.H && gx < a.W) {
         const size_t o = ((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * C + oc;
-        const float v = fmaf(acc2[reg], 1.0f / ENH_WS, b) + a.res[o];
+        const float v = fmaf(acc2[reg], inv_ws2, b) + a.res[o];
         a.O[o] = v;
         cs += v;
       }

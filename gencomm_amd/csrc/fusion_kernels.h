@@ -279,6 +279,10 @@ __global__ __launch_bounds__(64) void fuse_bwd_plan_kernel(const FuseBwdArgs a, 
   for (int j = 0; j < N; ++j) {
     const double* th = a.theta + (size_t)(off + j) * 6;
     int ok;
+    if (N > 8) {   // the pixel pass instantiates 1..8 agents per scene: nothing of such a scene is computed (its gradients stay zero; the
+      a.plan[off + j] = 0;   // Python modules refuse it before any launch, MAX_AGENTS_PER_SCENE), so the gather must not read its scratch
+      continue;
+    }
     if (j == 0) {
       ok = th[0] == 1.0 && th[1] == 0.0 && th[2] == 0.0 && th[3] == 0.0 && th[4] == 1.0 && th[5] == 0.0;
     } else {
@@ -317,18 +321,18 @@ __global__ __launch_bounds__(128) void fuse_bwd_gather_kernel(const FuseBwdArgs 
   const int qy = live ? q / W : 0, qx = live ? q - qy * W : 0;
   const double* __restrict__ th = a.theta + (size_t)ag * 6;
   int cnt = 0;
-  if (live) {
-    // pre-image of q in output pixel coordinates (float64)
+  const float2* __restrict__ wsp = reinterpret_cast<const float2*>(a.ws) + (size_t)ag * HW;
+  // every output pixel p whose bilinear cell contains q, with its tap weight: f(p, wgt).  Candidates = a window around q's pre-image
+  // (float64); each candidate's cell is recomputed with exactly fuse_body's arithmetic
+  auto for_each_match = [&](auto&& f) {
     const double gx = (2.0 * qx + 1.0) / (double)W - 1.0, gy = (2.0 * qy + 1.0) / (double)H - 1.0;
     const double det = th[0] * th[4] - th[1] * th[3];
     const double xb = (th[4] * (gx - th[2]) - th[1] * (gy - th[5])) / det, yb = (-th[3] * (gx - th[2]) + th[0] * (gy - th[5])) / det;
     const double pxf = ((xb + 1.0) * W - 1.0) * 0.5, pyf = ((yb + 1.0) * H - 1.0) * 0.5;
     const int x_lo = max((int)floor(pxf - 1.6), 0), x_hi = min((int)ceil(pxf + 1.6), W - 1);
     const int y_lo = max((int)floor(pyf - 1.6), 0), y_hi = min((int)ceil(pyf + 1.6), H - 1);
-    const float2* __restrict__ wsp = reinterpret_cast<const float2*>(a.ws) + (size_t)ag * HW;
     for (int py = y_lo; py <= y_hi; ++py)
       for (int px = x_lo; px <= x_hi; ++px) {
-        // exactly fuse_body's tap computation for output pixel (px, py)
         const double oxb = (2.0 * px + 1.0) / (double)W - 1.0, oyb = (2.0 * py + 1.0) / (double)H - 1.0;
         const float sgx = (float)(th[0] * oxb + th[1] * oyb + th[2]);
         const float sgy = (float)(th[3] * oxb + th[4] * oyb + th[5]);
@@ -341,25 +345,41 @@ __global__ __launch_bounds__(128) void fuse_bwd_gather_kernel(const FuseBwdArgs 
         const float tx = ix - fx, ty = iy - fy;
         const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty);
         if (wgt == 0.f) continue;
-        if (cnt < FUSE_KM) {
-          const int p = py * W + px;
-          const float2 sd = wsp[p];
-          s_p[cnt][tid] = p; s_wa[cnt][tid] = wgt * sd.x; s_wb[cnt][tid] = wgt * sd.y;
-        }
-        ++cnt;
+        f(py * W + px, wgt);
       }
+  };
+  if (live) {
+    for_each_match([&](int p, float wgt) {
+      if (cnt < FUSE_KM) {
+        const float2 sd = wsp[p];
+        s_p[cnt][tid] = p; s_wa[cnt][tid] = wgt * sd.x; s_wb[cnt][tid] = wgt * sd.y;
+      }
+      ++cnt;
+    });
   }
-  // (cnt > FUSE_KM cannot happen for the transforms the plan admits; the bound is asserted by the tests through the error of the result)
-  cnt = min(cnt, FUSE_KM);
+  // More than FUSE_KM matches (the plan's bound is on the pre-image's AREA, not on its lattice-point count: a thin sheared cell can hold
+  // more): the first FUSE_KM come from LDS, the rest are found again per channel -- slow, exact, and never silently dropped
+  const bool overflow = cnt > FUSE_KM;
+  const int kept = min(cnt, FUSE_KM);
   const float* __restrict__ x0p = a.x + (size_t)off * a.C * HW;
   const float* __restrict__ gp = a.gout + (size_t)b * a.C * HW;
   float* __restrict__ out = a.gx + (size_t)ag * a.C * HW + q;
   for (int c = 0; c < a.C; ++c) {
     float acc = 0.f;
-    for (int k = 0; k < cnt; ++k) {
+    for (int k = 0; k < kept; ++k) {
       const int p = s_p[k][tid];
       acc = fmaf(s_wa[k][tid], gp[(size_t)c * HW + p], acc);
       acc = fmaf(s_wb[k][tid], x0p[(size_t)c * HW + p], acc);
+    }
+    if (overflow) {
+      int m = 0;
+      for_each_match([&](int p, float wgt) {
+        if (m++ >= FUSE_KM) {
+          const float2 sd = wsp[p];
+          acc = fmaf(wgt * sd.x, gp[(size_t)c * HW + p], acc);
+          acc = fmaf(wgt * sd.y, x0p[(size_t)c * HW + p], acc);
+        }
+      });
     }
     if (live) out[(size_t)c * HW] = acc;
   }

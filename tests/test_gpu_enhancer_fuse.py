@@ -50,3 +50,29 @@ def test_pipeline_token_path_finds_the_enhancer_result(modes, fuse):
             outs.append(pipe.run(inp["feat"].contiguous(), inp["cond"].contiguous(), seed=3).clone())
     err = (outs[0] - outs[1]).abs()
     assert (err <= 2e-5 + 1e-4 * outs[1].abs()).all(), err.max().item()
+
+
+@pytest.mark.parametrize("big", [20.0, 300.0])
+def test_fused_enhancer_with_large_linear_weights_stays_finite_and_close(modes, big):
+    """the fused structure's operand tables used a static weight scale of 2^12, so a Linear weight of magnitude >= 16 became
+    inf in fp16 and NaN reached the output silently.  The scale is now chosen per tensor on the device (enh_wscale_kernel): a few entries of
+    Linear1 / Linear2 are set to +-`big`, the result must match the oracle at the elementwise tolerance relative to its magnitude."""
+    from gencomm_amd import Enhancer, synth
+    from oracle import torch_port as O
+    n, C, H, W = 2, 64, 16, 24
+    modes(enh_fuse=2)
+    enh = Enhancer(C, [8, 8], 4).eval()
+    synth.fill_params_(enh, 43)
+    with torch.no_grad():
+        w1, w2 = enh.block_1.mlp.linear1[0].weight, enh.block_1.mlp.linear2[0].weight
+        w1[3, 5], w1[200, 60], w2[7, 11], w2[40, 100] = big, -big, big, -big
+    g = torch.Generator().manual_seed(44)
+    x = torch.randn(n, C, H, W, generator=g) * 0.5
+    with torch.no_grad():
+        ref = O.enhancer_forward({k: v.detach() for k, v in enh.state_dict().items()}, x, [n])
+        got = enh.to(DEV)(x.to(DEV), None, [n]).cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    tol = 1e-5 * ref.abs().max() + 1e-4 * ref.abs()
+    print(f"large weights {big}: max |ref| {ref.abs().max().item():.3e}, worst err/tol {(err / tol).max().item():.3f}")
+    assert (err <= tol).all()
