@@ -281,7 +281,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-enhancer", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 pass (profiling runs)")
-    ap.add_argument("--no-timer", action="store_true", help="skip the per-kernel HIP-event passes")
+    ap.add_argument("--no-timer", action="store_true",
+                    help="profiling runs: only warm-up + the K-step region (no per-kernel HIP-event passes, no >= 1 s repeat, no single-scene latency leg)")
     ap.add_argument("--batch", type=int, default=4, help="scenes per step (batched in one launch sequence, record_len=[N]*B)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
@@ -406,15 +407,32 @@ def main():
                         break
                 except Exception:
                     traffic = None
+            # the second resource: vector-instruction issue, from the committed SQ counter pass of the same command (stamped like the
+            # traffic): fraction of a wave's resident cycles with an instruction in flight x the three waves a SIMD holds
+            issue = None
+            sq = os.path.join(REPO, "profiles", "r4_pmc_sq.json")
+            if os.path.exists(sq):
+                try:
+                    sj = json.load(open(sq))
+                    if sj.get("workload") == args.workload and sj.get("library_src") == _lib.library_src_hash():
+                        ks = {k: v for k, v in sj["kernels"].items() if "conv8h_kernel<" in k}
+                        w = sum(v["launches"] * v["raw_means"]["SQ_WAVE_CYCLES"] for v in ks.values())
+                        act = sum(v["launches"] * v["raw_means"]["SQ_ACTIVE_INST_ANY"] for v in ks.values()) / w
+                        wait = sum(v["launches"] * v["raw_means"]["SQ_WAIT_ANY"] for v in ks.values()) / w
+                        issue = {"active_inst_frac_per_wave": act, "waves_per_simd": 3, "simd_issue_busy": min(1.0, 3 * act),
+                                 "parked_on_waitcnt_or_barrier_frac_per_wave": wait, "source": "profiles/r4_pmc_sq.json (tools/pmc_sq_pass.sh)"}
+                except Exception:
+                    issue = None
             out["roofline"] = {
                 "kernel": "conv8h_kernel<NSRC, GN, UP, RES> (8-channel 3x3 layers of the UNet: ResnetBlock conv1 / conv2, Upsample; all levels)",
-                "bound": "hbm", "achieved": c_b / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "issue": issue, "achieved": c_b / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": c_b / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": c_n, "avg_launch_ms": c_ms / c_n, "algorithmic_bytes_per_launch": c_b / c_n,
                 "share_of_kernel_time": c_ms / tot_ms,
                 "variants": [{"variant": CONV8_FAMILIES[f], "launches": v["launches"], "avg_launch_ms": v["ms"] / v["launches"],
                               "achieved_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for f, v in conv.items()],
-                "note": "achieved = ALGORITHMIC bytes (source maps + residual sources + destination of each launch, fp32, computed by the "
+                "note": "bound = the roof the number is priced against; `issue` = the co-limiting resource measured by the SQ counters (null unless "
+                        "profiles/r4_pmc_sq.json was taken on this library). achieved = ALGORITHMIC bytes (source maps + residual sources + destination of each launch, fp32, computed by the "
                         "host from the launch shape) / HIP-event time of the launches, one scene batch in flight; averages over the full- "
                         "and half-resolution levels. traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from the committed rocprofv3 --pmc "
                         "passes of this command (profiles/r4_pmc_traffic.json, tools/pmc_pass.sh), null unless that file was measured on this workload "
@@ -429,8 +447,11 @@ def main():
                 "frac": fl / (ms1 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": v["launches"], "avg_launch_ms": ms1,
                 "flops_per_launch": fl, "share_of_kernel_time": v["ms"] / tot_ms,
                 "achieved_algorithmic_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
-                "note": "algorithmic FLOPs = 2*(1600 + 72*C) per agent-pixel against the 157.3 TFLOP/s fp32 matrix/vector peak (the dtype of "
-                        "the path); bound by the in-kernel Philox4x32-7 + Box-Muller VALU work, not by the matrix pipe or HBM"}
+                "note": "algorithmic FLOPs = 2*(1600 + 72*C) per agent-pixel (conv_out 8 -> C, posterior update, conv_in C + 2 -> 8 and the noise's "
+                        "conv_in, fused by linearity) against the 157.3 TFLOP/s fp32 matrix/vector peak (the dtype of the path); every product block is "
+                        "six f16-pipe matrix instructions on three-term operands, so the matrix pipe itself runs 6x these FLOPs. The in-kernel "
+                        "Philox4x32-7 + Box-Muller generator is 13.5 % of the kernel's time (measured by subtraction with diagnostic builds: "
+                        "profiles/r4_latent_noise_budget.txt), not its bound"}
         out["kernel_time_shares"] = {v["name"]: round(v["ms"] / tot_ms, 4) for f, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         return out
 
@@ -441,13 +462,13 @@ def main():
         # the K-step region above is the reported number; when it is shorter than a second (20 steps = 0.4 s: too short for a
         # 5 s-period utilisation sampler to see), the same loop is repeated to >= 1.2 s in ONE bracket and reported beside it
         sustained = None
-        if elapsed < 1.0:
+        if elapsed < 1.0 and not args.no_timer:   # profiling runs (--no-timer) execute the K-step region only
             reps = int(np.ceil(1.2 / max(elapsed, 1e-3)))
             ts = timed_region(args.steps * reps, 2500)
             sustained = {"steps": args.steps * reps, "seconds": ts, "value_this_rank": args.steps * reps * B / ts, "unit": "scenes/sec"}
         # latency of ONE scene alone (one stream, batch 1): throughput above needs S x B scenes in flight
         latency = None
-        if rank == 0:
+        if rank == 0 and not args.no_timer:
             f1, c1, p1 = make_scene(N, C, H, W, 77, device, 1)
             pipe1 = ScenePipeline(gen, None if args.no_enhancer else enh, [N], C, H, W, device)
             pipe1.set_affine(normalize_pairwise_tfm(p1, H * PX_M, W * PX_M, 1))

@@ -2,6 +2,7 @@
 # Dynamic instruction mix per wave of the benchmark's kernels: one SQ PMC pass (8 slots).
 set -o pipefail
 WL=${1:-metric}
+export PMC_WORKLOAD=$WL
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf gpurun_out/r4_pmc_INSTS
@@ -26,6 +27,11 @@ for k, d in acc.items():
               "per_wave": {c[len('SQ_INSTS_'):].lower(): round(v / w, 1) for c, v in m.items() if c != 'SQ_WAVES'}}
 res = {"_about": "dynamic instructions per wave (one SQ PMC pass, tools/pmc_insts_pass.sh): VALU includes MFMA, transcendental and conversion instructions",
        "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]['waves_per_launch'] * kv[1]['launches'] * kv[1]['per_wave'].get('valu', 0)))}
+import os, sys
+sys.path.insert(0, os.getcwd())
+from gencomm_amd import _lib
+res['library_src'] = _lib.library_src_hash()   # the kernels these counters were taken on (bench.py ignores a file from another library)
+res['workload'] = os.environ.get('PMC_WORKLOAD', 'metric')
 json.dump(res, open('gpurun_out/r4_pmc_insts.json', 'w'), indent=1)
 for k, v in list(res['kernels'].items())[:10]:
     print(k[:60].ljust(60), v['launches'], v['waves_per_launch'], v['per_wave'])

@@ -5,6 +5,7 @@
 #   bash tools/pmc_sq_pass.sh [workload]   (on the GPU box; output gpurun_out/r4_pmc_sq.json)
 set -o pipefail
 WL=${1:-metric}
+export PMC_WORKLOAD=$WL
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf gpurun_out/r4_pmc_SQ
@@ -35,6 +36,11 @@ for k, d in acc.items():
 res = {"_about": "per-kernel means of one SQ PMC pass (tools/pmc_sq_pass.sh): fractions of SQ_WAVE_CYCLES (quad-cycle units) the waves spend "
                  "parked on s_waitcnt / barriers (wait_any), stalled at issue (wait_inst), issuing (active_inst); MFMA busy cycles over SQ busy cycles; "
                  "LDS bank-conflict cycles over LDS active cycles", "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]['raw_means'].get('SQ_WAVE_CYCLES', 0) * kv[1]['launches']))}
+import os, sys
+sys.path.insert(0, os.getcwd())
+from gencomm_amd import _lib
+res['library_src'] = _lib.library_src_hash()   # the kernels these counters were taken on (bench.py ignores a file from another library)
+res['workload'] = os.environ.get('PMC_WORKLOAD', 'metric')
 json.dump(res, open('gpurun_out/r4_pmc_sq.json', 'w'), indent=1)
 for k, v in list(res['kernels'].items())[:14]:
     print(k[:64].ljust(64), v['launches'], 'wait', v['wait_any_frac'], 'stall', v['wait_inst_frac'], 'active', v['active_inst_frac'], 'mfma', v['mfma_busy_over_busy_cycles'], 'ldsconf', v['lds_conflict_over_lds_active'])
