@@ -735,7 +735,11 @@ int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, flo
   GC_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && scratch && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "bad arguments");
   hipStream_t st = (hipStream_t)stream;
   LnArgs a{x, gamma, nullptr, dy, dx, scratch, eps, C, HW, 0, accumulate};
-  ln_nchw_bwd_kernel<<<dim3((HW + 255) / 256, n), 256, 0, st>>>(a);
+  const dim3 g4((HW + 63) / 64, n);
+  if (C <= 64) ln_nchw_bwd4_kernel<16><<<g4, 256, 0, st>>>(a);
+  else if (C <= 128) ln_nchw_bwd4_kernel<32><<<g4, 256, 0, st>>>(a);
+  else if (C <= 256) ln_nchw_bwd4_kernel<64><<<g4, 256, 0, st>>>(a);
+  else ln_nchw_bwd_kernel<<<dim3((HW + 255) / 256, n), 256, 0, st>>>(a);
   ln_nchw_param_grad_kernel<<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 128)), 256, 0, st>>>(x, dy, scratch, dgamma, dbeta, n, C, HW);
   GC_HIP(hipGetLastError());
   return GC_OK;
@@ -743,13 +747,21 @@ int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, flo
 
 int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream) {
   GC_CHECK_ARG(x && w && y && n >= 1 && C >= 1 && (long long)n * C <= 65535 && H >= 1 && W >= 1, "bad arguments");
-  dwconv3x3_kernel<<<dim3((H * ((W + 3) / 4) + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
+  if ((W & 3) == 0)   // sliding three-row window, 128-bit loads, neighbours by lane shuffle
+    dwconv3x3_rows_kernel<<<dim3((W / 4 + 63) / 64, (H + 4 * DW_RB - 1) / (4 * DW_RB), n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
+  else
+    dwconv3x3_kernel<<<dim3((H * ((W + 3) / 4) + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
 
 int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream) {
   GC_CHECK_ARG(x && dy && dw && n >= 1 && C >= 1 && C <= 65535 && H >= 1 && W >= 1, "bad arguments");
+  if ((W & 3) == 0) {
+    const long long items = (long long)n * ((H + DW_RB - 1) / DW_RB);
+    const unsigned gy = (unsigned)std::min<long long>((items + 3) / 4, 32);   // <= 32 workgroups (atomics) per channel and column strip
+    dwconv3x3_wgrad_rows_kernel<<<dim3((W / 4 + 63) / 64, gy, C), 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
+  } else
   dwconv3x3_wgrad_kernel<<<dim3(C, (unsigned)std::min<long long>(((long long)n * H * ((W + 3) / 4) + 1023) / 1024, 128)), 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
   GC_HIP(hipGetLastError());
   return GC_OK;

@@ -111,6 +111,62 @@ __global__ __launch_bounds__(256) void ln_nchw_bwd_kernel(const LnArgs a) {
   }
 }
 
+// Round 4: the backward in ln_nchw_fwd4_kernel's structure (workgroup = 64 pixels x 4 channel quarters, a thread's C / 4 values of x and
+// dy in registers): ONE read of x and dy instead of four / two channel-strided passes through the cache (1.9 TB/s at 4 x 64 x 200 x 704).
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_nchw_bwd4_kernel(const LnArgs a) {
+  __shared__ float s_part[2][4][64];
+  const int n = blockIdx.y, pl = threadIdx.x & 63, cq = threadIdx.x >> 6, p = blockIdx.x * 64 + pl;
+  const bool ok = p < a.HW;
+  const size_t base = (size_t)n * a.C * a.HW + (ok ? p : 0);
+  const float* __restrict__ xp = a.x + base;
+  const float* __restrict__ gp = a.dy + base;
+  float v[CPT], g[CPT];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int c = 4 * k + cq;
+    v[k] = (c < a.C) ? xp[(size_t)c * a.HW] : 0.f;
+    g[k] = (c < a.C) ? a.gamma[c] * gp[(size_t)c * a.HW] : 0.f;
+    s += v[k];
+  }
+  s_part[0][cq][pl] = s;
+  __syncthreads();
+  const float mean = (s_part[0][0][pl] + s_part[0][1][pl] + s_part[0][2][pl] + s_part[0][3][pl]) / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const float d = (4 * k + cq < a.C) ? v[k] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  s_part[1][cq][pl] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((s_part[1][0][pl] + s_part[1][1][pl] + s_part[1][2][pl] + s_part[1][3][pl]) / (float)a.C + a.eps);
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    if (4 * k + cq < a.C) { m1 += g[k]; m2 = fmaf(g[k], (v[k] - mean) * rstd, m2); }
+  }
+  __syncthreads();   // every wave has read the variance partials
+  s_part[0][cq][pl] = m1;
+  s_part[1][cq][pl] = m2;
+  __syncthreads();
+  m1 = (s_part[0][0][pl] + s_part[0][1][pl] + s_part[0][2][pl] + s_part[0][3][pl]) / (float)a.C;
+  m2 = (s_part[1][0][pl] + s_part[1][1][pl] + s_part[1][2][pl] + s_part[1][3][pl]) / (float)a.C;
+  if (!ok) return;
+  if (cq == 0) { a.mean_rstd[((size_t)n * a.HW + p) * 2] = mean; a.mean_rstd[((size_t)n * a.HW + p) * 2 + 1] = rstd; }
+  float* __restrict__ op = a.out + (size_t)n * a.C * a.HW + p;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int c = 4 * k + cq;
+    if (c < a.C) {
+      const float xh = (v[k] - mean) * rstd;
+      const float r = rstd * (g[k] - m1 - xh * m2);
+      op[(size_t)c * a.HW] = a.accumulate ? op[(size_t)c * a.HW] + r : r;
+    }
+  }
+}
+
 // d gamma[c] += sum dy xhat, d beta[c] += sum dy : grid (channel, pixel chunk); a chunk's partial sums (f64) are committed
 // with one f32 atomic per output
 __global__ __launch_bounds__(256) void ln_nchw_param_grad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean_rstd,
@@ -174,6 +230,102 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   else
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (x0 + j < W) yp[j] = acc[j];
+}
+// Round 4, W % 4 == 0: a lane owns one aligned pixel quad of a column strip and walks DW_RB output rows with a three-row window in
+// registers: per input row ONE 128-bit load, the left / right neighbour pixels come from the adjacent lanes (the wave's 64 lanes = 256
+// consecutive pixels; only lanes 0 / 63 load their outer neighbour), (DW_RB + 2) / DW_RB input rows per output row instead of three.
+// The round-3 form above issued 18 stride-4 dword loads per quad (1.67 TB/s at 4 x 128 x 200 x 704); it stays for ragged widths.
+constexpr int DW_RB = 8;
+__device__ __forceinline__ void dw_row6_shfl(const float* __restrict__ row /* image row or null */, int x0, int W, bool lane_ok, int lane, float v[6]) {
+  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row != nullptr && lane_ok) c = *reinterpret_cast<const float4*>(row + x0);
+  float left = __shfl_up(c.w, 1, 64), right = __shfl_down(c.x, 1, 64);
+  if (lane == 0) left = (row != nullptr && lane_ok && x0 > 0) ? row[x0 - 1] : 0.f;
+  if (lane == 63 || !lane_ok) right = 0.f;
+  if (lane == 63 && row != nullptr && lane_ok && x0 + 4 < W) right = row[x0 + 4];
+  // a lane whose right neighbour lane is beyond the row end got that lane's zero quad: correct (zero padding)
+  v[0] = left; v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w; v[5] = right;
+}
+__global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                             float* __restrict__ y, int C, int H, int W, int flip) {
+  const int nc = blockIdx.z, lane = threadIdx.x & 63, rb = threadIdx.x >> 6;
+  const int x0 = 4 * (blockIdx.x * 64 + lane), r0 = (blockIdx.y * 4 + rb) * DW_RB;
+  if (r0 >= H) return;                       // whole wave
+  const bool lane_ok = x0 < W;
+  const int c = nc % C;
+  const float* __restrict__ xp = x + (size_t)nc * H * W;
+  float* __restrict__ yp = y + (size_t)nc * H * W;
+  float wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + (flip ? 8 - t : t)];
+  const float b0 = (b != nullptr && !flip) ? b[c] : 0.f;
+  float win[3][6];
+  dw_row6_shfl(r0 - 1 >= 0 ? xp + (size_t)(r0 - 1) * W : nullptr, x0, W, lane_ok, lane, win[0]);
+  dw_row6_shfl(xp + (size_t)r0 * W, x0, W, lane_ok, lane, win[1]);
+#pragma unroll
+  for (int r = 0; r < DW_RB; ++r) {
+    const int h = r0 + r;
+    if (h >= H) break;                       // wave-uniform
+    dw_row6_shfl(h + 1 < H ? xp + (size_t)(h + 1) * W : nullptr, x0, W, lane_ok, lane, win[(r + 2) % 3]);
+    float acc[4] = {b0, b0, b0, b0};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[j] = fmaf(wk[ky * 3 + kx], win[(r + ky) % 3][j + kx], acc[j]);
+    if (lane_ok) *reinterpret_cast<float4*>(yp + (size_t)h * W + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+// the weight gradient with the same walk: a wave owns (sample, 256-pixel column strip, DW_RB rows); 10 partial sums per lane, wave
+// reduction, one atomic per (workgroup, tap)
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int n, int C, int H, int W) {
+  __shared__ float s_red[4][10];
+  const int c = blockIdx.z, lane = threadIdx.x & 63, rb = threadIdx.x >> 6;
+  const int x0 = 4 * (blockIdx.x * 64 + lane);
+  const bool lane_ok = x0 < W;
+  const int rblocks = (H + DW_RB - 1) / DW_RB;
+  float acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+  // blockIdx.y walks (sample, row block) items in chunks of 4 per workgroup (one per wave)
+  for (int item = blockIdx.y * 4 + rb; item < n * rblocks; item += gridDim.y * 4) {
+    const int s = item / rblocks, r0 = (item - s * rblocks) * DW_RB;
+    const float* __restrict__ xp = x + ((size_t)s * C + c) * H * W;
+    const float* __restrict__ dp = dy + ((size_t)s * C + c) * H * W;
+    float win[3][6];
+    dw_row6_shfl(r0 - 1 >= 0 ? xp + (size_t)(r0 - 1) * W : nullptr, x0, W, lane_ok, lane, win[0]);
+    dw_row6_shfl(xp + (size_t)r0 * W, x0, W, lane_ok, lane, win[1]);
+#pragma unroll
+    for (int r = 0; r < DW_RB; ++r) {
+      const int h = r0 + r;
+      if (h >= H) break;
+      dw_row6_shfl(h + 1 < H ? xp + (size_t)(h + 1) * W : nullptr, x0, W, lane_ok, lane, win[(r + 2) % 3]);
+      float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane_ok) d4 = *reinterpret_cast<const float4*>(dp + (size_t)h * W + x0);
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+      acc[9] += (d[0] + d[1]) + (d[2] + d[3]);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ky * 3 + kx] = fmaf(d[j], win[(r + ky) % 3][j + kx], acc[ky * 3 + kx]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    float v = acc[t];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_red[rb][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    if (threadIdx.x < 9) atomicAdd(&dw[c * 9 + threadIdx.x], v);
+    else if (db != nullptr) atomicAdd(&db[c], v);
+  }
 }
 // dw[c][tap] += sum_{n,p} dy[n][c](p) x[n][c](p + tap), db[c] += sum dy: grid (channel, pixel chunk), one f32 atomic per
 // output and workgroup; the same four-pixel, branch-free loads

@@ -122,7 +122,8 @@ def test_sampler_and_enhancer_glue_kernels_vs_torch():
     assert torch.allclose(T.nc_dot(x, None).double(), x.double().sum((2, 3)), rtol=1e-6, atol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 12, 9, 13), (1, 8, 16, 24), (2, 4, 7, 5)])
+@pytest.mark.parametrize("shape", [(2, 12, 9, 13), (1, 8, 16, 24), (2, 4, 7, 5),
+                                   (2, 3, 37, 704), (1, 2, 70, 264), (3, 5, 8, 256), (1, 4, 33, 4)])   # W % 4 == 0: the sliding-window kernels
 def test_depthwise_kernels_vs_torch(shape):
     from gencomm_amd import train_ops as T
     n, C, H, W = shape
@@ -137,7 +138,8 @@ def test_depthwise_kernels_vs_torch(shape):
     dx = T.dwconv3x3(dy.to(DEV), w.to(DEV), None, flip=True)
     assert torch.allclose(dx.double().cpu(), xd.grad, atol=2e-6)
     dw, db = T.dwconv3x3_wgrad(x.to(DEV), dy.to(DEV))
-    assert torch.allclose(dw.double().cpu(), wd.grad, rtol=1e-5, atol=2e-5) and torch.allclose(db.double().cpu(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
+    scale = max(1.0, float(n * H * W) ** 0.5 / 16)   # fp32 sums of n H W products
+    assert torch.allclose(dw.double().cpu(), wd.grad, rtol=1e-5, atol=2e-5 * scale) and torch.allclose(db.double().cpu(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-5 * scale)
 
 
 def test_modules_on_two_concurrent_streams_match_sequential_runs():
