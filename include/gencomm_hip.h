@@ -80,7 +80,11 @@ const char* gencomm_build_info(void);
  *   GENCOMM_MODE_XCD_REMAP    1 (default): workgroup -> tile mapping keeps neighbouring tiles on one XCD; 0: grid order
  *   GENCOMM_MODE_DATAFLOW     1: the body of a UNet call (every layer between conv_in and conv_out) runs as ONE persistent launch
  *                             whose workgroups take (layer, agent, tile) items from per-XCD queues and wait on per-(layer, agent)
- *                             completion counters (no grid barrier); 0: one launch per layer.  Same device functions, same results
+ *                             completion counters (no grid barrier); 0 (default): one launch per layer.  Same device functions, same results
+ *                             -- EXCEPT when a dependency wait exhausts its bounded spin (a busy or shared GPU): the remaining tiles are
+ *                             then skipped so that the grid drains, the entry point still returns GC_OK, and the activations are
+ *                             invalid.  A caller that turns this mode on MUST poll gencomm_dataflow_error() after the call.  The mode
+ *                             is opt-in, measured 2x slower than the per-layer launches, and kept for that measurement only
  *   GENCOMM_MODE_RESFUSE_EMU  0 (default).  1: TIMING EXPERIMENT ONLY -- the 8 -> 8 ResnetBlocks run the launch pattern a fused
  *                             conv1 + conv2 block would have (statistics-only conv1 pass; conv2 pass reading the block input with twice
  *                             the matrix work), an upper bound of that fusion's gain; the outputs are NOT the UNet's */
