@@ -659,7 +659,12 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
         }
       }
   }
-  if (NSRC == 2 && wvec) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
+#ifdef HC_NSRC2_LATE   // diagnostic builds: the second source is requested AFTER the first matrix phase (full-register matrix phase, exposed load)
+  constexpr bool LATE2 = true;
+#else
+  constexpr bool LATE2 = false;
+#endif
+  if (NSRC == 2 && wvec && !LATE2) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
     stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   }
@@ -668,7 +673,11 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
 #ifdef HC_PRIO_MFMA   // diagnostic builds (tools/diag/prio_ab.sh): static wave priority from the matrix phase on
   __builtin_amdgcn_s_setprio(HC_PRIO_MFMA);
 #endif
-  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2>(tile, a.wh, acc, off, lane, a.term_mask);
+  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2 && !LATE2>(tile, a.wh, acc, off, lane, a.term_mask);
+  if (NSRC == 2 && wvec && LATE2) {
+    stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  }
   // diagnostic instantiation, MODE_RESFUSE_EMU: the matrix work of a second convolution on the same tile (its result is added: the
   // numbers are meaningless, the instruction count is that of a fused conv1 + conv2 workgroup)
   if (DIAG && (a.term_mask & 128) && wave_live) conv_tile_mfma3<DIAG, NSRC == 2>(tile, a.wh, acc, off, lane, a.term_mask);
