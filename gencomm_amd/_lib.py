@@ -38,6 +38,7 @@ _SIGNATURES = {
     "gencomm_timer_stop_families": (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double), _i]),
     "gencomm_klog_start": (_i, []),
     "gencomm_klog_stop": (_i, [C.c_char_p, _i]),
+    "gencomm_clock_probe": (_i, [_p, _i, _p]),
     "gencomm_unet_num_params": (_i, [_i, _i, _i, _i]),
     "gencomm_unet_param_info": (_i, [_i, _i, _i, _i, _i, C.c_char_p, _i, C.POINTER(_ll), C.POINTER(_ll)]),
     "gencomm_unet_raw_floats": (_ll, [_i, _i, _i, _i]),

@@ -146,6 +146,20 @@ int gencomm_klog_start(void) {
   g_klog_armed.store(true, std::memory_order_relaxed);
   return GC_OK;
 }
+__global__ void clock_probe_kernel(unsigned long long* out, long long spin_ticks) {
+  const unsigned long long w0 = wall_clock64(), c0 = clock64();
+  unsigned long long w1 = w0;
+  while ((long long)(w1 - w0) < spin_ticks) w1 = wall_clock64();     // bounded by construction: the 100 MHz counter always advances
+  const unsigned long long c1 = clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+int gencomm_clock_probe(unsigned long long* out_dev, int spin_us, void* stream) {
+  GC_CHECK_ARG(out_dev && spin_us >= 1 && spin_us <= 100000, "bad arguments");
+  clock_probe_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out_dev, (long long)spin_us * 100);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 int gencomm_klog_stop(char* buf, int cap) {
   g_klog_armed.store(false, std::memory_order_relaxed);
   std::lock_guard<std::mutex> lk(g_klog_mu);

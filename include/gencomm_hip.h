@@ -117,6 +117,12 @@ int gencomm_timer_stop_families(double* ms, int* launches, double* algorithmic_b
 int gencomm_klog_start(void);
 int gencomm_klog_stop(char* buf, int cap);
 
+/* Diagnostic: the shader clock the device actually runs at while other work is in flight.  One wave spins for about `spin_us`
+ * microseconds of the constant 100 MHz counter (s_memrealtime) and writes {shader-clock ticks (s_memtime), 100 MHz ticks} to
+ * out_dev[2] (unsigned long long, device memory): MHz = 100 * ticks[0] / ticks[1].  Launch it on a stream of its own beside the
+ * workload (tools/diag/clock_under_load.py). */
+int gencomm_clock_probe(unsigned long long* out_dev, int spin_us, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * UNet parameters.  The "raw" blob is the concatenation of the module's parameters in EXECUTION
  * order; enumerate it with gencomm_unet_param_info (name = the reference's state_dict key under
