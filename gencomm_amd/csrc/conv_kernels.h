@@ -36,9 +36,12 @@ struct Conv2dArgs {
   const float* res = nullptr;  // optional residual, same layout as y, added after the activation
 };
 
-template <int KH, int KW, int CC, int STRIDE>
+// TY = 8 (round 4): a wave owns TWO 32 x 32 accumulators (the same 32 output channels on two groups of four output rows), so the
+// weight slab of a chunk -- 18 of the 22 floats a thread stages per 3 x 3 chunk -- serves twice the matrix work.
+template <int KH, int KW, int CC, int STRIDE, int TY = 4>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(const Conv2dArgs a) {
-  constexpr int TY = 4, TX = 16, KHW = KH * KW;
+  constexpr int TX = 16, KHW = KH * KW, NA = TY / 4;
+  static_assert(TY == 4 || TY == 8, "row groups of four");
   constexpr int PH = (TY - 1) * STRIDE + KH, PW = (TX - 1) * STRIDE + KW;
   constexpr int PS = PH * PW;            // patch plane (one channel)
   static_assert(CC % 2 == 0, "channel pairs");
@@ -58,9 +61,12 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(const Conv2dArgs a) {
   const int pyl = 2 * (wv >> 1) + (r >> 4), pxl = r & 15;
   const int b_base = ((pyl * STRIDE) * PW + pxl * STRIDE) * 2 + h;
 
-  f32x16c acc;
+  constexpr int G_STRIDE = 4 * STRIDE * PW * 2;   // words between the operand bases of two row groups
+  f32x16c acc[NA];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int g = 0; g < NA; ++g)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
 
   // Software pipeline: chunk c0 + CC travels from global memory into registers while chunk c0 is on the
   // matrix cores; it is written to LDS after the MFMAs.
@@ -111,46 +117,52 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(const Conv2dArgs a) {
 #pragma unroll
       for (int cp = 0; cp < CC / 2; ++cp) {
         const float av = Ws[(tap * (CC / 2) + cp) * 128 + a_base];
-        const float bv = Ps[(cp * PS + ky * PW + kx) * 2 + b_base];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NA; ++g) {
+          const float bv = Ps[(cp * PS + ky * PW + kx) * 2 + b_base + g * G_STRIDE];
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g], 0, 0, 0);
+        }
       }
     }
   }
 
-  // epilogue: lane = pixel (pyl, pxl), register = output channel row
-  const int oy = ty0 + pyl, ox = tx0 + pxl;
-  if (oy >= a.Ho || ox >= a.Wo) return;
+  // epilogue: lane = pixel (4 g + pyl, pxl), register = output channel row
   const int s = a.ups, s2 = s * s;
   const size_t oplane = (size_t)a.Ho * s * a.Wo * s;
   float* __restrict__ yn = a.y + ((size_t)n * a.out_ctotal + a.out_coff) * oplane;
-  if (s == 1) {  // plain convolution: no sub-pixel arithmetic (integer divisions by a run-time value, 16 times per lane)
-    const size_t po = (size_t)oy * a.Wo + ox;
+#pragma unroll
+  for (int g = 0; g < NA; ++g) {
+    const int oy = ty0 + 4 * g + pyl, ox = tx0 + pxl;
+    if (oy >= a.Ho || ox >= a.Wo) continue;
+    if (s == 1) {  // plain convolution: no sub-pixel arithmetic (integer divisions by a run-time value, 16 times per lane)
+      const size_t po = (size_t)oy * a.Wo + ox;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = co0 + 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (co >= a.CoutP) continue;
+        float v = fmaf(acc[g][reg], a.scale[co], a.shift[co]);
+        if (a.relu == 1) v = fmaxf(v, 0.f);
+        else if (a.relu == 2) v = gelu_erf_f(v);
+        const size_t oi = (size_t)co * oplane + po;
+        if (a.res != nullptr) v += a.res[((size_t)n * a.out_ctotal + a.out_coff) * oplane + oi];
+        if (a.relu == 3) v = fmaxf(v, 0.f);
+        yn[oi] = v;
+      }
+      continue;
+    }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int co = co0 + 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      if (co >= a.CoutP) continue;
-      float v = fmaf(acc[reg], a.scale[co], a.shift[co]);
+      const int gco = co0 + 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (gco >= a.CoutP) continue;
+      const int co = gco / s2, sub = gco - co * s2, dy = sub / s, dx = sub - dy * s;
+      float v = fmaf(acc[g][reg], a.scale[co], a.shift[co]);
       if (a.relu == 1) v = fmaxf(v, 0.f);
       else if (a.relu == 2) v = gelu_erf_f(v);
-      const size_t oi = (size_t)co * oplane + po;
+      const size_t oi = (size_t)co * oplane + (size_t)(oy * s + dy) * (a.Wo * s) + (ox * s + dx);
       if (a.res != nullptr) v += a.res[((size_t)n * a.out_ctotal + a.out_coff) * oplane + oi];
-      if (a.relu == 3) v = fmaxf(v, 0.f);
+      if (a.relu == 3) v = fmaxf(v, 0.f);   // ReLU AFTER the residual add (ResNet BasicBlock)
       yn[oi] = v;
     }
-    return;
-  }
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int gco = co0 + 32 * (wv & 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    if (gco >= a.CoutP) continue;
-    const int co = gco / s2, sub = gco - co * s2, dy = sub / s, dx = sub - dy * s;
-    float v = fmaf(acc[reg], a.scale[co], a.shift[co]);
-    if (a.relu == 1) v = fmaxf(v, 0.f);
-    else if (a.relu == 2) v = gelu_erf_f(v);
-    const size_t oi = (size_t)co * oplane + (size_t)(oy * s + dy) * (a.Wo * s) + (ox * s + dx);
-    if (a.res != nullptr) v += a.res[((size_t)n * a.out_ctotal + a.out_coff) * oplane + oi];
-    if (a.relu == 3) v = fmaxf(v, 0.f);   // ReLU AFTER the residual add (ResNet BasicBlock)
-    yn[oi] = v;
   }
 }
 
@@ -534,13 +546,16 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
     GC_HIP(hipGetLastError());
     return GC_OK;
   }
-  const int tiles = ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
+  // 8-row tiles (two accumulators per wave) whenever they still give the launch >= 2 workgroups per CU
+  const long long tiles8 = (long long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+  const bool ty8 = a.Ho >= 8 && tiles8 * ((a.CoutP + 63) / 64) * N >= 512;
+  const int tiles = ty8 ? (int)tiles8 : ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
   const dim3 grid(tiles, (a.CoutP + 63) / 64, N);
   if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");
-  if (KH == 3 && KW == 3 && a.stride == 1) conv2d_igemm_kernel<3, 3, 8, 1><<<grid, 256, 0, st>>>(a);
-  else if (KH == 3 && KW == 3 && a.stride == 2) conv2d_igemm_kernel<3, 3, 8, 2><<<grid, 256, 0, st>>>(a);
-  else if (KH == 1 && KW == 1 && a.stride == 1) conv2d_igemm_kernel<1, 1, 32, 1><<<grid, 256, 0, st>>>(a);
-  else if (KH == 2 && KW == 2 && a.stride == 1) conv2d_igemm_kernel<2, 2, 8, 1><<<grid, 256, 0, st>>>(a);   // sub-pixel form of a transposed 3x3 stride-2 conv
+  if (KH == 3 && KW == 3 && a.stride == 1) { if (ty8) conv2d_igemm_kernel<3, 3, 8, 1, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<3, 3, 8, 1><<<grid, 256, 0, st>>>(a); }
+  else if (KH == 3 && KW == 3 && a.stride == 2) { if (ty8) conv2d_igemm_kernel<3, 3, 8, 2, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<3, 3, 8, 2><<<grid, 256, 0, st>>>(a); }
+  else if (KH == 1 && KW == 1 && a.stride == 1) { if (ty8) conv2d_igemm_kernel<1, 1, 32, 1, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<1, 1, 32, 1><<<grid, 256, 0, st>>>(a); }
+  else if (KH == 2 && KW == 2 && a.stride == 1) { if (ty8) conv2d_igemm_kernel<2, 2, 8, 1, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<2, 2, 8, 1><<<grid, 256, 0, st>>>(a); }   // sub-pixel form of a transposed 3x3 stride-2 conv
   else return fail(GC_ERR_ARG, "conv2d: supported shapes are 3x3 stride 1/2 and 1x1 stride 1 (ConvTranspose2d with kernel == stride runs as 1x1)");
   GC_HIP(hipGetLastError());
   return GC_OK;
