@@ -110,6 +110,8 @@ _SIGNATURES = {
     "gencomm_slot_max_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "gencomm_dcn_sample_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_dcn_scatter_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_dcn_scatter_scratch_floats": (_ll, [_i, _i, _i, _i]),
+    "gencomm_dcn_scatter_bwd_ws": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_sp_out_dims": (_i, [_p, _p, _p, _p, _p]),
     "gencomm_sp_index_workspace_bytes": (_ll, [_i]),
     "gencomm_sp_index_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _ll, _p]),

@@ -724,12 +724,27 @@ int gencomm_dcn_sample_fwd(const float* x, const float* offset, float* col, int 
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
-int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int n, int C, int H, int W,
-                            void* stream) {
+long long gencomm_dcn_scatter_scratch_floats(int n, int C, int H, int W) {
+  if (!(n >= 1 && C >= 1 && H >= 1 && W >= 1)) { fail(GC_ERR_ARG, "gencomm_dcn_scatter_scratch_floats: bad dims"); return -1; }
+  return (long long)dcn_scatter_scratch_floats(n, C, H, W);
+}
+int gencomm_dcn_scatter_bwd_ws(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int n, int C, int H, int W,
+                               float* scratch, long long scratch_floats, void* stream) {
   GC_CHECK_ARG(x && offset && dcol && dx && doffset && n >= 1 && n <= 65535 && C >= 1 && H >= 1 && W >= 1, "bad arguments");
-  dcn_scatter_bwd_kernel<<<dim3((H * W + 255) / 256, 9, n), 256, 0, (hipStream_t)stream>>>(x, offset, dcol, dx, doffset, C, H, W);
+  GC_CHECK_ARG((C + DCN_CH - 1) / DCN_CH <= 65535 && C <= 65535, "too many channels");
+  GC_CHECK_ARG(scratch == nullptr || scratch_floats >= (long long)dcn_scatter_scratch_floats(n, C, H, W), "scratch smaller than gencomm_dcn_scatter_scratch_floats");
+  hipStream_t st = (hipStream_t)stream;
+  // offset gradients per (pixel, tap); the input gradient through LDS tiles (dx zeroed by the caller)
+  dcn_scatter_bwd_kernel<false><<<dim3((H * W + 255) / 256, 9, n), 256, 0, st>>>(x, offset, dcol, dx, doffset, C, H, W);
+  const unsigned tiles = ((H + DCN_T - 1) / DCN_T) * ((W + DCN_T - 1) / DCN_T), chunks = (C + DCN_CH - 1) / DCN_CH;
+  dcn_scatter_dx_tile_kernel<<<dim3(tiles, chunks, n), 256, 0, st>>>(offset, dcol, dx, C, H, W, scratch);
+  if (scratch != nullptr) dcn_scatter_dx_gather_kernel<<<dim3((H * W + 255) / 256, C, n), 256, 0, st>>>(scratch, dx, C, H, W, (int)chunks * DCN_CH);
   GC_HIP(hipGetLastError());
   return GC_OK;
+}
+int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int n, int C, int H, int W,
+                            void* stream) {
+  return gencomm_dcn_scatter_bwd_ws(x, offset, dcol, dx, doffset, n, C, H, W, nullptr, 0, stream);
 }
 
 int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream) {

@@ -785,6 +785,8 @@ __global__ __launch_bounds__(256) void dcn_sample_kernel(const float* __restrict
     cn[((size_t)c * 9 + k) * HW + pix] = w00 * pl[t.j00] + w01 * pl[t.j01] + w10 * pl[t.j10] + w11 * pl[t.j11];
   }
 }
+// DX = false (round 4): only the offset gradients -- the input gradient comes from dcn_scatter_dx_tile_kernel below
+template <bool DX>
 __global__ __launch_bounds__(256) void dcn_scatter_bwd_kernel(const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ dcol,
                                                               float* __restrict__ dx, float* __restrict__ doff, int C, int H, int W) {
   const int n = blockIdx.z, k = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x, HW = H * W;
@@ -799,18 +801,108 @@ __global__ __launch_bounds__(256) void dcn_scatter_bwd_kernel(const float* __res
   for (int c = 0; c < C; ++c) {
     const float dv = dn[((size_t)c * 9 + k) * HW + pix];
     const float* __restrict__ pl = xn + (size_t)c * HW;
-    float* __restrict__ dpl = dxn + (size_t)c * HW;
     const float v00 = t.c00 ? pl[t.j00] : 0.f, v01 = t.c01 ? pl[t.j01] : 0.f, v10 = t.c10 ? pl[t.j10] : 0.f, v11 = t.c11 ? pl[t.j11] : 0.f;
     // val = hy hx v00 + hy lx v01 + ly hx v10 + ly lx v11;  d ly / d py = 1, d hy / d py = -1 (floor is constant almost everywhere)
     gy = fmaf(dv, t.hx * (v10 - v00) + t.lx * (v11 - v01), gy);
     gx = fmaf(dv, t.hy * (v01 - v00) + t.ly * (v11 - v10), gx);
-    if (t.c00) atomicAdd(&dpl[t.j00], w00 * dv);
-    if (t.c01) atomicAdd(&dpl[t.j01], w01 * dv);
-    if (t.c10) atomicAdd(&dpl[t.j10], w10 * dv);
-    if (t.c11) atomicAdd(&dpl[t.j11], w11 * dv);
+    if constexpr (DX) {
+      float* __restrict__ dpl = dxn + (size_t)c * HW;
+      if (t.c00) atomicAdd(&dpl[t.j00], w00 * dv);
+      if (t.c01) atomicAdd(&dpl[t.j01], w01 * dv);
+      if (t.c10) atomicAdd(&dpl[t.j10], w10 * dv);
+      if (t.c11) atomicAdd(&dpl[t.j11], w11 * dv);
+    }
   }
   doff[((size_t)n * 18 + 2 * k) * HW + pix] = gy;
   doff[((size_t)n * 18 + 2 * k + 1) * HW + pix] = gx;
+}
+
+// Input gradient of the deformable sampling through an LDS tile (round 4): the one-atomic-per-corner form above issued
+// 4 x 9 x C x HW x n device-scope float atomics (151 M at 4 x 128 x 64 x 128: 1.2 ms per training step).  A workgroup = 16 x 16 sampling
+// pixels x 8 channels; the corners of its 9 x 256 samples fall almost always inside the tile grown by DCN_R pixels, where they are
+// added with LDS atomics (ds_add_f32); the rare corner further out goes to global memory directly; at the end every touched cell of the
+// (16 + 2 DCN_R)^2 x 8 region is committed with ONE global atomic (the regions of neighbouring workgroups overlap).  dx must be zeroed.
+constexpr int DCN_T = 16, DCN_R = 4, DCN_L = DCN_T + 2 * DCN_R, DCN_CH = 8;
+// `part` != null: the region is STORED (coalesced, every cell) at part[((n tiles + tile) Cpad + channel)][DCN_L^2] and
+// dcn_scatter_dx_gather_kernel sums, per output pixel, the <= 3 x 3 regions that contain it -- no global atomic at all for in-region
+// corners (the flush with one atomic per touched cell still cost 0.76 ms: 9 M uncoalesced device-scope read-modify-writes).
+__global__ __launch_bounds__(256) void dcn_scatter_dx_tile_kernel(const float* __restrict__ off, const float* __restrict__ dcol, float* __restrict__ dx,
+                                                                  int C, int H, int W, float* __restrict__ part) {
+  __shared__ float s_acc[DCN_CH][DCN_L * DCN_L];
+  const int tid = threadIdx.x, n = blockIdx.z, c0 = blockIdx.y * DCN_CH, HW = H * W;
+  const int tiles_x = (W + DCN_T - 1) / DCN_T;
+  const int ty0 = (blockIdx.x / tiles_x) * DCN_T, tx0 = (blockIdx.x % tiles_x) * DCN_T;
+  for (int i = tid; i < DCN_CH * DCN_L * DCN_L; i += 256) (&s_acc[0][0])[i] = 0.f;
+  __syncthreads();
+  const int y = ty0 + (tid >> 4), xx = tx0 + (tid & 15);
+  const bool live = y < H && xx < W;
+  const int pix = y * W + xx;
+  const int nch = min(DCN_CH, C - c0);
+  float* __restrict__ dxn = dx + ((size_t)n * C + c0) * HW;
+  const float* __restrict__ dn = dcol + ((size_t)n * C + c0) * 9 * HW;
+  if (live) {
+    for (int k = 0; k < 9; ++k) {
+      // the tap's cell exactly as dcn_tap computes it, with the corner's coordinates kept
+      const float py = (float)(y - 1 + k / 3) + off[((size_t)n * 18 + 2 * k) * HW + pix];
+      const float px = (float)(xx - 1 + k % 3) + off[((size_t)n * 18 + 2 * k + 1) * HW + pix];
+      if (!(py > -1.f && py < (float)H && px > -1.f && px < (float)W)) continue;
+      const float fy = floorf(py), fx = floorf(px);
+      const int iy = (int)fy, ix = (int)fx;
+      const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+      const float wgt[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+      float dvs[DCN_CH];   // the chunk's eight gradient values of this tap: eight loads in flight, not one per memory round trip
+#pragma unroll
+      for (int c = 0; c < DCN_CH; ++c) dvs[c] = c < nch ? dn[((size_t)c * 9 + k) * HW + pix] : 0.f;
+#pragma unroll
+      for (int c = 0; c < DCN_CH; ++c) {
+        if (c >= nch) break;
+        const float dv = dvs[c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cy = iy + (q >> 1), cx = ix + (q & 1);
+          if (cy < 0 || cy > H - 1 || cx < 0 || cx > W - 1) continue;
+          const int ry = cy - (ty0 - DCN_R), rx = cx - (tx0 - DCN_R);
+          if (ry >= 0 && ry < DCN_L && rx >= 0 && rx < DCN_L) atomicAdd(&s_acc[c][ry * DCN_L + rx], wgt[q] * dv);
+          else atomicAdd(&dxn[(size_t)c * HW + (size_t)cy * W + cx], wgt[q] * dv);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (part != nullptr) {
+    const size_t cpad = (size_t)gridDim.y * DCN_CH;
+    float* __restrict__ pp = part + (((size_t)n * gridDim.x + blockIdx.x) * cpad + c0) * (DCN_L * DCN_L);
+    for (int i = tid; i < DCN_CH * DCN_L * DCN_L; i += 256) pp[i] = (&s_acc[0][0])[i];
+    return;
+  }
+  for (int i = tid; i < nch * DCN_L * DCN_L; i += 256) {
+    const int c = i / (DCN_L * DCN_L), r = i - c * (DCN_L * DCN_L), ry = r / DCN_L, rx = r - ry * DCN_L;
+    const int gy = ty0 - DCN_R + ry, gx = tx0 - DCN_R + rx;
+    const float v = s_acc[c][r];
+    if (v != 0.f && gy >= 0 && gy < H && gx >= 0 && gx < W) atomicAdd(&dxn[(size_t)c * HW + (size_t)gy * W + gx], v);
+  }
+}
+
+// dx[n][c][y][x] += sum over the tiles whose grown region contains (y, x) of that region's cell (plain read-add-store: runs after the
+// tile kernel on the same stream; the rare out-of-region corners were added to dx by atomics before)
+__global__ __launch_bounds__(256) void dcn_scatter_dx_gather_kernel(const float* __restrict__ part, float* __restrict__ dx, int C, int H, int W, int cpad) {
+  const int n = blockIdx.z, c = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= H * W) return;
+  const int y = pix / W, x = pix - y * W;
+  const int tiles_x = (W + DCN_T - 1) / DCN_T, tiles_y = (H + DCN_T - 1) / DCN_T, tiles = tiles_x * tiles_y;
+  // tile t covers rows [16 t - R, 16 t + 16 + R)
+  const int ty_lo = max(0, (y - (DCN_T + DCN_R - 1) + DCN_T - 1) / DCN_T), ty_hi = min(tiles_y - 1, (y + DCN_R) / DCN_T);
+  const int tx_lo = max(0, (x - (DCN_T + DCN_R - 1) + DCN_T - 1) / DCN_T), tx_hi = min(tiles_x - 1, (x + DCN_R) / DCN_T);
+  float s = 0.f;
+  for (int ty = ty_lo; ty <= ty_hi; ++ty)
+    for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+      const int ry = y - (ty * DCN_T - DCN_R), rx = x - (tx * DCN_T - DCN_R);
+      s += part[(((size_t)n * tiles + ty * tiles_x + tx) * cpad + c) * (DCN_L * DCN_L) + ry * DCN_L + rx];
+    }
+  dx[((size_t)n * C + c) * H * W + pix] += s;
+}
+inline size_t dcn_scatter_scratch_floats(int n, int C, int H, int W) {
+  return (size_t)n * ((H + DCN_T - 1) / DCN_T) * ((W + DCN_T - 1) / DCN_T) * ((size_t)(C + DCN_CH - 1) / DCN_CH * DCN_CH) * (DCN_L * DCN_L);
 }
 
 // ---- BatchNorm2d in TRAINING mode (batch statistics) for the conv stacks around the hot path -------------------------------

@@ -242,6 +242,9 @@ def dcn_scatter_bwd(x: torch.Tensor, offset: torch.Tensor, dcol: torch.Tensor):
     n, C, H, W = x.shape
     dx = torch.zeros_like(x)
     doff = torch.empty(n, 18, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().gencomm_dcn_scatter_bwd(ptr(x), ptr(offset), ptr(dcol), ptr(dx), ptr(doff), n, C, H, W, stream_ptr(x.device)),
-               "gencomm_dcn_scatter_bwd")
+    l = _lib.lib()
+    need = _lib.check_size(l.gencomm_dcn_scatter_scratch_floats(n, C, H, W), "gencomm_dcn_scatter_scratch_floats")
+    scratch = torch.empty(need, dtype=torch.float32, device=x.device)   # per-tile regions of the input gradient (no global atomics)
+    _lib.check(l.gencomm_dcn_scatter_bwd_ws(ptr(x), ptr(offset), ptr(dcol), ptr(dx), ptr(doff), n, C, H, W, ptr(scratch), need, stream_ptr(x.device)),
+               "gencomm_dcn_scatter_bwd_ws")
     return dx, doff

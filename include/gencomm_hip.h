@@ -475,6 +475,12 @@ int gencomm_slot_max_bwd(const float* dout, const unsigned char* arg, float* dx,
 int gencomm_dcn_sample_fwd(const float* x, const float* offset, float* col, int n, int C, int H, int W, void* stream);
 int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int n, int C, int H, int W,
                             void* stream);
+/* The same with caller-owned scratch of gencomm_dcn_scatter_scratch_floats(n, C, H, W) floats: the input gradient is then formed without
+ * global atomics for every bilinear corner within 4 pixels of its sampling pixel's 16 x 16 tile (per-tile regions stored, then summed per
+ * output pixel); dx must be zero on entry in both forms. */
+long long gencomm_dcn_scatter_scratch_floats(int n, int C, int H, int W);
+int gencomm_dcn_scatter_bwd_ws(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int n, int C, int H, int W,
+                               float* scratch, long long scratch_floats, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Sparse 3-D convolutions of the SECOND encoder without spconv (opencood/models/heter_encoders.py:52-81,

@@ -195,3 +195,32 @@ def test_stride2_input_gradient_subpixel_form_vs_float64(shape):
         dx = T.conv2d_dgrad_strided(dy.float().to(DEV), w.to(DEV), 1, 2, (h, wd))
         err = (dx.double().cpu() - x.grad).abs().max().item()
         assert dx.shape == x.grad.shape and err <= 3e-6 * x.grad.abs().max().item(), (shape, h, wd, err)
+
+
+@pytest.mark.parametrize("C,H,W,n,spread", [(12, 20, 36, 2, 0.8), (8, 33, 18, 1, 7.0), (20, 16, 16, 2, 2.5)])
+def test_deformable_sampling_gradients_vs_oracle_autograd(C, H, W, n, spread):
+    """gencomm_dcn_scatter_bwd (offset gradients per (pixel, tap) + input gradient through LDS tiles with one global atomic per touched
+    cell) against float64 autograd through the oracle's DCNv1 restatement: small offsets (everything lands in the workgroup's LDS
+    region), offsets of several pixels (corners beyond the region take the direct global atomic; samples outside the map) and a map
+    that is not a multiple of the 16 x 16 tile; channel counts that are not a multiple of the 8-channel chunk."""
+    from gencomm_amd import train_ops as T
+    from oracle import torch_port as O
+    g = torch.Generator().manual_seed(C * H + W)
+    x = torch.randn(n, C, H, W, generator=g)
+    off = torch.randn(n, 18, H, W, generator=g) * spread
+    dcol = torch.randn(n, C * 9, H, W, generator=g)
+    xd, od = x.double().requires_grad_(True), off.double().requires_grad_(True)
+    # identity "weight": output channel (c, k) of the deformable conv = sampled column (c, k)
+    wid = torch.zeros(C * 9, C, 3, 3, dtype=torch.float64)
+    for c in range(C):
+        for k in range(9):
+            wid[c * 9 + k, c, k // 3, k % 3] = 1.0
+    col = O.deform_conv2d_ref(xd, od, wid, None, 1)
+    (col * dcol.double()).sum().backward()
+    got_col = T.dcn_sample(x.to(DEV), off.to(DEV))
+    assert torch.allclose(got_col.double().cpu(), col.detach(), atol=2e-5)
+    dx, doff = T.dcn_scatter_bwd(x.to(DEV), off.to(DEV), dcol.to(DEV))
+    ex = (dx.double().cpu() - xd.grad).abs().max().item()
+    eo = (doff.double().cpu() - od.grad).abs().max().item()
+    assert ex <= 1e-5 * max(1.0, xd.grad.abs().max().item()), (ex, xd.grad.abs().max().item())
+    assert eo <= 1e-4 * max(1.0, od.grad.abs().max().item()), (eo, od.grad.abs().max().item())
