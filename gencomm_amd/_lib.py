@@ -82,6 +82,7 @@ _SIGNATURES = {
     "gencomm_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gencomm_conv2d_wgrad_scratch_floats": (_ll, [_i] * 8),
     "gencomm_conv2d_wgrad_ws": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_gn_nchw_fwd": (_i, [_p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _i, _p]),
     "gencomm_ln_nchw_fwd": (_i, [_p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
     "gencomm_ln_nchw_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
     "gencomm_dwconv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -45,7 +45,8 @@ class GenComm(nn.Module):
         self.v_posterior = 0
         self.loss_type = "l2"
         self.signal_scaling_rate = 1
-        self.denoiser = DiffusionUNet(config)
+        self.denoiser = DiffusionUNet(config)   # widths outside ch 8 / ch_mult all ones: the general-width module (unet_generic.py)
+        self._generic = type(self.denoiser) is not DiffusionUNet
 
         # cond_diff.py:209-257, all float64 then cast
         betas = make_beta_schedule(timesteps)
@@ -149,8 +150,38 @@ class GenComm(nn.Module):
             noise = (n0, sn)
         return feat, cond, noise
 
+    def _denoise_generic(self, feat, cond, src_rows, noise, seed) -> torch.Tensor:
+        """The sampler loop (cond_diff.py:321-329, :302-315) around a general-width denoiser (unet_generic.py): q_sample and the step
+        noise are the accelerated path's own kernels (same Philox field for the same seed), the update x_{t-1} = c1 x0_hat + c2 x_t +
+        nu_t is gencomm_lincomb_fwd, the UNet call is the layer-by-layer general path."""
+        from .autograd import _lincomb
+        feat, cond, noise = self._checked(feat, cond, src_rows, noise)
+        n, C, H, W = cond.shape[0], feat.shape[1], feat.shape[2], feat.shape[3]
+        T, dev, l, st = self.num_timesteps, feat.device, _lib.lib(), stream_ptr(feat.device)
+        sched, coef = self._sched_table(dev), self._sched_host(dev)
+        rows = dev_ints(src_rows, dev)
+        n0, sn = noise if noise is not None else (None, None)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        x = torch.empty((n, C, H, W), dtype=torch.float32, device=dev)
+        _lib.check(l.gencomm_q_sample_fwd(ptr(sched[T - 1]), ptr(feat), feat.shape[0], ptr(rows), ptr(n0), int(seed), T, ptr(x), n, C, H, W, st),
+                   "gencomm_q_sample_fwd")
+        for i, t in enumerate(reversed(range(T))):
+            x0 = self.denoiser(torch.cat([cond, x], dim=1), torch.full((n,), float(t), device=dev))
+            if t == 0:
+                return x0
+            if sn is None:
+                nu = torch.empty_like(x)
+                _lib.check(l.gencomm_step_noise_fwd(ptr(sched[t]), int(seed), t, ptr(nu), n, C, H, W, 0, st), "gencomm_step_noise_fwd")
+                x = _lincomb(nu, x0, coef[t][2], x, coef[t][3], nu, 1.0)
+            else:
+                x = _lincomb(torch.empty_like(x), x0, coef[t][2], x, coef[t][3], sn[i], coef[t][4])
+        return x
+
     def _denoise(self, feat: torch.Tensor, cond: torch.Tensor, src_rows: Sequence[int],
                  noise: Optional[Tuple[torch.Tensor, torch.Tensor]], seed: Optional[int]) -> torch.Tensor:
+        if self._generic:
+            return self._denoise_generic(feat, cond, src_rows, noise, seed)
         feat, cond, noise = self._checked(feat, cond, src_rows, noise)
         n, C, H, W = cond.shape[0], feat.shape[1], feat.shape[2], feat.shape[3]
         T = self.num_timesteps
@@ -185,6 +216,9 @@ class GenComm(nn.Module):
         (``autograd.sampler_forward``: ``gencomm_unet_fwd`` / ``gencomm_unet_bwd`` per step, T saved x_t maps)."""
         if not self._needs_grad(feat, cond):
             return self._denoise(feat, cond, src_rows, noise, seed)
+        if self._generic:
+            raise NotImplementedError("gencomm_amd.GenComm: gradients through a general-width denoiser (ch != 8 or ch_mult not all ones) are not "
+                                      "implemented; run under torch.no_grad() or freeze the denoiser's parameters")
         from .autograd import sampler_forward
         feat, cond, noise = self._checked(feat, cond, src_rows, noise)
         if noise is None:   # the sampler's own in-kernel Philox field of `seed` (what inference adds for the same seed)

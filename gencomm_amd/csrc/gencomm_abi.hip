@@ -747,6 +747,17 @@ int gencomm_dcn_scatter_bwd(const float* x, const float* offset, const float* dc
   return gencomm_dcn_scatter_bwd_ws(x, offset, dcol, dx, doffset, n, C, H, W, nullptr, 0, stream);
 }
 
+// GroupNorm (+ SiLU when silu != 0) over NCHW for any channel count; stat: n * groups * 2 floats of scratch (mean, rstd)
+int gencomm_gn_nchw_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float eps, int silu,
+                        int n, int C, int groups, int HW, void* stream) {
+  GC_CHECK_ARG(x && gamma && beta && y && stat && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && groups >= 1 && C % groups == 0 && HW >= 1, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  gn_nchw_stats_kernel<<<dim3(groups, n), 256, 0, st>>>(x, stat, C, groups, HW, eps);
+  gn_nchw_apply_kernel<<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, stat, gamma, beta, y, C, groups, HW, silu);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream) {
   GC_CHECK_ARG(x && gamma && beta && out && n >= 1 && n <= 65535 && C >= 1 && HW >= 1, "bad arguments");
   LnArgs a{x, gamma, beta, nullptr, out, nullptr, eps, C, HW, residual, 0};

@@ -78,6 +78,21 @@ class DiffusionUNet(nn.Module):
     from the library's own enumeration of the UNet's parameters (``gencomm_unet_param_info``: ``state_dict`` key, size and
     execution order for this C / depth / res-block count / attention mask), so module and kernels cannot drift apart."""
 
+    def __new__(cls, config):
+        """Widths outside the accelerated family (ch = 8, ch_mult all ones) get the general-width module of unet_generic.py: same
+        state_dict keys, forward composed from the library's general convolution / GroupNorm primitives, inference only."""
+        m = _cfg_get(config, "model")
+        ch, mult = _cfg_get(m, "ch"), tuple(_cfg_get(m, "ch_mult"))
+        if cls is DiffusionUNet and (ch != 8 or any(v != 1 for v in mult)):
+            from .unet_generic import GenericDiffusionUNet
+            if _cfg_get(m, "dropout") != 0.0:
+                raise NotImplementedError("gencomm_amd.DiffusionUNet: dropout > 0 is not supported")
+            g = GenericDiffusionUNet(ch, _cfg_get(m, "out_ch"), mult, _cfg_get(m, "num_res_blocks"), _cfg_get(m, "in_channels") + 2,
+                                     _cfg_get(m, "resamp_with_conv"), list(_cfg_get(m, "attn_resolutions")))
+            g.config = config
+            return g
+        return super().__new__(cls)
+
     def __init__(self, config):
         super().__init__()
         m = _cfg_get(config, "model")
@@ -114,7 +129,7 @@ class DiffusionUNet(nn.Module):
     def _check_supported(self) -> None:
         why = None
         if self.ch != 8 or any(m != 1 for m in self.ch_mult):
-            why = f"ch={self.ch}, ch_mult={self.ch_mult}: the HIP kernels cover ch=8 with ch_mult all ones"
+            why = f"ch={self.ch}, ch_mult={self.ch_mult}: the fused HIP kernels cover ch=8 with ch_mult all ones (other widths: unet_generic.py)"
         elif not self.resamp_with_conv:
             why = "resamp_with_conv=False is not supported"
         elif self.training and self.dropout_p != 0.0:

@@ -373,6 +373,10 @@ int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, 
 long long gencomm_conv2d_wgrad_scratch_floats(int N, int Cin, int Hi, int Wi, int Cout, int K, int stride, int pad);
 int gencomm_conv2d_wgrad_ws(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout,
                             int K, int stride, int pad, float* scratch, long long scratch_floats, void* stream);
+/* GroupNorm (+ SiLU when silu != 0) over NCHW for any channel count and group size (unet.py:36-37, :31-33): the general-width
+ * DiffusionUNet's normalisation; stat = n * groups * 2 floats of caller scratch (mean, rstd per sample and group). */
+int gencomm_gn_nchw_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float eps, int silu,
+                        int n, int C, int groups, int HW, void* stream);
 int gencomm_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float* out, float eps, int residual, int n, int C, int HW, void* stream);
 int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* scratch,
                         float eps, int accumulate, int n, int C, int HW, void* stream);

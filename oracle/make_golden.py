@@ -747,6 +747,33 @@ def run_apchain_case() -> None:
     print(f"apchain: wrote apchain.npz ({os.path.getsize(os.path.join(OUT, 'apchain.npz')) / 1024:.0f} KiB)")
 
 
+def run_wide_case() -> None:
+    """General DiffusionUNet widths: the reference's own GenComm with ch = 16, ch_mult [1, 2], num_res_blocks 1 --
+    every block of the up path then has a 1x1 nin_shortcut with unequal sides, the levels differ in width, GroupNorm groups hold 4 / 8 /
+    12 channels.  Single UNet calls for every t and the whole eval forward with injected noise."""
+    from opencood.models.gencomm_modules.cond_diff import GenComm
+    C, H, W, T, rl = 24, 12, 20, 3, [2, 1]
+    cfg = synth.default_gencomm_cfg(C, T)
+    cfg["model"].update({"ch": 16, "ch_mult": [1, 2], "num_res_blocks": 1})
+    gen = GenComm(cfg).eval()
+    synth.fill_params_(gen, WEIGHT_SEED + 70)
+    n = sum(rl)
+    inp = synth.make_inputs(rl, C, H, W, DATA_SEED + 70)
+    feat, cond = torch.from_numpy(inp["feat"]), torch.from_numpy(inp["cond"])
+    import json
+    rec = dict(cfg=json.dumps(cfg), C=C, H=H, W=W, T=T, record_len=np.asarray(rl), weight_seed=WEIGHT_SEED + 70, data_seed=DATA_SEED + 70,
+               noise_seed=NOISE_SEED + 70, keys=np.asarray(sorted(gen.state_dict().keys())),
+               shapes=json.dumps({k: list(v.shape) for k, v in gen.state_dict().items()}))
+    with torch.no_grad():
+        for t in range(T):
+            tt = torch.full((n,), t, dtype=torch.long)
+            rec[f"unet_out_t{t}"] = gen.denoiser(torch.cat([cond, feat], dim=1), tt.float()).numpy()
+        with PatchedNoise(NOISE_SEED + 70):
+            rec["pred_feature"] = gen(feat, cond, torch.tensor(rl))["pred_feature"].numpy()
+    np.savez_compressed(os.path.join(OUT, "unet_wide.npz"), **rec)
+    print(f"wide: wrote unet_wide.npz ({os.path.getsize(os.path.join(OUT, 'unet_wide.npz')) / 1024:.0f} KiB), {len(rec['keys'])} state_dict keys")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -774,7 +801,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "apchain": run_apchain_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "apchain": run_apchain_case, "wide": run_wide_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()
