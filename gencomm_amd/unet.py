@@ -78,9 +78,11 @@ class DiffusionUNet(nn.Module):
     from the library's own enumeration of the UNet's parameters (``gencomm_unet_param_info``: ``state_dict`` key, size and
     execution order for this C / depth / res-block count / attention mask), so module and kernels cannot drift apart."""
 
-    def __new__(cls, config):
+    def __new__(cls, config=None):
         """Widths outside the accelerated family (ch = 8, ch_mult all ones) get the general-width module of unet_generic.py: same
         state_dict keys, forward composed from the library's general convolution / GroupNorm primitives, inference only."""
+        if config is None:   # copy.deepcopy / pickle reconstruct with cls.__new__(cls) and restore the state afterwards
+            return super().__new__(cls)
         m = _cfg_get(config, "model")
         ch, mult = _cfg_get(m, "ch"), tuple(_cfg_get(m, "ch_mult"))
         if cls is DiffusionUNet and (ch != 8 or any(v != 1 for v in mult)):

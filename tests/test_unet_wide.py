@@ -74,3 +74,19 @@ def test_wide_unet_guards():
     cfg["model"]["attn_resolutions"] = [64]
     with pytest.raises(NotImplementedError, match="AttnBlocks"):
         GenComm(cfg)
+
+
+def test_both_unet_families_survive_deepcopy_and_pickle():
+    """copy.deepcopy / pickle rebuild a module with cls.__new__(cls): the width-dispatching __new__ must accept that."""
+    import copy
+    import pickle
+    from gencomm_amd import GenComm, synth
+    from gencomm_amd.unet import DiffusionUNet
+    from gencomm_amd.unet_generic import GenericDiffusionUNet
+    narrow = GenComm(synth.default_gencomm_cfg(16, 3))
+    wide = _gen(load_case("unet_wide"))
+    for gen, cls in ((narrow, DiffusionUNet), (wide, GenericDiffusionUNet)):
+        for clone in (copy.deepcopy(gen), pickle.loads(pickle.dumps(gen))):
+            assert type(clone.denoiser) is cls
+            a, b = gen.state_dict(), clone.state_dict()
+            assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
