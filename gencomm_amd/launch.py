@@ -89,7 +89,12 @@ def spawn_ranks(argv: Sequence[str], nproc: int, *, share_device: bool = False, 
     threads: List[threading.Thread] = []
     rank0_out: List[str] = []
     for r in range(nproc):
-        p = subprocess.Popen(list(argv), env=rank_env(r, nproc, port, share_device, env), stdout=subprocess.PIPE, text=True, bufsize=1)
+        try:
+            p = subprocess.Popen(list(argv), env=rank_env(r, nproc, port, share_device, env), stdout=subprocess.PIPE, text=True, bufsize=1)
+        except Exception:
+            for q in procs:          # a rank that cannot be started must not leave the earlier ones waiting at the rendezvous
+                q.terminate()
+            raise
         procs.append(p)
         sinks = ([sys.stdout] if echo else []) if r == 0 else [sys.stderr]
         t = threading.Thread(target=_pump, args=(p.stdout, sinks, rank0_out if r == 0 else None), daemon=True)
