@@ -774,6 +774,57 @@ def run_wide_case() -> None:
     print(f"wide: wrote unet_wide.npz ({os.path.getsize(os.path.join(OUT, 'unet_wide.npz')) / 1024:.0f} KiB), {len(rec['keys'])} state_dict keys")
 
 
+def stage2_args(T: int = 3) -> dict:
+    """A reduced stage-2 `model.args` block (structure of opv2v/GenComm_yamls/gencomm/stage2/m1m2_att.yaml): two lidar modalities with
+    their own PointPillars encoder / backbone / shrink header / message extractor (m2: the new agent type, a lighter backbone), the
+    reference's `diffcomm:` key spelling (stage2.py:36), `trick` (predicted features masked by the occupied cells of the originals)."""
+    a = shell_args(T)
+    a["diffcomm"] = a.pop("gencomm")
+    m2 = json_roundtrip(a["m1"])
+    m2["backbone_args"]["layer_nums"] = [1, 2, 1]
+    a["m2"] = m2
+    a["trick"] = True
+    return a
+
+
+def json_roundtrip(o):
+    import json
+    return json.loads(json.dumps(o))
+
+
+def run_shell2_case() -> None:
+    """The reference's own stage-2 shell (heter_model_baseline_w_gencomm_stage2.py:31-328) end to end on CPU: ego of modality m1 with
+    collaborators of m1 and m2 in two scenes (agents m1 m2 m1 | m1 m2), eval mode.  As in the stage-1 case everything is reference code
+    except torchvision's DeformConv2d (the oracle's DCNv1 restatement: PARITY UNPINNED for that op)."""
+    import copy
+    import json
+    from opencood.models.heter_model_baseline_w_gencomm_stage2 import HeterModelBaselineWDiffCommStage2
+    args = stage2_args()
+    model = HeterModelBaselineWDiffCommStage2(copy.deepcopy(args)).eval()
+    synth.fill_params_(model, WEIGHT_SEED + 120)
+    synth.fill_bn_stats_(model, WEIGHT_SEED + 121)
+    rl, mods = [3, 2], ["m1", "m2", "m1", "m1", "m2"]
+    nx, ny = 128, 64
+    pil = {m: synth.make_pillars(4000, mods.count(m), nx, ny, DATA_SEED + 120 + i, voxel_size=[0.4, 0.4, 4.0], pc_range=args["lidar_range"])
+           for i, m in enumerate(("m1", "m2"))}
+    ptm = synth.make_pairwise_t_matrix(rl, 5, DATA_SEED + 123, max_shift=6.0)
+    data = {"agent_modality_list": mods, "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm)}
+    for m in ("m1", "m2"):
+        data[f"inputs_{m}"] = {k: torch.from_numpy(pil[m][k]) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
+    import contextlib, io
+    with torch.no_grad(), PatchedNoise(NOISE_SEED + 120), contextlib.redirect_stdout(io.StringIO()):   # the reference prints every forward
+        out = model(data)
+    rec = dict(args=json.dumps(args), weight_seed=WEIGHT_SEED + 120, bn_seed=WEIGHT_SEED + 121, data_seed=DATA_SEED + 120, pose_seed=DATA_SEED + 123,
+               noise_seed=NOISE_SEED + 120, record_len=np.asarray(rl), mods=np.asarray(mods), M=4000, nx=nx, ny=ny, max_shift=6.0,
+               out_keys=np.asarray(sorted(out.keys())), keys=np.asarray(sorted(model.state_dict().keys())),
+               frozen=np.asarray(sorted(n for n, p in model.named_parameters() if not p.requires_grad)),
+               message=out["message"].numpy(), gt_feature=sub(out["gt_feature"].numpy(), 5), pred_feature=sub(out["pred_feature"].numpy(), 5),
+               cls_preds=out["cls_preds"].numpy(), reg_preds=out["reg_preds"].numpy(), dir_preds=out["dir_preds"].numpy())
+    np.savez_compressed(os.path.join(OUT, "shell2.npz"), **rec)
+    print(f"shell2: wrote shell2.npz ({os.path.getsize(os.path.join(OUT, 'shell2.npz')) / 1024:.0f} KiB), {len(rec['keys'])} state_dict keys, "
+          f"{len(rec['frozen'])} frozen parameters, |cls| mean {out['cls_preds'].abs().mean().item():.4f}")
+
+
 def dump_state_dict_keys() -> None:
     """Key names + shapes of the reference modules: the checkpoint contract."""
     from opencood.models.gencomm_modules.cond_diff import GenComm
@@ -801,7 +852,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "apchain": run_apchain_case, "wide": run_wide_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "apchain": run_apchain_case, "wide": run_wide_case, "shell2": run_shell2_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()

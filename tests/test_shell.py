@@ -243,3 +243,41 @@ def test_second_shell_forward_runs_on_the_hip_path():
     assert list(out["cls_preds"].shape) == [2, 2, 16, 32] and list(out["pred_feature"].shape) == [3, 128, 16, 32]
     for k in ("cls_preds", "reg_preds", "dir_preds", "pred_feature", "message"):
         assert torch.isfinite(out[k]).all(), k
+
+
+def test_stage2_shell_has_the_reference_keys_and_frozen_set():
+    """tests/golden/shell2.npz: the reference's own stage-2 shell (two lidar modalities, `diffcomm:` key spelling, `trick`): same
+    state_dict keys, and the same parameters frozen by model_train_init (stage2.py:180-185: everything but the new agent type's
+    message extractor)."""
+    g = load_case("shell2")
+    args = json.loads(str(g["args"]))
+    model = _resolve("heter_model_baseline_w_gencomm_stage2")(copy.deepcopy(args))
+    assert sorted(model.state_dict().keys()) == list(g["keys"])
+    assert sorted(n for n, p in model.named_parameters() if not p.requires_grad) == list(g["frozen"])
+
+
+@pytest.mark.gpu
+def test_stage2_shell_forward_vs_reference_golden():
+    g = load_case("shell2")
+    args = json.loads(str(g["args"]))
+    dev = "cuda:0"
+    model = _resolve("heter_model_baseline_w_gencomm_stage2")(copy.deepcopy(args)).eval()
+    synth.fill_params_(model, int(g["weight_seed"]))
+    synth.fill_bn_stats_(model, int(g["bn_seed"]))
+    model = model.to(dev)
+    rl, mods = [int(v) for v in g["record_len"]], [str(m) for m in g["mods"]]
+    ptm = synth.make_pairwise_t_matrix(rl, 5, int(g["pose_seed"]), max_shift=float(g["max_shift"]))
+    data = {"agent_modality_list": mods, "record_len": torch.tensor(rl), "pairwise_t_matrix": torch.from_numpy(ptm).to(dev)}
+    for i, m in enumerate(("m1", "m2")):
+        pil = synth.make_pillars(int(g["M"]), mods.count(m), int(g["nx"]), int(g["ny"]), int(g["data_seed"]) + i, voxel_size=[0.4, 0.4, 4.0],
+                                 pc_range=args["lidar_range"])
+        data[f"inputs_{m}"] = {k: torch.from_numpy(pil[k]).to(dev) for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
+    with torch.no_grad(), shell_noise(model.gencomm, int(g["noise_seed"]), sum(rl), 128, 16, 32, dev):
+        out = model(data)
+    assert sorted(out.keys()) == list(g["out_keys"])
+    tol = dict(rtol=2e-4, atol=5e-5)
+    assert_close(out["message"].cpu().numpy(), g["message"], what="message", **tol)
+    assert_close(sub(out["gt_feature"], 5), g["gt_feature"], what="gt_feature", **tol)
+    assert_close(sub(out["pred_feature"], 5), g["pred_feature"], what="pred_feature", **tol)
+    for k in ("cls_preds", "reg_preds", "dir_preds"):
+        assert_close(out[k].cpu().numpy(), g[k], what=k, **tol)
