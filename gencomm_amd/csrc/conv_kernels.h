@@ -548,13 +548,14 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
   }
   // 8-row tiles (two accumulators per wave) whenever they still give the launch >= 2 workgroups per CU
   const long long tiles8 = (long long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
-  const bool ty8 = a.Ho >= 8 && tiles8 * ((a.CoutP + 63) / 64) * N >= 512;
+  // (not for 1 x 1: its weight slab is small against the pixel patch, and the doubled patch staging cost 9 % on the Enhancer's Linear layers)
+  const bool ty8 = a.Ho >= 8 && KH > 1 && tiles8 * ((a.CoutP + 63) / 64) * N >= 512;
   const int tiles = ty8 ? (int)tiles8 : ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
   const dim3 grid(tiles, (a.CoutP + 63) / 64, N);
   if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");
   if (KH == 3 && KW == 3 && a.stride == 1) { if (ty8) conv2d_igemm_kernel<3, 3, 8, 1, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<3, 3, 8, 1><<<grid, 256, 0, st>>>(a); }
   else if (KH == 3 && KW == 3 && a.stride == 2) { if (ty8) conv2d_igemm_kernel<3, 3, 8, 2, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<3, 3, 8, 2><<<grid, 256, 0, st>>>(a); }
-  else if (KH == 1 && KW == 1 && a.stride == 1) { if (ty8) conv2d_igemm_kernel<1, 1, 32, 1, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<1, 1, 32, 1><<<grid, 256, 0, st>>>(a); }
+  else if (KH == 1 && KW == 1 && a.stride == 1) conv2d_igemm_kernel<1, 1, 32, 1><<<grid, 256, 0, st>>>(a);
   else if (KH == 2 && KW == 2 && a.stride == 1) { if (ty8) conv2d_igemm_kernel<2, 2, 8, 1, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<2, 2, 8, 1><<<grid, 256, 0, st>>>(a); }   // sub-pixel form of a transposed 3x3 stride-2 conv
   else return fail(GC_ERR_ARG, "conv2d: supported shapes are 3x3 stride 1/2 and 1x1 stride 1 (ConvTranspose2d with kernel == stride runs as 1x1)");
   GC_HIP(hipGetLastError());
