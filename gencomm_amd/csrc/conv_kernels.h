@@ -204,9 +204,17 @@ __global__ void conv_prep_w_kernel(const PrepWArgs a) {
     const long long k = i / a.Cout;
     const int ci = (int)(k / khw), tap = (int)(k - (long long)ci * khw);
     a.out[i] = a.w[((size_t)co * a.Cin + ci) * khw + tap];
-  } else {
+  } else if (a.transposed == 1) {
     // 1x1 GEMM with CoutP = Cout*khw rows: out[ci][co*khw + tap] = w[ci][co][tap]  (already that order)
     a.out[i] = a.w[i];
+  } else {
+    // transposed == 2, the INPUT-GRADIENT convolution of a stride-1 layer with forward weights w[Cout][Cin][KH][KW] (here "Cin" / "Cout" are
+    // the gradient convolution's own: its input channels = the forward's outputs): out[(g*KHW + tap)][c] = w[g][c][KHW - 1 - tap] with
+    // g over a.Cin (forward outputs) and c over a.Cout (forward inputs) -- the flip + transpose + contiguous + prepare of four launches in one
+    const int c = (int)(i % a.Cout);
+    const long long k = i / a.Cout;
+    const int g = (int)(k / khw), tap = (int)(k - (long long)g * khw);
+    a.out[i] = a.w[((size_t)g * a.Cout + c) * khw + (khw - 1 - tap)];
   }
 }
 

@@ -44,10 +44,36 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad: int
     return y
 
 
+_UNIT_SS = {}
+
+
+def _unit_scale_shift(c: int, device) -> torch.Tensor:
+    """[2, c]: scale 1, shift 0 (a convolution without bias or folded norm) -- cached per (c, device): no fold launch per call."""
+    key = (c, str(device))
+    if key not in _UNIT_SS:
+        ss = torch.zeros(2, c, dtype=torch.float32, device=device)
+        ss[0].fill_(1.0)
+        _UNIT_SS[key] = ss
+    return _UNIT_SS[key]
+
+
 def conv2d_dgrad(dy: torch.Tensor, w: torch.Tensor, pad: int) -> torch.Tensor:
-    """Input gradient of a stride-1 convolution: the same kernel with the transposed, tap-flipped weight."""
-    k = w.shape[2]
-    return conv2d(dy, w.detach().flip(2, 3).transpose(0, 1).contiguous(), None, k - 1 - pad)
+    """Input gradient of a stride-1 convolution: the same kernel with the transposed, tap-flipped weight -- laid out by ONE prepare
+    launch (gencomm_conv2d_prepare, transposed = 2) instead of flip + transpose + contiguous + prepare, and with a cached unit
+    scale / zero shift instead of a fold launch."""
+    dy, w = _c(dy), _c(w)
+    cout, cin, kh, kw = w.shape            # forward weights: the gradient convolution maps cout -> cin channels
+    n, _, H, W = dy.shape
+    l, st, dev = _lib.lib(), stream_ptr(dy.device), dy.device
+    prepared = torch.empty(w.numel(), dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cout, cin, kh, kw, 2, st), "gencomm_conv2d_prepare")
+    ss = _unit_scale_shift(cin, dev)
+    p = kh - 1 - pad
+    Ho, Wo = H + 2 * p - kh + 1, W + 2 * p - kw + 1
+    dx = torch.empty(n, cin, Ho, Wo, dtype=torch.float32, device=dev)
+    _lib.check(l.gencomm_conv2d_fwd(ptr(dy), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(dx), n, cout, H, W, cin, kh, kw, 1, p, 0, 1, cin, 0, st),
+               "gencomm_conv2d_fwd")
+    return dx
 
 
 def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, k: int, pad: int, bias: bool, stride: int = 1) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -103,8 +129,7 @@ def _conv3x3_s2_dgrad_subpixel(dy: torch.Tensor, w: torch.Tensor) -> torch.Tenso
     l, st = _lib.lib(), stream_ptr(dev)
     prepared = torch.empty(wp.numel(), dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_conv2d_prepare(ptr(wp), ptr(prepared), cout, cin * 4, 2, 2, 0, st), "gencomm_conv2d_prepare")
-    ss = torch.empty(2, cin, dtype=torch.float32, device=dev)
-    _lib.check(l.gencomm_conv2d_fold(None, None, None, None, None, 0.0, cin, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
+    ss = _unit_scale_shift(cin, dev)
     dx = torch.empty(n, cin, 2 * Ho, 2 * Wo, dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_conv2d_fwd(ptr(dy), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(dx), n, cout, Ho, Wo, cin, 2, 2, 1, 0, 0, 2, cin, 0, st),
                "gencomm_conv2d_fwd")

@@ -276,7 +276,9 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  *   BaseBEVBackbone            opencood/models/sub_modules/base_bev_backbone.py:40-92, :94-123
  *   DownsampleConv/DoubleConv  opencood/models/sub_modules/downsample_conv.py:17-24
  *   cls/reg/dir heads          opencood/models/heter_model_baseline_w_gencomm_stage1.py:137-142
- * prepare: OIHW (transposed = 0) or ConvTranspose2d IOHW with kernel == stride (transposed = 1) -> k-major matrix
+ * prepare: OIHW (transposed = 0), ConvTranspose2d IOHW with kernel == stride (transposed = 1), or (transposed = 2) the INPUT-GRADIENT
+ *          convolution of a stride-1 layer straight from its forward OIHW weights (Cin = the forward's output channels, Cout = its input
+ *          channels; taps flipped, channels transposed: what flip + transpose + contiguous + prepare did in four launches) -> k-major matrix
  *          [Cin*KH*KW][Cout] (resp. [Cin][Cout*KH*KW]) of the same number of floats.
  * fold:    BatchNorm2d (eval) and/or conv bias -> per-channel scale/shift; pass NULL for the four BN tensors
  *          (and/or conv_bias) when absent.
