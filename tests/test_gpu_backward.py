@@ -41,7 +41,8 @@ def _oracle_grads(cfg, gen, feat, cond, rl, n0, sn, single_t=None):
     return out.detach(), float(loss), dict(zip(names, grads[:-2])), grads[-2], grads[-1]
 
 
-@pytest.mark.parametrize("C,H,W,n,levels,t", [(16, 16, 24, 2, 2, 1), (8, 24, 40, 1, 3, 0), (32, 20, 68, 3, 2, 2)])
+@pytest.mark.parametrize("C,H,W,n,levels,t", [(16, 16, 24, 2, 2, 1), (8, 24, 40, 1, 3, 0), (32, 20, 68, 3, 2, 2),
+                                              (8, 192, 384, 4, 2, 1)])   # > 768 tile-items per weight-gradient launch: several tiles per workgroup + partial sums
 def test_unet_call_backward_all_gradients_vs_oracle_autograd(C, H, W, n, levels, t):
     from gencomm_amd import GenComm, synth
     from gencomm_amd.autograd import UNetFunction

@@ -14,7 +14,9 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 8, 37, 50, 3), (1, 16, 8, 16, 24, 3), (2, 16, 8, 20, 36, 1), (1, 66, 8, 18, 26, 3), (1, 8, 64, 18, 26, 3),
-                                   (3, 8, 8, 200, 64, 3)])
+                                   (3, 8, 8, 200, 64, 3),
+                                   # enough tiles for several tiles per workgroup (the prefetching tile loop), the last workgroup short
+                                   (4, 8, 8, 200, 672, 3), (4, 16, 8, 200, 352, 3), (4, 16, 8, 200, 704, 1)])
 def test_weight_gradient_on_the_matrix_cores_vs_float64(shape):
     from gencomm_amd import train_ops as T
     N, Cin, Cout, H, W, K = shape
