@@ -288,7 +288,7 @@ def main():
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the scene's launch sequence as a captured HIP graph")
     ap.add_argument("--mode", action="append", default=[], metavar="KEY=VALUE",
-                    help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow), e.g. --mode xcd=0")
+                    help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow resfuse_emu tile8), e.g. --mode xcd=0")
     ap.add_argument("--share-device", action="store_true",
                     help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
     ap.add_argument("--train-batch", type=int, default=2, help="--workload train: scenes per rank and step (m1_att.yaml batch_size: 2)")
@@ -328,7 +328,7 @@ def main():
     lib = _lib.lib()
     mode_keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
                  "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP,
-                 "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU}
+                 "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU, "tile8": _lib.MODE_TILE8}
     for kv in args.mode:
         k, v = kv.split("=")
         _lib.check(lib.gencomm_set_mode(mode_keys[k], int(v)), "gencomm_set_mode")

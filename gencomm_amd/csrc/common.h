@@ -54,7 +54,9 @@ enum ModeKey : int {
   MODE_XCD_REMAP = 5,    // 1: workgroup -> tile mapping keeps neighbouring tiles on one XCD (default); 0: plain grid order
   MODE_DATAFLOW = 6,     // 1: the UNet body of a call runs as ONE persistent dataflow launch (dataflow_kernels.h); 0: one launch per layer
   MODE_RESFUSE_EMU = 7,  // TIMING EXPERIMENT ONLY, off by default -- the results are NOT the UNet's: unet_host.h "ResnetBlock fusion, emulated"
-  MODE_COUNT = 8
+  MODE_TILE8 = 8,        // n > 0: GroupNorm'd 8-channel layers on the f16 pipe whose launch has fewer than n workgroups of 64 x 16 pixels run
+                         // 64 x 8 tiles (conv8h8_kernels.h; VERDICT r3 item 3b: the half-resolution level); 0 (default): 64 x 16 everywhere
+  MODE_COUNT = 9
 };
 struct Modes {
   long long v[MODE_COUNT];

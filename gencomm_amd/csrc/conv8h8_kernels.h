@@ -1,0 +1,280 @@
+// conv8h_kernel's layer (8 or 8 + 8 -> 8 channels, 3x3, GroupNorm + SiLU staging, three-term f16-pipe products: conv8h_kernels.h) on
+// 64 x 8-pixel tiles -- VERDICT r3 item 3(b): the half-resolution level of the metric workload gives a launch only 672 workgroups of
+// 64 x 16 pixels (less than one round of the 768 resident), so its time is one workgroup's dependent chain; a 64 x 8 tile has half the
+// chain, 28.8 KB of LDS instead of 51.8 (four or five workgroups per CU) and twice the workgroups.
+//
+// Same arithmetic, same LDS record layout per row ([4 phases][18 slots][8 ch] fp16, hi / lo planes + bf8 third-term plane) with
+// 10 rows instead of 18; wave w owns ONE row pair (output rows 2w, 2w + 1): M = 16 = 8 channels x 2 rows, three tap groups, six matrix
+// instructions per product block, 16 accumulator registers.  Selected by GENCOMM_MODE_TILE8 (unet_host.h); no nearest-x2 variant
+// (the Upsample convolution only exists at full resolution).
+#pragma once
+#include "conv8h_kernels.h"
+
+namespace gc {
+
+constexpr int H8_TH = 8, H8_LH = H8_TH + 2;
+constexpr int H8_PLANE = H8_LH * HC_ROW;        // 11520 bytes per fp16 plane
+constexpr int H8_TPLANE = H8_PLANE / 2;         // bf8 third-term plane
+constexpr int H8_TOFF = 2 * H8_PLANE;
+constexpr int H8_TILE_BYTES = 2 * H8_PLANE + H8_TPLANE;   // 28800
+
+// this thread's share of the 10 x 66 x 8 tile: rows 0..9 x 16 quads by threads 0..159 (8 channels each), halo columns by threads 0..79
+struct Tile8Regs {
+  float4 v[8];
+  float2 h;
+};
+template <bool GN>
+__device__ __forceinline__ void h8_load(Tile8Regs& R, const float* __restrict__ sp, unsigned plane_in, int H, int W, int x0, int y0, int tid) {
+  const int r0 = tid >> 4, qx = tid & 15;
+  if (r0 < H8_LH) {
+    const int gy = y0 - 1 + r0, gx = x0 + 4 * qx;
+    if (GN) {   // every quad loaded from the nearest in-image position; out-of-image quads are blanked through the coefficients (stage)
+      const int cy = min(max(gy, 0), H - 1), cx = min(gx, W - 4);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) R.v[c] = *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)cy * (unsigned)W + (unsigned)cx));
+    } else {
+      const bool ok = gy >= 0 && gy < H && gx < W;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        R.v[c] = ok ? *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)gy * (unsigned)W + (unsigned)gx)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  R.h = make_float2(0.f, 0.f);
+  if (tid < H8_LH * 8) {
+    const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
+    const int gy = y0 - 1 + r, gx = side ? x0 + HC_TW : x0 - 1;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const unsigned o = (unsigned)gy * (unsigned)W + (unsigned)gx;
+      R.h.x = sp[(unsigned)(2 * cp) * plane_in + o];
+      R.h.y = sp[(unsigned)(2 * cp + 1) * plane_in + o];
+    }
+  }
+}
+// GroupNorm + SiLU (GN) or a power-of-two scale, three-term split, LDS records (conv8h's hc_store_main3 / hc_store_halo3 at this tile's offsets)
+template <bool GN>
+__device__ __forceinline__ void h8_stage(unsigned char* tile, const Tile8Regs& R, int H, int W, int x0, int y0, const float (*ab)[2], int tid, float mul) {
+  const int r0 = tid >> 4, qx = tid & 15;
+  if (r0 < H8_LH) {
+    const int gy = y0 - 1 + r0, gx = x0 + 4 * qx;
+    const bool ok = gy >= 0 && gy < H && gx < W;
+    float e[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      e[c][0] = R.v[c].x; e[c][1] = R.v[c].y; e[c][2] = R.v[c].z; e[c][3] = R.v[c].w;
+      if (GN) {
+        const float A = ok ? ab[c][0] : 0.f, B = ok ? ab[c][1] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[c][j] = silu_f(fmaf(A, e[c][j], B));
+      } else if (mul != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[c][j] *= mul;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 hi, lo;
+      float t[8];
+      split3_pair(e[0][j], e[1][j], hi.x, lo.x, t[0], t[1]);
+      split3_pair(e[2][j], e[3][j], hi.y, lo.y, t[2], t[3]);
+      split3_pair(e[4][j], e[5][j], hi.z, lo.z, t[4], t[5]);
+      split3_pair(e[6][j], e[7][j], hi.w, lo.w, t[6], t[7]);
+      const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
+      *reinterpret_cast<uint4*>(tile + addr) = hi;
+      *reinterpret_cast<uint4*>(tile + H8_PLANE + addr) = lo;
+      *reinterpret_cast<uint2*>(tile + H8_TOFF + (addr >> 1)) = make_uint2(bf8x4s(t[0], t[1], t[2], t[3]), bf8x4s(t[4], t[5], t[6], t[7]));
+    }
+  }
+  if (tid < H8_LH * 8) {
+    const int cp = tid & 3, side = (tid >> 2) & 1, r = tid >> 3;
+    float e0 = R.h.x, e1 = R.h.y;
+    if (GN) {
+      const int gy = y0 - 1 + r, gx = side ? x0 + HC_TW : x0 - 1;
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      e0 = ok ? silu_f(fmaf(ab[2 * cp][0], e0, ab[2 * cp][1])) : 0.f;
+      e1 = ok ? silu_f(fmaf(ab[2 * cp + 1][0], e1, ab[2 * cp + 1][1])) : 0.f;
+    } else if (mul != 1.0f) {
+      e0 *= mul;
+      e1 *= mul;
+    }
+    uint32_t hi, lo;
+    float ta, tb;
+    split3_pair(e0, e1, hi, lo, ta, tb);
+    const int addr = hc_addr(r, side ? HC_TW : -1) + cp * 4;
+    *reinterpret_cast<uint32_t*>(tile + addr) = hi;
+    *reinterpret_cast<uint32_t*>(tile + H8_PLANE + addr) = lo;
+    *reinterpret_cast<uint16_t*>(tile + H8_TOFF + (addr >> 1)) = (uint16_t)bf8x2s(ta, tb);
+  }
+}
+// per-lane B-operand byte offsets of wave `wave`'s row pair (rows 2 wave, 2 wave + 1 of the tile): hc_lane_offsets with a 2-row pitch
+__device__ __forceinline__ void h8_lane_offsets(int (&off)[4][3], int wave, int lane) {
+  const int n = lane & 15, kg = lane >> 4;
+  constexpr int WRAP = 4 * HC_PHASE - 16;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int t = 4 * c + kg, dyp = t / 3, sx = t - 3 * dyp - 1;
+    const int base = (2 * wave + dyp) * HC_ROW + (n + 1) * 16 + sx * HC_PHASE;
+    off[0][c] = base + (sx < 0 ? WRAP : 0);
+    off[1][c] = base + HC_PHASE;
+    off[2][c] = base + 2 * HC_PHASE;
+    off[3][c] = base + 3 * HC_PHASE - (sx > 0 ? WRAP : 0);
+  }
+}
+// one 8-input-channel source, ONE row pair: acc[j] += W (*) tile.  The bf8 pass of a tap group comes first (fenced), its five f16
+// passes follow: >= 4 matrix instructions between instructions of different input type on one accumulator (conv_tile_mfma3's rule)
+__device__ __forceinline__ void h8_mfma3(const unsigned char* tile, const float* __restrict__ tab, f32x4 (&acc)[4], const int (&off)[4][3], int lane) {
+  WA3 cur, nxt;
+  load_wa3(cur, tab, 0, lane);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (c < 2) load_wa3(nxt, tab, c + 1, lane);
+    long bt[4];
+    half8_t bh[4], bl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bt[j] = *reinterpret_cast<const long*>(tile + H8_TOFF + (off[j][c] >> 1));
+      bh[j] = *reinterpret_cast<const half8_t*>(tile + off[j][c]);
+      bl[j] = *reinterpret_cast<const half8_t*>(tile + H8_PLANE + off[j][c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // the order is pinned: a matrix instruction of the other input type must not follow its accumulator's
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(cur.wb, bt[j], acc[j], 0, 0, 0);   // writer within two instructions (tests/test_abi.py)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[2], bh[j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[1], bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[1], bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[0], bl[j], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.w[0], bh[j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c < 2) cur = nxt;
+  }
+}
+
+// NSRC 1 | 2, GN (GroupNorm + SiLU staging; !GN: raw input with a power-of-two range scale from a.amax / the statistics), RES 0 | 1 | 2
+template <int NSRC, bool GN, int RES>
+__global__ __launch_bounds__(HC_NT, NSRC == 2 ? 3 : 4) void conv8h8_kernel(const Conv8Args a) {
+  __shared__ __align__(16) unsigned char tile[H8_TILE_BYTES];
+  __shared__ float s_ab[16][2];
+  __shared__ float s_red[HC_NT / 64][16];
+  fp16_ovfl_clamp();
+  const BlockId bid = xcd_block(a.xcd);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = bid.z, x0 = bid.x * HC_TW, y0 = bid.y * H8_TH;
+  const size_t plane = (size_t)a.H * a.W;
+  // output ownership: pixels x0 + 4 ln .. + 3, row y0 + 2 wave + rr, channels 4 ch + i
+  const int ln = lane & 15, g = lane >> 4, ch = g & 1, rr = g >> 1;
+  const int gx = x0 + 4 * ln, gy = y0 + 2 * wave + rr;
+  const bool vec_ok = gx + 3 < a.W;
+  const bool wave_live = y0 + 2 * wave < a.H;
+  float mul = 1.0f;
+  if (!GN) {
+    float bound = 0.f;
+    if (a.amax != nullptr) {
+      bound = *a.amax;
+    } else if (a.sstat[0] != nullptr) {
+      const double* st = a.sstat[0] + (size_t)n * 16;
+      double q = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) q = fmax(q, __hip_atomic_load(st + 2 * c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      bound = sqrtf((float)q) * 1.0001f;
+    }
+    mul = act_scale(bound);
+  }
+  const float inv_s = a.wh[NSRC * HC_WTAB3] / mul;
+  const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + 4 * ch);
+  const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+  Tile8Regs R;
+  h8_load<GN>(R, a.src[0] + (size_t)n * 8 * plane, (unsigned)plane, a.H, a.W, x0, y0, tid);
+  if (GN) {
+    if (tid < NSRC * 8) {
+      const int s = tid >> 3, c = tid & 7;
+      float A, B;
+      gn_coeff(a.sstat[s] + (size_t)n * 16, c, 2 * NSRC, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
+      s_ab[tid][0] = A;
+      s_ab[tid][1] = B;
+    }
+    __syncthreads();
+  }
+  f32x4 acc[4];
+  {
+    const float sc = a.wh[NSRC * HC_WTAB3 + 1] * mul;
+    const f32x4 b0 = {bias[0] * sc, bias[1] * sc, bias[2] * sc, bias[3] * sc};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = b0;
+  }
+  h8_stage<GN>(tile, R, a.H, a.W, x0, y0, &s_ab[0], tid, mul);
+  int off[4][3];
+  h8_lane_offsets(off, wave, lane);
+  float resv[RES == 1 ? 4 : 1][4];
+  if (RES == 1 && wave_live) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_ok && gy < a.H) r = *reinterpret_cast<const float4*>(rp);
+      resv[i][0] = r.x; resv[i][1] = r.y; resv[i][2] = r.z; resv[i][3] = r.w;
+    }
+  }
+  if (NSRC == 2) h8_load<GN>(R, a.src[1] + (size_t)n * 8 * plane, (unsigned)plane, a.H, a.W, x0, y0, tid);   // in flight during the first matrix phase
+  __syncthreads();
+  if (wave_live) h8_mfma3(tile, a.wh, acc, off, lane);
+  if (NSRC == 2) {
+    __syncthreads();
+    h8_stage<GN>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid, 1.0f);
+    __syncthreads();
+    if (wave_live) h8_mfma3(tile, a.wh + HC_WTAB3, acc, off, lane);
+  }
+  float part[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[i] = 0.f;
+  if (wave_live) {
+    float out[4][4];  // [channel i][pixel j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[i][j] = RES == 1 ? fmaf(acc[j][i], inv_s, resv[i][j]) : acc[j][i] * inv_s;
+    if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
+#pragma unroll 8
+      for (int c = 0; c < 16; ++c) {
+        const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + c * 8 + 4 * ch);
+        const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+        const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + (size_t)gy * a.W + gx;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec_ok && gy < a.H) t = *reinterpret_cast<const float4*>(rp);
+        const float r[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[i][j] = fmaf(wv[i], r[j], out[i][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (vec_ok && gy < a.H) {
+        float* __restrict__ dp = a.dst + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
+        *reinterpret_cast<float4*>(dp) = make_float4(out[i][0], out[i][1], out[i][2], out[i][3]);
+        float s = out[i][0] + out[i][1], q = out[i][0] * out[i][0];
+        q = fmaf(out[i][1], out[i][1], q);
+#pragma unroll
+        for (int j = 2; j < 4; ++j) { s += out[i][j]; q = fmaf(out[i][j], out[i][j], q); }
+        part[i] = s;
+        part[4 + i] = q;
+      }
+    }
+  }
+  if (a.dstat != nullptr) hc_stats_commit(part, s_red, a.dstat + (size_t)n * 16, tid);
+}
+
+}  // namespace gc

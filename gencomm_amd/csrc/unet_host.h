@@ -5,6 +5,7 @@
 #include "attn_kernels.h"
 #include "conv8b_kernels.h"
 #include "conv8h_kernels.h"
+#include "conv8h8_kernels.h"
 #include "dataflow_kernels.h"
 #include "latent_kernels.h"
 #include "latenth_kernels.h"
@@ -52,6 +53,13 @@ inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, h
   const int variant = UP ? 16 : (RES == 2 ? 8 : (RES == 1 ? 4 : (NSRC == 2 ? 2 : 1)));  // MODE_CONV8H_MASK: diagnostic
   if constexpr (RES != 3)   // RES 3 = the backward's GroupNorm epilogue: exact-fp32 kernel only
   if (t == TILE_64x16 && a.wh != nullptr && m.split() && (m.v[MODE_CONV8H_MASK] & variant)) {
+    if constexpr (GN && !UP) {   // 64 x 8 tiles for launches with few workgroups (MODE_TILE8: the half-resolution level)
+      if (m.v[MODE_TILE8] > 0 && (long long)grid.x * grid.y * grid.z < m.v[MODE_TILE8] && (a.W & 3) == 0 && a.W >= 4) {
+        GC_KLOG(NSRC == 2 ? "conv8h8_kernel<2,GN,0> (64x8 tiles)" : RES == 2 ? "conv8h8_kernel<1,GN,2> (64x8 tiles)" : RES == 1 ? "conv8h8_kernel<1,GN,1> (64x8 tiles)" : "conv8h8_kernel<1,GN,0> (64x8 tiles)");
+        conv8h8_kernel<NSRC, GN, RES><<<dim3(cdiv(a.W, 64), cdiv(a.H, 8), n), 256, 0, st>>>(a);
+        return;
+      }
+    }
     GC_KLOG(UP ? "conv8h_kernel<1,0,UP,0>" : NSRC == 2 ? "conv8h_kernel<2,GN,0,0>" : RES == 2 ? "conv8h_kernel<1,GN,0,2>" : RES == 1 ? "conv8h_kernel<1,GN,0,1>" : GN ? "conv8h_kernel<1,GN,0,0>" : "conv8h_kernel<1,0,0,0>");
     conv8h_kernel<NSRC, GN, UP, RES><<<grid, 256, 0, st>>>(a);
     return;

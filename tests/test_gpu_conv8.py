@@ -294,3 +294,59 @@ def test_forced_tiles_vs_oracle_on_odd_shapes(modes, shape):
         assert_close(e.cpu().numpy(), ref["enhanced"].numpy(), 1e-4, 1e-5, "enhanced (oracle input)")
         f = AttFusion(C)(ref["enhanced"].to(DEV), inp["record_len"], affine)
         assert_close(f.cpu().numpy(), ref["fused"].numpy(), 1e-4, 1e-5, "fused (oracle input)")
+
+
+# ---------------------------------------------------------------------- 64x8 tiles (GENCOMM_MODE_TILE8; conv8h8_kernels.h)
+@pytest.mark.parametrize("sampler", ["latent", "direct"])
+@pytest.mark.parametrize("name", ["tiny", "ragged", "mid", "shipped"])
+def test_golden_path_with_64x8_tiles_forced(modes, name, sampler):
+    modes(tile_want=1, tile8=10 ** 9, sampler=sampler)
+    g = load_case(name)
+    _, gen, _ = build_modules(g, "cuda:0")
+    inp = build_inputs(g, "cuda:0")
+    with torch.no_grad():
+        pred = gen(inp["feat"], inp["cond"], inp["record_len"], noise=eval_noise(g, "cuda:0"))["pred_feature"]
+    assert_close(sub(pred, int(g["stride"])), g["pred_feature"], 1e-4, 1e-5, f"pred_feature ({sampler}, 64x8 tiles)")
+
+
+@pytest.mark.parametrize("shape", [(8, 200, 704), (3, 100, 352), (2, 36, 68), (1, 8, 64), (2, 10, 60), (2, 18, 132)])
+def test_64x8_tiles_equal_64x16_tiles(modes, shape):
+    """Same arithmetic per pixel in both tilings: only the order of the f64 statistics atomics may differ."""
+    from gencomm_amd import GenComm, synth
+    n, H, W = shape
+    gen = GenComm(synth.default_gencomm_cfg(64, 20)).eval()
+    synth.fill_params_(gen, 5)
+    gen = gen.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(n, 66, H, W, generator=g, device=DEV)
+    t = torch.full((n,), 4.0, device=DEV)
+    ys = []
+    for tile8 in (0, 10 ** 9, 0, 10 ** 9):
+        modes(tile_want=1, tile8=tile8)
+        with torch.no_grad():
+            ys.append(gen.denoiser(x, t, T=20).clone())
+    assert float((ys[0] - ys[2]).abs().max()) < 1e-6
+    assert float((ys[1] - ys[3]).abs().max()) < 1e-6
+    assert float((ys[0] - ys[1]).abs().max()) < 1e-6
+    assert torch.isfinite(ys[1]).all()
+
+
+def test_64x8_tiles_vs_oracle_with_partial_tiles(modes):
+    """Height 34 -> 5 row tiles of 8 with 2 live rows in the last; half-resolution level 17 x 36 (3 row tiles, 1 live row)."""
+    from gencomm_amd import Enhancer, GenComm, synth
+    from oracle import torch_port as O
+    modes(tile_want=1, tile8=10 ** 9)
+    C, H, W, T, rl = 16, 34, 72, 3, [1, 3]
+    n = sum(rl)
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen, enh = GenComm(cfg).eval(), Enhancer(C, [8, 8], 4).eval()
+    synth.fill_params_(gen, 41)
+    synth.fill_params_(enh, 42)
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(rl, C, H, W, 43, max_shift=6.0).items()}
+    n0, sn = (torch.from_numpy(a) for a in synth.make_eval_noise(44, n, C, H, W, T))
+    ref = O.path_forward({k: v.detach() for k, v in gen.state_dict().items()}, {k: v.detach() for k, v in enh.state_dict().items()},
+                         cfg, inp["feat"], inp["cond"], inp["record_len"], inp["pairwise_t_matrix"], H * 0.8, W * 0.8, n0, sn)
+    gen = gen.to(DEV)
+    with torch.no_grad():
+        pred = gen(inp["feat"].to(DEV), inp["cond"].to(DEV), inp["record_len"], noise=(n0.to(DEV), sn.to(DEV)))["pred_feature"]
+    assert_close(pred.cpu().numpy(), ref["pred_feature"].numpy(), 1e-4, 1e-5, "pred_feature (64x8 tiles)")
