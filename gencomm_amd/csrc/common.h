@@ -56,7 +56,10 @@ enum ModeKey : int {
   MODE_RESFUSE_EMU = 7,  // TIMING EXPERIMENT ONLY, off by default -- the results are NOT the UNet's: unet_host.h "ResnetBlock fusion, emulated"
   MODE_TILE8 = 8,        // n > 0: GroupNorm'd 8-channel layers on the f16 pipe whose launch has fewer than n workgroups of 64 x 16 pixels run
                          // 64 x 8 tiles (conv8h8_kernels.h; VERDICT r3 item 3b: the half-resolution level); 0 (default): 64 x 16 everywhere
-  MODE_COUNT = 9
+  MODE_BWD_STREAMS = 9,  // 1 (default): gencomm_unet_bwd enqueues its weight-gradient launches on a library-owned side stream (forked from and
+                         // joined back to the caller's stream inside the call), so that they overlap the input-gradient chain, when the call
+                         // has at least 2^17 pixels (n H W); 2: always; 0: one stream
+  MODE_COUNT = 10
 };
 struct Modes {
   long long v[MODE_COUNT];

@@ -257,8 +257,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 template <int K>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs a) {
   constexpr int TW = 32, TH = 16, PAD = K / 2, PW = TW + 2 * PAD, PHt = TH + 2 * PAD, KK = K * K;
-  constexpr int NC = 8 * KK + 1, NT = (NC + 15) / 16;          // columns: (ic, tap) pairs + the ones column
-  constexpr int DPS = TH * TW + 4;                             // dY plane stride: +4 words puts the 8 channels of a pixel on 8 x 4 distinct banks
+  // K = 3 (PACK): the 16 rows of the A operand are the 8 output channels at dY rows y AND y + 1, the columns (ic, window row 0..3, dx):
+  // rows 0..7 take their taps from window rows 0..2, rows 8..15 from window rows 1..3 (the same X rows seen from one dY row lower), so one
+  // instruction serves two image rows -- 6 column tiles per row PAIR instead of 5 per row (8 of the 16 A rows were zeros); the bias gradient
+  // is the plain sum of the A values a lane reads.  K = 1: rows 8..15 are zeros and a column of ones carries the bias, as before.
+  constexpr bool PACK = K == 3;
+  constexpr int NC = 8 * KK + 1, NTO = (NC + 15) / 16;         // record layout of the partial sums: (ic, tap) pairs + the bias column
+  constexpr int NT = PACK ? 6 : NTO;                           // column tiles of the matrix phase (PACK: 8 x 12 = 96 columns)
+  constexpr int DRS = PACK ? TW + 4 : TW;                      // dY row stride (PACK: = 4 mod 32 words, plane = 8 mod 32: rows y / y + 1 of a channel on distinct banks)
+  constexpr int DPS = PACK ? TH * DRS + 8 : TH * TW + 4;       // dY plane stride: +4 words puts the 8 channels of a pixel on 8 x 4 distinct banks
 #ifdef WG_DIAG   // diagnostic builds (tools/diag/wgrad_ab.sh; results are wrong by construction): 1 = no matrix phase, 2 = no B-operand LDS reads,
                  // 4 = LDS reads without matrix instructions, 8 = no SiLU in the staging, 16 = no LDS stores of the X tile, 32 = no global loads
   constexpr int WGD = WG_DIAG;
@@ -271,12 +278,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
   constexpr int LEAD = PAD ? 4 : 0;
   constexpr int XQ = (LEAD + TW + PAD + 3) / 4;                // aligned quads per haloed row: 10 for K = 3 (columns -4 .. 35), 8 for K = 1
   constexpr int PWS = 4 * XQ, XPS = PHt * PWS + (K == 3 ? 20 : 4);   // X row / plane stride
-  constexpr int RED = 4 * NT * 16 * 8;                         // reduction buffer of the four waves (aliases the tiles)
-  constexpr int TILE_WORDS = 9 * DPS + 9 * XPS;
-  __shared__ float smem[TILE_WORDS > RED ? TILE_WORDS : RED];
+  constexpr int RED = PACK ? 4 * NT * 256 + 32 : 4 * NT * 16 * 8;   // reduction buffer of the four waves (aliases the tiles)
+  constexpr int NPL = PACK ? 8 : 9;                            // planes per operand tile (K = 1: + the zero / ones plane)
+  constexpr int TILE_WORDS = NPL * DPS + NPL * XPS;
+  __shared__ __align__(16) float smem[TILE_WORDS > RED ? TILE_WORDS : RED];
   __shared__ float s_gn[8][2];
-  float* const sdy = smem;                // [9][DPS], plane 8 = zeros (rows 8..15 of the A operand)
-  float* const sx = smem + 9 * DPS;       // [9][XPS], plane 8 = ones
+  float* const sdy = smem;                // [NPL][DPS]; K = 1: plane 8 = zeros (rows 8..15 of the A operand)
+  float* const sx = smem + NPL * DPS;     // [9][XPS], plane 8 = ones
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.z;
   const int Cin = a.c0 + a.c1, icc = (Cin + 7) / 8;
   const int occ = blockIdx.y / icc, ich = blockIdx.y - occ * icc;
@@ -297,18 +305,26 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
     if (ic < Cin) gn_coeff(a.gn_stat[ic < a.c0 ? 0 : 1] + (size_t)n * 16, tid, a.gn_gs, a.gn_inv_cnt, a.gn_gamma[ic], a.gn_beta[ic], &A, &B);
     s_gn[tid][0] = A; s_gn[tid][1] = B;
   }
-  for (int i = tid; i < DPS; i += 256) sdy[8 * DPS + i] = 0.f;                 // the zero plane (rows 8..15 of the A operand)
-  for (int i = tid; i < PHt * PWS; i += 256) sx[8 * XPS + i] = 1.0f;             // the plane of ones (bias column)
+  if constexpr (!PACK) {
+    for (int i = tid; i < DPS; i += 256) sdy[8 * DPS + i] = 0.f;                 // the zero plane (rows 8..15 of the A operand)
+    for (int i = tid; i < PHt * PWS; i += 256) sx[8 * XPS + i] = 1.0f;             // the plane of ones (bias column)
+  }
 
   const int j = lane & 15, kq = lane >> 4;
-  const int aoff = (j < 8 ? j : 8) * DPS + kq;
+  const int aoff = PACK ? (j & 7) * DPS + (j >> 3) * DRS + kq : (j < 8 ? j : 8) * DPS + kq;
   int boff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int c = 16 * t + j;
-    const int ic = c < 8 * KK ? c / KK : 8, tap = c < 8 * KK ? c - ic * KK : 0;
-    boff[t] = ic * XPS + (tap / K) * PWS + (tap % K) + kq + (LEAD - PAD);
+    if constexpr (PACK) {
+      const int ic = c / 12, w = c - ic * 12;                   // w = window row (0..3) * 3 + dx
+      boff[t] = ic * XPS + (w / 3) * PWS + (w % 3) + kq + (LEAD - PAD);
+    } else {
+      const int ic = c < 8 * KK ? c / KK : 8, tap = c < 8 * KK ? c - ic * KK : 0;
+      boff[t] = ic * XPS + (tap / K) * PWS + (tap % K) + kq + (LEAD - PAD);
+    }
   }
+  float bsum = 0.f;   // PACK: sum of this lane's A values = its share of the bias gradient of channel j & 7
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -353,8 +369,8 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
 #pragma unroll
       for (int k = 0; k < QD; ++k) {
         const int i = tid + 256 * k;
-        const int o = i / (TH * (TW / 4)), r = i - o * (TH * (TW / 4));
-        *reinterpret_cast<float4*>(sdy + o * DPS + 4 * r) = qd[k];
+        const int o = i / (TH * (TW / 4)), r = i - o * (TH * (TW / 4)), py = r / (TW / 4), q4 = r - py * (TW / 4);
+        *reinterpret_cast<float4*>(sdy + o * DPS + py * DRS + 4 * q4) = qd[k];
       }
 #pragma unroll
       for (int k = 0; k < QX; ++k) {
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
         const int i = tid + 256 * k;
         const int o = i / (TH * TW), r = i - o * (TH * TW), py = r / TW, px = r - py * TW;
         const int oc = occ * 8 + o, oy = oy0 + py, ox = ox0 + px;
-        sdy[o * DPS + r] = (oc < a.Cout && oy < a.Ho && ox < a.Wo) ? a.dy[(((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox] : 0.f;
+        sdy[o * DPS + py * DRS + px] = (oc < a.Cout && oy < a.Ho && ox < a.Wo) ? a.dy[(((size_t)n * a.Cout + oc) * a.Ho + oy) * a.Wo + ox] : 0.f;
       }
 #pragma unroll 1
       for (int k = 0; k < NX; ++k) {
@@ -401,10 +417,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
     }
     if (!(WGD & 1)) {
 #pragma unroll 1
-    for (int y = 4 * wave; y < 4 * wave + 4; ++y) {
+    for (int y = 4 * wave; y < 4 * wave + 4; y += PACK ? 2 : 1) {
 #pragma unroll 4
       for (int s4 = 0; s4 < TW / 4; ++s4) {
-        const float av = sdy[aoff + y * TW + 4 * s4];
+        const float av = sdy[aoff + y * DRS + 4 * s4];
+        if constexpr (PACK) bsum += av;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const float bv = (WGD & 2) ? av : sx[boff[t] + y * PWS + 4 * s4];
@@ -416,19 +433,39 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_mfma_kernel(const WgradArgs
     }
   }
   __syncthreads();   // the tiles are dead: the reduction buffer aliases them
-  if (kq < 2) {      // rows 0..7 = output channels 4 kq + reg live in lanes 0..31
+  if constexpr (PACK) {
+    // all 16 rows are live: [wave][column 16 t + j][row 4 kq + reg]; the wave's bias sums go behind the four waves' records
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(smem + ((wave * NT + t) * 16 + j) * 16 + 4 * kq) = acc[t];
+    bsum += __shfl_xor(bsum, 8, 64);
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 8) smem[4 * NT * 256 + wave * 8 + lane] = bsum;
+  } else if (kq < 2) {      // rows 0..7 = output channels 4 kq + reg live in lanes 0..31
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) smem[((wave * NT + t) * 16 + j) * 8 + 4 * kq + reg] = acc[t][reg];
   }
   __syncthreads();
-  for (int i = tid; i < NT * 16 * 8; i += 256) {
+  for (int i = tid; i < NTO * 16 * 8; i += 256) {
     const int c = i >> 3, o = i & 7, oc = occ * 8 + o;
-    const float v = smem[i] + smem[NT * 128 + i] + smem[2 * NT * 128 + i] + smem[3 * NT * 128 + i];
-    if (a.part != nullptr) {   // [pair][workgroup of the pair][NT * 128]: coalesced, summed by conv_wgrad_reduce_kernel
+    float v = 0.f;
+    if constexpr (PACK) {
+      if (c < 8 * KK) {        // dW[o][ic][ty][tx] = row o of column (ic, ty, tx) + row 8 + o of column (ic, ty + 1, tx)
+        const int icl = c / KK, tap = c - icl * KK, c0 = (icl * 12 + tap) * 16 + o, c1 = (icl * 12 + tap + 3) * 16 + 8 + o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += smem[w * NT * 256 + c0] + smem[w * NT * 256 + c1];
+      } else if (c == 8 * KK) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += smem[4 * NT * 256 + w * 8 + o];
+      }
+    } else {
+      v = smem[i] + smem[NT * 128 + i] + smem[2 * NT * 128 + i] + smem[3 * NT * 128 + i];
+    }
+    if (a.part != nullptr) {   // [pair][workgroup of the pair][NTO * 128]: coalesced, summed by conv_wgrad_reduce_kernel
       const size_t wg = blockIdx.x + (size_t)gridDim.x * blockIdx.z;
-      a.part[((size_t)blockIdx.y * gridDim.x * gridDim.z + wg) * (NT * 128) + i] = v;
+      a.part[((size_t)blockIdx.y * gridDim.x * gridDim.z + wg) * (NTO * 128) + i] = v;
       continue;
     }
     if (oc >= a.Cout) continue;

@@ -88,13 +88,18 @@ const char* gencomm_build_info(void);
  *   GENCOMM_MODE_TILE8        0 (default): 64x16-pixel tiles in every 8-channel layer of the f16 pipe; n > 0: launches with fewer than n
  *                             such workgroups run 64x8 tiles (half the dependent chain per workgroup, 28.8 KB of LDS: the half-resolution
  *                             level of large maps).  Same arithmetic; results identical up to the summation order of the statistics
+ *   GENCOMM_MODE_BWD_STREAMS  1 (default): on calls of at least 2^17 pixels (n H W) gencomm_unet_bwd forks its weight-gradient launches onto a
+ *                             library-owned side stream of the device (hipEventRecord on the caller's stream / hipStreamWaitEvent) and joins
+ *                             them back before its last launches, so they overlap the input-gradient chain (15.2 -> 13.7 ms per training step
+ *                             at 4 x 64 x 200 x 704); every buffer is still ordered on the caller's stream when the call returns.  2: on every
+ *                             call (costs host time on small maps).  0: every launch on the caller's stream
  *   GENCOMM_MODE_RESFUSE_EMU  0 (default).  1: TIMING EXPERIMENT ONLY -- the 8 -> 8 ResnetBlocks run the launch pattern a fused
  *                             conv1 + conv2 block would have (statistics-only conv1 pass; conv2 pass reading the block input with twice
  *                             the matrix work), an upper bound of that fusion's gain; the outputs are NOT the UNet's */
 enum {
   GENCOMM_MODE_ARITH = 0, GENCOMM_MODE_SAMPLER = 1, GENCOMM_MODE_TILE_WANT = 2, GENCOMM_MODE_ENH_FUSE = 3,
   GENCOMM_MODE_CONV8H_MASK = 4, GENCOMM_MODE_XCD_REMAP = 5, GENCOMM_MODE_DATAFLOW = 6, GENCOMM_MODE_RESFUSE_EMU = 7,
-  GENCOMM_MODE_TILE8 = 8
+  GENCOMM_MODE_TILE8 = 8, GENCOMM_MODE_BWD_STREAMS = 9
 };
 int gencomm_set_mode(int key, long long value);
 long long gencomm_get_mode(int key);

@@ -167,7 +167,8 @@ def test_two_rank_ddp_gradient_sync_matches_single_process(tmp_path):
     print(f"2-rank DDP (gloo) averaged gradients vs single process: worst relative difference {worst:.2e}")
 
 
-@pytest.mark.parametrize("C,H,W,rl", [(16, 12, 20, [2, 1]), (64, 24, 40, [3]), (128, 16, 16, [1, 2])])
+@pytest.mark.parametrize("C,H,W,rl", [(16, 12, 20, [2, 1]), (64, 24, 40, [3]), (128, 16, 16, [1, 2]),
+                                      (16, 192, 384, [2])])   # >= 2^17 pixels: the weight gradients run on the side stream
 def test_enhancer_backward_hip_vs_torch_autograd(C, H, W, rl):
     """EnhancerFunction.backward (LayerNorm / conv / depthwise / GELU gradient kernels, gencomm_amd/train_ops.py) against
     torch autograd through the differentiable restatement of the stage: input gradient and every live parameter gradient."""

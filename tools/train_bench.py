@@ -12,6 +12,13 @@ DEV = "cuda:0"
 OPTIMIZER = "--no-optimizer" not in sys.argv
 ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""   # "shipped" / "large": one shape (profiling runs)
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1   # scenes per step (the shipped yamls train with batch_size 1, 2 or 4)
+if "--mode" in sys.argv:   # library modes for this run, e.g. --mode bwd_streams=0 (repeatable)
+    from gencomm_amd import _lib
+    _keys = {"arith": _lib.MODE_ARITH, "xcd": _lib.MODE_XCD_REMAP, "bwd_streams": _lib.MODE_BWD_STREAMS, "tile_want": _lib.MODE_TILE_WANT}
+    for _i, _a in enumerate(sys.argv):
+        if _a == "--mode":
+            _k, _v = sys.argv[_i + 1].split("=")
+            _lib.check(_lib.lib().gencomm_set_mode(_keys[_k], int(_v)), "gencomm_set_mode")
 SHAPES = {"shipped (2 agents, C=128, 64x128, T=3)": (2, 128, 64, 128, 3), "large: 4 agents, C=64, 200x704, T=3": (4, 64, 200, 704, 3)}
 for name, (N, C, H, W, T) in SHAPES.items():
     if ONLY and not name.startswith(ONLY):
