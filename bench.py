@@ -214,7 +214,12 @@ def train_main(args, rank, world, device, backend):
     model = model.to(device).train()
     # gradient_as_bucket_view: the gradients live in the all-reduce buckets (no per-parameter copy in and out of them: ~770 framework
     # launches per step less in profiles/r4_train_leg_kernel_stats.csv); same arithmetic as the reference's plain DDP wrapper
-    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True, gradient_as_bucket_view=True)
+    sync = None
+    if args.grad_sync == "ddp":
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True, gradient_as_bucket_view=True)
+    else:          # one flat bucket per step (gencomm_amd/dist.py FlatGradSync): the same average, 4 launches instead of 2 per parameter
+        ddp = model
+        sync = gdist.FlatGradSync(model.parameters(), dist)
     crit = PointPillarGencommLoss(synth.STAGE1_LOSS_ARGS)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=2e-3, eps=1e-10, weight_decay=1e-4, fused=True)   # m1_att.yaml:191-196
@@ -236,6 +241,8 @@ def train_main(args, rank, world, device, backend):
             labels = {k: torch.from_numpy(li[k]).to(device) for k in ("pos_equal_one", "neg_equal_one", "targets")}
         loss = crit(out, labels)
         loss.backward()
+        if sync is not None:
+            sync.sync()
         opt.step()
         return loss
 
@@ -254,7 +261,7 @@ def train_main(args, rank, world, device, backend):
     elapsed_here = time.perf_counter() - t0
     assert torch.isfinite(loss.detach()).all(), "non-finite training loss"
     value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed_here, dist, red_dev)
-    grad_bytes = sum(p.numel() * p.element_size() for p in params)
+    grad_bytes = sum(p.numel() * p.element_size() for p in params) if sync is None else sync.bucket_bytes
     if rank == 0:
         d = crit.logging(0, args.steps - 1, args.steps)
         print(json.dumps({
@@ -263,10 +270,12 @@ def train_main(args, rank, world, device, backend):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train: stage-1 recipe (opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml), {N} agents/scene, {B} scene(s)/step/GPU, "
                                    f"512x256 pillars -> 128x64x128 BEV, GenComm T={T}, forward + backward + Adam",
-                       "parallelism": f"dp{world} (DistributedDataParallel, find_unused_parameters=True)", "process_group": backend,
+                       "parallelism": (f"dp{world} (DistributedDataParallel, find_unused_parameters=True)" if sync is None else
+                                       f"dp{world} (one flat gradient bucket per step: cat -> all_reduce -> scale -> multi-tensor copy)"),
+                       "grad_sync": args.grad_sync, "process_group": backend,
                        "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "share_device": backend != "nccl",
                        "grad_bytes_allreduced_per_step": grad_bytes, "trainable_parameters": sum(p.numel() for p in params),
-                       "ddp_bucket_cap_mb": 25, "pillars_per_agent": 12000},
+                       "ddp_bucket_cap_mb": 25 if sync is None else None, "pillars_per_agent": 12000},
             "loss": d, "roofline": None, "cpu_baseline": None}), file=RESULT_OUT, flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -291,6 +300,8 @@ def main():
                     help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow resfuse_emu tile8), e.g. --mode xcd=0")
     ap.add_argument("--share-device", action="store_true",
                     help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
+    ap.add_argument("--grad-sync", choices=["flat", "ddp"], default="flat",
+                    help="--workload train: gradient averaging -- one flat bucket per step (gencomm_amd.dist.FlatGradSync) or torch DistributedDataParallel")
     ap.add_argument("--train-batch", type=int, default=2, help="--workload train: scenes per rank and step (m1_att.yaml batch_size: 2)")
     ap.add_argument("--train-agents", type=int, default=2, help="--workload train: agents per scene")
     ap.add_argument("--launch-timeout", type=float, default=None, help="seconds before the self-launcher stops its ranks")

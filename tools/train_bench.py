@@ -29,7 +29,7 @@ for name, (N, C, H, W, T) in SHAPES.items():
     feat = torch.randn(N * BATCH, C, H, W, generator=g, device=DEV).clamp_(min=0)
     cond = torch.randn(N * BATCH, 2, H, W, generator=g, device=DEV).requires_grad_(True)
     ptm = torch.from_numpy(synth.make_pairwise_t_matrix(rl, 5, 7, 10.0))
-    affine = normalize_pairwise_tfm(ptm, H * 0.4, W * 0.4, 1)
+    affine = normalize_pairwise_tfm(ptm, H * 0.4, W * 0.4, 1).to(DEV)   # the training loop moves the batch to the device before the model (train_utils.to_device)
     params = [p for p in list(gen.parameters()) + list(enh.parameters()) if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-5, fused=True) if OPTIMIZER else None   # train.py uses Adam (hypes_yaml optimizer block)
 
