@@ -254,9 +254,15 @@ def train_main(args, rank, world, device, backend):
     for _ in range(max(1, args.warmup)):
         step()
     barrier()
+    if args.sync_debug:      # diagnostic: one step with torch's synchronisation detector (every host <-> device sync point warns with a stack)
+        torch.cuda.set_sync_debug_mode("warn")
+        step()
+        torch.cuda.set_sync_debug_mode("default")
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    enqueue_here = time.perf_counter() - t0      # the host is done issuing; close to the elapsed time = the step is host-bound
     barrier()
     elapsed_here = time.perf_counter() - t0
     assert torch.isfinite(loss.detach()).all(), "non-finite training loss"
@@ -267,6 +273,7 @@ def train_main(args, rank, world, device, backend):
         print(json.dumps({
             "metric": "train scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_scene_per_gpu": 1e3 * elapsed / args.steps / B, "total_scenes": total_scenes,
+            "host_enqueue_ms_per_step": 1e3 * enqueue_here / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train: stage-1 recipe (opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml), {N} agents/scene, {B} scene(s)/step/GPU, "
                                    f"512x256 pillars -> 128x64x128 BEV, GenComm T={T}, forward + backward + Adam",
@@ -300,6 +307,7 @@ def main():
                     help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow resfuse_emu tile8), e.g. --mode xcd=0")
     ap.add_argument("--share-device", action="store_true",
                     help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
+    ap.add_argument("--sync-debug", action="store_true", help="--workload train: run one untimed step under torch.cuda.set_sync_debug_mode('warn')")
     ap.add_argument("--grad-sync", choices=["flat", "ddp"], default="flat",
                     help="--workload train: gradient averaging -- one flat bucket per step (gencomm_amd.dist.FlatGradSync) or torch DistributedDataParallel")
     ap.add_argument("--train-batch", type=int, default=2, help="--workload train: scenes per rank and step (m1_att.yaml batch_size: 2)")

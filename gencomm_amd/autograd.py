@@ -173,17 +173,6 @@ def sampler_forward(gen, feat, cond, src_rows: Sequence[int], noise0, step_noise
 
 
 # ----------------------------------------------------------------------------------------- Enhancer
-_SIDE_STREAMS = {}
-
-
-def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
-    """One side stream per device for the weight-gradient launches of the Enhancer's backward."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _SIDE_STREAMS[key]
-
-
 def _gate_mlp(sa, gap, params):
     """split_attn's channel gate on [n, C] vectors (enhancer.py:315-333): fc1 -> LayerNorm -> ReLU -> fc2 -> sigmoid."""
     return torch.sigmoid(F.linear(F.relu(F.layer_norm(F.linear(gap, params[0]), (params[0].shape[0],), params[1], params[2], 1e-5)), params[3]))
@@ -249,18 +238,9 @@ class EnhancerFunction(torch.autograd.Function):
             dgap, *dgate = torch.autograd.grad(a, [gap] + local, da)
         # Weight gradients feed nothing in this walk: on large maps they run on a side stream beside the input-gradient chain (the same
         # overlap as GENCOMM_MODE_BWD_STREAMS inside gencomm_unet_bwd) and are joined before d y2 is overwritten by LayerNorm2's backward.
-        cur = torch.cuda.current_stream(x.device)
-        side = _side_stream(x.device) if n * HW >= (1 << 17) and _lib.lib().gencomm_get_mode(_lib.MODE_BWD_STREAMS) != 0 else None
-        forked = []
-
-        def on_side(fn):
-            if side is None:
-                return fn()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                out = fn()
-            forked.extend(t for t in out if t is not None)
-            return out
+        from .runtime import overlap
+        ov = overlap(x.device, n * HW).__enter__()
+        on_side = ov.run
 
         with torch.no_grad():
             dy2 = T.nc_scale(go, a.detach(), dgap / HW)
@@ -281,10 +261,7 @@ class EnhancerFunction(torch.autograd.Function):
             T.conv2d(dzi1, m.partial_conv3.weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, 1, out=dzi, out_coff=0)
             dz = dzi
             dWp, _ = on_side(lambda: T.conv2d_wgrad(dzi1, z1, 3, 1, False))
-            if side is not None:
-                cur.wait_stream(side)
-                for t_ in forked:            # allocated under the side stream, consumed on this one from here on
-                    t_.record_stream(cur)
+            ov.join()
             # ---- LayerNorms and residuals
             dy, dg2, db2n = T.ln_bwd(y, b1.norm2.weight, dz, 1e-5, accumulate_into=dy2)       # d y = d y2 + LN2 backward
             dx, dg1, db1n = T.ln_bwd(x, b1.norm1.weight, dy, 1e-5)

@@ -53,12 +53,14 @@ def _conv_backward(x, g, conv, pad, need_x):
         return None
     k, st = conv.kernel_size[0], conv.stride[0]
     p = conv.padding[0] if pad is None else pad
-    if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
-        dw, db = T.conv2d_wgrad(g, x, k, p, conv.bias is not None, st)
-        grads[conv.weight] = dw
-        if conv.bias is not None:
-            grads[conv.bias] = db
-    dx = T.conv2d_dgrad_strided(g, conv.weight, p, st, (x.shape[2], x.shape[3])) if need_x else None
+    from .runtime import overlap
+    with overlap(x.device, x.shape[0] * x.shape[2] * x.shape[3] if need_x else 0) as ov:   # the weight gradient beside the input gradient
+        if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+            dw, db = ov.run(lambda: T.conv2d_wgrad(g, x, k, p, conv.bias is not None, st))
+            grads[conv.weight] = dw
+            if conv.bias is not None:
+                grads[conv.bias] = db
+        dx = T.conv2d_dgrad_strided(g, conv.weight, p, st, (x.shape[2], x.shape[3])) if need_x else None
     return dx, grads
 
 

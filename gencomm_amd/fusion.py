@@ -25,7 +25,10 @@ def normalize_pairwise_tfm(pairwise_t_matrix: torch.Tensor, H, W, discrete_ratio
     """[B,L,L,4,4] -> [B,L,L,2,3] normalised affine for ``affine_grid`` (transformation_utils.py:68-92).
     A few dozen float64 scalars per batch: done with torch indexing on whatever device the poses
     are on. Unlike the reference this does not modify a view of its argument."""
-    a = pairwise_t_matrix[:, :, :, [0, 1], :][:, :, :, :, [0, 1, 3]].clone()
+    # rows 0, 1 and columns 0, 1, 3 by slicing: indexing with Python lists builds index tensors on the host and copies them to the
+    # device -- a host <-> device synchronisation in the middle of every forward (torch.cuda.set_sync_debug_mode found it)
+    r = pairwise_t_matrix[:, :, :, 0:2, :]
+    a = torch.cat([r[..., 0:2], r[..., 3:4]], dim=-1)
     a[..., 0, 1] = a[..., 0, 1] * H / W
     a[..., 1, 0] = a[..., 1, 0] * W / H
     a[..., 0, 2] = a[..., 0, 2] / (downsample_rate * discrete_ratio * W) * 2

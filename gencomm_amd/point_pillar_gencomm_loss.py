@@ -60,7 +60,10 @@ class PointPillarGencommLoss(nn.Module):
 
     def direction_target(self, reg_targets):  # point_pillar_loss.py:142-170 -> class index per anchor [N, H*W*A]
         a = self.dir["args"]
-        anchor_yaw = torch.as_tensor(np.deg2rad(np.array(a["anchor_yaw"])), device=reg_targets.device, dtype=torch.float64)
+        key = (str(reg_targets.device), tuple(a["anchor_yaw"]))
+        if getattr(self, "_yaw_key", None) != key:          # uploaded once per device: a per-step host-to-device copy is a synchronisation
+            self._yaw, self._yaw_key = torch.as_tensor(np.deg2rad(np.array(a["anchor_yaw"])), device=reg_targets.device, dtype=torch.float64), key
+        anchor_yaw = self._yaw
         A = anchor_yaw.numel()
         rot_gt = reg_targets[..., -1] + anchor_yaw.repeat(reg_targets.shape[1] // A).view(1, -1)   # float64 like the reference's numpy map
         off = limit_period(rot_gt - a["dir_offset"], 0, 2 * math.pi)

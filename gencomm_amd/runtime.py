@@ -117,3 +117,54 @@ def record_len_list(record_len) -> List[int]:
     if isinstance(record_len, torch.Tensor):
         return [int(v) for v in record_len.detach().cpu().tolist()]
     return [int(v) for v in record_len]
+
+
+# ----------------------------------------------------------------------------------------- side stream for weight gradients
+_SIDE_STREAMS: dict = {}
+SIDE_MIN_PIXELS = 1 << 17      # n * H * W below which the fork / join costs the host more than the overlap returns (measured: 64 x 128 maps)
+
+
+def side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
+class overlap:
+    """``with overlap(device, pixels) as ov: dw = ov.run(lambda: wgrad(...)); dx = dgrad(...)`` -- work that nothing inside the block
+    depends on (weight gradients) runs on the device's side stream beside the block's own launches and is joined when the block ends:
+    from there on its results are ordered on the current stream.  Inputs of the side work must not be written inside the block.
+    Disabled (plain calls) on small maps and when GENCOMM_MODE_BWD_STREAMS is 0."""
+
+    def __init__(self, device: torch.device, pixels: int):
+        from . import _lib
+        mode = _lib.lib().gencomm_get_mode(_lib.MODE_BWD_STREAMS)
+        self.on = device.type == "cuda" and (mode == 2 or (mode == 1 and pixels >= SIDE_MIN_PIXELS))
+        self.device, self.outs, self.used = device, [], False
+
+    def __enter__(self):
+        if self.on:
+            self.cur, self.side = torch.cuda.current_stream(self.device), side_stream(self.device)
+        return self
+
+    def run(self, fn):
+        if not self.on:
+            return fn()
+        self.side.wait_stream(self.cur)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        self.used = True
+        self.outs.extend(t for t in (out if isinstance(out, (tuple, list)) else (out,)) if isinstance(t, torch.Tensor))
+        return out
+
+    def join(self):
+        if self.on and self.used:
+            self.cur.wait_stream(self.side)
+            for t in self.outs:              # allocated under the side stream, consumed on the current one from here on
+                t.record_stream(self.cur)
+            self.outs, self.used = [], False
+
+    def __exit__(self, *exc):
+        self.join()
+        return False
