@@ -259,6 +259,20 @@ def train_main(args, rank, world, device, backend):
         step()
         torch.cuda.set_sync_debug_mode("default")
         barrier()
+    if args.host_profile:    # diagnostic: cProfile of the host side of 10 steps (autograd on this thread), written to stderr
+        import cProfile, io, pstats
+        torch.autograd.set_multithreading_enabled(False)
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(10):
+            step()
+        pr.disable()
+        torch.autograd.set_multithreading_enabled(True)
+        barrier()
+        for key in ("tottime", "cumulative"):
+            sio = io.StringIO()
+            pstats.Stats(pr, stream=sio).sort_stats(key).print_stats(60)
+            print("\n".join(l[:180] for l in sio.getvalue().split("\n")), file=sys.stderr)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -307,7 +321,8 @@ def main():
                     help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow resfuse_emu tile8), e.g. --mode xcd=0")
     ap.add_argument("--share-device", action="store_true",
                     help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
-    ap.add_argument("--sync-debug", action="store_true", help="--workload train: run one untimed step under torch.cuda.set_sync_debug_mode('warn')")
+    ap.add_argument("--host-profile", action="store_true", help="--workload train: cProfile of the host side of 10 untimed steps, to stderr")
+    ap.add_argument("--sync-debug", action="store_true", help="run one untimed step under torch.cuda.set_sync_debug_mode('warn'): every host <-> device synchronisation warns with its stack")
     ap.add_argument("--grad-sync", choices=["flat", "ddp"], default="flat",
                     help="--workload train: gradient averaging -- one flat bucket per step (gencomm_amd.dist.FlatGradSync) or torch DistributedDataParallel")
     ap.add_argument("--train-batch", type=int, default=2, help="--workload train: scenes per rank and step (m1_att.yaml batch_size: 2)")
@@ -477,6 +492,13 @@ def main():
     with torch.no_grad():
         for i in range(args.warmup):
             run_scene(i, 1000 + i)
+        if args.sync_debug:      # diagnostic: one scene batch per stream under torch's synchronisation detector (warnings carry the stack)
+            torch.cuda.synchronize(device)
+            torch.cuda.set_sync_debug_mode("warn")
+            for i in range(S):
+                run_scene(i, 1900 + i)
+            torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize(device)
         elapsed = timed_region(args.steps, 2000)
         # the K-step region above is the reported number; when it is shorter than a second (20 steps = 0.4 s: too short for a
         # 5 s-period utilisation sampler to see), the same loop is repeated to >= 1.2 s in ONE bracket and reported beside it

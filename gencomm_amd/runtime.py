@@ -81,7 +81,9 @@ class PackedParams:
             if t.numel() != numel:
                 raise ValueError(f"parameter '{name}' has {t.numel()} elements, the HIP library expects {numel}")
             tensors.append(t)
-        key = tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in tensors)
+        if any(t.device != tensors[0].device or t.dtype != tensors[0].dtype for t in tensors):
+            raise ValueError("the parameters handed to the HIP library must share one device and dtype")
+        key = (tensors[0].device, tensors[0].dtype) + tuple([(t.data_ptr(), t._version) for t in tensors])   # storage + in-place version of each
         if key == self._key and self.flat is not None:
             return False
         with torch.no_grad():

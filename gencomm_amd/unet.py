@@ -150,6 +150,23 @@ class DiffusionUNet(nn.Module):
         """bit l = level l carries AttnBlocks (nominal resolution 128 >> l in attn_resolutions; unet.py:237,:252-253,:286)."""
         return self._attn_mask
 
+    def _named_params(self) -> dict:
+        """``dict(self.named_parameters())`` without walking the module tree on every call (6 walks of ~150 modules per training step were
+        1.3 ms of a 7 ms host-bound step): the (owning module, attribute) pairs are collected once and read through the modules'
+        own ``_parameters`` tables, so a Parameter that is REPLACED (``m.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)``)
+        is seen; a submodule that is replaced after the first call is not -- call ``_named_params_reset()`` after such surgery."""
+        slots = self.__dict__.get("_param_slots")
+        if slots is None:
+            slots = []
+            for mname, mod in self.named_modules():
+                for pname in mod._parameters:
+                    slots.append(((mname + "." if mname else "") + pname, mod, pname))
+            self.__dict__["_param_slots"] = slots
+        return {name: mod._parameters[pname] for name, mod, pname in slots if mod._parameters[pname] is not None}
+
+    def _named_params_reset(self) -> None:
+        self.__dict__.pop("_param_slots", None)
+
     def _ensure_packed(self) -> None:
         if self._packed is None:
             C, L, R, A = self.feature_channels, self.num_resolutions, self.num_res_blocks, self.attn_mask
@@ -162,7 +179,7 @@ class DiffusionUNet(nn.Module):
         l = _lib.lib()
         C, L, R, A = self.feature_channels, self.num_resolutions, self.num_res_blocks, self.attn_mask
         self._ensure_packed()
-        named = dict(self.named_parameters())
+        named = self._named_params()
         for p in named.values():
             require_gpu(p, "DiffusionUNet parameters")
             break
@@ -209,7 +226,7 @@ class DiffusionUNet(nn.Module):
         """Every parameter as one differentiable float32 vector in the order / layout of the library's raw blob
         (``gencomm_unet_param_info``): the parameter input of ``autograd.UNetFunction``."""
         self._ensure_packed()
-        named = dict(self.named_parameters())
+        named = self._named_params()
         flat = torch.cat([named[name].reshape(-1).float() for name, _, _ in self._packed.table])
         assert flat.numel() == self._packed.total
         return flat

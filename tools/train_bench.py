@@ -46,10 +46,16 @@ for name, (N, C, H, W, T) in SHAPES.items():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    if "--sync-debug" in sys.argv:   # one step under torch's synchronisation detector (warnings carry the stack)
+        torch.cuda.set_sync_debug_mode("warn")
+        step()
+        torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     K = 5
     for _ in range(K):
         step()
+    t_enq = (time.perf_counter() - t0) / K / BATCH     # the host is done issuing
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K / BATCH
-    print(f"train step [{name}, {BATCH} scene(s) per step]: {1e3 * dt:.1f} ms per scene (forward + backward{' + Adam step' if OPTIMIZER else ''}) = {1.0 / dt:.2f} scenes/s", flush=True)
+    print(f"train step [{name}, {BATCH} scene(s) per step]: {1e3 * dt:.1f} ms per scene (forward + backward{' + Adam step' if OPTIMIZER else ''}) = {1.0 / dt:.2f} scenes/s; host enqueue {1e3 * t_enq:.1f} ms", flush=True)
