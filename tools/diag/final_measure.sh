@@ -53,7 +53,7 @@ step "pmc insts"; bash tools/pmc_insts_pass.sh metric > $O/r4_pmc_insts_pass.log
 rm -rf $O/r4_pmc_FETCH_SIZE $O/r4_pmc_WRITE_SIZE $O/r4_pmc_SQ $O/r4_pmc_INSTS
 step "parity margins"; timeout -k 10 600 python -m pytest tests/test_gpu_philox_replay.py tests/test_gpu_configs.py -m gpu -q -s -k "metric" > $O/r4_parity.log 2>&1 || { tail -n 20 $O/r4_parity.log; exit 1; }
 grep -E "vs float64|vs float32 oracle" $O/r4_parity.log > $O/r4_parity_margins.txt; cat $O/r4_parity_margins.txt | cut -c1-260
-step "bench default again (traffic now stamped)"; cp $O/r4_pmc_traffic.json profiles/r4_pmc_traffic.json
+step "bench default again (traffic and issue now stamped)"; cp $O/r4_pmc_traffic.json profiles/r4_pmc_traffic.json; cp $O/r4_pmc_sq.json profiles/r4_pmc_sq.json
 timeout -k 10 400 python bench.py > $O/r4_bench_default.json 2> $O/r4_bench_default.err || { tail -n 20 $O/r4_bench_default.err; exit 1; }
 python -c "
 import json;d=json.load(open('gpurun_out/r4_bench_default.json'));print('default (2nd): %.1f scenes/s, frac %.3f, traffic %s (%s)'%(d['value'],d['roofline']['frac'],d['roofline']['traffic'],d['roofline']['traffic_source']))"
