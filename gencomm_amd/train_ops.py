@@ -161,8 +161,7 @@ def bn2d_train_bwd(x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, save: tor
     x, y, dy = _c(x), _c(y), _c(dy)
     n, C, H, W = x.shape
     dx = torch.empty_like(x)
-    dg = torch.zeros(C, dtype=torch.float32, device=x.device)
-    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    dg, db = torch.zeros(2, C, dtype=torch.float32, device=x.device).unbind(0)   # one fill launch for both
     scratch = torch.empty(2 * C, dtype=torch.float64, device=x.device)
     _lib.check(_lib.lib().gencomm_bn2d_train_bwd(ptr(x), ptr(y), ptr(dy), ptr(save), ptr(_c(gamma)), ptr(dx), ptr(dg), ptr(db), ptr(scratch), int(relu),
                                                  n, C, H * W, stream_ptr(x.device)), "gencomm_bn2d_train_bwd")
@@ -183,8 +182,7 @@ def ln_bwd(x: torch.Tensor, gamma, dy: torch.Tensor, eps: float, accumulate_into
     x, dy = _c(x), _c(dy)
     n, C, H, W = x.shape
     dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
-    dg = torch.zeros(C, dtype=torch.float32, device=x.device)
-    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    dg, db = torch.zeros(2, C, dtype=torch.float32, device=x.device).unbind(0)   # one fill launch for both
     scratch = torch.empty(n * H * W * 2, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().gencomm_ln_nchw_bwd(ptr(x), ptr(_c(gamma)), ptr(dy), ptr(dx), ptr(dg), ptr(db), ptr(scratch), float(eps),
                                               int(accumulate_into is not None), n, C, H * W, stream_ptr(x.device)), "gencomm_ln_nchw_bwd")
@@ -239,8 +237,8 @@ def dwconv3x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], flip:
 def dwconv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor):
     x, dy = _c(x), _c(dy)
     n, C, H, W = x.shape
-    dw = torch.zeros(C, 1, 3, 3, dtype=torch.float32, device=x.device)
-    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    blob = torch.zeros(C * 10, dtype=torch.float32, device=x.device)              # one fill launch for both gradients
+    dw, db = blob[:C * 9].view(C, 1, 3, 3), blob[C * 9:]
     _lib.check(_lib.lib().gencomm_dwconv3x3_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(db), n, C, H, W, stream_ptr(x.device)), "gencomm_dwconv3x3_wgrad")
     return dw, db
 

@@ -464,3 +464,35 @@ def test_gradient_path_validates_shapes_before_taking_pointers_and_refuses_a_sec
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="already differentiated"):
         loss.backward()
+
+
+def test_side_stream_weight_gradients_equal_the_single_stream_walk(modes):
+    """GENCOMM_MODE_BWD_STREAMS: the UNet call's weight gradients on the library's side stream (2 = on every call) against the same
+    walk on the caller's stream (0); and the call must leave its results ordered on the CALLER's stream: they are read right after it,
+    on that stream, with no device synchronisation in between."""
+    from gencomm_amd import GenComm, synth
+    from gencomm_amd.autograd import UNetFunction
+    C, H, W, n, T, t = 16, 48, 80, 3, 3, 1
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen = GenComm(cfg).train()
+    synth.fill_params_(gen, 77)
+    gen = gen.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(n, C, H, W, generator=g, device=DEV)
+    cond = torch.randn(n, 2, H, W, generator=g, device=DEV)
+    got = {}
+    for mode in (0, 2, 2, 0):
+        modes(bwd_streams=mode)
+        for p in gen.parameters():
+            p.grad = None
+        xd, cd = x.clone().requires_grad_(True), cond.clone().requires_grad_(True)
+        out = UNetFunction.apply(gen.denoiser, t, T, xd, cd, gen.denoiser.flat_params())
+        (out ** 2).mean().backward()
+        flat = torch.cat([p.grad.reshape(-1) for p in gen.denoiser.parameters()] + [xd.grad.reshape(-1), cd.grad.reshape(-1)]).clone()
+        got.setdefault(mode, []).append(flat)
+    ref = got[0][0]
+    scale = float(ref.abs().max())
+    for mode, runs in got.items():
+        for r in runs:
+            assert torch.isfinite(r).all()
+            assert float((r - ref).abs().max()) <= 2e-6 * scale, (mode, float((r - ref).abs().max()), scale)   # float atomics of the reduce stage: order only
