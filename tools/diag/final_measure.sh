@@ -24,10 +24,11 @@ step "bench --gpus 2 --share-device (self-launched)"; timeout -k 10 300 python b
 python -c "
 import json;d=json.load(open('gpurun_out/r4_bench_share2.json'));print('share2: %.1f scenes/s over %d ranks, %d scenes, group %s'%(d['value'],d['n_gpus'],d['total_scenes'],d['config']['process_group']))"
 step "train leg N=1 (RCCL, world 1)"; timeout -k 10 400 python bench.py --workload train --steps 20 --warmup 3 > $O/r4_train_leg_n1.json 2> $O/r4_train_leg_n1.err || { tail -n 30 $O/r4_train_leg_n1.err; exit 1; }
+step "train leg N=1 under torch DistributedDataParallel"; timeout -k 10 400 python bench.py --workload train --grad-sync ddp --steps 20 --warmup 3 > $O/r4_train_leg_n1_ddp.json 2> $O/r4_train_leg_n1_ddp.err || { tail -n 30 $O/r4_train_leg_n1_ddp.err; exit 1; }
 step "train leg N=2 share-device (gloo)"; timeout -k 10 400 python bench.py --workload train --gpus 2 --share-device --steps 10 --warmup 3 > $O/r4_train_leg_share2.json 2> $O/r4_train_leg_share2.err || { tail -n 30 $O/r4_train_leg_share2.err; exit 1; }
 python - <<'PY'
 import json
-for f in ("n1","share2"):
+for f in ("n1","n1_ddp","share2"):
     d=json.load(open(f"gpurun_out/r4_train_leg_{f}.json"))
     print("train leg %s: %.1f scenes/s, %.1f ms/step, group %s rccl_ranks %d, %d grad bytes/step"%(f,d["value"],d["ms_per_step"],d["config"]["process_group"],d["config"]["rccl_ranks"],d["config"]["grad_bytes_allreduced_per_step"]))
 PY
