@@ -195,6 +195,29 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   const float h = 0.5f * x;
   return fmaf(h, copysignf(erf_abs, x), h);
 }
+// GELU(x) and d/dx GELU(x) = Phi(x) + x phi(x) from ONE evaluation of the erf form above (Phi = 0.5 + 0.5 erf(x / sqrt 2), error
+// <= 0.85e-7) and one more v_exp_f32 for the density phi(x) = exp(-x^2 / 2) / sqrt(2 pi): the Enhancer's backward kernels (train_kernels.h)
+// evaluated the library's erff + expf here (two divergent branches and a range reduction per element: 2.3 TB/s on a pass that moves
+// 864 MB); branch-free, 2 transcendentals + ~20 VALU for both values.
+__device__ __forceinline__ void gelu_and_grad_f(float x, float* gelu, float* grad) {
+  const float t = fminf(fabsf(x) * 0.70710678118654752440f, 4.3f);
+  float q = fmaf(-1.0021018e-4f, t, 4.6151079e-4f);
+  q = fmaf(q, t, 2.3023714e-3f);
+  q = fmaf(q, t, -2.9452650e-2f);
+  q = fmaf(q, t, 1.4896373e-1f);
+  q = fmaf(q, t, 9.1832864e-1f);
+  q = fmaf(q, t, 1.6279137e+0f);
+  const float erf_abs = 1.0f - __builtin_amdgcn_exp2f(-t * q);
+  const float Phi = fmaf(0.5f, copysignf(erf_abs, x), 0.5f);
+  const float phi = 0.3989422804014327f * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-x^2 / 2)
+  *gelu = x * Phi;
+  *grad = fmaf(x, phi, Phi);
+}
+__device__ __forceinline__ float gelu_grad_fast_f(float x) {
+  float g, d;
+  gelu_and_grad_f(x, &g, &d);
+  return d;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Range guard of the fp16 hi/lo operand splits (conv8h_kernels.h).  A two-term split x = hi + lo needs |x| < 65504:

@@ -787,26 +787,44 @@ int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, flo
   return GC_OK;
 }
 
-int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream) {
-  GC_CHECK_ARG(x && w && y && n >= 1 && C >= 1 && (long long)n * C <= 65535 && H >= 1 && W >= 1, "bad arguments");
-  if ((W & 3) == 0)   // sliding three-row window, 128-bit loads, neighbours by lane shuffle
-    dwconv3x3_rows_kernel<<<dim3((W / 4 + 63) / 64, (H + 4 * DW_RB - 1) / (4 * DW_RB), n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
-  else
-    dwconv3x3_kernel<<<dim3((H * ((W + 3) / 4) + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, w, b, y, C, H, W, flip);
+int gencomm_dwconv3x3_act_fwd(const float* x, int x_ct, int act, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream) {
+  GC_CHECK_ARG(x && w && y && n >= 1 && C >= 1 && x_ct >= C && (long long)n * C <= 65535 && H >= 1 && W >= 1 && (act == 0 || act == 1), "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if ((W & 3) == 0) {   // sliding three-row window, 128-bit loads, neighbours by lane shuffle
+    const dim3 grid((W / 4 + 63) / 64, (H + 4 * DW_RB - 1) / (4 * DW_RB), n * C);
+    if (act) dwconv3x3_rows_kernel<true><<<grid, 256, 0, st>>>(x, w, b, y, C, H, W, flip, x_ct);
+    else dwconv3x3_rows_kernel<false><<<grid, 256, 0, st>>>(x, w, b, y, C, H, W, flip, x_ct);
+  } else {
+    const dim3 grid((H * ((W + 3) / 4) + 255) / 256, n * C);
+    if (act) dwconv3x3_kernel<true><<<grid, 256, 0, st>>>(x, w, b, y, C, H, W, flip, x_ct);
+    else dwconv3x3_kernel<false><<<grid, 256, 0, st>>>(x, w, b, y, C, H, W, flip, x_ct);
+  }
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
+int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream) {
+  return gencomm_dwconv3x3_act_fwd(x, C, 0, w, b, y, n, C, H, W, flip, stream);
+}
 
-int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream) {
-  GC_CHECK_ARG(x && dy && dw && n >= 1 && C >= 1 && C <= 65535 && H >= 1 && W >= 1, "bad arguments");
+int gencomm_dwconv3x3_act_wgrad(const float* x, int x_ct, int act, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream) {
+  GC_CHECK_ARG(x && dy && dw && n >= 1 && C >= 1 && x_ct >= C && C <= 65535 && H >= 1 && W >= 1 && (act == 0 || act == 1), "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
   if ((W & 3) == 0) {
     const long long items = (long long)n * ((H + DW_RB - 1) / DW_RB);
     const unsigned gy = (unsigned)std::min<long long>((items + 3) / 4, 32);   // <= 32 workgroups (atomics) per channel and column strip
-    dwconv3x3_wgrad_rows_kernel<<<dim3((W / 4 + 63) / 64, gy, C), 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
-  } else
-  dwconv3x3_wgrad_kernel<<<dim3(C, (unsigned)std::min<long long>(((long long)n * H * ((W + 3) / 4) + 1023) / 1024, 128)), 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, n, C, H, W);
+    const dim3 grid((W / 4 + 63) / 64, gy, C);
+    if (act) dwconv3x3_wgrad_rows_kernel<true><<<grid, 256, 0, st>>>(x, dy, dw, db, n, C, H, W, x_ct);
+    else dwconv3x3_wgrad_rows_kernel<false><<<grid, 256, 0, st>>>(x, dy, dw, db, n, C, H, W, x_ct);
+  } else {
+    const dim3 grid(C, (unsigned)std::min<long long>(((long long)n * H * ((W + 3) / 4) + 1023) / 1024, 128));
+    if (act) dwconv3x3_wgrad_kernel<true><<<grid, 256, 0, st>>>(x, dy, dw, db, n, C, H, W, x_ct);
+    else dwconv3x3_wgrad_kernel<false><<<grid, 256, 0, st>>>(x, dy, dw, db, n, C, H, W, x_ct);
+  }
   GC_HIP(hipGetLastError());
   return GC_OK;
+}
+int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream) {
+  return gencomm_dwconv3x3_act_wgrad(x, C, 0, dy, dw, db, n, C, H, W, stream);
 }
 
 int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream) {
@@ -818,17 +836,23 @@ int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count
 
 int gencomm_ew_slice_fwd(int op, const float* a, const float* b, const float* c, const float* d, float* o0, float* o1, int n, int nch, int HW,
                          int a_ct, int a_c0, int o0_ct, int o0_c0, int o1_ct, int o1_c0, void* stream) {
-  GC_CHECK_ARG(a && o0 && n >= 1 && n <= 65535 && nch >= 1 && nch <= 65535 && HW >= 1 && op >= 0 && op <= 4, "bad arguments");
+  GC_CHECK_ARG(a && o0 && n >= 1 && n <= 65535 && nch >= 1 && nch <= 65535 && HW >= 1 && op >= 0 && op <= 6, "bad arguments");
   SliceArgs s{a, b, c, d, o0, o1, n, nch, HW, a_ct, a_c0, 0, 0, o0_ct, o0_c0, o1_ct, o1_c0};
-  const dim3 grid((HW + 255) / 256, nch, n);
   hipStream_t st = (hipStream_t)stream;
+  // HW % 4 == 0 and 16-byte aligned tensors: every slice base is aligned too -> four pixels per lane
+  const bool v4 = (HW & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)o0 | (uintptr_t)o1) & 15) == 0);
+  const dim3 grid(v4 ? (HW / 4 + 255) / 256 : (HW + 255) / 256, nch, n);
+#define GC_EW_LAUNCH(OP) do { if (v4) ew_slice4_kernel<OP><<<grid, 256, 0, st>>>(s); else ew_slice_kernel<OP><<<grid, 256, 0, st>>>(s); } while (0)
   switch (op) {
-    case EW_COPY: ew_slice_kernel<EW_COPY><<<grid, 256, 0, st>>>(s); break;
-    case EW_GELU_SPLIT: GC_CHECK_ARG(o1, "null pointer"); ew_slice_kernel<EW_GELU_SPLIT><<<grid, 256, 0, st>>>(s); break;
-    case EW_GELU_GATE: GC_CHECK_ARG(b, "null pointer"); ew_slice_kernel<EW_GELU_GATE><<<grid, 256, 0, st>>>(s); break;
-    case EW_GATE_BWD: GC_CHECK_ARG(b && c && d && o1, "null pointer"); ew_slice_kernel<EW_GATE_BWD><<<grid, 256, 0, st>>>(s); break;
-    default: GC_CHECK_ARG(b, "null pointer"); ew_slice_kernel<EW_GELU_BWD><<<grid, 256, 0, st>>>(s); break;
+    case EW_COPY: GC_EW_LAUNCH(EW_COPY); break;
+    case EW_GELU_SPLIT: GC_CHECK_ARG(o1, "null pointer"); GC_EW_LAUNCH(EW_GELU_SPLIT); break;
+    case EW_GELU_GATE: GC_CHECK_ARG(b, "null pointer"); GC_EW_LAUNCH(EW_GELU_GATE); break;
+    case EW_GATE_BWD: GC_CHECK_ARG(b && c && d && o1, "null pointer"); GC_EW_LAUNCH(EW_GATE_BWD); break;
+    case EW_GELU_BWD: GC_CHECK_ARG(b, "null pointer"); GC_EW_LAUNCH(EW_GELU_BWD); break;
+    case EW_GELU2_GATE: GC_CHECK_ARG(d, "null pointer"); GC_EW_LAUNCH(EW_GELU2_GATE); break;
+    default: GC_CHECK_ARG(c && d && o1, "null pointer"); GC_EW_LAUNCH(EW_GATE_BWD2); break;
   }
+#undef GC_EW_LAUNCH
   GC_HIP(hipGetLastError());
   return GC_OK;
 }

@@ -228,21 +228,24 @@ __global__ __launch_bounds__(256) void gn_nchw_apply_kernel(const float* __restr
 // Round 3: four consecutive pixels of a row per thread, every tap LOADED (rows / columns clamped into the map, the out-of-range taps
 // replaced by exact zeros afterwards) -- with one branch per tap the nine loads of a pixel were issued one memory latency after the
 // other (1 TB/s at 4 x 128 x 200 x 704).
+template <bool ACT = false>   // ACT: the map is GELU(x), evaluated on the values read (GELU(0) = 0 keeps the zero padding)
 __device__ __forceinline__ void dw_load_row6(const float* __restrict__ row, int x0, int W, bool row_ok, float v[6]) {
   // v[0..5] = row[x0 - 1 .. x0 + 4], zero outside [0, W) or when the row itself is outside the map
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int xx = x0 - 1 + j;
     const float t = row[min(max(xx, 0), W - 1)];
-    v[j] = (row_ok && xx >= 0 && xx < W) ? t : 0.f;
+    v[j] = (row_ok && xx >= 0 && xx < W) ? (ACT ? gelu_erf_f(t) : t) : 0.f;
   }
 }
+// x_ct: channels of the tensor x points into (the layer reads its first C channels: x_ct = C for a dense input)
+template <bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                        float* __restrict__ y, int C, int H, int W, int flip) {
+                                                        float* __restrict__ y, int C, int H, int W, int flip, int x_ct) {
   const int nc = blockIdx.y, W4 = (W + 3) >> 2, q = blockIdx.x * 256 + threadIdx.x;
   if (q >= H * W4) return;
   const int c = nc % C, h = q / W4, x0 = 4 * (q - h * W4);
-  const float* __restrict__ xp = x + (size_t)nc * H * W;
+  const float* __restrict__ xp = x + ((size_t)(nc / C) * x_ct + c) * H * W;
   float wk[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + (flip ? 8 - t : t)];
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   for (int ky = 0; ky < 3; ++ky) {
     const int yy = h + ky - 1;
     float v[6];
-    dw_load_row6(xp + (size_t)min(max(yy, 0), H - 1) * W, x0, W, yy >= 0 && yy < H, v);
+    dw_load_row6<ACT>(xp + (size_t)min(max(yy, 0), H - 1) * W, x0, W, yy >= 0 && yy < H, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -269,37 +272,42 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 // consecutive pixels; only lanes 0 / 63 load their outer neighbour), (DW_RB + 2) / DW_RB input rows per output row instead of three.
 // The round-3 form above issued 18 stride-4 dword loads per quad (1.67 TB/s at 4 x 128 x 200 x 704); it stays for ragged widths.
 constexpr int DW_RB = 8;
+template <bool ACT = false>
 __device__ __forceinline__ void dw_row6_shfl(const float* __restrict__ row /* image row or null */, int x0, int W, bool lane_ok, int lane, float v[6]) {
   float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row != nullptr && lane_ok) c = *reinterpret_cast<const float4*>(row + x0);
+  if (row != nullptr && lane_ok) {
+    c = *reinterpret_cast<const float4*>(row + x0);
+    if (ACT) c = make_float4(gelu_erf_f(c.x), gelu_erf_f(c.y), gelu_erf_f(c.z), gelu_erf_f(c.w));
+  }
   float left = __shfl_up(c.w, 1, 64), right = __shfl_down(c.x, 1, 64);
-  if (lane == 0) left = (row != nullptr && lane_ok && x0 > 0) ? row[x0 - 1] : 0.f;
+  if (lane == 0) left = (row != nullptr && lane_ok && x0 > 0) ? (ACT ? gelu_erf_f(row[x0 - 1]) : row[x0 - 1]) : 0.f;
   if (lane == 63 || !lane_ok) right = 0.f;
-  if (lane == 63 && row != nullptr && lane_ok && x0 + 4 < W) right = row[x0 + 4];
+  if (lane == 63 && row != nullptr && lane_ok && x0 + 4 < W) right = ACT ? gelu_erf_f(row[x0 + 4]) : row[x0 + 4];
   // a lane whose right neighbour lane is beyond the row end got that lane's zero quad: correct (zero padding)
   v[0] = left; v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w; v[5] = right;
 }
+template <bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                             float* __restrict__ y, int C, int H, int W, int flip) {
+                                                             float* __restrict__ y, int C, int H, int W, int flip, int x_ct) {
   const int nc = blockIdx.z, lane = threadIdx.x & 63, rb = threadIdx.x >> 6;
   const int x0 = 4 * (blockIdx.x * 64 + lane), r0 = (blockIdx.y * 4 + rb) * DW_RB;
   if (r0 >= H) return;                       // whole wave
   const bool lane_ok = x0 < W;
   const int c = nc % C;
-  const float* __restrict__ xp = x + (size_t)nc * H * W;
+  const float* __restrict__ xp = x + ((size_t)(nc / C) * x_ct + c) * H * W;
   float* __restrict__ yp = y + (size_t)nc * H * W;
   float wk[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + (flip ? 8 - t : t)];
   const float b0 = (b != nullptr && !flip) ? b[c] : 0.f;
   float win[3][6];
-  dw_row6_shfl(r0 - 1 >= 0 ? xp + (size_t)(r0 - 1) * W : nullptr, x0, W, lane_ok, lane, win[0]);
-  dw_row6_shfl(xp + (size_t)r0 * W, x0, W, lane_ok, lane, win[1]);
+  dw_row6_shfl<ACT>(r0 - 1 >= 0 ? xp + (size_t)(r0 - 1) * W : nullptr, x0, W, lane_ok, lane, win[0]);
+  dw_row6_shfl<ACT>(xp + (size_t)r0 * W, x0, W, lane_ok, lane, win[1]);
 #pragma unroll
   for (int r = 0; r < DW_RB; ++r) {
     const int h = r0 + r;
     if (h >= H) break;                       // wave-uniform
-    dw_row6_shfl(h + 1 < H ? xp + (size_t)(h + 1) * W : nullptr, x0, W, lane_ok, lane, win[(r + 2) % 3]);
+    dw_row6_shfl<ACT>(h + 1 < H ? xp + (size_t)(h + 1) * W : nullptr, x0, W, lane_ok, lane, win[(r + 2) % 3]);
     float acc[4] = {b0, b0, b0, b0};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -312,8 +320,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
 }
 // the weight gradient with the same walk: a wave owns (sample, 256-pixel column strip, DW_RB rows); 10 partial sums per lane, wave
 // reduction, one atomic per (workgroup, tap)
+template <bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                                   float* __restrict__ db, int n, int C, int H, int W) {
+                                                                   float* __restrict__ db, int n, int C, int H, int W, int x_ct) {
   __shared__ float s_red[4][10];
   const int c = blockIdx.z, lane = threadIdx.x & 63, rb = threadIdx.x >> 6;
   const int x0 = 4 * (blockIdx.x * 64 + lane);
@@ -325,16 +334,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_rows_kernel(const float* 
   // blockIdx.y walks (sample, row block) items in chunks of 4 per workgroup (one per wave)
   for (int item = blockIdx.y * 4 + rb; item < n * rblocks; item += gridDim.y * 4) {
     const int s = item / rblocks, r0 = (item - s * rblocks) * DW_RB;
-    const float* __restrict__ xp = x + ((size_t)s * C + c) * H * W;
+    const float* __restrict__ xp = x + ((size_t)s * x_ct + c) * H * W;
     const float* __restrict__ dp = dy + ((size_t)s * C + c) * H * W;
     float win[3][6];
-    dw_row6_shfl(r0 - 1 >= 0 ? xp + (size_t)(r0 - 1) * W : nullptr, x0, W, lane_ok, lane, win[0]);
-    dw_row6_shfl(xp + (size_t)r0 * W, x0, W, lane_ok, lane, win[1]);
+    dw_row6_shfl<ACT>(r0 - 1 >= 0 ? xp + (size_t)(r0 - 1) * W : nullptr, x0, W, lane_ok, lane, win[0]);
+    dw_row6_shfl<ACT>(xp + (size_t)r0 * W, x0, W, lane_ok, lane, win[1]);
 #pragma unroll
     for (int r = 0; r < DW_RB; ++r) {
       const int h = r0 + r;
       if (h >= H) break;
-      dw_row6_shfl(h + 1 < H ? xp + (size_t)(h + 1) * W : nullptr, x0, W, lane_ok, lane, win[(r + 2) % 3]);
+      dw_row6_shfl<ACT>(h + 1 < H ? xp + (size_t)(h + 1) * W : nullptr, x0, W, lane_ok, lane, win[(r + 2) % 3]);
       float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (lane_ok) d4 = *reinterpret_cast<const float4*>(dp + (size_t)h * W + x0);
       const float d[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -362,8 +371,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_rows_kernel(const float* 
 }
 // dw[c][tap] += sum_{n,p} dy[n][c](p) x[n][c](p + tap), db[c] += sum dy: grid (channel, pixel chunk), one f32 atomic per
 // output and workgroup; the same four-pixel, branch-free loads
+template <bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                              float* __restrict__ db, int n, int C, int H, int W) {
+                                                              float* __restrict__ db, int n, int C, int H, int W, int x_ct) {
   __shared__ float s_red[4][10];
   const int c = blockIdx.x, tid = threadIdx.x, W4 = (W + 3) >> 2;
   float acc[10];
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
   for (int t = 0; t < 10; ++t) acc[t] = 0.f;
   for (long long i = (long long)blockIdx.y * 256 + tid; i < (long long)n * H * W4; i += (long long)gridDim.y * 256) {
     const int s = (int)(i / (H * W4)), q = (int)(i - (long long)s * H * W4), h = q / W4, x0 = 4 * (q - h * W4);
-    const size_t base = ((size_t)s * C + c) * H * W;
+    const size_t base = ((size_t)s * C + c) * H * W, xbase = ((size_t)s * x_ct + c) * H * W;
     float d[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const float t = dy[base + (size_t)h * W + min(x0 + j, W - 1)]; d[j] = x0 + j < W ? t : 0.f; }
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
     for (int ky = 0; ky < 3; ++ky) {
       const int yy = h + ky - 1;
       float v[6];
-      dw_load_row6(x + base + (size_t)min(max(yy, 0), H - 1) * W, x0, W, yy >= 0 && yy < H, v);
+      dw_load_row6<ACT>(x + xbase + (size_t)min(max(yy, 0), H - 1) * W, x0, W, yy >= 0 && yy < H, v);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -694,16 +704,12 @@ inline int wgrad3x3_wide_enqueue(const float* dy, const float* x, float* dw, flo
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ out, long long count) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
-  const float x = v[i];
-  out[i] = g[i] * (0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x));
+  out[i] = g[i] * gelu_grad_fast_f(v[i]);
 }
 
 // ---- elementwise / per-(sample, channel) pieces of the Enhancer's backward (enhancer.py:222-250, :315-333, :346-357), so that the
 // training step's own arithmetic runs on this library's kernels only (round 2 composed them from framework tensor operations).
 // All tensors NCHW fp32; a "slice" is channels [c0, c0 + nch) of a tensor with ctotal channels.
-__device__ __forceinline__ float gelu_grad_f(float x) {   // d/dx GELU(x), erf form
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-}
 struct SliceArgs {
   const float* a; const float* b; const float* c; const float* d;
   float* o0; float* o1;
@@ -716,27 +722,88 @@ enum EwOp : int {
   EW_GELU_GATE = 2,   // o0 = GELU(a) * b                         (g = GELU(u) x2)
   EW_GATE_BWD = 3,    // o0 = GELU'(a) * c * b  (du);  o1 slice = GELU'(d slice) * c * GELU(a)   (a = u, b = h2, c = dg, d = v)
   EW_GELU_BWD = 4,    // o0 slice = GELU'(a slice) * b            (dv[:, :hid] = GELU'(v1) dh1)
+  // second half of round 4: the GELU outputs h1 / h2 of Linear1 are no longer materialised -- their consumers evaluate GELU on the
+  // slice of v they read (the depthwise kernels take an activation flag), so the forward's split pass and two saved tensors disappear
+  EW_GELU2_GATE = 5,  // o0 = GELU(a) * GELU(d slice)             (g = GELU(u) GELU(v2); d has o1_ct channels, slice at o1_c0)
+  EW_GATE_BWD2 = 6,   // o0 = GELU'(a) * c * GELU(d slice) (du);  o1 slice = GELU'(d slice) * c * GELU(a)   (op 3 without its b operand)
+};
+// one element of an op: in[] = a, b, c, d at this element (unused ones 0), out[] = o0, o1
+template <int OP>
+__device__ __forceinline__ void ew_apply(float a, float b, float c, float d, float* o0, float* o1) {
+  if (OP == EW_COPY) {
+    *o0 = a;
+  } else if (OP == EW_GELU_SPLIT) {
+    *o0 = gelu_erf_f(a);
+    *o1 = gelu_erf_f(b);
+  } else if (OP == EW_GELU_GATE) {
+    *o0 = gelu_erf_f(a) * b;
+  } else if (OP == EW_GATE_BWD) {
+    float gu, du, gv, dv;
+    gelu_and_grad_f(a, &gu, &du);
+    gelu_and_grad_f(d, &gv, &dv);
+    *o0 = du * (c * b);
+    *o1 = dv * (c * gu);
+  } else if (OP == EW_GELU_BWD) {
+    *o0 = gelu_grad_fast_f(a) * b;
+  } else if (OP == EW_GELU2_GATE) {
+    *o0 = gelu_erf_f(a) * gelu_erf_f(d);
+  } else {
+    float gu, du, gv, dv;
+    gelu_and_grad_f(a, &gu, &du);
+    gelu_and_grad_f(d, &gv, &dv);
+    *o0 = du * (c * gv);
+    *o1 = dv * (c * gu);
+  }
+}
+// operand slices of an op at (sample n, channel c): offsets in floats.  EW_GELU_SPLIT reads its second input from a's upper half;
+// ops 3 / 6 read d and write o1 at the same slice (o1_ct, o1_c0), op 5 reads d there; op 4 reads a and writes o0 at (o0_ct, o0_c0).
+template <int OP>
+struct EwOffsets {
+  size_t a, b, c, d, o0, o1;
+  __device__ __forceinline__ EwOffsets(const SliceArgs& s, int n, int c_) {
+    const size_t HW = (size_t)s.HW;
+    const size_t dense = ((size_t)n * s.nch + c_) * HW;
+    a = b = c = d = o0 = o1 = dense;
+    if (OP == EW_COPY) { a = ((size_t)n * s.a_ct + s.a_c0 + c_) * HW; o0 = ((size_t)n * s.o0_ct + s.o0_c0 + c_) * HW; }
+    if (OP == EW_GELU_SPLIT) { a = ((size_t)n * 2 * s.nch + c_) * HW; b = a + (size_t)s.nch * HW; }
+    if (OP == EW_GATE_BWD || OP == EW_GATE_BWD2 || OP == EW_GELU2_GATE) d = o1 = ((size_t)n * s.o1_ct + s.o1_c0 + c_) * HW;
+    if (OP == EW_GELU_BWD) a = o0 = ((size_t)n * s.o0_ct + s.o0_c0 + c_) * HW;
+  }
 };
 template <int OP>
 __global__ __launch_bounds__(256) void ew_slice_kernel(const SliceArgs s) {
   const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, n = blockIdx.z;
   if (p >= s.HW) return;
-  auto at = [&](const float* t, int ct, int c0) { return t[((size_t)n * ct + c0 + c) * s.HW + p]; };
-  auto to = [&](float* t, int ct, int c0) -> float& { return t[((size_t)n * ct + c0 + c) * s.HW + p]; };
-  if (OP == EW_COPY) {
-    to(s.o0, s.o0_ct, s.o0_c0) = at(s.a, s.a_ct, s.a_c0);
-  } else if (OP == EW_GELU_SPLIT) {
-    to(s.o0, s.nch, 0) = gelu_erf_f(at(s.a, 2 * s.nch, 0));
-    to(s.o1, s.nch, 0) = gelu_erf_f(at(s.a, 2 * s.nch, s.nch));
-  } else if (OP == EW_GELU_GATE) {
-    to(s.o0, s.nch, 0) = gelu_erf_f(at(s.a, s.nch, 0)) * at(s.b, s.nch, 0);
-  } else if (OP == EW_GATE_BWD) {
-    const float u = at(s.a, s.nch, 0), h2 = at(s.b, s.nch, 0), dg = at(s.c, s.nch, 0);
-    to(s.o0, s.nch, 0) = gelu_grad_f(u) * (dg * h2);
-    to(s.o1, s.o1_ct, s.o1_c0) = gelu_grad_f(at(s.d, s.o1_ct, s.o1_c0)) * (dg * gelu_erf_f(u));
-  } else {
-    to(s.o0, s.o0_ct, s.o0_c0) = gelu_grad_f(at(s.a, s.o0_ct, s.o0_c0)) * at(s.b, s.nch, 0);
-  }
+  const EwOffsets<OP> o(s, n, c);
+  constexpr bool use_b = OP == EW_GELU_GATE || OP == EW_GATE_BWD || OP == EW_GELU_BWD, use_c = OP == EW_GATE_BWD || OP == EW_GATE_BWD2;
+  constexpr bool use_d = OP == EW_GATE_BWD || OP == EW_GATE_BWD2 || OP == EW_GELU2_GATE, two = OP == EW_GELU_SPLIT || OP == EW_GATE_BWD || OP == EW_GATE_BWD2;
+  const float a = s.a[o.a + p];
+  const float b = OP == EW_GELU_SPLIT ? s.a[o.b + p] : use_b ? s.b[o.b + p] : 0.f;
+  const float cc = use_c ? s.c[o.c + p] : 0.f, d = use_d ? s.d[o.d + p] : 0.f;
+  float r0, r1 = 0.f;
+  ew_apply<OP>(a, b, cc, d, &r0, &r1);
+  s.o0[o.o0 + p] = r0;
+  if (two) s.o1[o.o1 + p] = r1;
+}
+// HW % 4 == 0: four pixels per lane, 128-bit loads and stores (every slice base is then 16-byte aligned with the tensors)
+template <int OP>
+__global__ __launch_bounds__(256) void ew_slice4_kernel(const SliceArgs s) {
+  const int p = 4 * (blockIdx.x * 256 + threadIdx.x), c = blockIdx.y, n = blockIdx.z;
+  if (p >= s.HW) return;
+  const EwOffsets<OP> o(s, n, c);
+  constexpr bool use_b = OP == EW_GELU_GATE || OP == EW_GATE_BWD || OP == EW_GELU_BWD, use_c = OP == EW_GATE_BWD || OP == EW_GATE_BWD2;
+  constexpr bool use_d = OP == EW_GATE_BWD || OP == EW_GATE_BWD2 || OP == EW_GELU2_GATE, two = OP == EW_GELU_SPLIT || OP == EW_GATE_BWD || OP == EW_GATE_BWD2;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 a4 = *reinterpret_cast<const float4*>(s.a + o.a + p);
+  const float4 b4 = OP == EW_GELU_SPLIT ? *reinterpret_cast<const float4*>(s.a + o.b + p) : use_b ? *reinterpret_cast<const float4*>(s.b + o.b + p) : z4;
+  const float4 c4 = use_c ? *reinterpret_cast<const float4*>(s.c + o.c + p) : z4;
+  const float4 d4 = use_d ? *reinterpret_cast<const float4*>(s.d + o.d + p) : z4;
+  const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
+  float r0[4], r1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ew_apply<OP>(a[j], b[j], cc[j], d[j], &r0[j], &r1[j]);
+  *reinterpret_cast<float4*>(s.o0 + o.o0 + p) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+  if (two) *reinterpret_cast<float4*>(s.o1 + o.o1 + p) = make_float4(r1[0], r1[1], r1[2], r1[3]);
 }
 // out[n][c][p] = x[n][c][p] * a[n][c] + b[n][c]       (d y2 = grad_out * gate + d gap / HW, enhancer.py:325-333)
 __global__ __launch_bounds__(256) void nc_scale_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,

@@ -2,7 +2,7 @@
 backward is composed of in ``autograd.py`` -- general convolution (3x3 / 1x1 = Linear) with its input and weight gradients,
 LayerNorm over channels, depthwise 3x3 convolution, erf-GELU backward, and the sampling / scatter halves of the message extractor's
 deformable convolution. Thin wrappers over the C ABI
-(``gencomm_conv2d_{prepare,fold,fwd,wgrad}``, ``gencomm_ln_nchw_{fwd,bwd}``, ``gencomm_dwconv3x3_{fwd,wgrad}``,
+(``gencomm_conv2d_{prepare,fold,fwd,wgrad}``, ``gencomm_ln_nchw_{fwd,bwd}``, ``gencomm_dwconv3x3_{act_fwd,act_wgrad}``,
 ``gencomm_gelu_bwd``); no torch convolution / normalisation call anywhere."""
 from __future__ import annotations
 
@@ -189,7 +189,7 @@ def ln_bwd(x: torch.Tensor, gamma, dy: torch.Tensor, eps: float, accumulate_into
     return dx, dg, db
 
 
-EW_COPY, EW_GELU_SPLIT, EW_GELU_GATE, EW_GATE_BWD, EW_GELU_BWD = range(5)
+EW_COPY, EW_GELU_SPLIT, EW_GELU_GATE, EW_GATE_BWD, EW_GELU_BWD, EW_GELU2_GATE, EW_GATE_BWD2 = range(7)
 
 
 def ew_slice(op: int, a, b=None, c=None, d=None, o0=None, o1=None, *, n: int, nch: int, HW: int, a_ct: int = 0, a_c0: int = 0,
@@ -225,21 +225,26 @@ def nc_dot(x: torch.Tensor, y: Optional[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-def dwconv3x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], flip: bool = False) -> torch.Tensor:
+def dwconv3x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], flip: bool = False, gelu_in: bool = False) -> torch.Tensor:
+    """Depthwise 3x3 over the FIRST C = w.shape[0] channels of x (x may carry more: Linear1's [n, 2 hidden, H, W] output), gelu_in: the
+    layer's input is GELU(x), evaluated on load (gencomm_dwconv3x3_act_fwd)."""
     x = _c(x)
-    n, C, H, W = x.shape
-    y = torch.empty_like(x)
-    _lib.check(_lib.lib().gencomm_dwconv3x3_fwd(ptr(x), ptr(_c(w)), ptr(_c(b)) if b is not None else None, ptr(y), n, C, H, W, int(flip),
-                                                stream_ptr(x.device)), "gencomm_dwconv3x3_fwd")
+    n, x_ct, H, W = x.shape
+    C = w.shape[0]
+    y = torch.empty(n, C, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gencomm_dwconv3x3_act_fwd(ptr(x), x_ct, int(gelu_in), ptr(_c(w)), ptr(_c(b)) if b is not None else None, ptr(y), n, C, H, W,
+                                                    int(flip), stream_ptr(x.device)), "gencomm_dwconv3x3_act_fwd")
     return y
 
 
-def dwconv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor):
+def dwconv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, gelu_in: bool = False):
+    """dw, db of the depthwise layer whose input was the first dy.shape[1] channels of x (GELU of them when gelu_in)."""
     x, dy = _c(x), _c(dy)
-    n, C, H, W = x.shape
+    n, C, H, W = dy.shape
     blob = torch.zeros(C * 10, dtype=torch.float32, device=x.device)              # one fill launch for both gradients
     dw, db = blob[:C * 9].view(C, 1, 3, 3), blob[C * 9:]
-    _lib.check(_lib.lib().gencomm_dwconv3x3_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(db), n, C, H, W, stream_ptr(x.device)), "gencomm_dwconv3x3_wgrad")
+    _lib.check(_lib.lib().gencomm_dwconv3x3_act_wgrad(ptr(x), x.shape[1], int(gelu_in), ptr(dy), ptr(dw), ptr(db), n, C, H, W, stream_ptr(x.device)),
+               "gencomm_dwconv3x3_act_wgrad")
     return dw, db
 
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 7
+#define GENCOMM_ABI_VERSION 8
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -393,6 +393,13 @@ int gencomm_ln_nchw_bwd(const float* x, const float* gamma, const float* dy, flo
                         float eps, int accumulate, int n, int C, int HW, void* stream);
 int gencomm_dwconv3x3_fwd(const float* x, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip, void* stream);
 int gencomm_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream);
+/* ABI v8: the same two with the depthwise layer's input taken as the first C channels of an [n][x_ct][H][W] tensor and, act = 1, as
+ * GELU(x) evaluated on the values read (enhancer.py:236-243: x1 = GELU(Linear1(.))[:, :hidden] feeds the depthwise convolution) -- the
+ * training forward no longer writes the GELU outputs of Linear1, the weight gradient reads Linear1's output instead. act = 0 and
+ * x_ct = C are the plain calls above. */
+int gencomm_dwconv3x3_act_fwd(const float* x, int x_ct, int act, const float* w, const float* b, float* y, int n, int C, int H, int W, int flip,
+                              void* stream);
+int gencomm_dwconv3x3_act_wgrad(const float* x, int x_ct, int act, const float* dy, float* dw, float* db, int n, int C, int H, int W, void* stream);
 int gencomm_gelu_bwd(const float* v, const float* g, float* out, long long count, void* stream);
 int gencomm_lincomb_fwd(float* out, const float* x, const float* y, const float* z, float a, float b, float c, long long count, void* stream);
 /* Elementwise pieces of the Enhancer's backward on channel slices (slice = channels [c0, c0 + nch) of an [n][ct][HW] tensor), op:
@@ -401,6 +408,11 @@ int gencomm_lincomb_fwd(float* out, const float* x, const float* y, const float*
  *   2 o0 = GELU(a) * b                                            (gated product, enhancer.py:241-246)
  *   3 o0 = GELU'(a) c b, o1 slice = GELU'(d slice) c GELU(a)      (a = u, b = x2, c = d gated, d = Linear1 output; o1 / d share ct, c0)
  *   4 o0 slice = GELU'(a slice) b                                 (a, o0 share ct, c0; b has nch channels)
+ *   5 o0 = GELU(a) * GELU(d slice)                                (ABI v8; d has o1_ct channels, its slice starts at o1_c0: op 2 reading
+ *                                                                  x2 = GELU(Linear1 output) from Linear1's output itself)
+ *   6 o0 = GELU'(a) c GELU(d slice), o1 slice = GELU'(d slice) c GELU(a)   (ABI v8; op 3 without b: x2 recomputed from d)
+ * GELU' = Phi(x) + x phi(x) with the library's erf form (|Phi error| <= 0.85e-7) and one v_exp_f32 for the density.
+ * When HW % 4 == 0 and every pointer is 16-byte aligned a lane handles four pixels with 128-bit accesses.
  * nc_scale: out = x * a[n][c] + b[n][c] (b may be NULL);  nc_dot: out[n][c] = sum_p x (* y) with f64 accumulation (out is zeroed). */
 int gencomm_ew_slice_fwd(int op, const float* a, const float* b, const float* c, const float* d, float* o0, float* o1, int n, int nch, int HW,
                          int a_ct, int a_c0, int o0_ct, int o0_c0, int o1_ct, int o1_c0, void* stream);

@@ -124,6 +124,62 @@ def test_sampler_and_enhancer_glue_kernels_vs_torch():
     assert torch.allclose(T.nc_dot(x, None).double(), x.double().sum((2, 3)), rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize("hw", [(9, 13), (8, 12), (33, 64)])   # ragged (one pixel per lane) and HW % 4 == 0 (four pixels per lane, 128-bit accesses)
+def test_enhancer_gate_ops_that_recompute_gelu_from_linear1_output(hw):
+    """ABI v8: ops 5 / 6 of gencomm_ew_slice_fwd read x2 = GELU(v[:, hid:]) from v itself, every op in both the scalar and the
+    four-pixel form; GELU' = Phi + x phi from the library's erf form against float64 autograd."""
+    from gencomm_amd import train_ops as T
+    g = torch.Generator(device=DEV).manual_seed(hw[1])
+    n, hid, (H, W) = 2, 12, hw
+    HW = H * W
+    u, dg = (torch.randn(n, hid, H, W, device=DEV, generator=g) * s for s in (1.5, 1.0))
+    v = torch.randn(n, 2 * hid, H, W, device=DEV, generator=g) * 2.0
+    v[0, 0, 0, :4] = torch.tensor([-9.0, 9.0, 0.0, -0.75], device=DEV)      # saturated tails, zero, GELU's minimum
+    gt = torch.empty_like(u)
+    T.ew_slice(T.EW_GELU2_GATE, u, d=v, o0=gt, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
+    assert torch.allclose(gt.double(), F.gelu(u.double()) * F.gelu(v.double())[:, hid:], atol=3e-6)
+    ud, vd = u.double().requires_grad_(True), v.double().requires_grad_(True)
+    (F.gelu(ud) * F.gelu(vd)[:, hid:] * dg.double()).sum().backward()
+    du, dv = torch.empty_like(u), torch.zeros_like(v)
+    T.ew_slice(T.EW_GATE_BWD2, u, None, dg, v, o0=du, o1=dv, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
+    assert torch.allclose(du.double(), ud.grad, atol=3e-6) and torch.allclose(dv[:, hid:].double(), vd.grad[:, hid:], atol=3e-6)
+    assert float(dv[:, :hid].abs().max()) == 0.0
+    # the older ops on the same shape (four-pixel form when HW % 4 == 0)
+    h1, h2 = torch.empty_like(u), torch.empty_like(u)
+    T.ew_slice(T.EW_GELU_SPLIT, v, o0=h1, o1=h2, n=n, nch=hid, HW=HW)
+    ref = F.gelu(v.double())
+    assert torch.allclose(h1.double(), ref[:, :hid], atol=5e-7) and torch.allclose(h2.double(), ref[:, hid:], atol=5e-7)
+    du3, dv3 = torch.empty_like(u), torch.zeros_like(v)
+    T.ew_slice(T.EW_GATE_BWD, u, h2, dg, v, o0=du3, o1=dv3, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
+    assert torch.allclose(du3.double(), ud.grad, atol=3e-6) and torch.allclose(dv3[:, hid:].double(), vd.grad[:, hid:], atol=3e-6)
+    T.ew_slice(T.EW_GELU_BWD, v, dg, o0=dv3, n=n, nch=hid, HW=HW, o0_ct=2 * hid, o0_c0=0)
+    vd2 = v.double().requires_grad_(True)
+    (F.gelu(vd2)[:, :hid] * dg.double()).sum().backward()
+    assert torch.allclose(dv3[:, :hid].double(), vd2.grad[:, :hid], atol=3e-6)
+    out = T.gelu_bwd(v, torch.ones_like(v))
+    vd3 = v.double().requires_grad_(True)
+    F.gelu(vd3).sum().backward()
+    assert torch.allclose(out.double(), vd3.grad, atol=5e-7)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 9, 13), (2, 5, 37, 704), (1, 4, 33, 8)])
+def test_depthwise_kernels_on_gelu_of_a_channel_slice(shape):
+    """ABI v8 (gencomm_dwconv3x3_act_{fwd,wgrad}): the layer's input is GELU of the first C channels of a 2 C-channel tensor."""
+    from gencomm_amd import train_ops as T
+    n, C, H, W = shape
+    g = torch.Generator().manual_seed(W + 1)
+    v, dy = torch.randn(n, 2 * C, H, W, generator=g) * 2.0, torch.randn(n, C, H, W, generator=g)
+    w, b = torch.randn(C, 1, 3, 3, generator=g), torch.randn(C, generator=g)
+    wd = w.double().requires_grad_(True)
+    yd = F.conv2d(F.gelu(v.double())[:, :C], wd, b.double(), padding=1, groups=C)
+    (yd * dy.double()).sum().backward()
+    y = T.dwconv3x3(v.to(DEV), w.to(DEV), b.to(DEV), gelu_in=True)
+    assert y.shape == (n, C, H, W) and torch.allclose(y.double().cpu(), yd.detach(), atol=4e-6)
+    dw, db = T.dwconv3x3_wgrad(v.to(DEV), dy.to(DEV), gelu_in=True)
+    scale = max(1.0, float(n * H * W) ** 0.5 / 16)
+    assert torch.allclose(dw.double().cpu(), wd.grad, rtol=1e-5, atol=2e-5 * scale) and torch.allclose(db.double().cpu(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-5 * scale)
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 9, 13), (1, 8, 16, 24), (2, 4, 7, 5),
                                    (2, 3, 37, 704), (1, 2, 70, 264), (3, 5, 8, 256), (1, 4, 33, 4)])   # W % 4 == 0: the sliding-window kernels
 def test_depthwise_kernels_vs_torch(shape):
