@@ -178,6 +178,11 @@ def _gate_mlp(sa, gap, params):
     return torch.sigmoid(F.linear(F.relu(F.layer_norm(F.linear(gap, params[0]), (params[0].shape[0],), params[1], params[2], 1e-5)), params[3]))
 
 
+# Diagnostic switch (tools/train_bench.py --enh-split): True = the first half of round 4's flow, which wrote x1, x2 = GELU(Linear1 output).chunk(2)
+# in a pass of their own and kept them for the backward; False (default) = their consumers evaluate GELU on the half of v they read.
+ENH_MATERIALIZE_GELU = False
+
+
 class EnhancerFunction(torch.autograd.Function):
     """The Enhancer for a call that will be differentiated.  The forward runs the stage layer by layer in NCHW on HIP primitives
     (gencomm_amd/train_ops.py: LayerNorm, the partial 3x3 and the Linear layers as convolutions, depthwise 3x3, fused GELU / gate
@@ -201,16 +206,25 @@ class EnhancerFunction(torch.autograd.Function):
             T.conv2d(z1, m.partial_conv3.weight, None, 1, out=zi, out_coff=0)
             w1 = m.linear1[0].weight.detach()[:, :, None, None]
             v = T.conv2d(zi, w1, m.linear1[0].bias, 0)                                # Linear1          :235
-            # x1, x2 = GELU(v).chunk(2) (:236-240) are never written: the depthwise layer and the gate evaluate GELU on the half of v they read
-            u = T.dwconv3x3(v, m.dwconv[0].weight, m.dwconv[0].bias, gelu_in=True)     # depthwise(x1)    :241-243
-            g = torch.empty_like(u)
-            T.ew_slice(T.EW_GELU2_GATE, u, d=v, o0=g, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)   # GELU(u) * x2     :244-246
+            h1 = h2 = None
+            if ENH_MATERIALIZE_GELU:
+                h1, h2 = torch.empty(n, hid, H, W, dtype=torch.float32, device=x.device), torch.empty(n, hid, H, W, dtype=torch.float32, device=x.device)
+                T.ew_slice(T.EW_GELU_SPLIT, v, o0=h1, o1=h2, n=n, nch=hid, HW=HW)         # GELU, chunk      :236-240
+                u = T.dwconv3x3(h1, m.dwconv[0].weight, m.dwconv[0].bias)
+                g = torch.empty_like(u)
+                T.ew_slice(T.EW_GELU_GATE, u, h2, o0=g, n=n, nch=hid, HW=HW)
+            else:
+                # x1, x2 = GELU(v).chunk(2) (:236-240) are never written: the depthwise layer and the gate evaluate GELU on the half of v they read
+                u = T.dwconv3x3(v, m.dwconv[0].weight, m.dwconv[0].bias, gelu_in=True)     # depthwise(x1)    :241-243
+                g = torch.empty_like(u)
+                T.ew_slice(T.EW_GELU2_GATE, u, d=v, o0=g, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)   # GELU(u) * x2     :244-246
             w2 = m.linear2[0].weight.detach()[:, :, None, None]
             y2 = T.conv2d(g, w2, m.linear2[0].bias, 0, residual=y)                     # Linear2 + residual :247, :354
             gap = T.nc_dot(y2, None) / HW                                              # global average pool   :325
             a = _gate_mlp(sa, gap, [sa.fc1.weight, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight])
             out = T.nc_scale(y2, a, None)                                              # x * gate         :333
         ctx.enh = enh
+        ctx.h12 = (h1, h2)
         ctx.save_for_backward(x, y, z1, zi, v, u, g, y2, gap)
         return out
 
@@ -247,9 +261,13 @@ class EnhancerFunction(torch.autograd.Function):
             dW2, db2 = on_side(lambda: T.conv2d_wgrad(dy2, g, 1, 0, True))
             # ---- gate, depthwise + GELU, Linear1's GELU: d u and the x2 half of d v in one pass, the x1 half behind the depthwise dgrad
             du, dv = torch.empty_like(u), torch.empty_like(v)
-            T.ew_slice(T.EW_GATE_BWD2, u, None, dg, v, o0=du, o1=dv, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
+            h1, h2 = ctx.h12
+            if h2 is not None:
+                T.ew_slice(T.EW_GATE_BWD, u, h2, dg, v, o0=du, o1=dv, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
+            else:
+                T.ew_slice(T.EW_GATE_BWD2, u, None, dg, v, o0=du, o1=dv, n=n, nch=hid, HW=HW, o1_ct=2 * hid, o1_c0=hid)
             dh1 = T.dwconv3x3(du, m.dwconv[0].weight, None, flip=True)
-            dWd, dbd = on_side(lambda: T.dwconv3x3_wgrad(v, du, gelu_in=True))
+            dWd, dbd = on_side((lambda: T.dwconv3x3_wgrad(h1, du)) if h1 is not None else (lambda: T.dwconv3x3_wgrad(v, du, gelu_in=True)))
             T.ew_slice(T.EW_GELU_BWD, v, dh1, o0=dv, n=n, nch=hid, HW=HW, o0_ct=2 * hid, o0_c0=0)
             # ---- Linear1
             dzi = T.conv2d(dv, w1.transpose(0, 1).contiguous(), None, 0)

@@ -554,6 +554,12 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
     GC_HIP(hipGetLastError());
     return GC_OK;
   }
+  // Measured and NOT adopted (second half of round 4, profiles/r4_train_lib_ab.txt): a dedicated Linear kernel over consecutive pixels
+  // (workgroup = 128 pixels x up to 128 output channels, 128-bit loads of 512-byte rows, 128-byte store runs, the input read once per
+  // 128 channels).  Its launches were shorter in the kernel trace (the Enhancer's four Linear launches at 4 x 200 x 704: 1 041 us against
+  // 1 190 us here), but the training step on one box was 0.45 ms SLOWER with it (13.65 against 13.2 ms per scene, three alternating
+  // rounds; cause not established -- the side stream's weight-gradient launches run beside these layers).
+  // 256 channels per workgroup: 702 us for Linear1 alone; several tiles per workgroup: 688 us (the next barrier waits for the stores).
   // 8-row tiles (two accumulators per wave) whenever they still give the launch >= 2 workgroups per CU
   const long long tiles8 = (long long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
   // (not for 1 x 1: its weight slab is small against the pixel patch, and the doubled patch staging cost 9 % on the Enhancer's Linear layers)

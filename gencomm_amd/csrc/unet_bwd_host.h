@@ -12,13 +12,15 @@ namespace gc {
 
 // dgrad weight table of one UNet call: every 3x3 stride-1 layer's input-gradient weights, in the order the backward walk uses
 // them (conv_out, then per op from the last to the first; conv_in contributes two entries: cond channels, x channels)
-struct DgradEntry { long long w_off; int cout, cin, ic0, nic; long long p_off; };
+struct DgradEntry { long long w_off; int cout, cin, ic0, nic; long long p_off; int blocked; long long floats; };
 inline std::vector<DgradEntry> dgrad_entries(const UNetPlan& p) {
   std::vector<DgradEntry> e;
   long long off = 0;
-  auto add = [&](long long w, int cout, int cin, int ic0, int nic) {
-    e.push_back(DgradEntry{w, cout, cin, ic0, nic, off});
-    off += (long long)align_up((size_t)cout * nic * 9, 64);
+  // blocked: conv_out_kernel's [ceil(nic / 16)][cout][9][16] layout (zero padded) instead of [(cout, flipped tap)][nic]
+  auto add = [&](long long w, int cout, int cin, int ic0, int nic, int blocked = 0) {
+    const long long fl = (long long)align_up(blocked ? (size_t)((nic + 15) / 16) * cout * 144 : (size_t)cout * nic * 9, 64);
+    e.push_back(DgradEntry{w, cout, cin, ic0, nic, off, blocked, fl});
+    off += fl;
   };
   for (int oi = (int)p.ops.size() - 1; oi >= 0; --oi) {
     const Op& o = p.ops[oi];
@@ -28,7 +30,11 @@ inline std::vector<DgradEntry> dgrad_entries(const UNetPlan& p) {
       case OP_RES_CONV1: for (int s0 = 0; s0 < p.blocks[o.blk].cin; s0 += 8) add(p.blocks[o.blk].c1w, 8, p.blocks[o.blk].cin, s0, 8); break;
       case OP_UP: add(p.up[o.level + 1].w, 8, 8, 0, 8); break;
       // conv_in's message-channel gradient through the 8 -> 8 kernel: input channels 0..7 (the 2 message channels + 6 of x_t, discarded)
+#ifdef GC_DIAG_IGEMM_CONVIN_DGRAD   // diagnostic build: conv_in's x_t gradient through the general implicit-GEMM kernel (the round-3 path)
       case OP_CONV_IN: add(p.conv_in.w, 8, p.C + 2, 0, 8); add(p.conv_in.w, 8, p.C + 2, 2, p.C); break;
+#else
+      case OP_CONV_IN: add(p.conv_in.w, 8, p.C + 2, 0, 8); add(p.conv_in.w, 8, p.C + 2, 2, p.C, 1); break;
+#endif
       default: break;
     }
   }
@@ -36,7 +42,7 @@ inline std::vector<DgradEntry> dgrad_entries(const UNetPlan& p) {
 }
 inline size_t dgrad_table_floats(const UNetPlan& p) {
   const std::vector<DgradEntry> e = dgrad_entries(p);
-  return e.empty() ? 64 : (size_t)(e.back().p_off + (long long)align_up((size_t)e.back().cout * e.back().nic * 9, 64));
+  return e.empty() ? 64 : (size_t)(e.back().p_off + e.back().floats);
 }
 
 struct UNetBwdWs {
@@ -142,6 +148,28 @@ inline int dgradC8_enqueue(const UNetBwdCall& b, const float* dy, const float* w
   return GC_OK;
 }
 
+// conv_in's gradient with respect to x_t (forward C -> 8, so 8 -> C here) through the UNet's own exact-fp32 8 -> C kernel (conv_out_kernel
+// without its GroupNorm): the general implicit-GEMM kernel stages 16-pixel row segments one float at a time and took 206 us per call at
+// 4 x 64 x 200 x 704 for 162 MB of traffic.  The table entry is in that kernel's blocked layout (prep_dgrad_all_kernel).
+inline int dgrad8C_enqueue(const UNetBwdCall& b, const float* dy, const float* w_fwd, int Cin_f, int ic0, int C, float* out, int n, int H, int W) {
+  const DgradEntry& e = (*b.dg)[b.dg_next++];
+  if (b.raw + e.w_off != w_fwd || e.cout != 8 || e.cin != Cin_f || e.ic0 != ic0 || e.nic != C || !e.blocked)
+    return fail(GC_ERR_ARG, "gencomm_unet_bwd: dgrad weight table out of step with the backward walk");
+  ConvOutArgs co{};
+  co.src = dy; co.w = b.F(b.bw->wtmp) + e.p_off; co.bias = b.F(b.bw->zeros); co.out = out;
+  co.C = C; co.H = H; co.W = W; co.xcd = b.c.m.xcd();
+  Modes mf = b.c.m;
+  mf.v[MODE_ARITH] = 1;
+  const int nocb = (C + 15) / 16;
+  const TileCfg tc = pick_tile(mf, n, H, W, nocb) == TILE_64x16 ? TILE_64x16 : TILE_32x8;
+  int tw, th;
+  tile_dims(tc, &tw, &th);
+  const dim3 grid(cdiv(W, tw), cdiv(H, th), n * nocb);
+  if (tc == TILE_64x16) conv_out_kernel<64, 16, 4, 0, false><<<grid, 256, 0, b.c.st>>>(co);
+  else conv_out_kernel<32, 8, 1, 0, false><<<grid, 256, 0, b.c.st>>>(co);
+  return GC_OK;
+}
+
 // weight gradient whose input is SiLU(GroupNorm(.)) of one or two 8-channel forward tensors, applied in the staging
 inline void wgrad_gn_sources(const UNetBwdCall& b, WgradArgs& wa, int src0, int src1, const float* gamma, const float* beta, int gs, int HW) {
   wa.x0 = b.c.tensor_ptr(src0);
@@ -229,7 +257,8 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
     for (size_t i = 0; i < e.size(); ++i) {
       pa.w_off[i] = (int)e[i].w_off; pa.p_off[i] = (int)e[i].p_off;
       pa.cout[i] = (short)e[i].cout; pa.cin[i] = (short)e[i].cin; pa.ic0[i] = (short)e[i].ic0; pa.nic[i] = (short)e[i].nic;
-      most = std::max(most, e[i].cout * e[i].nic * 9);
+      pa.blocked[i] = (unsigned char)e[i].blocked;
+      most = std::max(most, (int)e[i].floats);
     }
     prep_dgrad_all_kernel<<<dim3(std::min(cdiv(most, 256), 8), (unsigned)e.size()), 256, 0, st>>>(pa);
   }
@@ -360,7 +389,11 @@ inline int unet_bwd_walk(const UNetBwdCall& b, const float* x_t, const float* co
           SliceArgs sa{DA, nullptr, nullptr, nullptr, grad_cond, nullptr, n, 2, Hl * Wl, 8, 0, 0, 0, 2, 0, 0, 0};
           ew_slice_kernel<EW_COPY><<<dim3(cdiv(Hl * Wl, 256), 2, n), 256, 0, st>>>(sa);
         }
+#ifdef GC_DIAG_IGEMM_CONVIN_DGRAD
         if (int rc = dgrad3x3_enqueue(b, gh, b.raw + p.conv_in.w, 8, C + 2, 2, C, grad_xt, C, 0, n, Hl, Wl)) return rc;
+#else
+        if (int rc = dgrad8C_enqueue(b, gh, b.raw + p.conv_in.w, C + 2, 2, C, grad_xt, n, Hl, Wl)) return rc;
+#endif
         break;
       }
       case OP_ATTN:

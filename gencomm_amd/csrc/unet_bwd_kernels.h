@@ -551,12 +551,22 @@ struct PrepDgradArgs {
   int layers;
   int w_off[kMaxDgradLayers], p_off[kMaxDgradLayers];
   short cout[kMaxDgradLayers], cin[kMaxDgradLayers], ic0[kMaxDgradLayers], nic[kMaxDgradLayers];
+  unsigned char blocked[kMaxDgradLayers];   // 1: conv_out_kernel's layout [ceil(nic / 16)][cout = 8][9][16], zero padded (conv_in's x_t gradient)
 };
 __global__ __launch_bounds__(256) void prep_dgrad_all_kernel(const PrepDgradArgs a) {
   const int L = blockIdx.y;
   const int Cin = a.cin[L], ic0 = a.ic0[L], nic = a.nic[L], total = a.cout[L] * nic * 9;
   const float* __restrict__ w = a.raw + a.w_off[L];
   float* __restrict__ P = a.P + a.p_off[L];
+  if (a.blocked[L]) {
+    const int cout = a.cout[L], tot = ((nic + 15) / 16) * cout * 144;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) {
+      const int o16 = i & 15, k = i >> 4, tp = k % 9, k2 = k / 9, oc = k2 % cout, ocb = k2 / cout;
+      const int icl = ocb * 16 + o16;
+      P[i] = icl < nic ? w[((size_t)oc * Cin + ic0 + icl) * 9 + (8 - tp)] : 0.f;
+    }
+    return;
+  }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int icl = i % nic, k = i / nic, oc = k / 9, tp = k - oc * 9;
     P[i] = w[((size_t)oc * Cin + ic0 + icl) * 9 + (8 - tp)];

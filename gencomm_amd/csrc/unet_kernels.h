@@ -784,7 +784,9 @@ struct ConvOutArgs {
   int src_bf16;         // bf16 denoise mode: `src` is a bf16 map (conv_out_h_kernel only)
 };
 
-template <int TW, int TH, int PPL, int POST>
+// GN = false (round 4, backward): a bare 3x3 8 -> C convolution of `src` -- conv_in's input gradient with respect to x_t
+// (unet_bwd_host.h: the weights come from the dgrad table in this kernel's blocked layout); sstat / gamma / beta are not read.
+template <int TW, int TH, int PPL, int POST, bool GN = true>
 __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOutArgs a) {
   constexpr int NT = (TW / PPL) * TH;
   constexpr int LH = TH + 2, LS = TW + 8;
@@ -804,15 +806,17 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv_out_kernel(const ConvOut
   load_wregs<18>(wr, a.w + (size_t)ocb * 1152, 1152, lane);
   TileRegs<TW, TH, NT, 8> R;
   if (wvec) stage_load<TW, TH, NT, 8, false>(R, a.src + (size_t)n * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, tid);
-  if (tid < 8) {
-    float A, B;
-    gn_coeff(a.sstat + (size_t)n * 16, tid, 2, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
-    s_ab[tid][0] = A;
-    s_ab[tid][1] = B;
+  if (GN) {
+    if (tid < 8) {
+      float A, B;
+      gn_coeff(a.sstat + (size_t)n * 16, tid, 2, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
+      s_ab[tid][0] = A;
+      s_ab[tid][1] = B;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (wvec) stage_store<TW, TH, NT, 8, true, LS>(tile, R, a.H, a.W, x0, y0, s_ab, tid);
-  else stage_tile_scalar<TW, TH, NT, 8, true, false, LS>(tile, a.src + (size_t)n * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, s_ab, tid);
+  if (wvec) stage_store<TW, TH, NT, 8, GN, LS>(tile, R, a.H, a.W, x0, y0, s_ab, tid);
+  else stage_tile_scalar<TW, TH, NT, 8, GN, false, LS>(tile, a.src + (size_t)n * 8 * plane, (unsigned)plane, a.W, a.H, a.W, x0, y0, s_ab, tid);
   __syncthreads();
 
   f32x4 acc[4][PPL];

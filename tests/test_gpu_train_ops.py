@@ -124,6 +124,40 @@ def test_sampler_and_enhancer_glue_kernels_vs_torch():
     assert torch.allclose(T.nc_dot(x, None).double(), x.double().sum((2, 3)), rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(40, 6), (64, 256), (128, 64), (24, 70), (72, 300)])
+def test_linear_over_a_large_map(cin, cout):
+    """1 x 1 convolutions (the Enhancer's Linear layers, conv_kernels.h) on a map of 32 760 pixels: channel counts below / across the
+    64-row tile and the 32-channel chunk, bias, residual and a write into a channel slice, against float64."""
+    from gencomm_amd import train_ops as T
+    g = torch.Generator().manual_seed(cin + cout)
+    n, H, W = 2, 130, 252
+    x = torch.randn(n, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    y = T.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), 0)
+    assert torch.allclose(y.double().cpu(), ref, rtol=1e-5, atol=2e-5)
+    y = T.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), 0, residual=res.to(DEV))
+    assert torch.allclose(y.double().cpu(), ref + res.double(), rtol=1e-5, atol=2e-5)
+    buf = torch.full((n, cout + 5, H, W), -3.0, device=DEV)
+    T.conv2d(x.to(DEV), w.to(DEV), None, 0, out=buf, out_coff=2)
+    assert torch.allclose(buf[:, 2:2 + cout].double().cpu(), F.conv2d(x.double(), w.double()), rtol=1e-5, atol=2e-5)
+    assert bool((buf[:, :2] == -3.0).all()) and bool((buf[:, 2 + cout:] == -3.0).all())
+
+
+def test_linear_at_the_metric_geometry():
+    """4 x 200 x 706 pixels, 16 -> 64 channels: ragged pixel tiles at the row ends."""
+    from gencomm_amd import train_ops as T
+    g = torch.Generator().manual_seed(9)
+    n, cin, cout, H, W = 4, 16, 64, 200, 706       # HW = 141200 = 1103 full tiles + 16 pixels
+    x = torch.randn(n, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / 4
+    b = torch.randn(cout, generator=g)
+    y = T.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), 0)
+    assert torch.allclose(y.double().cpu(), F.conv2d(x.double(), w.double(), b.double()), rtol=1e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("hw", [(9, 13), (8, 12), (33, 64)])   # ragged (one pixel per lane) and HW % 4 == 0 (four pixels per lane, 128-bit accesses)
 def test_enhancer_gate_ops_that_recompute_gelu_from_linear1_output(hw):
     """ABI v8: ops 5 / 6 of gencomm_ew_slice_fwd read x2 = GELU(v[:, hid:]) from v itself, every op in both the scalar and the

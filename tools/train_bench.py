@@ -12,6 +12,9 @@ DEV = "cuda:0"
 OPTIMIZER = "--no-optimizer" not in sys.argv
 ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""   # "shipped" / "large": one shape (profiling runs)
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1   # scenes per step (the shipped yamls train with batch_size 1, 2 or 4)
+if "--enh-split" in sys.argv:   # diagnostic: the Enhancer's training forward writes GELU(Linear1 output) in a pass of its own again
+    from gencomm_amd import autograd as _ag
+    _ag.ENH_MATERIALIZE_GELU = True
 if "--mode" in sys.argv:   # library modes for this run, e.g. --mode bwd_streams=0 (repeatable)
     from gencomm_amd import _lib
     _keys = {"arith": _lib.MODE_ARITH, "xcd": _lib.MODE_XCD_REMAP, "bwd_streams": _lib.MODE_BWD_STREAMS, "tile_want": _lib.MODE_TILE_WANT}
