@@ -10,6 +10,12 @@
 
 namespace gc {
 
+#ifdef GC_DIAG_SCALAR_GN_APPLY   // diagnostic build (tools/diag/train_lib_ab.sh): one dword per lane in the GroupNorm-backward apply / nin_dgrad, separate axpy
+constexpr bool kBwdVec4 = false;
+#else
+constexpr bool kBwdVec4 = true;
+#endif
+
 // dgrad weight table of one UNet call: every 3x3 stride-1 layer's input-gradient weights, in the order the backward walk uses
 // them (conv_out, then per op from the last to the first; conv_in contributes two entries: cond channels, x channels)
 struct DgradEntry { long long w_off; int cout, cin, ic0, nic; long long p_off; int blocked; long long floats; };
@@ -186,8 +192,9 @@ inline void gn_fwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma,
   gn_silu_fwd_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, b.c.st>>>(g);
 }
 // G[src] += backward of SiLU(GN(src)) given dA (channels coff.. of a ctotal-channel tensor); d gamma / d beta accumulated
+// add: optional further gradient of the same tensor, summed in the same pass (the identity shortcut's d out: saves the axpy launch)
 inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, const float* beta, int gs, int HW, const float* dA, int ctotal,
-                          int coff, long long dgamma_off, long long dbeta_off, bool fused = false) {
+                          int coff, long long dgamma_off, long long dbeta_off, bool fused = false, const float* add = nullptr) {
   hipStream_t st = b.c.st;
   const int u = b.gp.uses;
   if (u >= kMaxGnUses) return fail(GC_ERR_ARG, "gencomm_unet_bwd: too many GroupNorm uses");
@@ -197,8 +204,10 @@ inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, 
   g.x = b.c.tensor_ptr(src_id); g.stat = b.c.stat_ptr(src_id); g.gamma = gamma; g.beta = beta; g.da = dA; g.out = b.G(src_id); g.red = red;
   g.inv_cnt = 1.0 / ((double)gs * HW); g.gs = gs; g.HW = HW; g.da_ctotal = ctotal; g.da_coff = coff;
   g.da_is_dz = fused ? 1 : 0;   // fused: dgrad8_enqueue's epilogue wrote d z and this slot's sums
+  g.add = add;
   if (!fused) gn_silu_bwd_reduce_kernel<<<dim3(std::min(cdiv(HW, 256), 64), 8, b.c.n), 256, 0, st>>>(g);
-  gn_silu_bwd_apply_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, st>>>(g);
+  if (kBwdVec4 && (HW & 3) == 0) gn_silu_bwd_apply4_kernel<<<dim3(cdiv(HW / 4, 256), 8, b.c.n), 256, 0, st>>>(g);   // workspace maps are 256-byte aligned
+  else gn_silu_bwd_apply_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, st>>>(g);
   return GC_OK;
 }
 
@@ -333,12 +342,16 @@ inline int unet_bwd_walk(const UNetBwdCall& b, const float* x_t, const float* co
         if (int rc = dgrad8_enqueue(b, go, b.raw + rb.c2w, 8, 0, DA, n, Hl, Wl, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2)) return rc;
         if (int rc = gn_bwd_enqueue(b, o.src[0], b.raw + rb.n2w, b.raw + rb.n2b, 2, HW, DA, 8, 0, rb.n2w, rb.n2b, true)) return rc;
         if (rb.cin == 8) {
-          axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
+          // identity shortcut: d in += d out rides in conv1's GroupNorm-backward apply below (OP_RES_CONV1 of this block, the next op of the
+          // walk: both add to G[in]); only a block whose conv1 does not follow directly keeps the separate pass
+          const bool rides = kBwdVec4 && oi > 0 && p.ops[oi - 1].kind == OP_RES_CONV1 && p.ops[oi - 1].blk == o.blk && p.ops[oi - 1].src[0] == o.res[0];
+          if (!rides) axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
         } else {
           WgradArgs wn{go, c.tensor_ptr(o.res[0]), c.tensor_ptr(o.res[1]), b.graw + rb.ninw, b.graw + rb.ninb, 8, 8, 8, Hl, Wl, Hl, Wl, 1, 1, 0, 0};
           wn.part = b.F(b.bw->wpart);
           if (int rc = conv_wgrad_enqueue(wn, n, st)) return rc;
-          nin_dgrad_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW);
+          if (kBwdVec4 && (HW & 3) == 0) nin_dgrad4_kernel<<<dim3(cdiv(HW / 4, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW);
+          else nin_dgrad_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW);
         }
         break;
       }
@@ -351,11 +364,15 @@ inline int unet_bwd_walk(const UNetBwdCall& b, const float* x_t, const float* co
         wgrad_gn_sources(b, wa, o.src[0], nsrc == 2 ? o.src[1] : -1, b.raw + rb.n1w, b.raw + rb.n1b, gs, HW);
         wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
+        // identity shortcut of this block (cin == 8): d in += d out, skipped by OP_RES_CONV2 above when this op follows it directly
+        const float* shortcut = nullptr;
+        if (kBwdVec4 && rb.cin == 8 && oi + 1 < (int)p.ops.size() && p.ops[oi + 1].kind == OP_RES_CONV2 && p.ops[oi + 1].blk == o.blk && p.ops[oi + 1].res[0] == o.src[0])
+          shortcut = b.G(p.ops[oi + 1].dst);
         for (int s = 0; s < nsrc; ++s) {   // one 8-channel input gradient per source (its epilogue = GroupNorm backward's reductions), then the apply
           if (int rc = dgrad8_enqueue(b, gt, b.raw + rb.c1w, rb.cin, 8 * s, DA + (size_t)s * n * 8 * HW, n, Hl, Wl, o.src[s], b.raw + rb.n1w + 8 * s,
                                       b.raw + rb.n1b + 8 * s, gs)) return rc;
           if (int rc = gn_bwd_enqueue(b, o.src[s], b.raw + rb.n1w + 8 * s, b.raw + rb.n1b + 8 * s, gs, HW, DA + (size_t)s * n * 8 * HW, 8, 0,
-                                      rb.n1w + 8 * s, rb.n1b + 8 * s, true)) return rc;
+                                      rb.n1w + 8 * s, rb.n1b + 8 * s, true, s == 0 ? shortcut : nullptr)) return rc;
         }
         break;
       }

@@ -26,6 +26,7 @@ struct GnArgs {
   double inv_cnt;        // 1 / (gs * HW)
   int gs, HW, out_ctotal, out_coff, da_ctotal, da_coff;
   int da_is_dz;          // backward apply: `da` already holds dz = dA * SiLU'(.) (written by the input-gradient convolution's epilogue)
+  const float* add;      // backward apply, optional [n][8][HW]: a further gradient of the same tensor added in this pass (the identity shortcut's d out)
 };
 
 __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const GnArgs a) {
@@ -70,8 +71,37 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const GnArgs a) 
     const float g = a.gamma[c], xh = (a.x[e] - mean) * rstd;
     const float d0 = a.da[((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p];
     const float dz = a.da_is_dz ? d0 : d0 * silu_grad_f(fmaf(g, xh, a.beta[c]));
-    a.out[e] += rstd * (g * dz - f1 - xh * f2);
+    a.out[e] += rstd * (g * dz - f1 - xh * f2) + (a.add != nullptr ? a.add[e] : 0.f);
   }
+}
+// HW % 4 == 0: four pixels per lane, 128-bit accesses (second half of round 4: 93 launches per UNet call backwards, one dword per lane before)
+__global__ __launch_bounds__(256) void gn_silu_bwd_apply4_kernel(const GnArgs a) {
+  const int n = blockIdx.z, c = blockIdx.y, p = 4 * (blockIdx.x * 256 + threadIdx.x);
+  float mean, rstd;
+  gn_mean_rstd(a.stat + (size_t)n * 16, c, a.gs, a.inv_cnt, &mean, &rstd);
+  const int g0 = c & ~(a.gs - 1);
+  double m1 = 0.0, m2 = 0.0;
+  for (int j = 0; j < a.gs; ++j) {
+    m1 += (double)a.gamma[g0 + j] * a.red[((size_t)n * 8 + g0 + j) * 2 + 0];
+    m2 += (double)a.gamma[g0 + j] * a.red[((size_t)n * 8 + g0 + j) * 2 + 1];
+  }
+  const float f1 = (float)(m1 * a.inv_cnt), f2 = (float)(m2 * a.inv_cnt);
+  if (p >= a.HW) return;
+  const size_t e = ((size_t)n * 8 + c) * a.HW + p;
+  const float g = a.gamma[c], bt = a.beta[c];
+  const float4 x4 = *reinterpret_cast<const float4*>(a.x + e);
+  const float4 d4 = *reinterpret_cast<const float4*>(a.da + ((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p);
+  float4 o4 = *reinterpret_cast<const float4*>(a.out + e);
+  const float4 a4 = a.add != nullptr ? *reinterpret_cast<const float4*>(a.add + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w}, as[4] = {a4.x, a4.y, a4.z, a4.w};
+  float os[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xh = (xs[j] - mean) * rstd;
+    const float dz = a.da_is_dz ? ds[j] : ds[j] * silu_grad_f(fmaf(g, xh, bt));
+    os[j] += rstd * (g * dz - f1 - xh * f2) + as[j];
+  }
+  *reinterpret_cast<float4*>(a.out + e) = make_float4(os[0], os[1], os[2], os[3]);
 }
 
 // d gamma[c] += sum_n red[n][c][1], d beta[c] += sum_n red[n][c][0] for EVERY GroupNorm use of a UNet call at once: the
@@ -628,6 +658,34 @@ __global__ __launch_bounds__(256) void nin_dgrad_kernel(const float* __restrict_
     for (int oc = 0; oc < 8; ++oc) { s0 = fmaf(as_const(w)[oc * 16 + ic], o[oc], s0); s1 = fmaf(as_const(w)[oc * 16 + 8 + ic], o[oc], s1); }
     g0[((size_t)n * 8 + ic) * HW + p] += s0;
     g1[((size_t)n * 8 + ic) * HW + p] += s1;
+  }
+}
+
+// HW % 4 == 0: four pixels per lane
+__global__ __launch_bounds__(256) void nin_dgrad4_kernel(const float* __restrict__ go, const float* __restrict__ w, float* __restrict__ g0,
+                                                         float* __restrict__ g1, int HW) {
+  const int n = blockIdx.y, p = 4 * (blockIdx.x * 256 + threadIdx.x);
+  if (p >= HW) return;
+  float o[8][4];
+#pragma unroll
+  for (int oc = 0; oc < 8; ++oc) {
+    const float4 v = *reinterpret_cast<const float4*>(go + ((size_t)n * 8 + oc) * HW + p);
+    o[oc][0] = v.x; o[oc][1] = v.y; o[oc][2] = v.z; o[oc][3] = v.w;
+  }
+#pragma unroll
+  for (int ic = 0; ic < 8; ++ic) {
+    float4 a0 = *reinterpret_cast<const float4*>(g0 + ((size_t)n * 8 + ic) * HW + p), a1 = *reinterpret_cast<const float4*>(g1 + ((size_t)n * 8 + ic) * HW + p);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int oc = 0; oc < 8; ++oc) {   // the same order of the eight products per output as nin_dgrad_kernel
+      const float w0 = as_const(w)[oc * 16 + ic], w1 = as_const(w)[oc * 16 + 8 + ic];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] = fmaf(w0, o[oc][j], s0[j]); s1[j] = fmaf(w1, o[oc][j], s1[j]); }
+    }
+    a0.x += s0[0]; a0.y += s0[1]; a0.z += s0[2]; a0.w += s0[3];
+    a1.x += s1[0]; a1.y += s1[1]; a1.z += s1[2]; a1.w += s1[3];
+    *reinterpret_cast<float4*>(g0 + ((size_t)n * 8 + ic) * HW + p) = a0;
+    *reinterpret_cast<float4*>(g1 + ((size_t)n * 8 + ic) * HW + p) = a1;
   }
 }
 
