@@ -679,10 +679,12 @@ int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta
   GC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or neither");
   hipStream_t st = (hipStream_t)stream;
   GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
-  const unsigned chunks = (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64);
-  bn2d_stats_kernel<<<dim3(C, chunks), 256, 0, st>>>(x, scratch, n, C, HW);
+  const bool v4 = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);   // four pixels per lane
+  if (v4) bn2d_stats_kernel<4><<<dim3(C, (unsigned)std::min((HW + 1023) / 1024, 64)), 256, 0, st>>>(x, scratch, n, C, HW);
+  else bn2d_stats_kernel<1><<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64)), 256, 0, st>>>(x, scratch, n, C, HW);
   bn2d_finish_kernel<<<(C + 63) / 64, 64, 0, st>>>(scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, C);
-  bn2d_apply_kernel<<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, save, gamma, beta, y, C, HW, relu);
+  if (v4) bn2d_apply_kernel<4><<<dim3((HW / 4 + 255) / 256, C, n), 256, 0, st>>>(x, save, gamma, beta, y, C, HW, relu);
+  else bn2d_apply_kernel<1><<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, save, gamma, beta, y, C, HW, relu);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -692,9 +694,14 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
   GC_CHECK_ARG(x && y && dy && save && gamma && dx && scratch && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "bad arguments");
   hipStream_t st = (hipStream_t)stream;
   GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
-  const unsigned chunks = (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64);
-  bn2d_bwd_reduce_kernel<<<dim3(C, chunks), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu);
-  bn2d_bwd_apply_kernel<<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, y, dy, save, gamma, scratch, dx, dgamma, dbeta, (long long)n * HW, C, HW, relu);
+  const bool v4 = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);   // four pixels per lane
+  if (v4) {
+    bn2d_bwd_reduce_kernel<4><<<dim3(C, (unsigned)std::min((HW + 1023) / 1024, 64)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu);
+    bn2d_bwd_apply_kernel<4><<<dim3((HW / 4 + 255) / 256, C, n), 256, 0, st>>>(x, y, dy, save, gamma, scratch, dx, dgamma, dbeta, (long long)n * HW, C, HW, relu);
+  } else {
+    bn2d_bwd_reduce_kernel<1><<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu);
+    bn2d_bwd_apply_kernel<1><<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, y, dy, save, gamma, scratch, dx, dgamma, dbeta, (long long)n * HW, C, HW, relu);
+  }
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -858,14 +865,16 @@ int gencomm_ew_slice_fwd(int op, const float* a, const float* b, const float* c,
 }
 int gencomm_nc_scale_fwd(const float* x, const float* a, const float* b, float* out, int n, int C, int HW, void* stream) {
   GC_CHECK_ARG(x && a && out && n >= 1 && C >= 1 && (long long)n * C <= 65535 && HW >= 1, "bad arguments");
-  nc_scale_kernel<<<dim3((HW + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, a, b, out, HW);
+  if ((HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0)) nc_scale_kernel<4><<<dim3((HW / 4 + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, a, b, out, HW);
+  else nc_scale_kernel<1><<<dim3((HW + 255) / 256, n * C), 256, 0, (hipStream_t)stream>>>(x, a, b, out, HW);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
 int gencomm_nc_dot_fwd(const float* x, const float* y, float* out, int n, int C, int HW, void* stream) {
   GC_CHECK_ARG(x && out && n >= 1 && C >= 1 && (long long)n * C <= 65535 && HW >= 1, "bad arguments");
   GC_HIP(hipMemsetAsync(out, 0, (size_t)n * C * sizeof(float), (hipStream_t)stream));
-  nc_dot_kernel<<<dim3(std::min((HW + 255) / 256, 64), n * C), 256, 0, (hipStream_t)stream>>>(x, y, out, HW);
+  if ((HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0)) nc_dot_kernel<4><<<dim3(std::min((HW / 4 + 255) / 256, 64), n * C), 256, 0, (hipStream_t)stream>>>(x, y, out, HW);
+  else nc_dot_kernel<1><<<dim3(std::min((HW + 255) / 256, 64), n * C), 256, 0, (hipStream_t)stream>>>(x, y, out, HW);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
