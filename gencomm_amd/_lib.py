@@ -87,6 +87,8 @@ _SIGNATURES = {
     "gencomm_ln_nchw_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_float, _i, _i, _i, _i, _p]),
     "gencomm_dwconv3x3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_dwconv3x3_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_conv3x3_c16_scratch_floats": (_ll, []),
+    "gencomm_conv3x3_c16_fwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     "gencomm_dwconv3x3_act_fwd": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "gencomm_dwconv3x3_act_wgrad": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_gelu_bwd": (_i, [_p, _p, _p, _ll, _p]),

@@ -181,6 +181,8 @@ def _gate_mlp(sa, gap, params):
 # Diagnostic switch (tools/train_bench.py --enh-split): True = the first half of round 4's flow, which wrote x1, x2 = GELU(Linear1 output).chunk(2)
 # in a pass of their own and kept them for the backward; False (default) = their consumers evaluate GELU on the half of v they read.
 ENH_MATERIALIZE_GELU = False
+# Diagnostic switch (tools/train_bench.py --pconv-general): False = FRFN.partial_conv3 and its input gradient through the general convolution at every size
+ENH_PCONV_C16 = True
 
 
 class EnhancerFunction(torch.autograd.Function):
@@ -203,7 +205,10 @@ class EnhancerFunction(torch.autograd.Function):
             z1 = T.copy_slice(z, 0, dc)
             zi = torch.empty_like(z)                                                # cat[pconv(z[:, :dc]), z[:, dc:]]   :229-232
             T.copy_slice(z, dc, C - dc, zi, dc)
-            T.conv2d(z1, m.partial_conv3.weight, None, 1, out=zi, out_coff=0)
+            if ENH_PCONV_C16 and dc == 16 and n * HW >= (1 << 16):   # C = 64 on large maps: the UNet's 8-channel kernel (the general one re-stages 16-pixel segments)
+                T.conv3x3_c16(z, m.partial_conv3.weight, zi)
+            else:
+                T.conv2d(z1, m.partial_conv3.weight, None, 1, out=zi, out_coff=0)
             w1 = m.linear1[0].weight.detach()[:, :, None, None]
             v = T.conv2d(zi, w1, m.linear1[0].bias, 0)                                # Linear1          :235
             h1 = h2 = None
@@ -274,7 +279,10 @@ class EnhancerFunction(torch.autograd.Function):
             dW1, db1l = on_side(lambda: T.conv2d_wgrad(dv, zi, 1, 0, True))
             # ---- partial conv: its input gradient overwrites the first dc channels of d zi (= d z)
             dzi1 = T.copy_slice(dzi, 0, dc)
-            T.conv2d(dzi1, m.partial_conv3.weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, 1, out=dzi, out_coff=0)
+            if ENH_PCONV_C16 and dc == 16 and n * HW >= (1 << 16):
+                T.conv3x3_c16(dzi1, m.partial_conv3.weight, dzi, transposed=True)
+            else:
+                T.conv2d(dzi1, m.partial_conv3.weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, 1, out=dzi, out_coff=0)
             dz = dzi
             dWp, _ = on_side(lambda: T.conv2d_wgrad(dzi1, z1, 3, 1, False))
             ov.join()

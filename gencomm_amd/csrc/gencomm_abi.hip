@@ -383,6 +383,40 @@ int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, 
   return GC_OK;
 }
 
+// 3x3 stride-1 pad-1 convolution 16 -> 16 channels without bias on the UNet's exact-fp32 two-source kernel (conv8_kernel<.., NSRC = 2>),
+// one launch per 8-channel output group.  transposed = 1: the input gradient of such a layer (w is the FORWARD weight [16][16][3][3]:
+// dx[c] = sum_{o, tap} dy[o](. - tap) w[o][c][tap], i.e. channels swapped and taps flipped).
+__global__ void prep_c16_kernel(const float* __restrict__ w, float* __restrict__ dst /*[2 groups][16 ic][9][8 oc] + 8 zeros*/, int transposed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 8) dst[2 * 1152 + i] = 0.f;
+  if (i >= 2 * 1152) return;
+  const int o = i & 7, tap = (i >> 3) % 9, ic = (i / 72) & 15, g = i / 1152;
+  const int oc = 8 * g + o;
+  dst[i] = transposed ? w[((size_t)ic * 16 + oc) * 9 + (8 - tap)] : w[((size_t)oc * 16 + ic) * 9 + tap];
+}
+long long gencomm_conv3x3_c16_scratch_floats(void) { return 2 * 1152 + 64; }
+int gencomm_conv3x3_c16_fwd(const float* x, int x_ct, const float* w, int transposed, float* y, int y_ct, float* scratch, int n, int H, int W,
+                            void* stream) {
+  GC_CHECK_ARG(x && w && y && scratch && n >= 1 && H >= 1 && W >= 1 && x_ct >= 16 && y_ct >= 16 && (transposed == 0 || transposed == 1), "bad arguments");
+  GC_CHECK_ARG(x != y, "in place is not supported (a tile reads its neighbours' pixels)");
+  hipStream_t st = (hipStream_t)stream;
+  prep_c16_kernel<<<cdiv(2 * 1152, 256), 256, 0, st>>>(w, scratch, transposed);
+  Modes m = modes_snapshot();
+  m.v[MODE_ARITH] = 1;   // exact fp32 (gradients pass through this layer)
+  const size_t plane = (size_t)H * W;
+  for (int g = 0; g < 2; ++g) {
+    Conv8Args a{};
+    a.src[0] = x; a.src[1] = x + 8 * plane; a.src_ct = x_ct;
+    a.w = scratch + g * 1152; a.bias = scratch + 2 * 1152;
+    a.dst = y + (size_t)8 * g * plane; a.dst_ct = y_ct;
+    a.H = a.Hin = H; a.W = a.Win = W;
+    a.xcd = m.xcd();
+    launch_conv8<2, false, false, 0>(m, pick_tile(m, n, H, W), a, n, st);
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 static void launch_q_sample(const QSampleArgs& q, int n, bool philox, hipStream_t st) {
   TimedLaunch tl(KF_Q_SAMPLE, st);
   // 8 octets (64 elements) per thread: few enough workgroups that the max|x| commit (one atomic each) stays cheap on small maps

@@ -335,6 +335,8 @@ struct Conv8Args {
   const float* amax;      // !GN on the f16 pipe: device bound on max|src| (or null: bound from sstat[0], or none)
   int term_mask;          // diagnostic instantiation of conv8h_kernel only (gencomm_conv8_fwd): which of the six terms run
   int gn_gs;              // RES == 3 (backward): channels per GroupNorm group of the tensor in res[0]
+  int src_ct, dst_ct;     // conv8_kernel only: channels of the tensors src[] / dst point into (0 = 8: dense 8-channel maps).  A source / the
+                          // destination may be an 8-channel group of a wider NCHW tensor: the pointer is the group's first channel of sample 0
 };
 
 template <int TW, int TH, int PPL, int NSRC, bool GN, bool UP, int RES>
@@ -352,6 +354,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
   const int x0 = bid.x * TW, y0 = bid.y * TH;
   const int tx = tid % (TW / PPL), ty = tid / (TW / PPL);
   const size_t plane_in = (size_t)a.Hin * a.Win;
+  const size_t src_ns = (size_t)(a.src_ct ? a.src_ct : 8) * plane_in;   // sample strides of the sources / the destination
   const size_t plane = (size_t)a.H * a.W;
   const bool wvec = UP ? ((a.Win & 1) == 0) : ((a.W & 3) == 0);
   const int gy = y0 + ty, gx = x0 + tx * PPL;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
   for (int o = 0; o < 8; ++o) bias[o] = as_const(a.bias)[o];
   TileRegs<TW, TH, NT, 8> R;
   if (GC_EXP & 16) R = TileRegs<TW, TH, NT, 8>{};
-  else if (wvec) stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  else if (wvec) stage_load<TW, TH, NT, 8, UP>(R, a.src[0] + (size_t)n * src_ns, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   // RES == 3 (backward, unet_bwd_host.h): this convolution is an input gradient d A, res[0] is the forward tensor x whose
   // SiLU(GroupNorm(x)) the forward layer consumed: the epilogue turns d A into d z = d A * SiLU'(gamma xhat + beta), stores d z and
   // accumulates sum d z / sum d z xhat where the forward accumulates sum / sum of squares (GroupNorm backward's two reductions: the
@@ -426,9 +429,9 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
     for (int p = 0; p < PPL; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (wvec) stage_store<TW, TH, NT, 8, GN && !(GC_EXP & 2), LS>(tile, R, a.H, a.W, x0, y0, &s_ab[0], tid);
-  else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
+  else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[0] + (size_t)n * src_ns, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[0], tid);
   if (NSRC == 2 && wvec)  // prefetch the skip tensor's tile while the first half is computed
-    stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    stage_load<TW, TH, NT, 8, UP>(R, a.src[1] + (size_t)n * src_ns, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
   __syncthreads();
   GC_STAMP(2);
   if (!(GC_EXP & 1) && wave_live) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[0], acc, tx, ty);
@@ -436,7 +439,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
   if (NSRC == 2) {
     __syncthreads();
     if (wvec) stage_store<TW, TH, NT, 8, GN && !(GC_EXP & 2), LS>(tile, R, a.H, a.W, x0, y0, &s_ab[8], tid);
-    else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
+    else stage_tile_scalar<TW, TH, NT, 8, GN, UP, LS>(tile, a.src[1] + (size_t)n * src_ns, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
     __syncthreads();
     if (!(GC_EXP & 1) && wave_live) conv_tile_mfma<8, 2, PPL, LH, LS, 9>(tile, wr[NSRC - 1], acc, tx, ty);
   }
@@ -489,7 +492,7 @@ __global__ __launch_bounds__((TW / PPL) * TH) void conv8_kernel(const Conv8Args 
 
   #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      float* __restrict__ dp = a.dst + ((size_t)n * 8 + o) * plane + pix;
+      float* __restrict__ dp = a.dst + ((size_t)n * (a.dst_ct ? a.dst_ct : 8) + o) * plane + pix;
       if ((GC_EXP & 4) && out[o][0] != 1.2345e30f) {
       } else if (vec_ok) {
         *reinterpret_cast<float4*>(dp) = make_float4(out[o][0], out[o][1 % PPL], out[o][2 % PPL], out[o][3 % PPL]);

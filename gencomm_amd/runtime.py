@@ -27,7 +27,16 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device: torch.device) -> int:
+    """The hipStream_t of torch's current stream on `device`. Called once per kernel launch (1 750 times per training-leg step):
+    torch's raw accessor returns the handle without building a `torch.cuda.Stream` object (measured per call in
+    tools/diag/host_call_cost.py); the object path stays as the fallback for a build without it."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -136,6 +136,18 @@ def _conv3x3_s2_dgrad_subpixel(dy: torch.Tensor, w: torch.Tensor) -> torch.Tenso
     return dx
 
 
+def conv3x3_c16(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """3x3 pad-1 convolution of the first 16 channels of x [n, >= 16, H, W] with w [16, 16, 3, 3] (no bias) into the first 16 channels of
+    `out` (gencomm_conv3x3_c16_fwd: the UNet's 8-channel kernel); transposed: the layer's input gradient from its forward weight."""
+    n, x_ct, H, W = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and tuple(w.shape) == (16, 16, 3, 3) and out.shape[0] == n and out.shape[2:] == x.shape[2:]
+    l = _lib.lib()
+    scratch = torch.empty(_lib.check_size(l.gencomm_conv3x3_c16_scratch_floats(), "gencomm_conv3x3_c16_scratch_floats"), dtype=torch.float32, device=x.device)
+    _lib.check(l.gencomm_conv3x3_c16_fwd(ptr(x), x_ct, ptr(_c(w)), int(transposed), ptr(out), out.shape[1], ptr(scratch), n, H, W, stream_ptr(x.device)),
+               "gencomm_conv3x3_c16_fwd")
+    return out
+
+
 def bn2d_train_fwd(x: torch.Tensor, bn, relu: bool):
     """(y, save): BatchNorm2d with batch statistics (+ ReLU) on the HIP kernels; updates bn.running_mean / running_var /
     num_batches_tracked exactly as nn.BatchNorm2d in training mode does."""

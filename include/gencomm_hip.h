@@ -175,6 +175,15 @@ int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, 
 int gencomm_conv8_fwd(const float* src, const float* w_oihw, const float* bias, float* dst, double* dstat,
                       float* scratch, int n, int H, int W, int split, void* stream);
 
+/* ABI v8: 3x3 stride-1 pad-1 convolution 16 -> 16 channels without bias -- FRFN.partial_conv3 at C = 64 (enhancer.py:218, :229-232: the
+ * first C / 4 channels of the LayerNorm output) and, transposed = 1, its input gradient (w is the forward weight [16][16][3][3] in both
+ * cases) -- on the UNet's exact-fp32 8-channel kernel: x / y are the first 16 channels of [n][x_ct][H][W] / [n][y_ct][H][W] tensors (so
+ * the layer reads its slice of the LayerNorm output and writes its slice of Linear1's input without copies); x != y; scratch of
+ * gencomm_conv3x3_c16_scratch_floats() floats. The general convolution took 160-250 us for this layer at 4 x 200 x 704 (72 MB of traffic). */
+long long gencomm_conv3x3_c16_scratch_floats(void);
+int gencomm_conv3x3_c16_fwd(const float* x, int x_ct, const float* w, int transposed, float* y, int y_ct, float* scratch, int n, int H, int W,
+                            void* stream);
+
 /* Scratch for one UNet call / the denoise loop on n agents of [C, H, W]. */
 long long gencomm_denoise_workspace_bytes(int n, int C, int H, int W, int levels, int res_blocks, int attn_mask);
 

@@ -146,6 +146,27 @@ def test_linear_over_a_large_map(cin, cout):
     assert bool((buf[:, :2] == -3.0).all()) and bool((buf[:, 2 + cout:] == -3.0).all())
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72), (3, 19, 37), (1, 200, 704)])
+def test_conv3x3_on_16_channel_slices_forward_and_input_gradient(shape):
+    """gencomm_conv3x3_c16_fwd (ABI v8): FRFN.partial_conv3 at C = 64 on the UNet's 8-channel exact-fp32 kernel, reading the first 16
+    channels of a wider tensor and writing the first 16 of another; transposed = its input gradient from the forward weight."""
+    from gencomm_amd import train_ops as T
+    n, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(n, 24, H, W, generator=g)
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12
+    out = torch.full((n, 20, H, W), -5.0, device=DEV)
+    T.conv3x3_c16(x.to(DEV), w.to(DEV), out)
+    ref = F.conv2d(x[:, :16].double(), w.double(), padding=1)
+    assert torch.allclose(out[:, :16].double().cpu(), ref, rtol=1e-5, atol=2e-5) and bool((out[:, 16:] == -5.0).all())
+    xd = x[:, :16].double().requires_grad_(True)
+    dy = torch.randn(n, 16, H, W, generator=g)
+    (F.conv2d(xd, w.double(), padding=1) * dy.double()).sum().backward()
+    dx = torch.empty(n, 16, H, W, device=DEV)
+    T.conv3x3_c16(dy.to(DEV), w.to(DEV), dx, transposed=True)
+    assert torch.allclose(dx.double().cpu(), xd.grad, rtol=1e-5, atol=2e-5)
+
+
 def test_linear_at_the_metric_geometry():
     """4 x 200 x 706 pixels, 16 -> 64 channels: ragged pixel tiles at the row ends."""
     from gencomm_amd import train_ops as T

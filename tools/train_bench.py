@@ -12,6 +12,12 @@ DEV = "cuda:0"
 OPTIMIZER = "--no-optimizer" not in sys.argv
 ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""   # "shipped" / "large": one shape (profiling runs)
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1   # scenes per step (the shipped yamls train with batch_size 1, 2 or 4)
+if "--stream-object" in sys.argv:   # diagnostic: the stream handle through a torch.cuda.Stream object per launch (before the raw accessor)
+    from gencomm_amd import runtime as _rt
+    _rt._raw_stream = None
+if "--pconv-general" in sys.argv:   # diagnostic: the Enhancer's partial 3x3 convolution through the general implicit-GEMM kernel
+    from gencomm_amd import autograd as _ag2
+    _ag2.ENH_PCONV_C16 = False
 if "--enh-split" in sys.argv:   # diagnostic: the Enhancer's training forward writes GELU(Linear1 output) in a pass of its own again
     from gencomm_amd import autograd as _ag
     _ag.ENH_MATERIALIZE_GELU = True
