@@ -79,6 +79,11 @@ def _lincomb(out, x, a, y=None, b=0.0, z=None, c=0.0):
     return out
 
 
+# Diagnostic switch (tools/train_bench.py --separate-update): False = the sampler's update between two UNet calls as separate noise /
+# linear-combination launches (the first two thirds of round 4) instead of conv_out's fused epilogue
+FUSED_SAMPLER_UPDATE = True
+
+
 class SamplerChainFunction(torch.autograd.Function):
     """The training branch's whole T-step chain (cond_diff.py:342-360, :262-264, :272-315) as ONE autograd node: q_sample, T HIP
     UNet calls with every intermediate kept (`gencomm_unet_fwd_train`), the posterior-mean update between them, and in backward
@@ -116,12 +121,20 @@ class SamplerChainFunction(torch.autograd.Function):
             coef = gen._sched_host(dev)            # [T][5]: sqrt_ac, sqrt_1m_ac, coef1, coef2, sigma (cached host copy: no sync)
             out = None
             for i, t in enumerate(reversed(range(T))):
-                x0, ws = unet.forward_train(x, cd, t, T)
                 xs.append(x)
-                wss.append(ws)
                 if t == 0:
-                    out = x0
+                    out, ws = unet.forward_train(x, cd, t, T)
+                    wss.append(ws)
                     break
+                if FUSED_SAMPLER_UPDATE:
+                    # x_{t-1} = coef1 x0_hat + coef2 x_t + sigma eps in conv_out's epilogue, as the inference loop runs it (eps: the explicit
+                    # tensor, or the sampler's Philox field of (seed, t)); x0_hat is never written
+                    nz = None if step_noise is None else step_noise[i].detach().float().contiguous()
+                    x, ws = unet.forward_train_step(x, cd, t, T, sched[t], nz, seed)
+                    wss.append(ws)
+                    continue
+                x0, ws = unet.forward_train(x, cd, t, T)
+                wss.append(ws)
                 if step_noise is None:   # nu_t = fp16(sigma_t z) of the sampler's Philox field, already scaled
                     nu = torch.empty_like(x)
                     _lib.check(l.gencomm_step_noise_fwd(ptr(sched[t]), int(seed), t, ptr(nu), n, C, H, W, 0, st), "gencomm_step_noise_fwd")

@@ -329,6 +329,39 @@ int gencomm_unet_fwd_train(const float* prepared, const float* x_t, const float*
   return unet_enqueue(c, x_t, cond, t, 0, co);
 }
 
+// The same with the sampler's update of step t > 0 fused into conv_out's epilogue, as the inference loop runs it (cond_diff.py:272-315):
+//   x_prev = coef1_t x0_hat + coef2_t x_t + sigma_t eps      (sched_row = the timestep's five schedule constants on the device)
+// eps = step_noise [n][C][H][W] when given, else the sampler's Philox field of (seed, stream t) -- exactly the field gencomm_denoise_fwd
+// adds.  x0_hat itself is not stored (the backward does not need it); x_t is only read.
+int gencomm_unet_fwd_train_step(const float* prepared, const float* x_t, const float* cond, float* x_prev, int t, const float* sched_row,
+                                const float* step_noise, unsigned long long seed, int n, int C, int H, int W, int levels, int res_blocks,
+                                int attn_mask, int T, void* workspace, long long workspace_bytes, void* stream) {
+  UNetPlan p;
+  if (const char* e = p.build(C, levels, res_blocks, attn_mask, T, true)) return fail(GC_ERR_ARG, e);
+  if (int rc = check_dims(n, C, H, W)) return rc;
+  GC_CHECK_ARG(attn_mask == 0, "gencomm_unet_fwd_train_step: AttnBlock backward is not implemented (attn_mask must be 0)");
+  GC_CHECK_ARG(prepared && x_t && cond && x_prev && sched_row && workspace && x_prev != x_t, "null pointer / in place (x_t is kept for the backward)");
+  GC_CHECK_ARG(t >= 1 && t < T, "timestep out of range (step 0 has no update: gencomm_unet_fwd_train)");
+  UNetWorkspace w;
+  if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
+  const UNetBwdWs bw = unet_bwd_ws(p, w, n, H, W);
+  if ((long long)bw.total > workspace_bytes) return fail(GC_ERR_WORKSPACE, "workspace too small (see gencomm_unet_bwd_workspace_bytes)");
+  UNetCall c{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()};
+  GC_CHECK_ARG(!c.m.bf16(), "gencomm_unet_fwd_train_step keeps fp32 intermediates: not available in bf16 denoise mode (GENCOMM_MODE_ARITH = 2)");
+  GC_HIP(hipMemsetAsync(c.amax(), 0, 256, c.st));
+  amax_kernel<<<256, 256, 0, c.st>>>(cond, (long long)n * 2 * H * W, c.amax());
+  amax_kernel<<<1024, 256, 0, c.st>>>(x_t, (long long)n * C * H * W, c.amax() + 1);
+  ConvOutArgs co{};
+  co.out = x_prev;
+  co.xt = x_t;
+  co.sched = sched_row;
+  co.noise = step_noise;
+  co.seed = seed;
+  co.stream_id = (unsigned)t;
+  const int rc = unet_enqueue(c, x_t, cond, t, step_noise != nullptr ? 1 : 2, co);
+  return rc;
+}
+
 int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
                      float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
                      int attn_mask, int T, int forward_done, void* workspace, long long workspace_bytes, void* stream) {

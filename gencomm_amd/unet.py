@@ -246,6 +246,23 @@ class DiffusionUNet(nn.Module):
                                             ptr(ws), ws.numel(), stream_ptr(dev)), "gencomm_unet_fwd_train")
         return out, ws
 
+    def forward_train_step(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, T: int, sched_row: torch.Tensor, step_noise, seed: int):
+        """x_{t-1} of sampler step t >= 1 for a call that will be differentiated (``gencomm_unet_fwd_train_step``): the UNet call with the
+        posterior update fused into conv_out's epilogue as the inference loop runs it -- x0_hat is not stored, no separate noise / update
+        passes. ``step_noise`` None: the sampler's in-kernel Philox field of (seed, t). Returns (x_{t-1}, workspace)."""
+        n, C, H, W = x_t.shape
+        dev = x_t.device
+        l = _lib.lib()
+        prepared = self.prepared_params(T, dev)
+        L, R, A = self.num_resolutions, self.num_res_blocks, self.attn_mask
+        ws = torch.empty(_lib.check_size(l.gencomm_unet_bwd_workspace_bytes(n, C, H, W, L, R, A), "gencomm_unet_bwd_workspace_bytes"),
+                         dtype=torch.uint8, device=dev)
+        out = torch.empty((n, C, H, W), dtype=torch.float32, device=dev)
+        _lib.check(l.gencomm_unet_fwd_train_step(ptr(prepared), ptr(x_t), ptr(cond), ptr(out), int(t_int), ptr(sched_row), ptr(step_noise),
+                                                 int(seed) & 0xFFFFFFFFFFFFFFFF, n, C, H, W, L, R, A, T, ptr(ws), ws.numel(), stream_ptr(dev)),
+                   "gencomm_unet_fwd_train_step")
+        return out, ws
+
     def backward_call(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, grad_x0: torch.Tensor, T: int, ws: torch.Tensor = None):
         """One UNet call backwards through ``gencomm_unet_bwd``: returns (grad_xt, grad_cond, grad_raw) where ``grad_raw`` is the
         gradient of the packed parameter blob (``self._packed.table`` gives every parameter's offset). ``ws``: the workspace

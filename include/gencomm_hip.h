@@ -162,6 +162,13 @@ long long gencomm_unet_bwd_workspace_bytes(int n, int C, int H, int W, int level
 int gencomm_unet_fwd_train(const float* prepared, const float* x_t, const float* cond, float* x0_out, int t,
                            int n, int C, int H, int W, int levels, int res_blocks, int attn_mask, int T,
                            void* workspace, long long workspace_bytes, void* stream);
+/* ABI v8: gencomm_unet_fwd_train with the sampler's update of step t >= 1 fused into conv_out's epilogue, as the inference loop runs it
+ * (cond_diff.py:272-279, :302-315): x_prev = coef1_t x0_hat + coef2_t x_t + sigma_t eps; sched_row = the five schedule constants of
+ * timestep t on the device (row t of the table gencomm_denoise_fwd takes); eps = step_noise [n][C][H][W] when given, else the sampler's
+ * in-kernel Philox field of (seed, t) -- the field gencomm_denoise_fwd adds. x0_hat is not stored, x_t is only read (x_prev != x_t). */
+int gencomm_unet_fwd_train_step(const float* prepared, const float* x_t, const float* cond, float* x_prev, int t, const float* sched_row,
+                                const float* step_noise, unsigned long long seed, int n, int C, int H, int W, int levels, int res_blocks,
+                                int attn_mask, int T, void* workspace, long long workspace_bytes, void* stream);
 int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
                      float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
                      int attn_mask, int T, int forward_done, void* workspace, long long workspace_bytes, void* stream);

@@ -18,6 +18,9 @@ if "--stream-object" in sys.argv:   # diagnostic: the stream handle through a to
 if "--pconv-general" in sys.argv:   # diagnostic: the Enhancer's partial 3x3 convolution through the general implicit-GEMM kernel
     from gencomm_amd import autograd as _ag2
     _ag2.ENH_PCONV_C16 = False
+if "--separate-update" in sys.argv:   # diagnostic: the sampler's update as separate noise / linear-combination launches
+    from gencomm_amd import autograd as _ag3
+    _ag3.FUSED_SAMPLER_UPDATE = False
 if "--enh-split" in sys.argv:   # diagnostic: the Enhancer's training forward writes GELU(Linear1 output) in a pass of its own again
     from gencomm_amd import autograd as _ag
     _ag.ENH_MATERIALIZE_GELU = True
