@@ -48,6 +48,7 @@ _SIGNATURES = {
     "gencomm_unet_fwd_train": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_unet_fwd_train_step": (_i, [_p, _p, _p, _p, _i, _p, _p, C.c_ulonglong, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_unet_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "gencomm_unet_bwd_chain": (_i, [_p, _p, _p, _p, _i, _p, C.c_float, C.c_float, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "gencomm_conv8_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_denoise_workspace_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
     "gencomm_dataflow_error": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -160,15 +160,22 @@ class SamplerChainFunction(torch.autograd.Function):
             g_cond = g_flat = None
             for t in range(T):       # the loop ran t = T-1 .. 0; xs[T-1-t] is the x_t the call at t saw
                 i = T - 1 - t
-                if t > 0:
-                    g_x0 = _lincomb(torch.empty_like(d_prev), d_prev, coef[t][2])
-                gx, gc, graw = unet.backward_call(ctx.xs[i], ctx.cond, t, g_x0, T, ws=ctx.wss[i])
+                if t > 0 and FUSED_SAMPLER_UPDATE:
+                    # d x0_hat = coef1_t d x_{t-1}: the call is linear in it, so d x_{t-1} goes in unscaled, d x_t = coef1 (input gradient)
+                    # + coef2 d x_{t-1} is formed in the last layer's epilogue, and the parameter / message gradients take coef1 below
+                    alpha = coef[t][2]
+                    gx, gc, graw = unet.backward_call(ctx.xs[i], ctx.cond, t, d_prev, T, ws=ctx.wss[i], chain=(alpha, coef[t][3], d_prev))
+                else:
+                    alpha = 1.0
+                    if t > 0:
+                        g_x0 = _lincomb(torch.empty_like(d_prev), d_prev, coef[t][2])
+                    gx, gc, graw = unet.backward_call(ctx.xs[i], ctx.cond, t, g_x0, T, ws=ctx.wss[i])
+                    if t > 0:
+                        _lincomb(gx, gx, 1.0, d_prev, coef[t][3])      # d x_t = UNet input gradient + c2_t d x_{t-1}
                 ctx.wss[i] = None
-                if t > 0:
-                    _lincomb(gx, gx, 1.0, d_prev, coef[t][3])      # d x_t = UNet input gradient + c2_t d x_{t-1}
                 d_prev = gx
-                g_cond = gc if g_cond is None else _lincomb(g_cond, g_cond, 1.0, gc, 1.0)
-                g_flat = graw if g_flat is None else _lincomb(g_flat, g_flat, 1.0, graw, 1.0)
+                g_cond = gc if g_cond is None else _lincomb(g_cond, g_cond, 1.0, gc, alpha)
+                g_flat = graw if g_flat is None else _lincomb(g_flat, g_flat, 1.0, graw, alpha)
             g_feat = None
             if need_feat:            # x_{T-1} = sqrt_ac feat[src_rows] + ...: rows of one scene all point at its ego row
                 g_feat = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=d_prev.device)

@@ -362,14 +362,20 @@ int gencomm_unet_fwd_train_step(const float* prepared, const float* x_t, const f
   return rc;
 }
 
-int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
-                     float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
-                     int attn_mask, int T, int forward_done, void* workspace, long long workspace_bytes, void* stream) {
+// grad_xt = alpha * (the call's gradient with respect to x_t) + beta * d_prev, formed in the epilogue of conv_in's input-gradient layer:
+// the adjoint of the sampler chain's x_{t-1} = coef1 x0_hat(x_t) + coef2 x_t + ... with grad_x0 = d_prev = d x_{t-1} UNSCALED
+// (alpha = coef1_t, beta = coef2_t).  grad_cond / grad_raw are the gradients for grad_x0 as given: the caller scales them by alpha when it
+// accumulates them (everything in this call is linear in grad_x0).  d_prev == NULL: alpha, beta ignored (gencomm_unet_bwd).
+int gencomm_unet_bwd_chain(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
+                           float alpha, float beta, const float* d_prev, float* grad_xt, float* grad_cond, float* grad_raw, int n, int C,
+                           int H, int W, int levels, int res_blocks, int attn_mask, int T, int forward_done, void* workspace,
+                           long long workspace_bytes, void* stream) {
   UNetPlan p;
   if (const char* e = p.build(C, levels, res_blocks, attn_mask, T, true)) return fail(GC_ERR_ARG, e);
   if (int rc = check_dims(n, C, H, W)) return rc;
   GC_CHECK_ARG(attn_mask == 0, "gencomm_unet_bwd: AttnBlock backward is not implemented (attn_mask must be 0)");
   GC_CHECK_ARG(prepared && raw && x_t && cond && grad_x0 && grad_xt && grad_cond && grad_raw && workspace, "null pointer");
+  GC_CHECK_ARG(d_prev != grad_xt, "grad_xt must not alias d_prev (tiles read d_prev while others write grad_xt)");
   GC_CHECK_ARG(t >= 0 && t < T, "timestep out of range");
   UNetWorkspace w;
   if (const char* e = w.build(p, n, H, W)) return fail(GC_ERR_ARG, e);
@@ -378,8 +384,15 @@ int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, 
   const std::vector<DgradEntry> dg = dgrad_entries(p);
   UNetBwdCall b{UNetCall{&p, &w, prepared, (char*)workspace, n, H, W, (hipStream_t)stream, modes_snapshot()}, &bw, raw, grad_raw};
   b.dg = &dg;
+  if (d_prev != nullptr) { b.chain_alpha = alpha; b.chain_beta = beta; b.chain_prev = d_prev; }
   GC_CHECK_ARG(!b.c.m.bf16(), "gencomm_unet_bwd reads fp32 intermediates: not available in bf16 denoise mode (GENCOMM_MODE_ARITH = 2)");
   return unet_bwd_enqueue(b, x_t, cond, t, grad_x0, grad_xt, grad_cond, forward_done != 0);
+}
+int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
+                     float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
+                     int attn_mask, int T, int forward_done, void* workspace, long long workspace_bytes, void* stream) {
+  return gencomm_unet_bwd_chain(prepared, raw, x_t, cond, t, grad_x0, 1.0f, 0.0f, nullptr, grad_xt, grad_cond, grad_raw, n, C, H, W, levels,
+                                res_blocks, attn_mask, T, forward_done, workspace, workspace_bytes, stream);
 }
 
 // One plain 8 -> 8 channel 3x3 convolution (stride 1, zero padding 1, bias, no norm, no residual) through the same

@@ -52,7 +52,7 @@ inline size_t dgrad_table_floats(const UNetPlan& p) {
 }
 
 struct UNetBwdWs {
-  size_t fwd_total, g_base, A, DA, red, wtmp, ones, zeros, wpart, total;
+  size_t fwd_total, g_base, A, DA, red, wtmp, ones, zeros, wpart, chain, total;
   std::vector<size_t> g_level_base;
 };
 inline UNetBwdWs unet_bwd_ws(const UNetPlan& p, const UNetWorkspace& w, int n, int H, int W) {
@@ -75,6 +75,7 @@ inline UNetBwdWs unet_bwd_ws(const UNetPlan& p, const UNetWorkspace& w, int n, i
   b.zeros = take((size_t)(p.C + 16) * sizeof(float));
   // partial sums of the weight-gradient kernels (conv_wgrad_scratch_floats): the largest layer is conv_in (C + 2 -> 8) / conv_out (8 -> C)
   b.wpart = take(std::max(conv_wgrad_scratch_floats(8, p.C + 2, 3, H, W, n), conv_wgrad_scratch_floats(p.C, 8, 3, H, W, n)) * sizeof(float));
+  b.chain = take(64);   // five floats: the schedule-row form (., ., alpha, beta, 0) conv_out_kernel's fused update reads (gencomm_unet_bwd_chain)
   b.total = off;
   return b;
 }
@@ -93,6 +94,9 @@ struct UNetBwdCall {
   const std::vector<DgradEntry>* dg = nullptr;
   mutable size_t dg_next = 0;
   mutable GnParamArgs gp{};
+  // gencomm_unet_bwd_chain: grad_xt = chain_alpha * (conv_in's x_t gradient) + chain_beta * chain_prev, in that layer's epilogue
+  float chain_alpha = 1.0f, chain_beta = 0.0f;
+  const float* chain_prev = nullptr;
 };
 
 // out[n][Cout][H][W] = 3x3 stride-1 pad-1 convolution of dy[n][Cin_d][H][W] with the input-gradient weights of a forward
@@ -171,6 +175,16 @@ inline int dgrad8C_enqueue(const UNetBwdCall& b, const float* dy, const float* w
   int tw, th;
   tile_dims(tc, &tw, &th);
   const dim3 grid(cdiv(W, tw), cdiv(H, th), n * nocb);
+  if (b.chain_prev != nullptr) {
+    // the sampler chain's adjoint d x_t = alpha (this gradient) + beta d x_{t-1} in the epilogue (the forward's fused update with
+    // coef1 = alpha, coef2 = beta, sigma = 0: the noise operand is read and multiplied by zero)
+    float* row = b.F(b.bw->chain);
+    set_chain_row_kernel<<<1, 64, 0, b.c.st>>>(row, b.chain_alpha, b.chain_beta);
+    co.xt = b.chain_prev; co.noise = b.chain_prev; co.sched = row;
+    if (tc == TILE_64x16) conv_out_kernel<64, 16, 4, 1, false><<<grid, 256, 0, b.c.st>>>(co);
+    else conv_out_kernel<32, 8, 1, 1, false><<<grid, 256, 0, b.c.st>>>(co);
+    return GC_OK;
+  }
   if (tc == TILE_64x16) conv_out_kernel<64, 16, 4, 0, false><<<grid, 256, 0, b.c.st>>>(co);
   else conv_out_kernel<32, 8, 1, 0, false><<<grid, 256, 0, b.c.st>>>(co);
   return GC_OK;

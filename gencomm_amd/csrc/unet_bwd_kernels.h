@@ -689,6 +689,11 @@ __global__ __launch_bounds__(256) void nin_dgrad4_kernel(const float* __restrict
   }
 }
 
+// schedule-row form (., ., coef1, coef2, sigma) = (0, 0, alpha, beta, 0) for conv_out_kernel's fused update used as a chain adjoint
+__global__ void set_chain_row_kernel(float* __restrict__ row, float alpha, float beta) {
+  if (threadIdx.x < 5) row[threadIdx.x] = threadIdx.x == 2 ? alpha : threadIdx.x == 3 ? beta : 0.f;
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long long count) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < count) y[i] = fmaf(alpha, x[i], y[i]);

@@ -263,10 +263,13 @@ class DiffusionUNet(nn.Module):
                    "gencomm_unet_fwd_train_step")
         return out, ws
 
-    def backward_call(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, grad_x0: torch.Tensor, T: int, ws: torch.Tensor = None):
+    def backward_call(self, x_t: torch.Tensor, cond: torch.Tensor, t_int: int, grad_x0: torch.Tensor, T: int, ws: torch.Tensor = None,
+                      chain=None):
         """One UNet call backwards through ``gencomm_unet_bwd``: returns (grad_xt, grad_cond, grad_raw) where ``grad_raw`` is the
         gradient of the packed parameter blob (``self._packed.table`` gives every parameter's offset). ``ws``: the workspace
-        ``forward_train`` filled (no recomputation); without it the library re-runs the forward."""
+        ``forward_train`` filled (no recomputation); without it the library re-runs the forward.
+        ``chain`` = (alpha, beta, d_prev): grad_xt = alpha * (this call's x_t gradient) + beta * d_prev in the last layer's epilogue
+        (``gencomm_unet_bwd_chain``); grad_cond / grad_raw stay the gradients for ``grad_x0`` as given."""
         n, C, H, W = x_t.shape
         dev = x_t.device
         l = _lib.lib()
@@ -279,6 +282,8 @@ class DiffusionUNet(nn.Module):
         gx = torch.empty_like(x_t)
         gc = torch.empty_like(cond)
         graw = torch.zeros_like(raw)
-        _lib.check(l.gencomm_unet_bwd(ptr(prepared), ptr(raw), ptr(x_t), ptr(cond), int(t_int), ptr(grad_x0), ptr(gx), ptr(gc), ptr(graw),
-                                      n, C, H, W, L, R, A, T, int(done), ptr(ws), ws.numel(), stream_ptr(dev)), "gencomm_unet_bwd")
+        alpha, beta, d_prev = chain if chain is not None else (1.0, 0.0, None)
+        _lib.check(l.gencomm_unet_bwd_chain(ptr(prepared), ptr(raw), ptr(x_t), ptr(cond), int(t_int), ptr(grad_x0), float(alpha), float(beta),
+                                            ptr(d_prev), ptr(gx), ptr(gc), ptr(graw), n, C, H, W, L, R, A, T, int(done), ptr(ws), ws.numel(),
+                                            stream_ptr(dev)), "gencomm_unet_bwd_chain")
         return gx, gc, graw

@@ -173,6 +173,16 @@ int gencomm_unet_bwd(const float* prepared, const float* raw, const float* x_t, 
                      float* grad_xt, float* grad_cond, float* grad_raw, int n, int C, int H, int W, int levels, int res_blocks,
                      int attn_mask, int T, int forward_done, void* workspace, long long workspace_bytes, void* stream);
 
+/* ABI v8: gencomm_unet_bwd for a call inside the sampler chain (cond_diff.py:272-315 differentiated): grad_x0 = d_prev = d x_{t-1} as it
+ * stands (NOT multiplied by coef1_t), and grad_xt = alpha * (the call's gradient with respect to x_t) + beta * d_prev is formed in the epilogue
+ * of conv_in's input-gradient layer (alpha = coef1_t, beta = coef2_t) -- the two elementwise passes around the call disappear. grad_cond and
+ * grad_raw are the gradients for grad_x0 as given: multiply them by alpha when accumulating (the call is linear in grad_x0). d_prev may be
+ * NULL (then alpha / beta are ignored: gencomm_unet_bwd); grad_xt must not alias d_prev. */
+int gencomm_unet_bwd_chain(const float* prepared, const float* raw, const float* x_t, const float* cond, int t, const float* grad_x0,
+                           float alpha, float beta, const float* d_prev, float* grad_xt, float* grad_cond, float* grad_raw, int n, int C,
+                           int H, int W, int levels, int res_blocks, int attn_mask, int T, int forward_done, void* workspace,
+                           long long workspace_bytes, void* stream);
+
 /* One 8 -> 8 channel 3x3 convolution (pad 1, bias) as the UNet's ResnetBlock / Upsample layers run it
  * (unet.py:52, :99-118), without norm or residual: dst[n,8,H,W] = conv(src[n,8,H,W], w[8,8,3,3]) + bias; dstat (nullable)
  * receives per-(sample, channel) {sum, sum of squares} of dst as [n][8][2] doubles. split = 1: the f16-pipe kernel with
