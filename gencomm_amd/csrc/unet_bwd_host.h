@@ -15,6 +15,11 @@ constexpr bool kBwdVec4 = false;
 #else
 constexpr bool kBwdVec4 = true;
 #endif
+#ifdef GC_DIAG_ZERO_GRAD_MAPS    // diagnostic build: every gradient map zeroed per call and every contribution accumulated (before first-write tracking)
+constexpr bool kBwdFirstWrite = false;
+#else
+constexpr bool kBwdFirstWrite = true;
+#endif
 
 // dgrad weight table of one UNet call: every 3x3 stride-1 layer's input-gradient weights, in the order the backward walk uses
 // them (conv_out, then per op from the last to the first; conv_in contributes two entries: cond channels, x channels)
@@ -97,6 +102,12 @@ struct UNetBwdCall {
   // gencomm_unet_bwd_chain: grad_xt = chain_alpha * (conv_in's x_t gradient) + chain_beta * chain_prev, in that layer's epilogue
   float chain_alpha = 1.0f, chain_beta = 0.0f;
   const float* chain_prev = nullptr;
+  // Gradient maps are never zeroed: the FIRST contribution to a tensor's gradient in the walk writes it, later ones accumulate (a memset of
+  // every map per call and one read per first contribution less).  take_first(id): true exactly once per tensor.
+  mutable std::vector<char> g_written;
+  bool take_first(int id) const { const bool f = !g_written[id]; g_written[id] = 1; return kBwdFirstWrite && f; }
+  // a gradient map about to be READ: every kept tensor has a consumer that contributed before its producer is walked
+  int need_written(int id) const { return g_written[id] ? GC_OK : fail(GC_ERR_ARG, "gencomm_unet_bwd: a tensor's gradient is read before anything contributed to it"); }
 };
 
 // out[n][Cout][H][W] = 3x3 stride-1 pad-1 convolution of dy[n][Cin_d][H][W] with the input-gradient weights of a forward
@@ -219,6 +230,7 @@ inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, 
   g.inv_cnt = 1.0 / ((double)gs * HW); g.gs = gs; g.HW = HW; g.da_ctotal = ctotal; g.da_coff = coff;
   g.da_is_dz = fused ? 1 : 0;   // fused: dgrad8_enqueue's epilogue wrote d z and this slot's sums
   g.add = add;
+  g.first = b.take_first(src_id) ? 1 : 0;
   if (!fused) gn_silu_bwd_reduce_kernel<<<dim3(std::min(cdiv(HW, 256), 64), 8, b.c.n), 256, 0, st>>>(g);
   if (kBwdVec4 && (HW & 3) == 0) gn_silu_bwd_apply4_kernel<<<dim3(cdiv(HW / 4, 256), 8, b.c.n), 256, 0, st>>>(g);   // workspace maps are 256-byte aligned
   else gn_silu_bwd_apply_kernel<<<dim3(cdiv(HW, 256), 8, b.c.n), 256, 0, st>>>(g);
@@ -267,9 +279,12 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
     if (int rc = unet_enqueue(c, x_t, cond, t, 0, co)) return rc;
   }
   // ---- gradient buffers, constants
-  size_t gbytes = 0;
-  for (int l = 0; l < p.L; ++l) gbytes += c.ws->slot_bytes[l] * p.slots_per_level[l];
-  GC_HIP(hipMemsetAsync(c.wsp + b.bw->g_base, 0, gbytes, st));
+  b.g_written.assign(p.tensors.size(), 0);   // no memset of the gradient maps: first contributions write (UNetBwdCall::take_first)
+  if (!kBwdFirstWrite) {
+    size_t gbytes = 0;
+    for (int l = 0; l < p.L; ++l) gbytes += c.ws->slot_bytes[l] * p.slots_per_level[l];
+    GC_HIP(hipMemsetAsync(c.wsp + b.bw->g_base, 0, gbytes, st));
+  }
   GC_HIP(hipMemsetAsync(c.wsp + b.bw->red, 0, (size_t)kMaxGnUses * n * 16 * sizeof(double), st));
   {
     const std::vector<DgradEntry>& e = *b.dg;
@@ -348,6 +363,7 @@ inline int unet_bwd_walk(const UNetBwdCall& b, const float* x_t, const float* co
       case OP_RES_CONV2: {
         // out = shortcut(in) + conv2(SiLU(GN2(tmp))) + b2 (+ nin bias)
         const ResBlockPlan& rb = p.blocks[o.blk];
+        if (int rc = b.need_written(o.dst)) return rc;
         const float* go = b.G(o.dst);
         WgradArgs wa{go, nullptr, nullptr, b.graw + rb.c2w, b.graw + rb.c2b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         wgrad_gn_sources(b, wa, o.src[0], -1, b.raw + rb.n2w, b.raw + rb.n2b, 2, HW);
@@ -359,19 +375,21 @@ inline int unet_bwd_walk(const UNetBwdCall& b, const float* x_t, const float* co
           // identity shortcut: d in += d out rides in conv1's GroupNorm-backward apply below (OP_RES_CONV1 of this block, the next op of the
           // walk: both add to G[in]); only a block whose conv1 does not follow directly keeps the separate pass
           const bool rides = kBwdVec4 && oi > 0 && p.ops[oi - 1].kind == OP_RES_CONV1 && p.ops[oi - 1].blk == o.blk && p.ops[oi - 1].src[0] == o.res[0];
-          if (!rides) axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW);
+          if (!rides) axpy_kernel<<<cdiv(n * 8 * HW, 256), 256, 0, st>>>(b.G(o.res[0]), go, 1.0f, (long long)n * 8 * HW, b.take_first(o.res[0]) ? 1 : 0);
         } else {
           WgradArgs wn{go, c.tensor_ptr(o.res[0]), c.tensor_ptr(o.res[1]), b.graw + rb.ninw, b.graw + rb.ninb, 8, 8, 8, Hl, Wl, Hl, Wl, 1, 1, 0, 0};
           wn.part = b.F(b.bw->wpart);
           if (int rc = conv_wgrad_enqueue(wn, n, st)) return rc;
-          if (kBwdVec4 && (HW & 3) == 0) nin_dgrad4_kernel<<<dim3(cdiv(HW / 4, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW);
-          else nin_dgrad_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW);
+          const int f0 = b.take_first(o.res[0]) ? 1 : 0, f1 = b.take_first(o.res[1]) ? 1 : 0;
+          if (kBwdVec4 && (HW & 3) == 0) nin_dgrad4_kernel<<<dim3(cdiv(HW / 4, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW, f0, f1);
+          else nin_dgrad_kernel<<<dim3(cdiv(HW, 256), n), 256, 0, st>>>(go, b.raw + rb.ninw, b.G(o.res[0]), b.G(o.res[1]), HW, f0, f1);
         }
         break;
       }
       case OP_RES_CONV1: {
         // tmp = conv1(SiLU(GN1(cat in))) + b1 + temb_proj(...)  (the timestep term only shifts the bias: its gradient is d b1)
         const ResBlockPlan& rb = p.blocks[o.blk];
+        if (int rc = b.need_written(o.dst)) return rc;
         const float* gt = b.G(o.dst);
         const int nsrc = rb.cin / 8, gs = rb.cin == 8 ? 2 : 4;
         WgradArgs wa{gt, nullptr, nullptr, b.graw + rb.c1w, b.graw + rb.c1b, 8, 8, nsrc == 2 ? 8 : 0, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
@@ -392,25 +410,28 @@ inline int unet_bwd_walk(const UNetBwdCall& b, const float* x_t, const float* co
       }
       case OP_DOWN: {
         const int lin = o.level - 1, Hi = c.ws->Hl[lin], Wi = c.ws->Wl[lin];
+        if (int rc = b.need_written(o.dst)) return rc;
         const float* gd = b.G(o.dst);
         WgradArgs wa{gd, c.tensor_ptr(o.src[0]), nullptr, b.graw + p.down[lin].w, b.graw + p.down[lin].b, 8, 8, 0, Hl, Wl, Hi, Wi, 3, 2, 0, 0};
         wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
-        DownDgradArgs da{gd, b.raw + p.down[lin].w, b.G(o.src[0]), Hl, Wl, Hi, Wi};
+        DownDgradArgs da{gd, b.raw + p.down[lin].w, b.G(o.src[0]), Hl, Wl, Hi, Wi, b.take_first(o.src[0]) ? 1 : 0};
         down_dgrad_kernel<<<dim3(cdiv(Hi * Wi, 256), 1, n), 256, 0, st>>>(da);
         break;
       }
       case OP_UP: {
         const int lin = o.level + 1, Hs = c.ws->Hl[lin], Ws = c.ws->Wl[lin];
+        if (int rc = b.need_written(o.dst)) return rc;
         const float* gu = b.G(o.dst);
         WgradArgs wa{gu, c.tensor_ptr(o.src[0]), nullptr, b.graw + p.up[lin].w, b.graw + p.up[lin].b, 8, 8, 0, Hl, Wl, Hl, Wl, 3, 1, 1, 1};
         wa.part = b.F(b.bw->wpart);
         if (int rc = conv_wgrad_enqueue(wa, n, st)) return rc;
         if (int rc = dgrad8_enqueue(b, gu, b.raw + p.up[lin].w, 8, 0, DA, n, Hl, Wl)) return rc;
-        sum2x2_add_kernel<<<cdiv(n * 8 * Hs * Ws, 256), 256, 0, st>>>(DA, b.G(o.src[0]), n * 8, Hs, Ws);
+        sum2x2_add_kernel<<<cdiv(n * 8 * Hs * Ws, 256), 256, 0, st>>>(DA, b.G(o.src[0]), n * 8, Hs, Ws, b.take_first(o.src[0]) ? 1 : 0);
         break;
       }
       case OP_CONV_IN: {
+        if (int rc = b.need_written(o.dst)) return rc;
         const float* gh = b.G(o.dst);
         WgradArgs wa{gh, cond, x_t, b.graw + p.conv_in.w, b.graw + p.conv_in.b, 8, 2, C, Hl, Wl, Hl, Wl, 3, 1, 1, 0};
         wa.part = b.F(b.bw->wpart);

@@ -27,6 +27,7 @@ struct GnArgs {
   int gs, HW, out_ctotal, out_coff, da_ctotal, da_coff;
   int da_is_dz;          // backward apply: `da` already holds dz = dA * SiLU'(.) (written by the input-gradient convolution's epilogue)
   const float* add;      // backward apply, optional [n][8][HW]: a further gradient of the same tensor added in this pass (the identity shortcut's d out)
+  int first;             // backward apply: this is the first contribution to G[x] in the walk -- `out` is written, not read (it was never zeroed)
 };
 
 __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const GnArgs a) {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const GnArgs a) 
     const float g = a.gamma[c], xh = (a.x[e] - mean) * rstd;
     const float d0 = a.da[((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p];
     const float dz = a.da_is_dz ? d0 : d0 * silu_grad_f(fmaf(g, xh, a.beta[c]));
-    a.out[e] += rstd * (g * dz - f1 - xh * f2) + (a.add != nullptr ? a.add[e] : 0.f);
+    a.out[e] = (a.first ? 0.f : a.out[e]) + rstd * (g * dz - f1 - xh * f2) + (a.add != nullptr ? a.add[e] : 0.f);
   }
 }
 // HW % 4 == 0: four pixels per lane, 128-bit accesses (second half of round 4: 93 launches per UNet call backwards, one dword per lane before)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply4_kernel(const GnArgs a)
   const float g = a.gamma[c], bt = a.beta[c];
   const float4 x4 = *reinterpret_cast<const float4*>(a.x + e);
   const float4 d4 = *reinterpret_cast<const float4*>(a.da + ((size_t)n * a.da_ctotal + a.da_coff + c) * a.HW + p);
-  float4 o4 = *reinterpret_cast<const float4*>(a.out + e);
+  const float4 o4 = a.first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.out + e);
   const float4 a4 = a.add != nullptr ? *reinterpret_cast<const float4*>(a.add + e) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w}, as[4] = {a4.x, a4.y, a4.z, a4.w};
   float os[4] = {o4.x, o4.y, o4.z, o4.w};
@@ -608,8 +609,9 @@ __global__ __launch_bounds__(256) void prep_dgrad_all_kernel(const PrepDgradArgs
 struct DownDgradArgs {
   const float* gd;  // [n][8][Ho][Wo]
   const float* w;   // raw [8][8][3][3]
-  float* gs;        // [n][8][Hi][Wi] (+=)
+  float* gs;        // [n][8][Hi][Wi] (+=, or = when `first`)
   int Ho, Wo, Hi, Wi;
+  int first;        // first contribution to gs in the walk: written, not accumulated
 };
 __global__ __launch_bounds__(256) void down_dgrad_kernel(const DownDgradArgs a) {
   const int n = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
@@ -630,22 +632,27 @@ __global__ __launch_bounds__(256) void down_dgrad_kernel(const DownDgradArgs a) 
     }
   }
 #pragma unroll
-  for (int ic = 0; ic < 8; ++ic) a.gs[((size_t)n * 8 + ic) * a.Hi * a.Wi + i] += acc[ic];
+  for (int ic = 0; ic < 8; ++ic) {
+    float* __restrict__ q = a.gs + ((size_t)n * 8 + ic) * a.Hi * a.Wi + i;
+    *q = a.first ? acc[ic] : *q + acc[ic];
+  }
 }
 
 // nearest x2 backward: gs[c](y, x) += sum of the 2x2 block of da
-__global__ __launch_bounds__(256) void sum2x2_add_kernel(const float* __restrict__ da, float* __restrict__ gs, int planes, int Hs, int Ws) {
+__global__ __launch_bounds__(256) void sum2x2_add_kernel(const float* __restrict__ da, float* __restrict__ gs, int planes, int Hs, int Ws, int first) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)planes * Hs * Ws) return;
   const int x = (int)(i % Ws), y = (int)((i / Ws) % Hs);
   const long long pl = i / ((long long)Hs * Ws);
   const float* __restrict__ d = da + (pl * (2 * Hs) + 2 * y) * (2 * Ws) + 2 * x;
-  gs[i] += d[0] + d[1] + d[2 * Ws] + d[2 * Ws + 1];
+  const float v = d[0] + d[1] + d[2 * Ws] + d[2 * Ws + 1];
+  gs[i] = first ? v : gs[i] + v;
 }
 
 // 1x1 nin_shortcut backward: g0[ic] += sum_oc w[oc][ic] go[oc], g1[ic] += sum_oc w[oc][8 + ic] go[oc]   (w raw [8][16])
+// f0 / f1: first contribution to g0 / g1 in the walk (written, not accumulated)
 __global__ __launch_bounds__(256) void nin_dgrad_kernel(const float* __restrict__ go, const float* __restrict__ w, float* __restrict__ g0,
-                                                        float* __restrict__ g1, int HW) {
+                                                        float* __restrict__ g1, int HW, int f0, int f1) {
   const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
   float o[8];
@@ -656,14 +663,16 @@ __global__ __launch_bounds__(256) void nin_dgrad_kernel(const float* __restrict_
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int oc = 0; oc < 8; ++oc) { s0 = fmaf(as_const(w)[oc * 16 + ic], o[oc], s0); s1 = fmaf(as_const(w)[oc * 16 + 8 + ic], o[oc], s1); }
-    g0[((size_t)n * 8 + ic) * HW + p] += s0;
-    g1[((size_t)n * 8 + ic) * HW + p] += s1;
+    float* __restrict__ q0 = g0 + ((size_t)n * 8 + ic) * HW + p;
+    float* __restrict__ q1 = g1 + ((size_t)n * 8 + ic) * HW + p;
+    *q0 = f0 ? s0 : *q0 + s0;
+    *q1 = f1 ? s1 : *q1 + s1;
   }
 }
 
 // HW % 4 == 0: four pixels per lane
 __global__ __launch_bounds__(256) void nin_dgrad4_kernel(const float* __restrict__ go, const float* __restrict__ w, float* __restrict__ g0,
-                                                         float* __restrict__ g1, int HW) {
+                                                         float* __restrict__ g1, int HW, int f0, int f1) {
   const int n = blockIdx.y, p = 4 * (blockIdx.x * 256 + threadIdx.x);
   if (p >= HW) return;
   float o[8][4];
@@ -674,7 +683,9 @@ __global__ __launch_bounds__(256) void nin_dgrad4_kernel(const float* __restrict
   }
 #pragma unroll
   for (int ic = 0; ic < 8; ++ic) {
-    float4 a0 = *reinterpret_cast<const float4*>(g0 + ((size_t)n * 8 + ic) * HW + p), a1 = *reinterpret_cast<const float4*>(g1 + ((size_t)n * 8 + ic) * HW + p);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a0 = f0 ? z4 : *reinterpret_cast<const float4*>(g0 + ((size_t)n * 8 + ic) * HW + p);
+    float4 a1 = f1 ? z4 : *reinterpret_cast<const float4*>(g1 + ((size_t)n * 8 + ic) * HW + p);
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int oc = 0; oc < 8; ++oc) {   // the same order of the eight products per output as nin_dgrad_kernel
@@ -694,9 +705,9 @@ __global__ void set_chain_row_kernel(float* __restrict__ row, float alpha, float
   if (threadIdx.x < 5) row[threadIdx.x] = threadIdx.x == 2 ? alpha : threadIdx.x == 3 ? beta : 0.f;
 }
 
-__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long long count) {
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long long count, int first) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < count) y[i] = fmaf(alpha, x[i], y[i]);
+  if (i < count) y[i] = first ? alpha * x[i] : fmaf(alpha, x[i], y[i]);
 }
 __global__ void add_vec_kernel(float* __restrict__ y, const float* __restrict__ x, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
