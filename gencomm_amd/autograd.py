@@ -221,12 +221,12 @@ class EnhancerFunction(torch.autograd.Function):
         dc, hid, HW = C // 4, m.dwconv[0].weight.shape[0], H * W
         with torch.no_grad():
             y = T.ln_fwd(x, b1.norm1.weight, b1.norm1.bias, 1e-5, True)            # x + LN1(x)       enhancer.py:351-352
-            z = T.ln_fwd(y, b1.norm2.weight, b1.norm2.bias, 1e-5, False)           # LN2              :354
-            z1 = T.copy_slice(z, 0, dc)
-            zi = torch.empty_like(z)                                                # cat[pconv(z[:, :dc]), z[:, dc:]]   :229-232
-            T.copy_slice(z, dc, C - dc, zi, dc)
+            # LN2 (:354) writes straight into Linear1's input zi = cat[pconv(z[:, :dc]), z[:, dc:]] (:229-232): its first dc channels are copied
+            # out (the partial convolution's input, kept for its weight gradient) and then overwritten by the convolution -- no z, no cat
+            zi = T.ln_fwd(y, b1.norm2.weight, b1.norm2.bias, 1e-5, False)
+            z1 = T.copy_slice(zi, 0, dc)
             if ENH_PCONV_C16 and dc == 16 and n * HW >= (1 << 16):   # C = 64 on large maps: the UNet's 8-channel kernel (the general one re-stages 16-pixel segments)
-                T.conv3x3_c16(z, m.partial_conv3.weight, zi)
+                T.conv3x3_c16(z1, m.partial_conv3.weight, zi)
             else:
                 T.conv2d(z1, m.partial_conv3.weight, None, 1, out=zi, out_coff=0)
             w1 = m.linear1[0].weight.detach()[:, :, None, None]

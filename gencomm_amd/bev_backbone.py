@@ -228,11 +228,16 @@ def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = 
         wd = f32c(w.detach())
         prepared = torch.empty(wd.numel(), dtype=torch.float32, device=x.device)
         _lib.check(l.gencomm_conv2d_prepare(ptr(wd), ptr(prepared), cin, cout, kh, kw, int(transposed), st), "gencomm_conv2d_prepare")
-        ss = torch.empty(2, cout, dtype=torch.float32, device=x.device)
-        d = [f32c(t.detach()) if t is not None else None for t in bnp]
         b = f32c(conv.bias.detach()) if conv.bias is not None else None
-        _lib.check(l.gencomm_conv2d_fold(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(b), float(bn.eps) if bn is not None else 0.0,
-                                         cout, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
+        if bn is None:   # scale 1, shift = bias: nothing to fold -- a cached unit row and the bias itself (training re-prepares every step)
+            from .train_ops import _unit_scale_shift
+            unit = _unit_scale_shift(cout, x.device)
+            ss = (unit[0], b if b is not None else unit[1])
+        else:
+            ss = torch.empty(2, cout, dtype=torch.float32, device=x.device)
+            d = [f32c(t.detach()) if t is not None else None for t in bnp]
+            _lib.check(l.gencomm_conv2d_fold(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(b), float(bn.eps), cout, ptr(ss[0]), ptr(ss[1]), st),
+                       "gencomm_conv2d_fold")
         cache = (key, prepared, ss)
         conv._gc_cache = cache
     _, prepared, ss = cache

@@ -28,9 +28,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad: int
     l, st, dev = _lib.lib(), stream_ptr(x.device), x.device
     prepared = torch.empty(w.numel(), dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cin, cout, kh, kw, 0, st), "gencomm_conv2d_prepare")
-    ss = torch.empty(2, cout, dtype=torch.float32, device=dev)
-    bb = _c(b) if b is not None else None
-    _lib.check(l.gencomm_conv2d_fold(None, None, None, None, ptr(bb), 0.0, cout, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")
+    unit = _unit_scale_shift(cout, dev)                     # scale 1; shift = the bias itself (or the cached zeros): no fold launch
+    ss = (unit[0], _c(b) if b is not None else unit[1])
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     if residual is not None:
         assert out is None
