@@ -9,7 +9,8 @@
 //                          f64, then dx = rstd (gamma dz - mean_g(gamma dz) - xhat mean_g(gamma dz xhat)), d gamma, d beta
 //   down_dgrad_kernel      transposed stride-2 convolution of the Downsample layer (unet.py:71-75)
 //   sum2x2_add_kernel      nearest-x2 upsampling backward;  nin_dgrad_kernel  1x1 shortcut backward;  axpy_kernel
-// Gradient tensors are ACCUMULATED (+=): a forward tensor may have several consumers (skip connections, residuals).
+// Gradient tensors are ACCUMULATED (+=): a forward tensor may have several consumers (skip connections, residuals) -- except the FIRST
+// contribution of a backward walk, which writes (the maps are not zeroed: unet_bwd_host.h, UNetBwdCall::take_first).
 #pragma once
 #include "unet_kernels.h"
 

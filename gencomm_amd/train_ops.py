@@ -143,7 +143,10 @@ def conv3x3_c16(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, transposed:
     """3x3 pad-1 convolution of the first 16 channels of x [n, >= 16, H, W] with w [16, 16, 3, 3] (no bias) into the first 16 channels of
     `out` (gencomm_conv3x3_c16_fwd: the UNet's 8-channel kernel); transposed: the layer's input gradient from its forward weight."""
     n, x_ct, H, W = x.shape
-    assert x.is_contiguous() and out.is_contiguous() and tuple(w.shape) == (16, 16, 3, 3) and out.shape[0] == n and out.shape[2:] == x.shape[2:]
+    if not (x.is_contiguous() and out.is_contiguous() and x.dtype == out.dtype == torch.float32 and x_ct >= 16 and out.shape[1] >= 16
+            and tuple(w.shape) == (16, 16, 3, 3) and out.shape[0] == n and out.shape[2:] == x.shape[2:]):
+        raise ValueError(f"conv3x3_c16: contiguous f32 x [n, >= 16, H, W] / out [n, >= 16, H, W] and w [16, 16, 3, 3] expected, got "
+                         f"{tuple(x.shape)}, {tuple(out.shape)}, {tuple(w.shape)}")
     l = _lib.lib()
     scratch = torch.empty(_lib.check_size(l.gencomm_conv3x3_c16_scratch_floats(), "gencomm_conv3x3_c16_scratch_floats"), dtype=torch.float32, device=x.device)
     _lib.check(l.gencomm_conv3x3_c16_fwd(ptr(x), x_ct, ptr(_c(w)), int(transposed), ptr(out), out.shape[1], ptr(scratch), n, H, W, stream_ptr(x.device)),
