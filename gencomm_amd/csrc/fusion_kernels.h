@@ -202,9 +202,15 @@ struct FuseBwdArgs {
   int* plan;             // scratch [n]: 1 = this agent's d x is formed by the gather pass, 0 = by the scatter (float atomics)
 };
 
+// Round 4 (last third): workgroup = 64 pixels x 4 channel quarters, as the forward (one wave per workgroup walked all C channels twice:
+// 2 200 single-wave workgroups per scene, two waves per SIMD -- latency-bound, 250 us at 4 x 64 x 200 x 704); the partial scores / d weights
+// of a pixel meet in LDS, and at C = 64 with up to four agents the 16 x N warped samples and the 16 output gradients of a thread stay in
+// registers between the two passes.
 template <int N>
-__device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int off, int pix) {
+__device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int off, int pix_raw, int cq, int pl, float (*s_part)[4][64]) {
   const int H = a.H, W = a.W, HW = H * W;
+  const bool live = pix_raw < HW;
+  const int pix = live ? pix_raw : HW - 1;
   const int h = pix / W, w = pix - h * W;
   const double xb = (2.0 * w + 1.0) / (double)W - 1.0;
   const double yb = (2.0 * h + 1.0) / (double)H - 1.0;
@@ -246,17 +252,54 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
   float score[N], dw[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) { score[j] = 0.f; dw[j] = 0.f; }
-  for (int c = 0; c < a.C; ++c) {
-    const float g = gp[(size_t)c * HW];
-    const float v0 = sample(0, xs + (size_t)c * HW);
-    score[0] = fmaf(v0, v0, score[0]);
-    dw[0] = fmaf(g, v0, dw[0]);
+#ifdef GC_DIAG_FUSE_NO_KEEP
+  constexpr bool KEEP = false;
+#else
+  constexpr bool KEEP = N <= 4;
+#endif
+  float keep[KEEP ? N : 1][KEEP ? 16 : 1], gk[KEEP ? 16 : 1];
+  const bool kept = KEEP && a.C == 64;
+  if (kept) {
 #pragma unroll
-    for (int j = 1; j < N; ++j) {
-      const float vj = sample(j, xs + ((size_t)j * a.C + c) * HW);
-      score[j] = fmaf(v0, vj, score[j]);
-      dw[j] = fmaf(g, vj, dw[j]);
+    for (int i = 0; i < 16; ++i) {
+      const int c = cq + 4 * i;
+      gk[KEEP ? i : 0] = gp[(size_t)c * HW];
+#pragma unroll
+      for (int j = 0; j < N; ++j) keep[KEEP ? j : 0][KEEP ? i : 0] = sample(j, xs + ((size_t)j * 64 + c) * HW);
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float g = gk[KEEP ? i : 0], v0 = keep[0][KEEP ? i : 0];
+      score[0] = fmaf(v0, v0, score[0]);
+      dw[0] = fmaf(g, v0, dw[0]);
+#pragma unroll
+      for (int j = 1; j < N; ++j) {
+        const float vj = keep[KEEP ? j : 0][KEEP ? i : 0];
+        score[j] = fmaf(v0, vj, score[j]);
+        dw[j] = fmaf(g, vj, dw[j]);
+      }
+    }
+  } else {
+    for (int c = cq; c < a.C; c += 4) {
+      const float g = gp[(size_t)c * HW];
+      const float v0 = sample(0, xs + (size_t)c * HW);
+      score[0] = fmaf(v0, v0, score[0]);
+      dw[0] = fmaf(g, v0, dw[0]);
+#pragma unroll
+      for (int j = 1; j < N; ++j) {
+        const float vj = sample(j, xs + ((size_t)j * a.C + c) * HW);
+        score[j] = fmaf(v0, vj, score[j]);
+        dw[j] = fmaf(g, vj, dw[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) { s_part[j][cq][pl] = score[j]; s_part[N + j][cq][pl] = dw[j]; }
+  __syncthreads();  // every thread of the workgroup gets here: dead pixels were clamped, not retired
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    score[j] = (s_part[j][0][pl] + s_part[j][1][pl]) + (s_part[j][2][pl] + s_part[j][3][pl]);
+    dw[j] = (s_part[N + j][0][pl] + s_part[N + j][1][pl]) + (s_part[N + j][2][pl] + s_part[N + j][3][pl]);
   }
   const float inv = 1.0f / sqrtf((float)a.C);
   float mx = -INFINITY;
@@ -275,15 +318,14 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     gat[j] = a.plan[off + j];
-    float2* __restrict__ wp = reinterpret_cast<float2*>(a.ws) + (size_t)(off + j) * HW + pix;
-    *wp = make_float2(score[j], ds[j]);
+    if (cq == 0 && live) {
+      float2* __restrict__ wp = reinterpret_cast<float2*>(a.ws) + (size_t)(off + j) * HW + pix;
+      *wp = make_float2(score[j], ds[j]);
+    }
   }
+  if (!live) return;   // after the only barrier
   float* __restrict__ gxs = a.gx + (size_t)off * a.C * HW;
-  for (int c = 0; c < a.C; ++c) {
-    const float g = gp[(size_t)c * HW];
-    float v[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = sample(j, xs + ((size_t)j * a.C + c) * HW);
+  auto emit = [&](int c, float g, const float (&v)[N]) {
     float d0 = fmaf(score[0], g, ds[0] * v[0]);
 #pragma unroll
     for (int j = 0; j < N; ++j) d0 = fmaf(ds[j], v[j], d0);
@@ -300,6 +342,23 @@ __device__ __forceinline__ void fuse_bwd_body(const FuseBwdArgs& a, int b, int o
       for (int k = 0; k < 4; ++k)
         if (((ok[j] >> k) & 1u) && wt[j][k] != 0.f) atomicAdd(plane + idx[j][k], wt[j][k] * dj);
     }
+  };
+  if (kept) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = keep[KEEP ? j : 0][KEEP ? i : 0];
+      emit(cq + 4 * i, gk[KEEP ? i : 0], v);
+    }
+    return;
+  }
+  for (int c = cq; c < a.C; c += 4) {
+    const float g = gp[(size_t)c * HW];
+    float v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = sample(j, xs + ((size_t)j * a.C + c) * HW);
+    emit(c, g, v);
   }
 }
 
@@ -421,20 +480,21 @@ __global__ __launch_bounds__(128) void fuse_bwd_gather_kernel(const FuseBwdArgs 
   }
 }
 
-__global__ __launch_bounds__(64) void warp_attfuse_bwd_kernel(const FuseBwdArgs a) {
+__global__ __launch_bounds__(256) void warp_attfuse_bwd_kernel(const FuseBwdArgs a) {
+  __shared__ float s_part[16][4][64];   // [score of agent j | N + j: d weight of agent j][channel quarter][pixel]
   const int b = blockIdx.y;
-  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;
-  const int pix = blockIdx.x * 64 + threadIdx.x;   // one wave per workgroup: a single scene is 2 200 workgroups instead of 550
-  if (pix >= a.H * a.W) return;
+  const int off = a.scene_off[b], N = a.scene_off[b + 1] - off;   // block-uniform
+  const int pl = threadIdx.x & 63, cq = threadIdx.x >> 6;
+  const int pix = blockIdx.x * 64 + pl;
   switch (N) {
-    case 1: fuse_bwd_body<1>(a, b, off, pix); break;
-    case 2: fuse_bwd_body<2>(a, b, off, pix); break;
-    case 3: fuse_bwd_body<3>(a, b, off, pix); break;
-    case 4: fuse_bwd_body<4>(a, b, off, pix); break;
-    case 5: fuse_bwd_body<5>(a, b, off, pix); break;
-    case 6: fuse_bwd_body<6>(a, b, off, pix); break;
-    case 7: fuse_bwd_body<7>(a, b, off, pix); break;
-    case 8: fuse_bwd_body<8>(a, b, off, pix); break;
+    case 1: fuse_bwd_body<1>(a, b, off, pix, cq, pl, s_part); break;
+    case 2: fuse_bwd_body<2>(a, b, off, pix, cq, pl, s_part); break;
+    case 3: fuse_bwd_body<3>(a, b, off, pix, cq, pl, s_part); break;
+    case 4: fuse_bwd_body<4>(a, b, off, pix, cq, pl, s_part); break;
+    case 5: fuse_bwd_body<5>(a, b, off, pix, cq, pl, s_part); break;
+    case 6: fuse_bwd_body<6>(a, b, off, pix, cq, pl, s_part); break;
+    case 7: fuse_bwd_body<7>(a, b, off, pix, cq, pl, s_part); break;
+    case 8: fuse_bwd_body<8>(a, b, off, pix, cq, pl, s_part); break;
     default: break;
   }
 }
@@ -452,7 +512,7 @@ inline int warp_attfuse_bwd_enqueue(const float* x, const double* theta, const i
   } else {
     return fail(GC_ERR_ARG, "warp_attfuse_bwd: scratch is required");
   }
-  warp_attfuse_bwd_kernel<<<dim3((H * W + 63) / 64, B), 64, 0, st>>>(a);
+  warp_attfuse_bwd_kernel<<<dim3((H * W + 63) / 64, B), 256, 0, st>>>(a);
   fuse_bwd_gather_kernel<<<dim3((H * W + 127) / 128, n), 128, 0, st>>>(a, B);
   GC_HIP(hipGetLastError());
   return GC_OK;
