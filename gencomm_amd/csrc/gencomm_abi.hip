@@ -762,9 +762,9 @@ int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta
   const bool v4 = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);   // four pixels per lane
   if (v4) bn2d_stats_kernel<4><<<dim3(C, (unsigned)std::min((HW + 1023) / 1024, 64)), 256, 0, st>>>(x, scratch, n, C, HW);
   else bn2d_stats_kernel<1><<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64)), 256, 0, st>>>(x, scratch, n, C, HW);
-  bn2d_finish_kernel<<<(C + 63) / 64, 64, 0, st>>>(scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, C);
-  if (v4) bn2d_apply_kernel<4><<<dim3((HW / 4 + 255) / 256, C, n), 256, 0, st>>>(x, save, gamma, beta, y, C, HW, relu);
-  else bn2d_apply_kernel<1><<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, save, gamma, beta, y, C, HW, relu);
+  // mean / rstd, save[] and the running statistics are formed inside the apply kernel: one launch less
+  if (v4) bn2d_apply_kernel<4><<<dim3((HW / 4 + 255) / 256, C, n), 256, 0, st>>>(x, scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, gamma, beta, y, C, HW, relu);
+  else bn2d_apply_kernel<1><<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, gamma, beta, y, C, HW, relu);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -776,10 +776,10 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
   GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
   const bool v4 = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);   // four pixels per lane
   if (v4) {
-    bn2d_bwd_reduce_kernel<4><<<dim3(C, (unsigned)std::min((HW + 1023) / 1024, 64)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu);
+    bn2d_bwd_reduce_kernel<4><<<dim3(C, (unsigned)std::min((HW + 1023) / 1024, 64)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu & 1);
     bn2d_bwd_apply_kernel<4><<<dim3((HW / 4 + 255) / 256, C, n), 256, 0, st>>>(x, y, dy, save, gamma, scratch, dx, dgamma, dbeta, (long long)n * HW, C, HW, relu);
   } else {
-    bn2d_bwd_reduce_kernel<1><<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu);
+    bn2d_bwd_reduce_kernel<1><<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu & 1);
     bn2d_bwd_apply_kernel<1><<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, y, dy, save, gamma, scratch, dx, dgamma, dbeta, (long long)n * HW, C, HW, relu);
   }
   GC_HIP(hipGetLastError());

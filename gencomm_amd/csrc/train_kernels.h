@@ -1030,7 +1030,7 @@ inline size_t dcn_scatter_scratch_floats(int n, int C, int H, int W) {
 // ---- BatchNorm2d in TRAINING mode (batch statistics) for the conv stacks around the hot path -------------------------------
 // (base_bev_backbone.py:47-52: conv -> BatchNorm2d(eps 1e-3, momentum 0.01) -> ReLU; stage 1 of the reference trains them).
 //   bn2d_stats_kernel      per-channel sum / sum of squares over (n, HW) in f64 (grid: channel x chunks)
-//   bn2d_finish_kernel     mean, rstd (biased variance) -> save[c][2]; running statistics updated with the UNBIASED variance
+//   (mean, rstd (biased variance) -> save[c][2] and the running statistics (UNBIASED variance) are formed inside bn2d_apply_kernel)
 //   bn2d_apply_kernel      y = act(gamma (x - mean) rstd + beta)
 //   bn2d_bwd_reduce_kernel sums of g and g xhat per channel (g = dy masked by y > 0 when the block has a ReLU)
 //   bn2d_bwd_apply_kernel  dx = gamma rstd (g - mean(g) - xhat mean(g xhat));  d gamma = sum g xhat, d beta = sum g
@@ -1062,27 +1062,30 @@ __global__ __launch_bounds__(256) void bn2d_stats_kernel(const float* __restrict
   __syncthreads();
   if (tid < 2) atomicAdd(&acc[c * 2 + tid], s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]);
 }
-__global__ void bn2d_finish_kernel(const double* __restrict__ acc, float* __restrict__ save /*[C][2] mean, rstd*/, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float momentum, float eps, long long count, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double m = acc[c * 2] / (double)count;
-  const double var = fmax(acc[c * 2 + 1] / (double)count - m * m, 0.0);
-  save[c * 2] = (float)m;
-  save[c * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean != nullptr) {
-    const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
+// The statistics' last step rides in this kernel (second half of round 4: one launch per BatchNorm less, 23 per training-leg step): every
+// block forms mean / rstd of its channel from the f64 sums (in double, as the separate finish launch did); the block (0, c, 0) also writes save[c] (read by
+// the backward) and moves the running statistics.
 template <int V>
-__global__ __launch_bounds__(256) void bn2d_apply_kernel(const float* __restrict__ x, const float* __restrict__ save, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ y, int C, int HW, int relu) {
+__global__ __launch_bounds__(256) void bn2d_apply_kernel(const float* __restrict__ x, const double* __restrict__ acc, float* __restrict__ save,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                                         long long count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ y, int C, int HW, int relu) {
   const int c = blockIdx.y, b = blockIdx.z, p = V * (blockIdx.x * 256 + threadIdx.x);
+  const double md = acc[c * 2] / (double)count;
+  const double var = fmax(acc[c * 2 + 1] / (double)count - md * md, 0.0);
+  const float mean = (float)md, k = (float)(1.0 / sqrt(var + (double)eps));
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    save[c * 2] = mean;
+    save[c * 2 + 1] = k;
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
   if (p >= HW) return;
   const size_t e = ((size_t)b * C + c) * HW + p;
-  const float mean = save[c * 2], k = save[c * 2 + 1], g = gamma[c], bt = beta[c];
+  const float g = gamma[c], bt = beta[c];
   if (V == 4) {
     const float4 v = *reinterpret_cast<const float4*>(x + e);
     float o[4] = {fmaf((v.x - mean) * k, g, bt), fmaf((v.y - mean) * k, g, bt), fmaf((v.z - mean) * k, g, bt), fmaf((v.w - mean) * k, g, bt)};
@@ -1141,9 +1144,9 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
   const int c = blockIdx.y, b = blockIdx.z, p = V * (blockIdx.x * 256 + threadIdx.x);
   const float mean = save[c * 2], rstd = save[c * 2 + 1];
   const float mg = (float)(acc[c * 2] / (double)count), mgx = (float)(acc[c * 2 + 1] / (double)count);
-  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
-    if (dgamma != nullptr) dgamma[c] += (float)acc[c * 2 + 1];
-    if (dbeta != nullptr) dbeta[c] += (float)acc[c * 2];
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {   // relu bit 1: the parameter gradients are WRITTEN (the caller did not zero them)
+    if (dgamma != nullptr) dgamma[c] = ((relu & 2) ? 0.f : dgamma[c]) + (float)acc[c * 2 + 1];
+    if (dbeta != nullptr) dbeta[c] = ((relu & 2) ? 0.f : dbeta[c]) + (float)acc[c * 2];
   }
   if (p >= HW) return;
   const size_t e = ((size_t)b * C + c) * HW + p;
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
   if (V == 4) {
     const float4 x4 = *reinterpret_cast<const float4*>(x + e), d4 = *reinterpret_cast<const float4*>(dy + e);
     float g[4] = {d4.x, d4.y, d4.z, d4.w};
-    if (relu) {
+    if (relu & 1) {
       const float4 y4 = *reinterpret_cast<const float4*>(y + e);
       if (!(y4.x > 0.f)) g[0] = 0.f;
       if (!(y4.y > 0.f)) g[1] = 0.f;
@@ -1164,7 +1167,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
     for (int j = 0; j < 4; ++j) o[j] = k * (g[j] - mg - ((xs[j] - mean) * rstd) * mgx);
     *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
   } else {
-    const float g = (relu && !(y[e] > 0.f)) ? 0.f : dy[e];
+    const float g = ((relu & 1) && !(y[e] > 0.f)) ? 0.f : dy[e];
     const float xh = (x[e] - mean) * rstd;
     dx[e] = k * (g - mg - xh * mgx);
   }

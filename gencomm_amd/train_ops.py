@@ -179,9 +179,9 @@ def bn2d_train_bwd(x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, save: tor
     x, y, dy = _c(x), _c(y), _c(dy)
     n, C, H, W = x.shape
     dx = torch.empty_like(x)
-    dg, db = torch.zeros(2, C, dtype=torch.float32, device=x.device).unbind(0)   # one fill launch for both
+    dg, db = torch.empty(2, C, dtype=torch.float32, device=x.device).unbind(0)   # written, not accumulated (relu bit 1): no fill launch
     scratch = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-    _lib.check(_lib.lib().gencomm_bn2d_train_bwd(ptr(x), ptr(y), ptr(dy), ptr(save), ptr(_c(gamma)), ptr(dx), ptr(dg), ptr(db), ptr(scratch), int(relu),
+    _lib.check(_lib.lib().gencomm_bn2d_train_bwd(ptr(x), ptr(y), ptr(dy), ptr(save), ptr(_c(gamma)), ptr(dx), ptr(dg), ptr(db), ptr(scratch), int(relu) | 2,
                                                  n, C, H * W, stream_ptr(x.device)), "gencomm_bn2d_train_bwd")
     return dx, dg, db
 

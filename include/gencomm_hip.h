@@ -507,7 +507,8 @@ int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, cons
 /* BatchNorm2d with BATCH statistics (training mode; base_bev_backbone.py:47-52: eps 1e-3, momentum 0.01) around the HIP convolutions of
  * the backbone / shrink stacks: y = act(gamma (x - mean_batch) / sqrt(var_batch + eps) + beta) over NCHW, running statistics updated as
  * nn.BatchNorm2d does (unbiased variance; pass null to leave them alone); save [C][2] = (mean, rstd) for the backward; scratch >= 2 C
- * doubles. Backward: dx overwritten, dgamma / dbeta accumulated, y = the forward's output (supplies the ReLU mask). */
+ * doubles. Backward: dx overwritten, dgamma / dbeta accumulated, y = the forward's output (supplies the ReLU mask).
+ * ABI v8: `relu` bit 1 of gencomm_bn2d_train_bwd set = dgamma / dbeta are WRITTEN (the caller need not zero them); clear = accumulated. */
 int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, float* save,
                            double* scratch, float momentum, float eps, int relu, int n, int C, int HW, void* stream);
 int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
