@@ -106,17 +106,13 @@ def conv2d_dgrad_strided(dy: torch.Tensor, w: torch.Tensor, pad: int, stride: in
     return conv2d_dgrad(up, w, pad)
 
 
-def _conv3x3_s2_dgrad_subpixel(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """dx of a 3x3 stride-2 pad-1 convolution over an even-sized input as ONE 2x2 sub-pixel convolution over dy
-    (gencomm_conv2d_fwd, KH = KW = 2, ups = 2): dx[ci][2u + a][2v + b] = sum_{co, ty, tx} W[co][ci][a + 1 - 2 ty][b + 1 - 2 tx] dy[co][u + ty][v + tx]
-    (taps outside 0..2 are zero).  16 tap-products per output quad instead of the 36 of the zero-stuffed form below."""
-    dy, w = _c(dy), _c(w)
-    n, cout, Ho, Wo = dy.shape
-    cin = w.shape[1]
-    dev = dy.device
-    # rows (ci, a, b), reduction (co, ty, tx): one gather from the taps padded with a zero (index 9) instead of a zero fill + nine slice
-    # assignments -- the weights change every training step, so this runs per call (ten launches and 0.2 ms of host time before)
-    key = str(dev)
+def s2_subpixel_weights(w: torch.Tensor) -> torch.Tensor:
+    """[ci, a, b, co, ty, tx] weights of the 2x2 sub-pixel form of a 3x3 stride-2 pad-1 convolution's input gradient from its forward weight
+    w [co, ci, 3, 3]: entry = w[co][ci][a + 1 - 2 ty][b + 1 - 2 tx], zero where that tap does not exist.  One gather from the taps padded
+    with a zero (index 9) instead of a zero fill + nine slice assignments -- the weights change every training step, so this runs per call
+    (ten launches and 0.2 ms of host time before)."""
+    cout, cin = w.shape[0], w.shape[1]
+    key = str(w.device)
     if key not in _S2_TAPS:
         idx = torch.full((2, 2, 2, 2), 9, dtype=torch.long)                          # [a, b, ty, tx] -> ky * 3 + kx, or 9 = the zero tap
         for a in (0, 1):
@@ -126,9 +122,20 @@ def _conv3x3_s2_dgrad_subpixel(dy: torch.Tensor, w: torch.Tensor) -> torch.Tenso
                         ky, kx = a + 1 - 2 * ty, b + 1 - 2 * tx
                         if 0 <= ky <= 2 and 0 <= kx <= 2:
                             idx[a, b, ty, tx] = ky * 3 + kx
-        _S2_TAPS[key] = idx.reshape(-1).to(dev)
+        _S2_TAPS[key] = idx.reshape(-1).to(w.device)
     wz = torch.nn.functional.pad(w.reshape(cout, cin, 9), (0, 1))                    # [co, ci, 10]
-    wp = wz.index_select(2, _S2_TAPS[key]).view(cout, cin, 2, 2, 2, 2).permute(1, 2, 3, 0, 4, 5).contiguous()   # [ci, a, b, co, ty, tx]
+    return wz.index_select(2, _S2_TAPS[key]).view(cout, cin, 2, 2, 2, 2).permute(1, 2, 3, 0, 4, 5).contiguous()
+
+
+def _conv3x3_s2_dgrad_subpixel(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """dx of a 3x3 stride-2 pad-1 convolution over an even-sized input as ONE 2x2 sub-pixel convolution over dy
+    (gencomm_conv2d_fwd, KH = KW = 2, ups = 2): dx[ci][2u + a][2v + b] = sum_{co, ty, tx} W[co][ci][a + 1 - 2 ty][b + 1 - 2 tx] dy[co][u + ty][v + tx]
+    (taps outside 0..2 are zero).  16 tap-products per output quad instead of the 36 of the zero-stuffed form below."""
+    dy, w = _c(dy), _c(w)
+    n, cout, Ho, Wo = dy.shape
+    cin = w.shape[1]
+    dev = dy.device
+    wp = s2_subpixel_weights(w)
     l, st = _lib.lib(), stream_ptr(dev)
     prepared = torch.empty(wp.numel(), dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_conv2d_prepare(ptr(wp), ptr(prepared), cout, cin * 4, 2, 2, 0, st), "gencomm_conv2d_prepare")
