@@ -55,7 +55,8 @@ enum ModeKey : int {
   MODE_DATAFLOW = 6,     // 1: the UNet body of a call runs as ONE persistent dataflow launch (dataflow_kernels.h); 0: one launch per layer
   MODE_RESFUSE_EMU = 7,  // TIMING EXPERIMENT ONLY, off by default -- the results are NOT the UNet's: unet_host.h "ResnetBlock fusion, emulated"
   MODE_TILE8 = 8,        // n > 0: GroupNorm'd 8-channel layers on the f16 pipe whose launch has fewer than n workgroups of 64 x 16 pixels run
-                         // 64 x 8 tiles (conv8h8_kernels.h; VERDICT r3 item 3b: the half-resolution level); 0 (default): 64 x 16 everywhere
+                         // 64 x 8 tiles (conv8h8_kernels.h; VERDICT r3 item 3b: the half-resolution level); 0: 64 x 16 everywhere; -1 (default):
+                         // automatic = 256 unless MODE_TILE_WANT forces a tile size (single-scene launches: latency 10.07 -> 9.78 ms)
   MODE_BWD_STREAMS = 9,  // 1 (default): gencomm_unet_bwd enqueues its weight-gradient launches on a library-owned side stream (forked from and
                          // joined back to the caller's stream inside the call), so that they overlap the input-gradient chain, when the call
                          // has at least 2^17 pixels (n H W); 2: always; 0: one stream

@@ -54,7 +54,11 @@ inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, h
   if constexpr (RES != 3)   // RES 3 = the backward's GroupNorm epilogue: exact-fp32 kernel only
   if (t == TILE_64x16 && a.wh != nullptr && m.split() && (m.v[MODE_CONV8H_MASK] & variant)) {
     if constexpr (GN && !UP) {   // 64 x 8 tiles for launches with few workgroups (MODE_TILE8: the half-resolution level)
-      if (m.v[MODE_TILE8] > 0 && (long long)grid.x * grid.y * grid.z < m.v[MODE_TILE8] && (a.W & 3) == 0 && a.W >= 4) {
+      // automatic (-1): launches below a third of a resident round (256 workgroups of 64 x 16: the half-resolution level of ONE four-agent
+      // scene, 168) take the 64 x 8 tiles -- single-scene latency 10.07 -> 9.78 ms, throughput at 16 agents per launch unchanged (its
+      // half-resolution launches have 672); not when the caller forces a tile size (MODE_TILE_WANT != 0: tests of the 64 x 16 kernels)
+      const long long t8 = m.v[MODE_TILE8] >= 0 ? m.v[MODE_TILE8] : (m.v[MODE_TILE_WANT] == 0 ? 256 : 0);
+      if (t8 > 0 && (long long)grid.x * grid.y * grid.z < t8 && (a.W & 3) == 0 && a.W >= 4) {
         GC_KLOG(NSRC == 2 ? "conv8h8_kernel<2,GN,0> (64x8 tiles)" : RES == 2 ? "conv8h8_kernel<1,GN,2> (64x8 tiles)" : RES == 1 ? "conv8h8_kernel<1,GN,1> (64x8 tiles)" : "conv8h8_kernel<1,GN,0> (64x8 tiles)");
         conv8h8_kernel<NSRC, GN, RES><<<dim3(cdiv(a.W, 64), cdiv(a.H, 8), n), 256, 0, st>>>(a);
         return;

@@ -85,9 +85,12 @@ const char* gencomm_build_info(void);
  *                             then skipped so that the grid drains, the entry point still returns GC_OK, and the activations are
  *                             invalid.  A caller that turns this mode on MUST poll gencomm_dataflow_error() after the call.  The mode
  *                             is opt-in, measured 2x slower than the per-layer launches, and kept for that measurement only
- *   GENCOMM_MODE_TILE8        0 (default): 64x16-pixel tiles in every 8-channel layer of the f16 pipe; n > 0: launches with fewer than n
+ *   GENCOMM_MODE_TILE8        0: 64x16-pixel tiles in every 8-channel layer of the f16 pipe; n > 0: launches with fewer than n
  *                             such workgroups run 64x8 tiles (half the dependent chain per workgroup, 28.8 KB of LDS: the half-resolution
- *                             level of large maps).  Same arithmetic; results identical up to the summation order of the statistics
+ *                             level of large maps).  Same arithmetic; results identical up to the summation order of the statistics.
+ *                             -1 (default): automatic = 256 (a third of a resident round: the half-resolution launches of ONE four-agent
+ *                             scene; single-scene latency 10.07 -> 9.78 ms, batched throughput unchanged), off while GENCOMM_MODE_TILE_WANT
+ *                             forces a tile size
  *   GENCOMM_MODE_BWD_STREAMS  1 (default): on calls of at least 2^17 pixels (n H W) gencomm_unet_bwd forks its weight-gradient launches onto a
  *                             library-owned side stream of the device (hipEventRecord on the caller's stream / hipStreamWaitEvent) and joins
  *                             them back before its last launches, so they overlap the input-gradient chain (15.2 -> 13.7 ms per training step
