@@ -46,6 +46,8 @@ WORKLOADS = {
 PX_M = 0.4           # metres per BEV pixel at 200x704 (OPV2V range +-140.8 x +-40 m)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+MFMA_TERMS = 6.0          # matrix instructions per fp32-grade product block (conv8h_kernels.h header)
 
 # Kernel families of the library's timer (include/gencomm_hip.h, csrc/common.h KernelFamily).  The dominant kernel is the
 # conv8h_kernel template -- the 8-channel 3x3 layers of the UNet (ResnetBlock conv1 / conv2, Upsample), ~55 % of kernel time in
@@ -54,6 +56,7 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA pe
 CONV8_FAMILIES = {1: "conv1 8->8 (GN+SiLU)", 16: "conv2 + identity residual", 17: "conv2 + 1x1 nin_shortcut", 2: "conv1 16->8 (skip concat)",
                   4: "Upsample conv (nearest x2)"}
 LATENT_FAMILY = 15
+ENH_FRONT_FAMILY = 9
 N_FAMILIES = 19
 RESULT_OUT = sys.stdout   # main() replaces it by a private copy of the original stdout
 
@@ -219,7 +222,7 @@ def train_main(args, rank, world, device, backend):
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True, gradient_as_bucket_view=True)
     else:          # one flat bucket per step (gencomm_amd/dist.py FlatGradSync): the same average, 4 launches instead of 2 per parameter
         ddp = model
-        sync = gdist.FlatGradSync(model.parameters(), dist)
+        sync = gdist.FlatGradSync(model.parameters(), dist, module=model)   # broadcasts rank 0's parameters and buffers
     crit = PointPillarGencommLoss(synth.STAGE1_LOSS_ARGS)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=2e-3, eps=1e-10, weight_decay=1e-4, fused=True)   # m1_att.yaml:191-196
@@ -316,6 +319,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="scenes per step (batched in one launch sequence, record_len=[N]*B)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent scenes in flight per GPU, each on its own HIP stream with its own buffers")
+    ap.add_argument("--sustain", type=float, default=12.0,
+                    help="seconds of the sustained repeat of the timed loop (reported beside `value`; long enough for a 5 s utilisation sampler)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the scene's launch sequence as a captured HIP graph")
     ap.add_argument("--mode", action="append", default=[], metavar="KEY=VALUE",
                     help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow resfuse_emu tile8), e.g. --mode xcd=0")
@@ -429,7 +434,7 @@ def main():
             # counter traffic is a committed measurement, valid only for the kernels it was taken on: the JSON carries the source
             # stamp of the library it ran (gencomm_build_info() " src=..."); any other library -> null
             traffic, traffic_src = None, None
-            for pmc in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):
+            for pmc in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
                 pmc = os.path.join(REPO, "profiles", pmc)
                 if not os.path.exists(pmc):
                     continue
@@ -444,17 +449,21 @@ def main():
             # the second resource: vector-instruction issue, from the committed SQ counter pass of the same command (stamped like the
             # traffic): fraction of a wave's resident cycles with an instruction in flight x the three waves a SIMD holds
             issue = None
-            sq = os.path.join(REPO, "profiles", "r4_pmc_sq.json")
-            if os.path.exists(sq):
+            for sq_name in ("r5_pmc_sq.json", "r4_pmc_sq.json"):
+                sq = os.path.join(REPO, "profiles", sq_name)
+                if issue is not None or not os.path.exists(sq):
+                    continue
                 try:
                     sj = json.load(open(sq))
-                    if sj.get("workload") == args.workload and sj.get("library_src") == _lib.library_src_hash():
+                    # an unstamped library (hash "") must never match an unstamped JSON: both sides have to carry a stamp
+                    if (sj.get("workload") == args.workload and sj.get("library_src")
+                            and sj.get("library_src") == _lib.library_src_hash()):
                         ks = {k: v for k, v in sj["kernels"].items() if "conv8h_kernel<" in k}
                         w = sum(v["launches"] * v["raw_means"]["SQ_WAVE_CYCLES"] for v in ks.values())
                         act = sum(v["launches"] * v["raw_means"]["SQ_ACTIVE_INST_ANY"] for v in ks.values()) / w
                         wait = sum(v["launches"] * v["raw_means"]["SQ_WAIT_ANY"] for v in ks.values()) / w
                         issue = {"active_inst_frac_per_wave": act, "waves_per_simd": 3, "simd_issue_busy": min(1.0, 3 * act),
-                                 "parked_on_waitcnt_or_barrier_frac_per_wave": wait, "source": "profiles/r4_pmc_sq.json (tools/pmc_sq_pass.sh)"}
+                                 "parked_on_waitcnt_or_barrier_frac_per_wave": wait, "source": f"profiles/{sq_name} (tools/pmc_sq_pass.sh)"}
                 except Exception:
                     issue = None
             out["roofline"] = {
@@ -475,17 +484,36 @@ def main():
             v = fam[LATENT_FAMILY]
             fl = 2.0 * (1600.0 + 72.0 * C) * HW * N * B
             ms1 = v["ms"] / v["launches"]
+            fp32_eq = fl / (ms1 * 1e-3) / 1e12
+            # north_star: "MFMA utilisation on the contractions against MI355X peak".  The contraction runs on the f16 matrix pipe,
+            # six instructions per fp32-grade product block, so the pipe executes 6 x the algorithmic FLOPs; frac is THAT against the
+            # dense f16 peak (2.5 PFLOP/s).  The fp32-equivalent rate (what the reference's arithmetic would need) is kept beside it.
             out["roofline_latent_step"] = {
                 "kernel": "latent_step_h_kernel (conv_out + sampler update + conv_in of one step fused by linearity, in-kernel noise)",
-                "bound": "mfma", "achieved": fl / (ms1 * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / (ms1 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": v["launches"], "avg_launch_ms": ms1,
-                "flops_per_launch": fl, "share_of_kernel_time": v["ms"] / tot_ms,
+                "bound": "mfma", "achieved": MFMA_TERMS * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": MFMA_TERMS * fp32_eq / F16_MFMA_PEAK_TFLOPS, "traffic": None, "launches": v["launches"], "avg_launch_ms": ms1,
+                "flops_per_launch": fl, "matrix_pipe_flops_per_launch": MFMA_TERMS * fl, "share_of_kernel_time": v["ms"] / tot_ms,
+                "fp32_equivalent": {"achieved": fp32_eq, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp32_eq / FP32_PEAK_TFLOPS},
                 "achieved_algorithmic_gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
                 "note": "algorithmic FLOPs = 2*(1600 + 72*C) per agent-pixel (conv_out 8 -> C, posterior update, conv_in C + 2 -> 8 and the noise's "
-                        "conv_in, fused by linearity) against the 157.3 TFLOP/s fp32 matrix/vector peak (the dtype of the path); every product block is "
-                        "six f16-pipe matrix instructions on three-term operands, so the matrix pipe itself runs 6x these FLOPs. The in-kernel "
+                        "conv_in, fused by linearity). achieved / frac = 6 x those FLOPs (a product block is six f16-pipe matrix instructions on "
+                        "three-term operands; the hi-only noise convolution issues three, so this is an upper estimate of the pipe's load) against the "
+                        "2.5 PFLOP/s dense f16 MFMA peak; fp32_equivalent = the algorithmic FLOPs against the 157.3 TFLOP/s fp32 peak. The in-kernel "
                         "Philox4x32-7 + Box-Muller generator is 13.5 % of the kernel's time (measured by subtraction with diagnostic builds: "
                         "profiles/r4_latent_noise_budget.txt), not its bound"}
+        if ENH_FRONT_FAMILY in fam and C == 64:
+            # Enhancer front: Linear C -> 4C, GELU, depthwise 3x3 + gate, Linear 2C -> C in one launch (enhancer.py:222-250); the two Linears
+            # are the contractions: 2 * (4C^2 + 2C^2) FLOPs per token
+            v = fam[ENH_FRONT_FAMILY]
+            fl = 2.0 * 6.0 * C * C * HW * N * B * v["launches"]
+            fp32_eq = fl / (v["ms"] * 1e-3) / 1e12
+            out["roofline_enh_front"] = {
+                "kernel": "enh_front_h_kernel (FRFN: Linear1 + GELU + depthwise 3x3 + gate + Linear2 + residual, fused)",
+                "bound": "mfma", "achieved": MFMA_TERMS * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": MFMA_TERMS * fp32_eq / F16_MFMA_PEAK_TFLOPS, "traffic": None, "launches": v["launches"], "avg_launch_ms": v["ms"] / v["launches"],
+                "fp32_equivalent": {"achieved": fp32_eq, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp32_eq / FP32_PEAK_TFLOPS},
+                "share_of_kernel_time": v["ms"] / tot_ms,
+                "note": "contraction FLOPs = 12*C^2 per token (the two Linears), x 6 matrix instructions per product block against the dense f16 peak"}
         out["kernel_time_shares"] = {v["name"]: round(v["ms"] / tot_ms, 4) for f, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         return out
 
@@ -500,11 +528,12 @@ def main():
             torch.cuda.set_sync_debug_mode("default")
             torch.cuda.synchronize(device)
         elapsed = timed_region(args.steps, 2000)
-        # the K-step region above is the reported number; when it is shorter than a second (20 steps = 0.4 s: too short for a
-        # 5 s-period utilisation sampler to see), the same loop is repeated to >= 1.2 s in ONE bracket and reported beside it
+        # the K-step region above is the reported number; 20 steps = 0.4 s is too short for a 5 s-period utilisation sampler to
+        # see, so the same loop is repeated to >= --sustain seconds (default 12: at least two sampler periods) in ONE bracket and
+        # reported beside it -- `value` stays on the K-step region
         sustained = None
-        if elapsed < 1.0 and not args.no_timer:   # profiling runs (--no-timer) execute the K-step region only
-            reps = int(np.ceil(1.2 / max(elapsed, 1e-3)))
+        if elapsed < args.sustain and not args.no_timer:   # profiling runs (--no-timer) execute the K-step region only
+            reps = int(np.ceil(args.sustain / max(elapsed, 1e-3)))
             ts = timed_region(args.steps * reps, 2500)
             sustained = {"steps": args.steps * reps, "seconds": ts, "value_this_rank": args.steps * reps * B / ts, "unit": "scenes/sec"}
         # latency of ONE scene alone (one stream, batch 1): throughput above needs S x B scenes in flight
@@ -587,6 +616,7 @@ def main():
         }
         out["roofline"] = roofs.get("roofline")
         out["roofline_latent_step"] = roofs.get("roofline_latent_step")
+        out["roofline_enh_front"] = roofs.get("roofline_enh_front")
         out["kernel_time_shares"] = roofs.get("kernel_time_shares")
         out["exact_fp32_mode"] = exact
         if world == 1 and not args.no_cpu_baseline:

@@ -276,10 +276,10 @@ class EnhancerFunction(torch.autograd.Function):
         # Weight gradients feed nothing in this walk: on large maps they run on a side stream beside the input-gradient chain (the same
         # overlap as GENCOMM_MODE_BWD_STREAMS inside gencomm_unet_bwd) and are joined before d y2 is overwritten by LayerNorm2's backward.
         from .runtime import overlap
-        ov = overlap(x.device, n * HW).__enter__()
-        on_side = ov.run
-
-        with torch.no_grad():
+        # (a `with` block: an exception between fork and join -- a shape error, a failed library call -- still joins the side stream and
+        # hands its outputs to the current stream before it propagates)
+        with overlap(x.device, n * HW) as ov, torch.no_grad():
+            on_side = ov.run
             dy2 = T.nc_scale(go, a.detach(), dgap / HW)
             # ---- Linear2
             dg = T.conv2d(dy2, w2.transpose(0, 1).contiguous(), None, 0)
@@ -305,7 +305,7 @@ class EnhancerFunction(torch.autograd.Function):
                 T.conv2d(dzi1, m.partial_conv3.weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, 1, out=dzi, out_coff=0)
             dz = dzi
             dWp, _ = on_side(lambda: T.conv2d_wgrad(dzi1, z1, 3, 1, False))
-            ov.join()
+            ov.join()                                                                      # idempotent; __exit__ joins again on every path
             # ---- LayerNorms and residuals
             dy, dg2, db2n = T.ln_bwd(y, b1.norm2.weight, dz, 1e-5, accumulate_into=dy2)       # d y = d y2 + LN2 backward
             dx, dg1, db1n = T.ln_bwd(x, b1.norm1.weight, dy, 1e-5)

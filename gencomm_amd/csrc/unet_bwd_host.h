@@ -239,7 +239,27 @@ inline int gn_bwd_enqueue(const UNetBwdCall& b, int src_id, const float* gamma, 
 
 // The library's side stream of a device (GENCOMM_MODE_BWD_STREAMS): created on first use, kept for the life of the process.  A call forks
 // work onto it with `fork` (recorded on the caller's stream, waited for by the side stream) and joins with `join` (the reverse).
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+// Two host threads may run gencomm_unet_bwd on one device (two autograd graphs, multi-stream training): the stream and the event pair
+// are shared, so every record + wait PAIR is made under `mu` -- hipStreamWaitEvent binds to the most recent record of the event at
+// the time of the call, and with the pair atomic that record is the caller's own (the two callers' side work then simply queues on
+// the one side stream in call order).
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::mutex mu;
+  int fork_from(hipStream_t st) {   // side stream waits for everything enqueued on st so far
+    std::lock_guard<std::mutex> lock(mu);
+    GC_HIP(hipEventRecord(fork, st));
+    GC_HIP(hipStreamWaitEvent(s, fork, 0));
+    return GC_OK;
+  }
+  int join_into(hipStream_t st) {   // st waits for everything enqueued on the side stream so far
+    std::lock_guard<std::mutex> lock(mu);
+    GC_HIP(hipEventRecord(join, s));
+    GC_HIP(hipStreamWaitEvent(st, join, 0));
+    return GC_OK;
+  }
+};
 inline int side_stream(SideStream** out) {
   static std::mutex mu;
   static SideStream tab[64];
@@ -315,8 +335,7 @@ inline int unet_bwd_enqueue(const UNetBwdCall& b, const float* x_t, const float*
     if (int rc = side_stream(&ss)) return rc;
   const int walk_rc = unet_bwd_walk(b, x_t, cond, grad_x0, grad_xt, grad_cond, ss);
   if (ss != nullptr) {   // joined on every path: the caller's buffers are ordered on its own stream when this call returns
-    GC_HIP(hipEventRecord(ss->join, ss->s));
-    GC_HIP(hipStreamWaitEvent(st, ss->join, 0));
+    if (int rc = ss->join_into(st)) return rc;
   }
   if (walk_rc) return walk_rc;
   if (b.gp.uses > 0) gn_param_grad_all_kernel<<<b.gp.uses, 64, 0, st>>>(b.gp);
@@ -341,8 +360,7 @@ inline int unet_bwd_walk(const UNetBwdCall& b, const float* x_t, const float* co
   float* DA = b.F(b.bw->DA);
   auto conv_wgrad_enqueue = [&](const WgradArgs& wa, int nn, hipStream_t) -> int {   // shadows the free function for the launches below
     if (ss == nullptr) return gc::conv_wgrad_enqueue(wa, nn, st);
-    GC_HIP(hipEventRecord(ss->fork, st));
-    GC_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+    if (int rc = ss->fork_from(st)) return rc;
     return gc::conv_wgrad_enqueue(wa, nn, ss->s);
   };
 

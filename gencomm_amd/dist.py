@@ -85,43 +85,82 @@ class FlatGradSync:
     walk of the autograd graph on the host.  Here the step's gradients are concatenated (one kernel), all-reduced (one collective),
     scaled (one kernel) and copied back with a multi-tensor copy: the same sum / world on every rank.
 
-    Semantics kept from DDP: the average over ranks of every parameter's gradient; parameters that received no gradient keep
-    ``grad = None`` (the optimiser skips them, as with DDP's globally-unused parameters).  Assumed, and checked on the first
-    ``check_steps`` calls with a fixed-size signature exchanged before the bucket: every rank produced gradients for the SAME
-    parameters (the unused parameters of the stage-1 / stage-2 recipes are structural -- Enhancer blocks 2 and 3, frozen modules)."""
+    Semantics kept from DDP:
+    * construction broadcasts rank 0's parameters (and, with ``module=``, its buffers) so that every rank starts from one state
+      (DDP's ``_sync_module_states``); ``broadcast=False`` skips it for callers that seeded identically;
+    * the bucket LAYOUT is fixed at the first ``sync()``: the union over ranks of the parameters that received a gradient (one
+      all-reduce(MAX) of a per-parameter mask, one host read, first step only).  From then on every rank reduces exactly that
+      layout -- a parameter of the set without a local gradient on some step contributes zeros and receives the average (DDP's
+      locally-unused parameter), so the collective's length can never differ between ranks;
+    * parameters outside the set keep ``grad = None`` (the optimiser skips them, as with DDP's globally-unused parameters: Enhancer
+      blocks 2 and 3, frozen modules).  A gradient that appears LATER on a parameter outside the set is an error (raised after the
+      collective, so the other ranks are not left inside it): such a model needs DistributedDataParallel(find_unused_parameters=True)."""
 
-    def __init__(self, params, dist=None, check_steps: int = 2):
+    def __init__(self, params, dist=None, check_steps: int = 2, module: torch.nn.Module = None, broadcast: bool = True):
         self.params = [p for p in params if p.requires_grad]
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
-        self.check_steps = check_steps
+        self.check_steps = check_steps   # kept for callers of the round-4 signature; the layout agreement replaced the per-step check
         self.calls = 0
         self.bucket_bytes = 0
+        self.used = None                 # indices into self.params of the agreed layout
+        if broadcast and dist is not None and self.world > 1:
+            tensors = [p.data for p in self.params]
+            if module is not None:
+                tensors += [b.data for b in module.buffers() if b is not None]
+            self._broadcast_(tensors)
+
+    def _broadcast_(self, tensors) -> None:
+        """rank 0's values into every rank, one broadcast per (dtype, device) group"""
+        groups = {}
+        for t in tensors:
+            groups.setdefault((t.dtype, t.device), []).append(t)
+        for (dt, dev), ts in groups.items():
+            if dt == torch.bool:
+                flat = torch.cat([t.reshape(-1).to(torch.uint8) for t in ts])
+            else:
+                flat = torch.cat([t.reshape(-1) for t in ts])
+            self.dist.broadcast(flat, src=0)
+            outs = flat.split([t.numel() for t in ts])
+            with torch.no_grad():
+                for t, o in zip(ts, outs):
+                    t.copy_(o.view_as(t).to(dt))
+
+    def _agree_layout(self, dev) -> None:
+        mask = torch.tensor([1 if p.grad is not None else 0 for p in self.params], dtype=torch.int32, device=dev)
+        if self.world > 1:
+            self.dist.all_reduce(mask, op=self.dist.ReduceOp.MAX)
+        self.used = [i for i, m in enumerate(mask.cpu().tolist()) if m]
+        if not self.used:
+            raise RuntimeError("FlatGradSync.sync: no parameter has a gradient on any rank (call it after backward)")
+        self.sizes = [self.params[i].numel() for i in self.used]
+        self.used_set = set(self.used)
 
     def sync(self) -> None:
         """Call between ``loss.backward()`` and ``optimizer.step()``."""
         if self.dist is None:
             return
-        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
-        grads = [self.params[i].grad for i in idx]
-        if not grads:
-            raise RuntimeError("FlatGradSync.sync: no parameter has a gradient (call it after backward)")
-        dev, dt = grads[0].device, grads[0].dtype
+        first = next((p.grad for p in self.params if p.grad is not None), None)
+        ref = first if first is not None else self.params[0]
+        dev, dt = ref.device, ref.dtype
+        if self.used is None:
+            self._agree_layout(dev)
+        late = [i for i, p in enumerate(self.params) if p.grad is not None and i not in self.used_set]
+        grads, missing = [], []
+        for i in self.used:
+            p = self.params[i]
+            if p.grad is None:               # used elsewhere (or earlier): zeros in, the average out
+                p.grad = torch.zeros_like(p)
+                missing.append(i)
+            grads.append(p.grad)
         if any(g.dtype != dt or g.device != dev for g in grads):
             raise RuntimeError("FlatGradSync: gradients must share one dtype and device")
-        sizes = [g.numel() for g in grads]
-        if self.calls < self.check_steps and self.world > 1:
-            # first steps only (a host read): every rank must be about to reduce the same parameters -- a bucket of another length would
-            # hang or corrupt the collective, so this is settled on a fixed-size signature first
-            sig = torch.tensor([len(idx), sum(sizes), sum((i + 1) * (i + 7) for i in idx) % (2 ** 31)], dtype=torch.int64, device=dev)
-            sigs = [torch.empty_like(sig) for _ in range(self.world)]
-            self.dist.all_gather(sigs, sig)
-            if any(not torch.equal(s.cpu(), sig.cpu()) for s in sigs):
-                raise RuntimeError("FlatGradSync: the ranks produced gradients for different sets of parameters (a parameter is unused on some "
-                                   "ranks only); use torch DistributedDataParallel(find_unused_parameters=True) for such a model")
         self.calls += 1
         flat = torch.cat([g.reshape(-1) for g in grads])
         self.bucket_bytes = flat.numel() * flat.element_size()
         self.dist.all_reduce(flat)
         flat.mul_(1.0 / self.world)
-        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split(sizes), grads)])
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split(self.sizes), grads)])
+        if late:
+            raise RuntimeError(f"FlatGradSync: {len(late)} parameter(s) outside the layout agreed at the first step received a gradient "
+                               "(conditionally used parameters); use torch DistributedDataParallel(find_unused_parameters=True) for such a model")

@@ -12,7 +12,9 @@ The maps are the head outputs ([B, 2 | 14 | 4, H, W] at the fused resolution): k
 framework elementwise ops (the boundary's plumbing); what differs from the reference is that nothing here synchronises the
 host -- the reference calls ``.item()`` six times per step (``point_pillar_loss.py:93,121-123``,
 ``point_pillar_gencomm_loss.py:50-55``), here ``loss_dict`` holds detached device scalars that ``logging`` converts when
-it prints.  Camera depth supervision (``depth_items*`` keys) and the IoU head are outside this build: their keys raise.
+it prints.  One exception, inherited: an output dict that carries a DEVICE ``record_len`` makes ``int(record_len.sum())`` a
+device-to-host read, as in the reference (``point_pillar_loss.py:43-44``); a list or CPU tensor does not, and this package's
+shells emit neither.  Camera depth supervision (``depth_items*`` keys) and the IoU head are outside this build: their keys raise.
 """
 from __future__ import annotations
 
@@ -73,11 +75,18 @@ class PointPillarGencommLoss(nn.Module):
         if any(k.startswith(f"depth_items{suffix}") for k in output_dict):
             raise NotImplementedError("depth supervision of camera agents is outside this build")
         if "record_len" in output_dict:
-            bs = int(output_dict["record_len"].sum())
+            # point_pillar_loss.py:43-44.  A list / CPU tensor costs nothing; a DEVICE tensor makes this line a device-to-host read,
+            # exactly as in the reference -- the shells of this package do not put `record_len` into their output dict, so the
+            # training leg never takes that branch (tests/test_loss.py checks both)
+            rl = output_dict["record_len"]
+            bs = int(sum(rl)) if isinstance(rl, (list, tuple)) else int(rl.sum())
         elif "batch_size" in output_dict:
             bs = output_dict["batch_size"]
         else:
             bs = target_dict["pos_equal_one"].shape[0]
+        for short, full in (("psm", "cls_preds"), ("rm", "reg_preds"), ("dm", "dir_preds")):   # point_pillar_loss.py:59-65 "rename variable"
+            if f"{short}{suffix}" in output_dict:
+                output_dict[f"{full}{suffix}"] = output_dict[f"{short}{suffix}"]
         cls_labels = target_dict["pos_equal_one"].view(bs, -1, 1)
         positives = cls_labels > 0
         negatives = target_dict["neg_equal_one"].view(bs, -1, 1) > 0

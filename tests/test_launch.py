@@ -44,6 +44,17 @@ def test_bench_self_launches_two_ranks_and_aggregates():
         assert r["env"] == {"RANK": str(r["rank"]), "LOCAL_RANK": str(r["rank"]), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "GENCOMM_LAUNCHED": "1"}
 
 
+def test_bench_self_launches_eight_ranks():
+    """world size 8 -- the node BASELINE.json names -- through the same launcher and aggregation (gloo on the CPU; reference
+    multi_gpu_utils.py:16-38 reads the same RANK / WORLD_SIZE / LOCAL_RANK environment)"""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--workload", "launch_selftest", "--steps", "3", "--batch", "2"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    d = _check_line(p.stdout, 8, 3, 2)
+    assert [r["env"]["LOCAL_RANK"] for r in d["ranks"]] == [str(i) for i in range(8)]
+    assert all(r["env"]["WORLD_SIZE"] == "8" for r in d["ranks"])
+
+
 def test_a_failing_rank_stops_the_job_with_its_exit_code():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "launch_selftest", "--steps", "3"],
                        env=dict(_clean_env(), GENCOMM_SELFTEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)

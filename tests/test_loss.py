@@ -43,6 +43,21 @@ def test_loss_matches_the_reference_criterion_gpu():
     _run("cuda:0")
 
 
+def test_psm_rm_dm_aliases_and_record_len_forms():
+    """point_pillar_loss.py:43-44, :59-65: `record_len` in the output dict sets the batch size; models that emit psm / rm / dm are
+    renamed to cls_preds / reg_preds / dir_preds"""
+    g = np.load(GOLD)
+    B, H, W, A, C = (int(v) for v in g["dims"])
+    t = {k: torch.from_numpy(v) for k, v in synth.make_loss_inputs(int(g["data_seed"]), B, H, W, A, C).items()}
+    crit = PointPillarGencommLoss(json.loads(str(g["args"])))
+    tgt = {k: t[k] for k in ("pos_equal_one", "neg_equal_one", "targets")}
+    for rl in ([1] * B, torch.ones(B, dtype=torch.int64)):
+        out = {"psm": t["cls_preds"], "rm": t["reg_preds"], "dm": t["dir_preds"], "gt_feature": t["gt_feature"], "pred_feature": t["pred_feature"],
+               "record_len": rl}
+        assert float(crit(out, tgt)) == pytest.approx(float(g["total"]), rel=2e-6)
+        assert out["cls_preds"] is t["cls_preds"] and out["reg_preds"] is t["reg_preds"] and out["dir_preds"] is t["dir_preds"]
+
+
 def test_resolver_name_and_unsupported_keys():
     import gencomm_amd.point_pillar_gencomm_loss as m
     # train_utils.create_loss: module `point_pillar_gencomm_loss`, class whose lower-cased name is the module name without underscores

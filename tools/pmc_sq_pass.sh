@@ -2,17 +2,18 @@
 # Where the waves of the benchmark's kernels spend their cycles: one rocprofv3 --pmc pass of the SQ block (8 slots on gfx950,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots"): SQ_WAIT_ANY (parked on s_waitcnt / barrier) + SQ_WAIT_INST_ANY (issue stall) +
 # SQ_ACTIVE_INST_ANY (issuing) ~ SQ_WAVE_CYCLES; SQ_VALU_MFMA_BUSY_CYCLES; LDS conflict / active cycles.
-#   bash tools/pmc_sq_pass.sh [workload]   (on the GPU box; output gpurun_out/r4_pmc_sq.json)
+#   bash tools/pmc_sq_pass.sh [workload]   (on the GPU box; output gpurun_out/${R}_pmc_sq.json)
 set -o pipefail
+export R=${ROUND:-r5}   # prefix of the output files (profiles/<round>_pmc_*.json)
 WL=${1:-metric}
 export PMC_WORKLOAD=$WL
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rm -rf gpurun_out/r4_pmc_SQ
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/r4_pmc_SQ -o pmc -- python3 bench.py --workload $WL --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-exact --no-timer > gpurun_out/r4_pmc_SQ.log 2>&1 || { tail -n 20 gpurun_out/r4_pmc_SQ.log; exit 1; }
+rm -rf gpurun_out/${R}_pmc_SQ
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/${R}_pmc_SQ -o pmc -- python3 bench.py --workload $WL --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-exact --no-timer > gpurun_out/${R}_pmc_SQ.log 2>&1 || { tail -n 20 gpurun_out/${R}_pmc_SQ.log; exit 1; }
 python - <<'PY'
-import csv, collections, json, re
-rows = csv.DictReader(open('gpurun_out/r4_pmc_SQ/pmc_counter_collection.csv'))
+import csv, collections, json, os, re
+rows = csv.DictReader(open('gpurun_out/' + os.environ['R'] + '_pmc_SQ/pmc_counter_collection.csv'))
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for r in rows:
     k = re.sub(r'^void ', '', r['Kernel_Name'])
@@ -41,7 +42,7 @@ sys.path.insert(0, os.getcwd())
 from gencomm_amd import _lib
 res['library_src'] = _lib.library_src_hash()   # the kernels these counters were taken on (bench.py ignores a file from another library)
 res['workload'] = os.environ.get('PMC_WORKLOAD', 'metric')
-json.dump(res, open('gpurun_out/r4_pmc_sq.json', 'w'), indent=1)
+json.dump(res, open('gpurun_out/' + os.environ['R'] + '_pmc_sq.json', 'w'), indent=1)
 for k, v in list(res['kernels'].items())[:14]:
     print(k[:64].ljust(64), v['launches'], 'wait', v['wait_any_frac'], 'stall', v['wait_inst_frac'], 'active', v['active_inst_frac'], 'mfma', v['mfma_busy_over_busy_cycles'], 'ldsconf', v['lds_conflict_over_lds_active'])
 PY
