@@ -747,6 +747,84 @@ def run_apchain_case() -> None:
     print(f"apchain: wrote apchain.npz ({os.path.getsize(os.path.join(OUT, 'apchain.npz')) / 1024:.0f} KiB)")
 
 
+ROBUST = dict(C=64, H=32, W=64, T=5, n=3, px_m=0.8, stride=29, pos_rot_std=[0.2, 0.4, 0.8], async_overhead=[100, 300, 500])
+
+
+def robust_frame_inputs(frame_of_agent):
+    """feat / cond of the robustness case: agent i's rows come from the synthetic frame `frame_of_agent[i]` (a stale collaborator = rows
+    of an earlier frame).  Shared with tests/test_gpu_robustness.py so that the fixture stores seeds, not tensors."""
+    c = ROBUST
+    per = {f: synth.make_inputs([c["n"]], c["C"], c["H"], c["W"], DATA_SEED + 200 + f) for f in set(frame_of_agent)}
+    feat = np.stack([per[f]["feat"][i] for i, f in enumerate(frame_of_agent)])
+    cond = np.stack([per[f]["cond"][i] for i, f in enumerate(frame_of_agent)])
+    return feat, cond
+
+
+def run_robust_case() -> None:
+    """BASELINE configs[4] (pose noise + communication delay) on synthetic inputs: both perturbations reach the hot path only through
+    `pairwise_t_matrix` and through WHICH frame a collaborator's feature / message rows come from.  This case builds them with the
+    reference's own code -- pose_utils.generate_noise under np.random.seed(303) for the std sweep of inference_w_noise.py:66-88,
+    the 'sim' / 'random' frame delay of opv2v_basedataset.py:706-744 for the overheads of inference_w_delay.py:66, poses -> pairwise
+    matrices through x_to_world / get_pairwise_transformation (transformation_utils.py:21-66, :264-307) -- and runs the reference's
+    GenComm -> Enhancer -> AttFusion on them."""
+    from collections import OrderedDict
+    from opencood.models.gencomm_modules.cond_diff import GenComm
+    from opencood.models.gencomm_modules.enhancer import Enhancer
+    from opencood.models.fuse_modules.fusion_in_one import AttFusion
+    from opencood.utils import pose_utils
+    from opencood.utils.transformation_utils import get_pairwise_transformation, normalize_pairwise_tfm
+    c = ROBUST
+    C, H, W, T, n, st = c["C"], c["H"], c["W"], c["T"], c["n"], c["stride"]
+    cfg = synth.default_gencomm_cfg(C, T)
+    gen, enh, fus = GenComm(cfg).eval(), Enhancer(C, [8, 8], 4).eval(), AttFusion(C).eval()
+    synth.fill_params_(gen, WEIGHT_SEED + 200)
+    synth.fill_params_(enh, WEIGHT_SEED + 201)
+    bev_h_m, bev_w_m = H * c["px_m"], W * c["px_m"]
+    # world: agent i at pose0[i] in frame 0, moving with velocity vel[i] per frame (10 Hz); the current frame is frame 6
+    rp = np.random.RandomState(DATA_SEED + 210)
+    pose0, vel = np.zeros((n, 6)), np.zeros((n, 6))
+    pose0[:, 0], pose0[:, 1], pose0[:, 4] = rp.uniform(-8, 8, n), rp.uniform(-4, 4, n), rp.uniform(-30, 30, n)
+    vel[:, 0], vel[:, 1], vel[:, 4] = rp.uniform(-0.8, 0.8, n), rp.uniform(-0.3, 0.3, n), rp.uniform(-1.0, 1.0, n)
+    CUR = 6
+    pose_at = lambda i, f: pose0[i] + vel[i] * f
+
+    def ptm_of(poses):
+        base = OrderedDict((i, {"params": {"lidar_pose": list(poses[i])}}) for i in range(n))
+        return get_pairwise_transformation(base, 5, False)[None]
+
+    variants = OrderedDict()
+    variants["clean"] = ([CUR] * n, np.stack([pose_at(i, CUR) for i in range(n)]))
+    for s_ in c["pos_rot_std"]:
+        np.random.seed(303)                                                   # inference_w_noise.py:88
+        poses = np.stack([pose_at(i, CUR) + pose_utils.generate_noise(s_, s_) for i in range(n)])   # pose_utils.py:14-33: every cav, ego included
+        variants[f"pose{s_}"] = ([CUR] * n, poses)
+    for ov in c["async_overhead"]:
+        torch.manual_seed(303)
+        frames = [CUR]                                                        # opv2v_basedataset.py:720-721: no delay for the ego
+        for i in range(1, n):
+            delay = (torch.randint(0, ov, (1,)).item() + 100) // 100          # :733-743, async_mode 'sim', async_method 'random'
+            frames.append(CUR - delay)
+        variants[f"delay{ov}"] = (frames, np.stack([pose_at(i, f) for i, f in enumerate(frames)]))   # stale rows AND the stale pose (:661)
+    rec = dict(C=C, H=H, W=W, T=T, n=n, px_m=c["px_m"], stride=st, weight_seed=WEIGHT_SEED + 200, noise_seed=NOISE_SEED + 200,
+               variants=np.asarray(list(variants)))
+    for name, (frames, poses) in variants.items():
+        feat, cond = robust_frame_inputs(frames)
+        ptm = ptm_of(poses)
+        with torch.no_grad(), PatchedNoise(NOISE_SEED + 200):
+            pred = gen(torch.from_numpy(feat), torch.from_numpy(cond), torch.tensor([n]))["pred_feature"]
+            affine = normalize_pairwise_tfm(torch.from_numpy(ptm).clone(), bev_h_m, bev_w_m, 1)
+            enhd = enh(pred, affine, torch.tensor([n]))
+            fused = fus(enhd, torch.tensor([n]), affine)
+        rec[f"{name}/frames"], rec[f"{name}/poses"], rec[f"{name}/ptm"] = np.asarray(frames), poses, ptm
+        rec[f"{name}/pred_feature"], rec[f"{name}/enhanced"], rec[f"{name}/fused"] = sub(pred.numpy(), st), sub(enhd.numpy(), st), sub(fused.numpy(), 7)
+        d = float((fused - (0 if name == "clean" else clean_fused)).abs().mean()) if name != "clean" else 0.0
+        if name == "clean":
+            clean_fused = fused
+        print(f"robust [{name}]: frames {frames}, |fused| {float(fused.abs().mean()):.4f}, mean |fused - clean| {d:.4f}")
+    np.savez_compressed(os.path.join(OUT, "robust.npz"), **rec)
+    print(f"robust: wrote robust.npz ({os.path.getsize(os.path.join(OUT, 'robust.npz')) / 1024:.0f} KiB)")
+
+
 def run_wide_case() -> None:
     """General DiffusionUNet widths: the reference's own GenComm with ch = 16, ch_mult [1, 2], num_res_blocks 1 --
     every block of the up path then has a 1x1 nin_shortcut with unequal sides, the levels differ in width, GroupNorm groups hold 4 / 8 /
@@ -852,7 +930,7 @@ def main() -> None:
     for case in CASES:
         if not only or case["name"] in only:
             run_case(case)
-    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "apchain": run_apchain_case, "wide": run_wide_case, "shell2": run_shell2_case, "keys": dump_state_dict_keys}
+    extra = {"attn": run_attn_case, "pillars": run_pillar_case, "backbone": run_backbone_case, "shell": run_shell_case, "postproc": run_postproc_case, "eval": run_eval_case, "v2xvit": run_v2xvit_case, "late": run_late_case, "where2comm": run_where2comm_case, "loss": run_loss_case, "apchain": run_apchain_case, "wide": run_wide_case, "shell2": run_shell2_case, "robust": run_robust_case, "keys": dump_state_dict_keys}
     for name, fn in extra.items():
         if not only or name in only:
             fn()
