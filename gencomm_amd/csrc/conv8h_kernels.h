@@ -71,16 +71,46 @@ __device__ __forceinline__ void split_one(float a, uint16_t& hi, uint16_t& lo) {
   lo = __builtin_bit_cast(uint16_t, l);
 }
 
+// 1.0f the optimiser cannot see through: fma(x, one, -fp16) stays a fused multiply-add and is selected as ONE v_fma_mix_f32 (an fp16
+// operand read in place); written as x - (float)h it becomes v_cvt_f32_f16 + v_sub_f32.  One s_mov per kernel (the asm is pure: CSE'd).
+__device__ __forceinline__ float hc_one() {
+  float o;
+  asm("s_mov_b32 %0, 1.0" : "=s"(o));
+  return o;
+}
 // exact three-term split of a pair: hi / lo packed fp16 pairs, ta / tb = the third terms, UNSCALED: the 2^20 rides inside the
 // conversion to bf8 (bf8x2s / bf8x4s: v_cvt_scalef32_pk_bf8_f32 divides by its scale operand 2^-20 -- one multiply per element less)
+// 7 vector instructions per pair: 2 packed conversions + 4 v_fma_mix_f32 (+ the bf8 conversion at the caller).
 __device__ __forceinline__ void split3_pair(float a, float b, uint32_t& hi, uint32_t& lo, float& ta, float& tb) {
+  const float one = hc_one();
   const half2_t h = __builtin_convertvector((float2_t){a, b}, half2_t);
-  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  const float ra = fmaf(a, one, -(float)h[0]), rb = fmaf(b, one, -(float)h[1]);
   const half2_t l = __builtin_convertvector((float2_t){ra, rb}, half2_t);
-  ta = ra - (float)l[0];
-  tb = rb - (float)l[1];
+  ta = fmaf(ra, one, -(float)l[0]);
+  tb = fmaf(rb, one, -(float)l[1]);
   hi = __builtin_bit_cast(uint32_t, h);
   lo = __builtin_bit_cast(uint32_t, l);
+}
+// The same for PRODUCTS za ra, zb rb (the GroupNorm + SiLU staging below forms its activation as such a product): hi = fp16 of the
+// rounded product, first residual = fma(z, r, -hi) -- the exact product minus hi, rounded once -- and on from there as above.
+__device__ __forceinline__ void split3_prod_pair(float za, float ra, float zb, float rb, uint32_t& hi, uint32_t& lo, float& ta, float& tb) {
+  const float one = hc_one();
+  const half2_t h = __builtin_convertvector((float2_t){za * ra, zb * rb}, half2_t);
+  const float qa = fmaf(za, ra, -(float)h[0]), qb = fmaf(zb, rb, -(float)h[1]);
+  const half2_t l = __builtin_convertvector((float2_t){qa, qb}, half2_t);
+  ta = fmaf(qa, one, -(float)l[0]);
+  tb = fmaf(qb, one, -(float)l[1]);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+// GroupNorm + SiLU in FIVE vector instructions per element (six before): the coefficients arrive pre-multiplied by -log2(e)
+// (hc_gn_coeff2: a2 = -log2e A, b2 = -log2e B), so z = a2 x + b2 = -log2e y with y = A x + B, e = 2^z = exp(-y),
+// d = -log2e (1 + e) as ONE fma, r = 1 / d, and SiLU(y) = y / (1 + e) = z r.  Out-of-image positions carry a2 = b2 = 0: z = 0 and
+// the product is 0, as zero padding needs; y -> -inf gives e = inf, r = -0, z r = -0; y -> +inf gives r = 1 / -log2e, z r = y.
+constexpr float HC_NL2E = -1.4426950408889634f;
+__device__ __forceinline__ void gn_silu_zr(float a2, float b2, float x, float& z, float& r) {
+  z = fmaf(a2, x, b2);
+  r = __builtin_amdgcn_rcpf(fmaf(HC_NL2E, __builtin_amdgcn_exp2f(z), HC_NL2E));
 }
 // two / four scaled third terms -> bf8 bytes (v_cvt_pk_bf8_f32: OCP e5m2, round to nearest even; powers of two are exact)
 __device__ __forceinline__ uint32_t bf8x2(float a, float b) {
@@ -100,7 +130,9 @@ __device__ __forceinline__ uint32_t bf8x2s(float a, float b) {
   return (uint32_t)(uint16_t)v[0];
 }
 __device__ __forceinline__ uint32_t bf8x4s(float a, float b, float c, float d) {
-  hc_s2_t v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32((hc_s2_t){0, 0}, a, b, 1.0f / HC_TSCALE, false);
+  hc_s2_t u;   // both 16-bit halves are written below: the "old" operand of the first conversion needs no zero fill (two v_mov per pixel)
+  u = __builtin_nondeterministic_value(u);
+  hc_s2_t v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(u, a, b, 1.0f / HC_TSCALE, false);
   v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(v, c, d, 1.0f / HC_TSCALE, true);
   return __builtin_bit_cast(uint32_t, v);
 }
