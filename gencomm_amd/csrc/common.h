@@ -153,6 +153,28 @@ __device__ __forceinline__ cfloat_p as_const(const float* p) { return (cfloat_p)
 // time and their shared lines are L2 hits.  Bijective for any grid size (XCD k gets total/8 tiles, +1 for k < total%8).
 // ---------------------------------------------------------------------------------------------
 struct BlockId { int x, y, z; };
+// the tile of the workgroup with linear id `lin` (blockIdx.x fastest) under the same rule
+__device__ __forceinline__ BlockId xcd_block_lin(int remap, unsigned lin) {
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  BlockId b;
+  {
+    const unsigned row = lin / gx;
+    b.x = (int)(lin - row * gx);
+    b.z = (int)(row / gy);
+    b.y = (int)(row - (unsigned)b.z * gy);
+  }
+  if (remap) {
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned nl = xcd * q + (xcd < r ? xcd : r) + j;
+    const unsigned row = nl / gx;
+    b.x = (int)(nl - row * gx);
+    b.z = (int)(row / gy);
+    b.y = (int)(row - (unsigned)b.z * gy);
+  }
+  return b;
+}
 __device__ __forceinline__ BlockId xcd_block(int remap) {
   BlockId b{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
   if (remap) {

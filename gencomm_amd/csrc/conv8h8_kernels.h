@@ -57,14 +57,14 @@ __device__ __forceinline__ void h8_stage(unsigned char* tile, const Tile8Regs& R
   if (r0 < H8_LH) {
     const int gy = y0 - 1 + r0, gx = x0 + 4 * qx;
     const bool ok = gy >= 0 && gy < H && gx < W;
-    float e[8][4];
+    float e[8][4], rr[GN ? 8 : 1][4];   // GN: element = e rr (gn_silu_zr, conv8h_kernels.h; `ab` = coefficients times -log2 e)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       e[c][0] = R.v[c].x; e[c][1] = R.v[c].y; e[c][2] = R.v[c].z; e[c][3] = R.v[c].w;
       if (GN) {
         const float A = ok ? ab[c][0] : 0.f, B = ok ? ab[c][1] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[c][j] = silu_f(fmaf(A, e[c][j], B));
+        for (int j = 0; j < 4; ++j) gn_silu_zr(A, B, e[c][j], e[c][j], rr[c][j]);
       } else if (mul != 1.0f) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[c][j] *= mul;
@@ -74,10 +74,17 @@ __device__ __forceinline__ void h8_stage(unsigned char* tile, const Tile8Regs& R
     for (int j = 0; j < 4; ++j) {
       uint4 hi, lo;
       float t[8];
-      split3_pair(e[0][j], e[1][j], hi.x, lo.x, t[0], t[1]);
-      split3_pair(e[2][j], e[3][j], hi.y, lo.y, t[2], t[3]);
-      split3_pair(e[4][j], e[5][j], hi.z, lo.z, t[4], t[5]);
-      split3_pair(e[6][j], e[7][j], hi.w, lo.w, t[6], t[7]);
+      if constexpr (GN) {
+        split3_prod_pair(e[0][j], rr[0][j], e[1][j], rr[1][j], hi.x, lo.x, t[0], t[1]);
+        split3_prod_pair(e[2][j], rr[2][j], e[3][j], rr[3][j], hi.y, lo.y, t[2], t[3]);
+        split3_prod_pair(e[4][j], rr[4][j], e[5][j], rr[5][j], hi.z, lo.z, t[4], t[5]);
+        split3_prod_pair(e[6][j], rr[6][j], e[7][j], rr[7][j], hi.w, lo.w, t[6], t[7]);
+      } else {
+        split3_pair(e[0][j], e[1][j], hi.x, lo.x, t[0], t[1]);
+        split3_pair(e[2][j], e[3][j], hi.y, lo.y, t[2], t[3]);
+        split3_pair(e[4][j], e[5][j], hi.z, lo.z, t[4], t[5]);
+        split3_pair(e[6][j], e[7][j], hi.w, lo.w, t[6], t[7]);
+      }
       const int addr = r0 * HC_ROW + j * HC_PHASE + (qx + 1) * 16;
       *reinterpret_cast<uint4*>(tile + addr) = hi;
       *reinterpret_cast<uint4*>(tile + H8_PLANE + addr) = lo;
@@ -90,8 +97,11 @@ __device__ __forceinline__ void h8_stage(unsigned char* tile, const Tile8Regs& R
     if (GN) {
       const int gy = y0 - 1 + r, gx = side ? x0 + HC_TW : x0 - 1;
       const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-      e0 = ok ? silu_f(fmaf(ab[2 * cp][0], e0, ab[2 * cp][1])) : 0.f;
-      e1 = ok ? silu_f(fmaf(ab[2 * cp + 1][0], e1, ab[2 * cp + 1][1])) : 0.f;
+      float z0, r0, z1, r1;
+      gn_silu_zr(ok ? ab[2 * cp][0] : 0.f, ok ? ab[2 * cp][1] : 0.f, e0, z0, r0);
+      gn_silu_zr(ok ? ab[2 * cp + 1][0] : 0.f, ok ? ab[2 * cp + 1][1] : 0.f, e1, z1, r1);
+      e0 = z0 * r0;
+      e1 = z1 * r1;
     } else if (mul != 1.0f) {
       e0 *= mul;
       e1 *= mul;
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(HC_NT, NSRC == 2 ? 3 : 4) void conv8h8_kernel(const
       const int s = tid >> 3, c = tid & 7;
       float A, B;
       gn_coeff(a.sstat[s] + (size_t)n * 16, c, 2 * NSRC, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
-      s_ab[tid][0] = A;
-      s_ab[tid][1] = B;
+      s_ab[tid][0] = HC_NL2E * A;   // h8_stage<true> / gn_silu_zr take the coefficients times -log2(e)
+      s_ab[tid][1] = HC_NL2E * B;
     }
     __syncthreads();
   }

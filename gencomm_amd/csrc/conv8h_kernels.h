@@ -108,9 +108,10 @@ __device__ __forceinline__ void split3_prod_pair(float za, float ra, float zb, f
 // d = -log2e (1 + e) as ONE fma, r = 1 / d, and SiLU(y) = y / (1 + e) = z r.  Out-of-image positions carry a2 = b2 = 0: z = 0 and
 // the product is 0, as zero padding needs; y -> -inf gives e = inf, r = -0, z r = -0; y -> +inf gives r = 1 / -log2e, z r = y.
 constexpr float HC_NL2E = -1.4426950408889634f;
-__device__ __forceinline__ void gn_silu_zr(float a2, float b2, float x, float& z, float& r) {
+// cs = -log2e / k gives k SiLU(y) = z r (the latent step scales its activation by the posterior coefficient: no extra multiply).
+__device__ __forceinline__ void gn_silu_zr(float a2, float b2, float x, float& z, float& r, float cs = HC_NL2E) {
   z = fmaf(a2, x, b2);
-  r = __builtin_amdgcn_rcpf(fmaf(HC_NL2E, __builtin_amdgcn_exp2f(z), HC_NL2E));
+  r = __builtin_amdgcn_rcpf(fmaf(cs, __builtin_amdgcn_exp2f(z), cs));
 }
 // two / four scaled third terms -> bf8 bytes (v_cvt_pk_bf8_f32: OCP e5m2, round to nearest even; powers of two are exact)
 __device__ __forceinline__ uint32_t bf8x2(float a, float b) {
@@ -130,8 +131,9 @@ __device__ __forceinline__ uint32_t bf8x2s(float a, float b) {
   return (uint32_t)(uint16_t)v[0];
 }
 __device__ __forceinline__ uint32_t bf8x4s(float a, float b, float c, float d) {
-  hc_s2_t u;   // both 16-bit halves are written below: the "old" operand of the first conversion needs no zero fill (two v_mov per pixel)
-  u = __builtin_nondeterministic_value(u);
+  // (an undefined "old" operand instead of the zero fill -- an empty volatile asm -- saves two v_mov per pixel and was measured 3.5 %
+  // SLOWER in latent_step_h_kernel, where the volatile statements pin the schedule: profiles/r5_conv8h_valu_diet.txt)
+  hc_s2_t u = {0, 0};
   hc_s2_t v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(u, a, b, 1.0f / HC_TSCALE, false);
   v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(v, c, d, 1.0f / HC_TSCALE, true);
   return __builtin_bit_cast(uint32_t, v);
@@ -207,6 +209,22 @@ __device__ __forceinline__ void hc_store_main3(unsigned char* tile, int r0, int 
     *reinterpret_cast<uint2*>(tile + HC_TOFF + (addr >> 1)) = make_uint2(bf8x4s(t[0], t[1], t[2], t[3]), bf8x4s(t[4], t[5], t[6], t[7]));
   }
 }
+// the same from (z, r) pairs: element = z r (gn_silu_zr / split3_prod_pair)
+__device__ __forceinline__ void hc_store_main3_zr(unsigned char* tile, int r0, int qx, const float (&z)[8][4], const float (&r)[8][4]) {
+  const int base = r0 * HC_ROW + (qx + 1) * 16;   // even: the third-term plane's offset is base / 2 + j * HC_PHASE / 2, no shift per pixel
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint4 hi, lo;
+    float t[8];
+    split3_prod_pair(z[0][j], r[0][j], z[1][j], r[1][j], hi.x, lo.x, t[0], t[1]);
+    split3_prod_pair(z[2][j], r[2][j], z[3][j], r[3][j], hi.y, lo.y, t[2], t[3]);
+    split3_prod_pair(z[4][j], r[4][j], z[5][j], r[5][j], hi.z, lo.z, t[4], t[5]);
+    split3_prod_pair(z[6][j], r[6][j], z[7][j], r[7][j], hi.w, lo.w, t[6], t[7]);
+    *reinterpret_cast<uint4*>(tile + base + j * HC_PHASE) = hi;
+    *reinterpret_cast<uint4*>(tile + HC_PLANE + base + j * HC_PHASE) = lo;
+    *reinterpret_cast<uint2*>(tile + HC_TOFF + (base >> 1) + j * (HC_PHASE / 2)) = make_uint2(bf8x4s(t[0], t[1], t[2], t[3]), bf8x4s(t[4], t[5], t[6], t[7]));
+  }
+}
 // rows 16, 17 (thread = one channel's quad, lane ^ 32 = the other channel of the pair; see hc_store_rem): the pair's two
 // bf8 bytes of a pixel are one 16-bit store, written by ONE lane (different lanes of an instruction never share a dword)
 __device__ __forceinline__ void hc_store_rem3(unsigned char* tile, int tid, const float (&e)[4]) {
@@ -246,11 +264,14 @@ __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileReg
                                               float2 hreg, int H, int W, int x0, int y0, const float (*ab)[2], int tid,
                                               float mul = 1.0f) {
   using TR = TileRegs<HC_TW, HC_TH, HC_NT, 8>;
+  // GN && T3 (the shipped path): `ab` holds the coefficients times -log2(e) (hc_gn_coeff2) and an element is formed as the product
+  // z r of gn_silu_zr -- five vector instructions for GroupNorm + SiLU and seven per pair for the split
+  constexpr bool ZR = GN && T3;
   {
     const int r0 = tid >> 4, qx = tid & 15;
     const int gy = y0 - 1 + r0, gx = x0 + 4 * qx;
     const bool ok = gy >= 0 && gy < H && gx < W;
-    float e[8][4];
+    float e[8][4], rr[ZR ? 8 : 1][4];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       e[c][0] = R.v[c].x; e[c][1] = R.v[c].y; e[c][2] = R.v[c].z; e[c][3] = R.v[c].w;
@@ -258,13 +279,17 @@ __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileReg
         // zero padding through the coefficients: out-of-image quads were loaded as 0 and silu(0*0+0) == 0
         const float A = ok ? ab[c][0] : 0.f, B = ok ? ab[c][1] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[c][j] = silu_f(fmaf(A, e[c][j], B));
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (ZR) gn_silu_zr(A, B, e[c][j], e[c][j], rr[c][j]);
+          else e[c][j] = silu_f(fmaf(A, e[c][j], B));
+        }
       } else if (mul != 1.0f) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[c][j] *= mul;
       }
     }
-    if constexpr (T3) hc_store_main3(tile, r0, qx, e);
+    if constexpr (ZR) hc_store_main3_zr(tile, r0, qx, e, rr);
+    else if constexpr (T3) hc_store_main3(tile, r0, qx, e);
     else hc_store_main<HC_PLANE>(tile, r0, qx, e);
   }
   {
@@ -275,7 +300,10 @@ __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileReg
     if (GN) {
       const float A = ok ? ab[cr][0] : 0.f, B = ok ? ab[cr][1] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = silu_f(fmaf(A, e[j], B));
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (ZR) { float z, r; gn_silu_zr(A, B, e[j], z, r); e[j] = z * r; }
+        else e[j] = silu_f(fmaf(A, e[j], B));
+      }
     } else if (mul != 1.0f) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) e[j] *= mul;
@@ -289,8 +317,16 @@ __device__ __forceinline__ void stage_store_h(unsigned char* tile, const TileReg
     if (GN) {
       const int gy = y0 - 1 + r, gx = side ? x0 + HC_TW : x0 - 1;
       const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-      e0 = ok ? silu_f(fmaf(ab[2 * cp][0], e0, ab[2 * cp][1])) : 0.f;
-      e1 = ok ? silu_f(fmaf(ab[2 * cp + 1][0], e1, ab[2 * cp + 1][1])) : 0.f;
+      if constexpr (ZR) {
+        float z0, r0, z1, r1;
+        gn_silu_zr(ok ? ab[2 * cp][0] : 0.f, ok ? ab[2 * cp][1] : 0.f, e0, z0, r0);
+        gn_silu_zr(ok ? ab[2 * cp + 1][0] : 0.f, ok ? ab[2 * cp + 1][1] : 0.f, e1, z1, r1);
+        e0 = z0 * r0;
+        e1 = z1 * r1;
+      } else {
+        e0 = ok ? silu_f(fmaf(ab[2 * cp][0], e0, ab[2 * cp][1])) : 0.f;
+        e1 = ok ? silu_f(fmaf(ab[2 * cp + 1][0], e1, ab[2 * cp + 1][1])) : 0.f;
+      }
     } else if (mul != 1.0f) {
       e0 *= mul;
       e1 *= mul;
@@ -332,7 +368,8 @@ __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ til
     if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
       e = UP ? sp[(unsigned)c * plane_in + (unsigned)(gy >> 1) * (unsigned)Win + (unsigned)(gx >> 1)]
              : sp[(unsigned)c * plane_in + (unsigned)gy * (unsigned)Win + (unsigned)gx];
-      if (GN) e = silu_f(fmaf(ab[c][0], e, ab[c][1]));
+      if (GN && T3) { float z, r; gn_silu_zr(ab[c][0], ab[c][1], e, z, r); e = z * r; }   // ab = coefficients x -log2(e), as in stage_store_h
+      else if (GN) e = silu_f(fmaf(ab[c][0], e, ab[c][1]));
       else e *= mul;
     }
     uint16_t hi, lo;
@@ -427,9 +464,12 @@ __device__ __forceinline__ void load_wa3(WA3& o, const float* __restrict__ tab, 
 // 3 lo w2, 4 hi w3, 5 t wb -- so that every operand plane and table is checked on its own (tests/test_gpu_conv8.py).
 // LOWREG (kernels that hold the NEXT chunk's tile in registers during this phase): no operand prefetch of the next tap group
 // and the lo records fetched behind the hi passes -- 30 fewer live registers.
-template <bool DIAG = false, bool LOWREG = false>
+// INIT: the accumulators are not read -- the first matrix instruction on each of them (the bf8 one of tap group 0) takes `init` as its
+// C operand instead (bias x scale for all eight: 28 register copies less per wave).  Not with DIAG, whose term mask may skip it.
+template <bool DIAG = false, bool LOWREG = false, bool INIT = false>
 __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const float* __restrict__ tab, f32x4 (&acc)[2][4],
-                                                const int (&off)[4][3], int lane, int mask = 63) {
+                                                const int (&off)[4][3], int lane, int mask = 63, f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f}) {
+  static_assert(!(DIAG && INIT), "the diagnostic term mask needs initialised accumulators");
   // ORDER MATTERS.  On gfx950 a v_mfma_f32_16x16x32_f16 issued fewer than 6 wait states after a v_mfma_f32_16x16x32_bf8_bf8
   // whose result it accumulates onto (or the other way round) reads a STALE half of the accumulator: the hardware forwards
   // SrcC only between matrix instructions of one input type, hipcc (ROCm 7.2) assumes it always does and schedules such a
@@ -453,7 +493,7 @@ __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const
       __builtin_amdgcn_sched_barrier(0);
       if (!DIAG || (mask & 32))
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(cur.wb, bt[p][j], acc[p][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(cur.wb, bt[p][j], (INIT && c == 0) ? init : acc[p][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -651,8 +691,8 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
       const int s = tid >> 3, c = tid & 7;
       float A, B;
       gn_coeff(a.sstat[s] + (size_t)n * 16, c, 2 * NSRC, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
-      s_ab[tid][0] = A;
-      s_ab[tid][1] = B;
+      s_ab[tid][0] = HC_NL2E * A;   // stage_store_h<true, true> / gn_silu_zr take the coefficients times -log2(e)
+      s_ab[tid][1] = HC_NL2E * B;
     }
     __syncthreads();
   }
@@ -660,9 +700,9 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
   GC_STAMP(1);
   // the accumulators start at bias * scale (exact: the scale is a power of two), so the epilogue is one multiply
   f32x4 acc[2][4];
-  {
-    const float sc = a.wh[NSRC * HC_WTAB3 + 1] * mul;
-    const f32x4 b0 = {bias[0] * sc, bias[1] * sc, bias[2] * sc, bias[3] * sc};
+  const float bsc = a.wh[NSRC * HC_WTAB3 + 1] * mul;
+  const f32x4 b0 = {bias[0] * bsc, bias[1] * bsc, bias[2] * bsc, bias[3] * bsc};
+  if (DIAG || !wave_live) {   // otherwise the first matrix instruction of every accumulator reads b0 directly (conv_tile_mfma3<.., INIT>)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -676,12 +716,13 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
   // identity residual: requested once the staging registers are free, so that it arrives during the matrix phase
   float resv[RES == 1 ? 2 : 1][4][4];
   if (RES == 1 && wave_live) {
+    const float* const lane_res = a.res[0] + ((size_t)n * 8 + 4 * ch) * plane + (size_t)gy0 * a.W + gx;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int gy = gy0 + 2 * p;
-        const float* __restrict__ rp = a.res[0] + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
+        const float* __restrict__ rp = lane_res + ((size_t)i * plane + (size_t)(2 * p) * a.W);   // lane pointer + uniform
         if (vec_ok && gy < a.H) {
           const float4 r = *reinterpret_cast<const float4*>(rp);
           resv[p][i][0] = r.x; resv[p][i][1] = r.y; resv[p][i][2] = r.z; resv[p][i][3] = r.w;
@@ -705,7 +746,7 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
 #ifdef HC_PRIO_MFMA   // diagnostic builds (tools/diag/prio_ab.sh): static wave priority from the matrix phase on
   __builtin_amdgcn_s_setprio(HC_PRIO_MFMA);
 #endif
-  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2 && !LATE2>(tile, a.wh, acc, off, lane, a.term_mask);
+  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2 && !LATE2, !DIAG>(tile, a.wh, acc, off, lane, a.term_mask, b0);
   if (NSRC == 2 && wvec && LATE2) {
     stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
@@ -730,6 +771,7 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
 #pragma unroll
   for (int i = 0; i < 8; ++i) part[i] = 0.f;
   if (wave_live) {
+    float* const lane_dst = a.dst + ((size_t)n * 8 + 4 * ch) * plane + (size_t)gy0 * a.W + gx;
     float out[2][4][4];  // [row pair][channel i][pixel j]
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -739,26 +781,67 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
         for (int j = 0; j < 4; ++j) out[p][i][j] = RES == 1 ? fmaf(acc[p][j][i], inv_s, resv[p][i][j]) : acc[p][j][i] * inv_s;
 
     if (RES == 2) {  // 1x1 nin_shortcut over the 16 raw input channels of the block
-#pragma unroll 8
-      for (int c = 0; c < 16; ++c) {
-        const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + c * 8 + 4 * ch);
-        const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+      const size_t lane_off = (size_t)n * 8 * plane;
+      if ((a.W & 3) == 0) {
+        // Branch-free, batched loads: with W % 4 == 0 a quad that starts inside the image lies inside it, and a lane whose outputs fall
+        // outside the image (never stored, never counted) reads the nearest in-image quad instead.  No exec-mask branch stands between
+        // the loads, so a batch of them is in flight while the previous batch's FMAs issue -- written with a conditional load per
+        // (channel, row pair) the 32 loads of this block each waited for an L2 round trip of their own (s_waitcnt vmcnt(0) in front of
+        // every FMA group: 23 us of a 57 us full-resolution launch).
+        int gxl = gx, gyl = gy0;
+        asm volatile("" : "+v"(gxl), "+v"(gyl));   // the address arithmetic below starts HERE: hoisted above the matrix phase it costs spills
+        const int cx = min(gxl, a.W - 4);
+        const int cy0 = min(gyl, a.H - 1), d1 = (min(gyl + 2, a.H - 1) - cy0) * a.W;   // second row pair: d1 floats further (0 when clamped)
+        const size_t o0 = lane_off + (size_t)cy0 * a.W + cx;
+        const float* const lp[2][2] = {{a.res[0] + o0, a.res[0] + o0 + d1}, {a.res[1] + o0, a.res[1] + o0 + d1}};
+        constexpr int CB = 4;   // channels per batch: 8 quads = 32 registers in flight per batch
+        float4 rq[2][CB][2];
+        auto issue = [&](int b, int st) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const int gy = gy0 + 2 * p;
-          const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + (size_t)gy * a.W + gx;
-          float r[4];
-          if (vec_ok && gy < a.H) {
-            const float4 t = *reinterpret_cast<const float4*>(rp);
-            r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-          } else {
+          for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const int cc = b * CB + c;
+              rq[st][c][p] = *reinterpret_cast<const float4*>(lp[cc >> 3][p] + (size_t)(cc & 7) * plane);
+            }
+        };
+        issue(0, 0);
+#pragma unroll
+        for (int b = 0; b < 16 / CB; ++b) {
+          __builtin_amdgcn_sched_barrier(0);   // at most two batches in flight: the scheduler would otherwise hoist every load and spill
+          if (b + 1 < 16 / CB) issue(b + 1, (b + 1) & 1);
+#pragma unroll
+          for (int c = 0; c < CB; ++c) {
+            const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + (b * CB + c) * 8 + 4 * ch);
+            const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const float4 t = rq[b & 1][c][p];
+              const float r[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[p][i][j] = fmaf(wv[i], r[j], out[p][i][j]);
+            }
+          }
+        }
+      } else {   // widths that are not a multiple of 4 (tests): element by element, kept small (no unrolling: its register needs must not spill the fast path)
+#pragma unroll 1
+        for (int c = 0; c < 16; ++c) {
+          const float4 wv4 = *reinterpret_cast<const float4*>(a.ninw + c * 8 + 4 * ch);
+          const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int gy = gy0 + 2 * p;
+            const float* __restrict__ rp = a.res[c >> 3] + ((size_t)n * 8 + (c & 7)) * plane + (size_t)gy * a.W + gx;
+            float r[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = (gy < a.H && gx + j < a.W) ? rp[j] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) out[p][i][j] = fmaf(wv[i], r[j], out[p][i][j]);
           }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) out[p][i][j] = fmaf(wv[i], r[j], out[p][i][j]);
         }
       }
     }
@@ -768,7 +851,7 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
       const int gy = gy0 + 2 * p;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float* __restrict__ dp = a.dst + ((size_t)n * 8 + 4 * ch + i) * plane + (size_t)gy * a.W + gx;
+        float* __restrict__ dp = lane_dst + ((size_t)i * plane + (size_t)(2 * p) * a.W);   // lane pointer + uniform: one 64-bit add per store
         float s = 0.f, q = 0.f;
         if (vec_ok && gy < a.H) {
           if (!(DIAG && (a.term_mask & 64)))   // diagnostic, MODE_RESFUSE_EMU: statistics-only pass (no store)

@@ -95,14 +95,21 @@ inline int enhancer_enqueue(const EnhancerPlan& p, const float* raw, const float
     if (C == 64) enh_ln64_kernel<<<dim3((HW + 255) / 256, n), 256, 0, st>>>(a);   // registers + per-wave transpose, no workgroup barriers
     else enh_ln_kernel<<<dim3((HW + 63) / 64, n), 256, sh, st>>>(a);
   }
-  if (m.split() && (p.dc == 16 || p.dc == 32) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
+  if (m.split() && (p.dc == 16 || p.dc == 32 || p.dc == 64) && (C & 3) == 0) {  // K2 on the f16 matrix pipe
     const int nslice = (9 * p.dc + 31) / 32;
     enh_prep_pconv_h_kernel<<<(p.dc / 16) * nslice * 4, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, nslice);   // <= 256 table entries per workgroup
     TimedLaunch tl(KF_ENH_PCONV, st);
     EnhPconvHArgs a{F(w.Zc), F(w.wT), F(w.Z), C, p.dc, H, W, nslice};
-    const size_t sh = (size_t)18 * 34 * p.dc * 5;   // fp16 hi + lo planes, bf8 third-term plane
-    if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)enh_pconv_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    enh_pconv_h_kernel<<<dim3((W + 31) / 32, (H + 15) / 16, n), 256, sh, st>>>(a);
+    // 32-pixel-wide tiles when they fit the LDS (dc <= 32) and still give every CU a workgroup; 16-pixel-wide ones otherwise
+    const bool wide = p.dc <= 32 && (long long)((W + 31) / 32) * ((H + 15) / 16) * n >= 256;
+    const size_t sh = (size_t)18 * (wide ? 34 : 18) * p.dc * 5;   // fp16 hi + lo planes, bf8 third-term plane
+    if (wide) {
+      if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)enh_pconv_h_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+      enh_pconv_h_kernel<32><<<dim3((W + 31) / 32, (H + 15) / 16, n), 256, sh, st>>>(a);
+    } else {
+      if (sh > 48 * 1024) GC_HIP(hipFuncSetAttribute((const void*)enh_pconv_h_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+      enh_pconv_h_kernel<16><<<dim3((W + 15) / 16, (H + 15) / 16, n), 256, sh, st>>>(a);
+    }
   } else
   {  // K2
     enh_prep_pconv_kernel<<<(9 * p.dc * p.dcp + 255) / 256, 256, 0, st>>>(raw + p.pcw, F(w.wT), p.dc, p.dcp);

@@ -534,8 +534,11 @@ __global__ __launch_bounds__(256) void enh_prep_pconv_h_kernel(const float* __re
   if (blockIdx.x == 0 && tid < 64) tab[total + tid] = (tid & 1) ? scale : 1.0f / scale;
 }
 
+// TW = 32 (two 16-pixel column groups per wave row) or 16 (one): the tile's LDS image is 18 x (TW + 2) x dc x 5 bytes, so dc = 64
+// (C = 256) fits with TW = 16 (104 KB) where TW = 32 would need 196 KB, and small maps get twice the workgroups.
+template <int TW>
 __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a) {
-  constexpr int TW = 32, TH = 16, LW = TW + 2, LH = TH + 2;
+  constexpr int TH = 16, LW = TW + 2, LH = TH + 2, NG = TW / 4;   // NG accumulator groups per wave: 4 rows x TW / 16 column groups
   fp16_ovfl_clamp();  // operands are LayerNorm outputs (bounded by the affine); saturate rather than overflow (common.h)
   extern __shared__ __align__(16) unsigned char pch_smem[];
   const int dc = a.dc, PB = dc * 2, plane = LH * LW * PB, q4 = dc >> 2;
@@ -560,9 +563,9 @@ __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a)
   const int nob = dc >> 4;
   const float inv_s = a.tab[nob * a.nslice * 896];
   for (int ob = 0; ob < nob; ++ob) {
-    ef32x4 acc[8], act[8];  // act: the bf8 third-term products, accumulators of their own (see the GEMM above)
+    ef32x4 acc[NG], act[NG];  // act: the bf8 third-term products, accumulators of their own (see the GEMM above)
 #pragma unroll
-    for (int g = 0; g < 8; ++g) { acc[g] = ef32x4{0.f, 0.f, 0.f, 0.f}; act[g] = ef32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int g = 0; g < NG; ++g) { acc[g] = ef32x4{0.f, 0.f, 0.f, 0.f}; act[g] = ef32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
     for (int sl = 0; sl < a.nslice; ++sl) {
       const int kidx0 = 32 * sl + 8 * kg;
@@ -574,31 +577,31 @@ __global__ __launch_bounds__(256) void enh_pconv_h_kernel(const EnhPconvHArgs a)
       for (int k = 0; k < 3; ++k) wa[k] = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(tb + (k * 64 + lane) * 4));
       const long wb = *reinterpret_cast<const long*>(tb + 768 + lane * 2);
       const int base = ((4 * wave + dy) * LW + ln + dx) * PB + ic0 * 2;
-      eh8_t bh[8], bl[8];
+      eh8_t bh[NG], bl[NG];
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int ad = base + ((g >> 1) * LW + 16 * (g & 1)) * PB;
+      for (int g = 0; g < NG; ++g) {
+        const int ad = base + (TW == 32 ? ((g >> 1) * LW + 16 * (g & 1)) : g * LW) * PB;
         bh[g] = *reinterpret_cast<const eh8_t*>(pch_smem + ad);
         bl[g] = *reinterpret_cast<const eh8_t*>(pch_smem + plane + ad);
         const long bt = *reinterpret_cast<const long*>(pch_smem + 2 * plane + (ad >> 1));
         act[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wb, bt, act[g], 0, 0, 0);
       }
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2], bh[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2], bh[g], acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], bl[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], bl[g], acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], bh[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], bh[g], acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], bl[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], bl[g], acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], bh[g], acc[g], 0, 0, 0);
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], bh[g], acc[g], 0, 0, 0);
     }
 #pragma unroll
-    for (int g = 0; g < 8; ++g) acc[g] += act[g];
+    for (int g = 0; g < NG; ++g) acc[g] += act[g];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int gy = y0 + 4 * wave + (g >> 1), gx = x0 + 16 * (g & 1) + ln;
+    for (int g = 0; g < NG; ++g) {
+      const int gy = y0 + 4 * wave + (TW == 32 ? (g >> 1) : g), gx = x0 + (TW == 32 ? 16 * (g & 1) : 0) + ln;
       if (gy < a.H && gx < a.W) {
         float* __restrict__ op = a.Z + ((size_t)n * a.H * a.W + (size_t)gy * a.W + gx) * a.C + 16 * ob + 4 * kg;
         *reinterpret_cast<float4*>(op) = make_float4(acc[g][0] * inv_s, acc[g][1] * inv_s, acc[g][2] * inv_s, acc[g][3] * inv_s);

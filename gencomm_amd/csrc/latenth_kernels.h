@@ -368,8 +368,8 @@ __global__ __launch_bounds__(HC_NT, 3) void conv_out_h_kernel(const ConvOutArgs 
   if (tid < 8) {
     float A, B;
     gn_coeff(a.sstat + (size_t)n * 16, tid, 2, a.inv_cnt, a.gamma[tid], a.beta[tid], &A, &B);
-    s_ab[tid][0] = A;
-    s_ab[tid][1] = B;
+    s_ab[tid][0] = HC_NL2E * A;   // stage_store_h<true, true> takes the coefficients times -log2(e) (gn_silu_zr)
+    s_ab[tid][1] = HC_NL2E * B;
   }
   __syncthreads();
   stage_store_h<true, true>(tile, R, hreg, H, W, x0, y0, s_ab, tid);
@@ -550,6 +550,8 @@ __global__ __launch_bounds__(HC_NT, 3) void latent_step_h_kernel(const LatentArg
     s_ab[tid][1] = B;
   }
   __syncthreads();
+  // (the z r product form of conv8h's staging -- gn_silu_zr -- was tried here in round 5 and measured 2 % SLOWER in this kernel, whose
+  // register budget is full: 162 -> 168 VGPRs; the plain form stays)
   auto act = [&](int c, float v, bool ok) { return ok ? c1 * silu_f(fmaf(s_ab[c][0], v, s_ab[c][1])) : 0.f; };
   uint2 tq[4];      // third terms of the main pass: pixel j -> 8 channels
   uint32_t tr2[2];  // rows 16..19: pixels (0, 1) and (2, 3) of the thread's channel pair, 16 bits each

@@ -155,8 +155,10 @@ __device__ __forceinline__ void stage_load(TileRegs<TW, TH, NT, NCH>& R, const f
   auto load_quad = [&](int c, int r, int qx) {
     const int gy = y0 - 1 + r, gx = x0 + 4 * qx;
     if constexpr (CLAMP && !UP) {
+      // uniform plane offset + one 32-bit byte offset per thread (one 64-bit vector add per load; two vector instructions before)
       const int cy = min(max(gy, 0), H - 1), cx = min(gx, W - 4);
-      return *reinterpret_cast<const float4*>(sp + ((unsigned)c * plane_in + (unsigned)cy * (unsigned)Win + (unsigned)cx));
+      const unsigned vo = ((unsigned)cy * (unsigned)Win + (unsigned)cx) * 4u;
+      return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sp) + (size_t)((unsigned)c * plane_in) * 4 + vo);
     }
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < TR::LH && gy >= 0 && gy < H && gx < W) {
