@@ -57,7 +57,8 @@ CONV8_FAMILIES = {1: "conv1 8->8 (GN+SiLU)", 16: "conv2 + identity residual", 17
                   4: "Upsample conv (nearest x2)"}
 LATENT_FAMILY = 15
 ENH_FRONT_FAMILY = 9
-N_FAMILIES = 19
+N_FAMILIES = 20
+CONV2D_FAMILY = 19      # the general convolution around the path (conv2d_igemm_kernel): its timer slot carries algorithmic FLOPs
 RESULT_OUT = sys.stdout   # main() replaces it by a private copy of the original stdout
 
 
@@ -154,6 +155,44 @@ def cpu_baseline(name, N, C, H, W, T, gen, enh, ptm, timed_steps=5):
             "scene_seconds": scene_s}
 
 
+def cpu_train_baseline(B, N, C, H, W, T, model):
+    """CPU baseline of the TRAINING leg: the hot-path part of the stage-1 step -- GenComm's training branch (per-agent chains, T
+    steps, cond_diff.py:342-360) -> Enhancer -> AttFusion -> the generation loss MSE(pred, gt) (point_pillar_gencomm_loss.py:46-52),
+    forward + backward through torch autograd -- on the oracle (oracle/torch_port.py) with this model's weights, one warm-up and
+    `reps` timed steps at the leg's shapes.  The encoder / backbone / heads AROUND the path have no training-mode restatement in the
+    oracle (its BatchNorm is the eval form), so they are not part of this number: it is the cost of the path the HIP kernels replace."""
+    from gencomm_amd import synth
+    from oracle import torch_port as O
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(16, avail)
+    torch.set_num_threads(cores)
+    cfg = synth.default_gencomm_cfg(C, T)
+    sd_g = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.gencomm.state_dict().items()}
+    sd_e = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.enhancer.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    n = B * N
+    feat = torch.randn(n, C, H, W, generator=g).clamp_(min=0).requires_grad_(True)
+    cond = torch.randn(n, 2, H, W, generator=g).requires_grad_(True)
+    n0, sn = torch.randn(n, C, H, W, generator=g), torch.randn(T, n, C, H, W, generator=g)
+    ptm = torch.from_numpy(synth.make_pairwise_t_matrix([N] * B, 5, 10, max_shift=20.0))
+    affine = O.normalize_pairwise_tfm(ptm, H * 1.6, W * 1.6, 1.0)
+    times, reps = [], 3
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        pred = O.gencomm_forward(sd_g, cfg, feat, cond, [N] * B, n0, sn, per_agent=True)
+        fused = O.att_fusion(O.enhancer_forward(sd_e, pred, [N] * B), [N] * B, affine)
+        loss = torch.nn.functional.mse_loss(pred, feat.detach()) + fused.pow(2).mean()     # the generation loss + a stand-in for the heads' gradient
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+    step_s = float(np.mean(times))
+    return {"value": B / step_s, "unit": "train scenes/sec", "cores": cores, "kind": "port", "step_seconds": step_s,
+            "sample": f"hot-path part of the step only (GenComm training branch T={T} -> Enhancer -> AttFusion -> MSE, forward + backward by torch "
+                      f"autograd on oracle/torch_port.py), {B} scene(s) x {N} agents, C={C}, {H}x{W}; 1 warm-up + {reps} timed steps, torch {torch.__version__} "
+                      f"CPU, {cores} threads (host exposes {avail}); encoder / backbone / heads / optimiser are NOT in it (no training-mode restatement)"}
+
+
 def selftest_main(args, rank, world):
     """`--workload launch_selftest`: the launcher, the rank environment, the process group (gloo, CPU only -- no GPU call anywhere),
     the barrier-bracketed timed region and the aggregation of bench.py with a stand-in step (rank r "processes" `--batch` scenes
@@ -225,7 +264,8 @@ def train_main(args, rank, world, device, backend):
         sync = gdist.FlatGradSync(model.parameters(), dist, module=model)   # broadcasts rank 0's parameters and buffers
     crit = PointPillarGencommLoss(synth.STAGE1_LOSS_ARGS)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=2e-3, eps=1e-10, weight_decay=1e-4, fused=True)   # m1_att.yaml:191-196
+    # m1_att.yaml:191-196; capturable: the step counter lives on the device, so that the whole step can be recorded into a HIP graph
+    opt = torch.optim.Adam(params, lr=2e-3, eps=1e-10, weight_decay=1e-4, fused=True, capturable=bool(args.graph))
     rng = margs["lidar_range"]
     n = B * N
     pil = synth.make_pillars(12000 * n, n, 512, 256, 9 + 31 * rank, voxel_size=[0.4, 0.4, 4.0], pc_range=rng)
@@ -257,11 +297,60 @@ def train_main(args, rank, world, device, backend):
     for _ in range(max(1, args.warmup)):
         step()
     barrier()
+    eager_step, graph_note = step, None
+    if args.graph:
+        # --graph 1: forward + backward + gradient averaging + Adam of ONE step recorded into a HIP graph on a side stream (after the
+        # eager warm-up: the gradient bucket's layout is agreed and every cache of the library is warm) and replayed per step -- the
+        # ~1 600 launches of a step cost one hipGraphLaunch on the host.  Same kernels, same arithmetic; inputs are the static synthetic
+        # shard.  The reference's loop is eager PyTorch (train_ddp.py:173-197); this is the MI355X-side answer to a host-bound step.
+        g = torch.cuda.CUDAGraph()
+        cs = torch.cuda.Stream(device=device)
+        cs.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(cs):
+            for _ in range(2):     # on the capture stream first: allocator pools and autograd's streams settle
+                eager_step()
+        torch.cuda.current_stream(device).wait_stream(cs)
+        barrier()
+        with torch.cuda.graph(g, stream=cs):
+            static_loss = eager_step()
+
+        def step():
+            g.replay()
+            return static_loss
+        graph_note = "one HIP graph per step (torch.cuda.CUDAGraph: forward + backward + flat gradient bucket + fused Adam), replayed"
+        barrier()
     if args.sync_debug:      # diagnostic: one step with torch's synchronisation detector (every host <-> device sync point warns with a stack)
         torch.cuda.set_sync_debug_mode("warn")
         step()
         torch.cuda.set_sync_debug_mode("default")
         barrier()
+    if args.op_census:       # diagnostic: which Python lines issue the step's small framework operators (wrappers around the torch entry points
+        import collections   # that launch fill / copy / elementwise kernels; the caller's file:line is the key), to stderr
+        torch.autograd.set_multithreading_enabled(False)
+        sites, saved = collections.Counter(), []
+
+        def wrap(owner, name):
+            orig = getattr(owner, name)
+
+            def w(*a, **k):
+                f = sys._getframe(1)
+                while f is not None and ("bench.py" in f.f_code.co_filename and f.f_code.co_name == "w"):
+                    f = f.f_back
+                sites[(name, f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno} {f.f_code.co_name}")] += 1
+                return orig(*a, **k)
+            saved.append((owner, name, orig))
+            setattr(owner, name, w)
+        for nm in ("fill_", "zero_", "copy_", "contiguous", "clone", "float", "sum", "__mul__", "__add__", "__iadd__", "__sub__", "__gt__", "mul", "add", "view_as", "t", "reshape"):
+            wrap(torch.Tensor, nm)
+        for nm in ("zeros", "ones", "full", "zeros_like", "ones_like", "empty_like", "cat", "stack", "rsqrt"):
+            wrap(torch, nm)
+        step()
+        for owner, name, orig in saved:
+            setattr(owner, name, orig)
+        torch.autograd.set_multithreading_enabled(True)
+        barrier()
+        for (name, where), c in sites.most_common(80):
+            print(f"{c:5d}  {name:12s} {where}", file=sys.stderr)
     if args.host_profile:    # diagnostic: cProfile of the host side of 10 steps (autograd on this thread), written to stderr
         import cProfile, io, pstats
         torch.autograd.set_multithreading_enabled(False)
@@ -285,6 +374,31 @@ def train_main(args, rank, world, device, backend):
     assert torch.isfinite(loss.detach()).all(), "non-finite training loss"
     value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed_here, dist, red_dev)
     grad_bytes = sum(p.numel() * p.element_size() for p in params) if sync is None else sync.bucket_bytes
+    # roofline of the step's dominant kernel family -- the general convolution on the exact-fp32 matrix cores (BEV backbone, shrink conv,
+    # heads, the Enhancer's Linear layers; forward and input gradients): HIP-event time and algorithmic FLOPs of every launch of ONE
+    # extra eager step (the library's kernel timer, family CONV2D_FAMILY), priced against the fp32 MFMA peak
+    roofline = None
+    if rank == 0:
+        from gencomm_amd import _lib
+        lib = _lib.lib()
+        ms = (ctypes.c_double * N_FAMILIES)()
+        cnt = (ctypes.c_int * N_FAMILIES)()
+        wk = (ctypes.c_double * N_FAMILIES)()
+        _lib.check(lib.gencomm_timer_start_mask(1 << CONV2D_FAMILY, 4096), "gencomm_timer_start_mask")
+        eager_step()
+        torch.cuda.synchronize(device)
+        _lib.check(lib.gencomm_timer_stop_families(ms, cnt, wk, N_FAMILIES), "gencomm_timer_stop_families")
+        if cnt[CONV2D_FAMILY] > 0:
+            f_ms, f_fl, f_n = ms[CONV2D_FAMILY], wk[CONV2D_FAMILY], cnt[CONV2D_FAMILY]
+            roofline = {"kernel": "conv2d_igemm_kernel<KH, KW, ...> (general 3x3 / 1x1 / 2x2 convolutions of the step on v_mfma_f32_32x32x2_f32: exact fp32)",
+                        "bound": "mfma", "achieved": f_fl / (f_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": f_fl / (f_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": f_n, "avg_launch_ms": f_ms / f_n,
+                        "flops_per_launch": f_fl / f_n, "share_of_step": f_ms / (1e3 * elapsed / args.steps),
+                        "note": "algorithmic FLOPs = 2 N Ho Wo Cout Cin KH KW per launch (host-computed from the launch shape), HIP events around "
+                                "every launch of one untimed eager step; share_of_step = the family's summed device time over the step's wall time"}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_train_baseline(B, N, 128, 64, 128, T, model)
     if rank == 0:
         d = crit.logging(0, args.steps - 1, args.steps)
         print(json.dumps({
@@ -296,11 +410,11 @@ def train_main(args, rank, world, device, backend):
                                    f"512x256 pillars -> 128x64x128 BEV, GenComm T={T}, forward + backward + Adam",
                        "parallelism": (f"dp{world} (DistributedDataParallel, find_unused_parameters=True)" if sync is None else
                                        f"dp{world} (one flat gradient bucket per step: cat -> all_reduce -> scale -> multi-tensor copy)"),
-                       "grad_sync": args.grad_sync, "process_group": backend,
+                       "grad_sync": args.grad_sync, "process_group": backend, "hip_graph": graph_note,
                        "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "share_device": backend != "nccl",
                        "grad_bytes_allreduced_per_step": grad_bytes, "trainable_parameters": sum(p.numel() for p in params),
                        "ddp_bucket_cap_mb": 25 if sync is None else None, "pillars_per_agent": 12000},
-            "loss": d, "roofline": None, "cpu_baseline": None}), file=RESULT_OUT, flush=True)
+            "loss": d, "roofline": roofline, "cpu_baseline": cpu}), file=RESULT_OUT, flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -326,6 +440,7 @@ def main():
                     help="library mode for this run (gencomm_set_mode; keys: arith sampler tile_want enh_fuse conv8h_mask xcd dataflow resfuse_emu tile8), e.g. --mode xcd=0")
     ap.add_argument("--share-device", action="store_true",
                     help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
+    ap.add_argument("--op-census", action="store_true", help="--workload train: call sites of the fill / zero / copy operators of one step (torch.profiler), to stderr")
     ap.add_argument("--host-profile", action="store_true", help="--workload train: cProfile of the host side of 10 untimed steps, to stderr")
     ap.add_argument("--sync-debug", action="store_true", help="run one untimed step under torch.cuda.set_sync_debug_mode('warn'): every host <-> device synchronisation warns with its stack")
     ap.add_argument("--grad-sync", choices=["flat", "ddp"], default="flat",

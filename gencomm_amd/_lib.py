@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW, MODE_RESFUSE_EMU, MODE_TILE8, MODE_BWD_STREAMS = range(10)
 
 _lock = threading.Lock()
@@ -111,7 +111,7 @@ _SIGNATURES = {
     "gencomm_iou3d_max_boxes": (_i, []),
     "gencomm_iou3d_nms_workspace_bytes": (_ll, [_i]),
     "gencomm_iou3d_nms_fwd": (_i, [_p, _i, C.c_float, _i, _p, _p, _p, _ll, _p]),
-    "gencomm_bn2d_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _i, _i, _i, _i, _p]),
+    "gencomm_bn2d_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _i, _i, _i, _i, _p, _p]),
     "gencomm_bn2d_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_slot_max_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "gencomm_slot_max_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),

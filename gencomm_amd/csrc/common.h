@@ -80,7 +80,10 @@ enum KernelFamily : int {
   KF_CONV_IN = 0, KF_CONV8 = 1, KF_CONV16 = 2, KF_DOWN = 3, KF_UP = 4, KF_CONV_OUT = 5, KF_Q_SAMPLE = 6,
   KF_ENH_LN = 7, KF_ENH_PCONV = 8, KF_ENH_GEMM1 = 9, KF_ENH_DWGATE = 10, KF_ENH_GEMM2 = 11,
   KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_LATENT_STEP = 15, KF_CONV8_RES1 = 16, KF_CONV8_RES2 = 17,
-  KF_DATAFLOW = 18, KF_COUNT = 19
+  KF_DATAFLOW = 18,
+  KF_CONV2D = 19,   // the general convolution around the path (conv2d_igemm_kernel: BEV backbone, shrink conv, heads, Linear layers): its
+                    // `bytes` slot carries algorithmic FLOPs (2 N Ho Wo Cout Cin KH KW): the family is priced against the fp32 MFMA roof
+  KF_COUNT = 20
 };
 inline const char* kernel_family_name(int id) {
   static const char* names[KF_COUNT] = {
@@ -91,7 +94,8 @@ inline const char* kernel_family_name(int id) {
       "gemm_*_mfma_kernel<1>", "enh_gate_kernel", "enh_scale_transpose_kernel", "warp_attfuse_kernel | warp_attfuse_tok_kernel",
       "latent_step_h_kernel | latent_step_kernel", "conv8h_kernel<1,GN,RES=1> | conv8_kernel (ResnetBlock conv2 + identity)",
       "conv8h_kernel<1,GN,RES=2> | conv8_kernel (ResnetBlock conv2 + nin_shortcut)",
-      "unet_dataflow_kernel (UNet body of one call, persistent)"};
+      "unet_dataflow_kernel (UNet body of one call, persistent)",
+      "conv2d_igemm_kernel (general 3x3 / 1x1 / 2x2 convolution on the exact-fp32 matrix cores; slot = FLOPs)"};
   return (id >= 0 && id < KF_COUNT) ? names[id] : "?";
 }
 struct KernelTimer {

@@ -567,6 +567,7 @@ inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_
   const int tiles = ty8 ? (int)tiles8 : ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
   const dim3 grid(tiles, (a.CoutP + 63) / 64, N);
   if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");
+  TimedLaunch tl(KF_CONV2D, st, 2.0 * N * a.Ho * a.Wo * (double)a.CoutP * a.Cin * KH * KW);   // algorithmic FLOPs (bench.py --workload train)
   if (KH == 3 && KW == 3 && a.stride == 1) { if (ty8) conv2d_igemm_kernel<3, 3, 8, 1, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<3, 3, 8, 1><<<grid, 256, 0, st>>>(a); }
   else if (KH == 3 && KW == 3 && a.stride == 2) { if (ty8) conv2d_igemm_kernel<3, 3, 8, 2, 8><<<grid, 256, 0, st>>>(a); else conv2d_igemm_kernel<3, 3, 8, 2><<<grid, 256, 0, st>>>(a); }
   else if (KH == 1 && KW == 1 && a.stride == 1) conv2d_igemm_kernel<1, 1, 32, 1><<<grid, 256, 0, st>>>(a);

@@ -754,17 +754,19 @@ int gencomm_conv2d_wgrad(const float* dy, const float* x, float* dw, float* db, 
 
 // BatchNorm2d with batch statistics (training mode) around the HIP convolutions: scratch >= 2 C doubles (zeroed here)
 int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, float* save,
-                           double* scratch, float momentum, float eps, int relu, int n, int C, int HW, void* stream) {
+                           double* scratch, float momentum, float eps, int relu, int n, int C, int HW, long long* num_batches_tracked,
+                           void* stream) {
   GC_CHECK_ARG(x && gamma && beta && y && save && scratch && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "bad arguments");
   GC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or neither");
   hipStream_t st = (hipStream_t)stream;
-  GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
+  if (!(relu & 4)) GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));   // bit 2: the caller's scratch is zero already
+  relu &= 1;
   const bool v4 = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);   // four pixels per lane
   if (v4) bn2d_stats_kernel<4><<<dim3(C, (unsigned)std::min((HW + 1023) / 1024, 64)), 256, 0, st>>>(x, scratch, n, C, HW);
   else bn2d_stats_kernel<1><<<dim3(C, (unsigned)std::min<long long>(((long long)n * HW + 4095) / 4096, 64)), 256, 0, st>>>(x, scratch, n, C, HW);
   // mean / rstd, save[] and the running statistics are formed inside the apply kernel: one launch less
-  if (v4) bn2d_apply_kernel<4><<<dim3((HW / 4 + 255) / 256, C, n), 256, 0, st>>>(x, scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, gamma, beta, y, C, HW, relu);
-  else bn2d_apply_kernel<1><<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, gamma, beta, y, C, HW, relu);
+  if (v4) bn2d_apply_kernel<4><<<dim3((HW / 4 + 255) / 256, C, n), 256, 0, st>>>(x, scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, gamma, beta, y, C, HW, relu, num_batches_tracked);
+  else bn2d_apply_kernel<1><<<dim3((HW + 255) / 256, C, n), 256, 0, st>>>(x, scratch, save, running_mean, running_var, momentum, eps, (long long)n * HW, gamma, beta, y, C, HW, relu, num_batches_tracked);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -773,7 +775,8 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
                            float* dbeta, double* scratch, int relu, int n, int C, int HW, void* stream) {
   GC_CHECK_ARG(x && y && dy && save && gamma && dx && scratch && n >= 1 && n <= 65535 && C >= 1 && C <= 65535 && HW >= 1, "bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));
+  if (!(relu & 4)) GC_HIP(hipMemsetAsync(scratch, 0, (size_t)C * 2 * sizeof(double), st));   // bit 2: the caller's scratch is zero already
+  relu &= 3;
   const bool v4 = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);   // four pixels per lane
   if (v4) {
     bn2d_bwd_reduce_kernel<4><<<dim3(C, (unsigned)std::min((HW + 1023) / 1024, 64)), 256, 0, st>>>(x, y, dy, save, scratch, n, C, HW, relu & 1);

@@ -69,6 +69,50 @@ class _Workspaces:
 workspaces = _Workspaces()
 
 
+class _ZeroPool:
+    """``zeros(shape, dtype, device)`` carved out of zero-filled blocks: ONE fill launch per ``BLOCK`` bytes instead of one per tensor
+    (the training leg asked for ~230 small zero-filled tensors per step -- weight-gradient blobs, statistics scratch -- each a launch of
+    its own: ``profiles/r4_train_leg_kernel_stats.csv``).  A carved tensor is a view that keeps its block alive and is never handed out
+    twice, so nothing aliases: a block is freed (back to torch's caching allocator) when its last view dies.  One pool per (device,
+    stream): the fill is ordered on the stream the views are used on.  While a HIP graph is being captured the pool steps aside
+    (plain ``torch.zeros``): a view of a block filled before the capture began would not be re-zeroed by a replay."""
+    BLOCK = 4 << 20
+    ALIGN = 256
+
+    def __init__(self):
+        self._cur: Dict[Tuple[int, int], list] = {}
+
+    def zeros(self, shape, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        if nbytes == 0 or nbytes > self.BLOCK // 4 or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return torch.zeros(shape, dtype=dtype, device=device)
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        key = (dev, stream_ptr(device))
+        cur = self._cur.get(key)
+        need = (nbytes + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        if cur is None or cur[1] + need > self.BLOCK:
+            cur = [torch.zeros(self.BLOCK, dtype=torch.uint8, device=device), 0]
+            self._cur[key] = cur
+        off = cur[1]
+        cur[1] = off + need
+        return cur[0][off:off + nbytes].view(dtype).view(shape)
+
+    def clear(self) -> None:
+        self._cur.clear()
+
+
+zero_pool = _ZeroPool()
+
+
+def zeros(shape, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """Zero-filled tensor from the per-stream pool (see ``_ZeroPool``); same contract as ``torch.zeros``."""
+    return zero_pool.zeros(shape, dtype, device)
+
+
 class PackedParams:
     """Flat float32 copy of selected parameters in the order the C side enumerates them, rebuilt
     only when a parameter changed (``_version`` / storage pointer / device)."""

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from .runtime import ptr, stream_ptr
+from .runtime import ptr, stream_ptr, zeros as pool_zeros
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -82,7 +82,7 @@ def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, k: int, pad: int, bias: bool
     cin, H, W = x.shape[1:]
     l = _lib.lib()
     # one zero-filled blob for both gradients (one fill launch instead of two)
-    blob = torch.zeros(cout * cin * k * k + (cout if bias else 0), dtype=torch.float32, device=x.device)
+    blob = pool_zeros(cout * cin * k * k + (cout if bias else 0), torch.float32, x.device)   # carved from a zero-filled block: no launch
     dw = blob[:cout * cin * k * k].view(cout, cin, k, k)
     db = blob[cout * cin * k * k:] if bias else None
     need = _lib.check_size(l.gencomm_conv2d_wgrad_scratch_floats(n, cin, H, W, cout, k, int(stride), pad), "gencomm_conv2d_wgrad_scratch_floats")
@@ -168,16 +168,21 @@ def bn2d_train_fwd(x: torch.Tensor, bn, relu: bool):
     n, C, H, W = x.shape
     y = torch.empty_like(x)
     save = torch.empty(C, 2, dtype=torch.float32, device=x.device)
-    scratch = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    scratch = pool_zeros(2 * C, torch.float64, x.device)          # arrives zeroed (flag 4): no memset launch inside the call
     track = bn.track_running_stats and bn.running_mean is not None
     momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+    nbt = None
     if track:
-        bn.num_batches_tracked += 1
-        if bn.momentum is None:
+        if bn.momentum is None:                                   # cumulative average: the factor is 1 / the counter AFTER this batch (a host read)
+            bn.num_batches_tracked += 1
             momentum = 1.0 / float(bn.num_batches_tracked)
+        elif bn.num_batches_tracked is not None and bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64:
+            nbt = bn.num_batches_tracked                          # incremented inside the normalisation kernel (ABI v9): no launch of its own
+        elif bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
     _lib.check(_lib.lib().gencomm_bn2d_train_fwd(ptr(x), ptr(_c(bn.weight)), ptr(_c(bn.bias)), ptr(bn.running_mean) if track else None,
                                                  ptr(bn.running_var) if track else None, ptr(y), ptr(save), ptr(scratch), momentum, float(bn.eps),
-                                                 int(relu), n, C, H * W, stream_ptr(x.device)), "gencomm_bn2d_train_fwd")
+                                                 int(relu) | 4, n, C, H * W, ptr(nbt), stream_ptr(x.device)), "gencomm_bn2d_train_fwd")
     return y, save
 
 
@@ -187,8 +192,8 @@ def bn2d_train_bwd(x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, save: tor
     n, C, H, W = x.shape
     dx = torch.empty_like(x)
     dg, db = torch.empty(2, C, dtype=torch.float32, device=x.device).unbind(0)   # written, not accumulated (relu bit 1): no fill launch
-    scratch = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-    _lib.check(_lib.lib().gencomm_bn2d_train_bwd(ptr(x), ptr(y), ptr(dy), ptr(save), ptr(_c(gamma)), ptr(dx), ptr(dg), ptr(db), ptr(scratch), int(relu) | 2,
+    scratch = pool_zeros(2 * C, torch.float64, x.device)          # arrives zeroed (flag 4)
+    _lib.check(_lib.lib().gencomm_bn2d_train_bwd(ptr(x), ptr(y), ptr(dy), ptr(save), ptr(_c(gamma)), ptr(dx), ptr(dg), ptr(db), ptr(scratch), int(relu) | 2 | 4,
                                                  n, C, H * W, stream_ptr(x.device)), "gencomm_bn2d_train_bwd")
     return dx, dg, db
 
@@ -207,7 +212,7 @@ def ln_bwd(x: torch.Tensor, gamma, dy: torch.Tensor, eps: float, accumulate_into
     x, dy = _c(x), _c(dy)
     n, C, H, W = x.shape
     dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
-    dg, db = torch.zeros(2, C, dtype=torch.float32, device=x.device).unbind(0)   # one fill launch for both
+    dg, db = pool_zeros((2, C), torch.float32, x.device).unbind(0)   # carved from a zero-filled block: no launch
     scratch = torch.empty(n * H * W * 2, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().gencomm_ln_nchw_bwd(ptr(x), ptr(_c(gamma)), ptr(dy), ptr(dx), ptr(dg), ptr(db), ptr(scratch), float(eps),
                                               int(accumulate_into is not None), n, C, H * W, stream_ptr(x.device)), "gencomm_ln_nchw_bwd")
@@ -266,7 +271,7 @@ def dwconv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, gelu_in: bool = False):
     """dw, db of the depthwise layer whose input was the first dy.shape[1] channels of x (GELU of them when gelu_in)."""
     x, dy = _c(x), _c(dy)
     n, C, H, W = dy.shape
-    blob = torch.zeros(C * 10, dtype=torch.float32, device=x.device)              # one fill launch for both gradients
+    blob = pool_zeros(C * 10, torch.float32, x.device)              # both gradients, carved from a zero-filled block: no launch
     dw, db = blob[:C * 9].view(C, 1, 3, 3), blob[C * 9:]
     _lib.check(_lib.lib().gencomm_dwconv3x3_act_wgrad(ptr(x), x.shape[1], int(gelu_in), ptr(dy), ptr(dw), ptr(db), n, C, H, W, stream_ptr(x.device)),
                "gencomm_dwconv3x3_act_wgrad")

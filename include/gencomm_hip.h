@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 8
+#define GENCOMM_ABI_VERSION 9
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -511,9 +511,13 @@ int gencomm_split3_attn_fwd(const float* a, const float* b, const float* c, cons
  * the backbone / shrink stacks: y = act(gamma (x - mean_batch) / sqrt(var_batch + eps) + beta) over NCHW, running statistics updated as
  * nn.BatchNorm2d does (unbiased variance; pass null to leave them alone); save [C][2] = (mean, rstd) for the backward; scratch >= 2 C
  * doubles. Backward: dx overwritten, dgamma / dbeta accumulated, y = the forward's output (supplies the ReLU mask).
- * ABI v8: `relu` bit 1 of gencomm_bn2d_train_bwd set = dgamma / dbeta are WRITTEN (the caller need not zero them); clear = accumulated. */
+ * ABI v8: `relu` bit 1 of gencomm_bn2d_train_bwd set = dgamma / dbeta are WRITTEN (the caller need not zero them); clear = accumulated.
+ * ABI v9: `relu` bit 2 (value 4) of either call set = `scratch` arrives ZEROED (the caller carved it from a zero-filled pool: no memset
+ * launch here); gencomm_bn2d_train_fwd takes `num_batches_tracked` (device int64, may be null) and adds 1 to it inside its own kernel --
+ * nn.BatchNorm2d's counter without a launch of its own (batchnorm.py: `self.num_batches_tracked.add_(1)`). */
 int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, float* save,
-                           double* scratch, float momentum, float eps, int relu, int n, int C, int HW, void* stream);
+                           double* scratch, float momentum, float eps, int relu, int n, int C, int HW, long long* num_batches_tracked,
+                           void* stream);
 int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
                            float* dbeta, double* scratch, int relu, int n, int C, int HW, void* stream);
 
