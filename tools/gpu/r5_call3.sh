@@ -2,7 +2,7 @@
 # per-family kernel times of two libraries on one box (HIP-event family pass of bench.py)
 set -o pipefail
 O=gpurun_out; mkdir -p $O
-for kv in new= old=gencomm_amd/libgencomm_base.so "$@"; do
+for kv in new= "$@"; do
   name=${kv%%=*}; path=${kv#*=}
   if [ -n "$path" ]; then export GENCOMM_HIP_LIB=$PWD/$path; else unset GENCOMM_HIP_LIB; fi
   timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact --sustain 1 > $O/r5c3_$name.json 2> $O/r5c3_$name.err || { tail -n 5 $O/r5c3_$name.err; exit 1; }
