@@ -385,8 +385,9 @@ def train_main(args, rank, world, device, backend):
         cnt = (ctypes.c_int * N_FAMILIES)()
         wk = (ctypes.c_double * N_FAMILIES)()
         _lib.check(lib.gencomm_timer_start_mask(1 << CONV2D_FAMILY, 4096), "gencomm_timer_start_mask")
-        eager_step()
-        torch.cuda.synchronize(device)
+    eager_step()        # EVERY rank runs the extra step (it contains the gradient collective); only rank 0's launches are timed
+    barrier()
+    if rank == 0:
         _lib.check(lib.gencomm_timer_stop_families(ms, cnt, wk, N_FAMILIES), "gencomm_timer_stop_families")
         if cnt[CONV2D_FAMILY] > 0:
             f_ms, f_fl, f_n = ms[CONV2D_FAMILY], wk[CONV2D_FAMILY], cnt[CONV2D_FAMILY]

@@ -2,7 +2,7 @@
 CPU oracle.
 
 Tolerance policy (SURVEY.md 8c sets rtol 1e-4 / atol 1e-5 for the float path), with the measurements behind it in
-DESIGN.md section 2 (tools/diag_r2.py):
+DESIGN.md section 2 / docs/history/DESIGN_rounds1-4.md section 2 (tools/diag_r2.py):
 
 * PER STAGE -- every stage fed the oracle's own output of the stage before: single sampler steps (UNet call + update from
   the oracle's x_t), the Enhancer on the oracle's pred_feature, warp + AttFusion on the oracle's enhanced map -- the bar is
