@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 export ROUND=r5
 O=gpurun_out; mkdir -p $O
 step() { echo "== $1"; }
+step "train leg N=1 (RCCL, world 1)"; timeout -k 10 400 python bench.py --workload train --steps 20 --warmup 3 > $O/r5_train_leg_n1.json 2> $O/r5_train_leg_n1.err || { tail -n 30 $O/r5_train_leg_n1.err; exit 1; }
+step "train leg N=1 under torch DistributedDataParallel"; timeout -k 10 400 python bench.py --workload train --grad-sync ddp --steps 20 --warmup 3 > $O/r5_train_leg_n1_ddp.json 2> $O/r5_train_leg_n1_ddp.err || { tail -n 30 $O/r5_train_leg_n1_ddp.err; exit 1; }
 step "train leg N=4 share-device (gloo)"; timeout -k 10 400 python bench.py --workload train --gpus 4 --share-device --steps 10 --warmup 3 > $O/r5_train_leg_share4.json 2> $O/r5_train_leg_share4.err || { tail -n 30 $O/r5_train_leg_share4.err; exit 1; }
 python - <<'PY'
 import json
