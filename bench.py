@@ -483,7 +483,7 @@ def main():
     lib = _lib.lib()
     mode_keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
                  "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP,
-                 "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU, "tile8": _lib.MODE_TILE8, "bwd_streams": _lib.MODE_BWD_STREAMS}
+                 "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU, "tile8": _lib.MODE_TILE8, "bwd_streams": _lib.MODE_BWD_STREAMS, "persist": _lib.MODE_PERSIST}
     for kv in args.mode:
         k, v = kv.split("=")
         _lib.check(lib.gencomm_set_mode(mode_keys[k], int(v)), "gencomm_set_mode")

@@ -16,7 +16,7 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
 ABI_VERSION = 9
-MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW, MODE_RESFUSE_EMU, MODE_TILE8, MODE_BWD_STREAMS = range(10)
+MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW, MODE_RESFUSE_EMU, MODE_TILE8, MODE_BWD_STREAMS, MODE_PERSIST = range(11)
 
 _lock = threading.Lock()
 _lib = None

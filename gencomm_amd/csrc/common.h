@@ -60,7 +60,11 @@ enum ModeKey : int {
   MODE_BWD_STREAMS = 9,  // 1 (default): gencomm_unet_bwd enqueues its weight-gradient launches on a library-owned side stream (forked from and
                          // joined back to the caller's stream inside the call), so that they overlap the input-gradient chain, when the call
                          // has at least 2^17 pixels (n H W); 2: always; 0: one stream
-  MODE_COUNT = 10
+  MODE_PERSIST = 10,     // bit mask of 8-channel f16-pipe layer variants (1: conv1 8->8, 2: conv1 16->8, 4: conv2 + identity, 8: conv2 + shortcut,
+                         // 16: Upsample) that run as the PERSISTENT kernel (conv8hp_kernel: at most 3 workgroups per CU walk the tiles, the next
+                         // tile's loads requested one tile ahead) whenever the launch has more tiles than resident slots; 0: one tile per workgroup.
+                         // Default 16: measured per variant (profiles/r5_persist_ab.txt) only the Upsample convolution gains (38.7 -> 35.0 us)
+  MODE_COUNT = 11
 };
 struct Modes {
   long long v[MODE_COUNT];
@@ -157,6 +161,21 @@ __device__ __forceinline__ cfloat_p as_const(const float* p) { return (cfloat_p)
 // time and their shared lines are L2 hits.  Bijective for any grid size (XCD k gets total/8 tiles, +1 for k < total%8).
 // ---------------------------------------------------------------------------------------------
 struct BlockId { int x, y, z; };
+// the tile with linear index `lin` of a (gx, gy, total / (gx gy)) tile grid under the same rule (persistent kernels: the launch grid is 1-D)
+__device__ __forceinline__ BlockId xcd_block_dims(int remap, unsigned lin, unsigned gx, unsigned gy, unsigned total) {
+  unsigned nl = lin;
+  if (remap) {
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    nl = xcd * q + (xcd < r ? xcd : r) + j;
+  }
+  BlockId b;
+  const unsigned row = nl / gx;
+  b.x = (int)(nl - row * gx);
+  b.z = (int)(row / gy);
+  b.y = (int)(row - (unsigned)b.z * gy);
+  return b;
+}
 // the tile of the workgroup with linear id `lin` (blockIdx.x fastest) under the same rule
 __device__ __forceinline__ BlockId xcd_block_lin(int remap, unsigned lin) {
   const unsigned gx = gridDim.x, gy = gridDim.y;

@@ -641,12 +641,26 @@ __device__ __forceinline__ void hc_stats_commit(float (&part)[8], float (*s_red)
 // the persistent dataflow kernel (dataflow_kernels.h).  LDS is the caller's: tile (2 * HC_PLANE + HC_TPLANE bytes, 16-byte
 // aligned), s_ab [16][2], s_red [4][16].
 constexpr int HC_TILE_BYTES = 2 * HC_PLANE + HC_TPLANE;
-template <int NSRC, bool GN, bool UP, int RES, bool DIAG = false>
+// PERSIST (conv8hp_kernel below: a workgroup walks several tiles): `R` / `hreg` arrive holding THIS tile's first source (loaded by the
+// caller's prologue or by the previous tile's call), and once they are free -- after the last staging pass of this tile -- the NEXT
+// tile's first source is requested into them (`have_next`, `next`) behind the last matrix phase, so that its loads are in flight during
+// this tile's epilogue, stores and statistics (requested earlier -- across a matrix phase -- the 38 registers spill).
+struct HcCarry {
+  TileRegs<HC_TW, HC_TH, HC_NT, 8> R;
+  float2 hreg;
+};
+template <int NSRC, bool GN, bool UP, int RES, bool DIAG = false, bool PERSIST = false>
 __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bid, unsigned char* tile, float (*s_ab)[2], float (*s_red)[16],
-                                            size_t bias_off = 0) {
+                                            size_t bias_off, HcCarry& carry, bool have_next, const BlockId next) {
   constexpr int NT = HC_NT, TW = HC_TW, TH = HC_TH;
+  TileRegs<TW, TH, NT, 8>& R = carry.R;
+  float2& hreg = carry.hreg;
   fp16_ovfl_clamp();
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid_ = threadIdx.x;
+  // PERSIST: everything derived from the thread index (lane offsets, tile addresses, ...) is re-derived per tile -- hoisted out of the
+  // tile loop as invariants these ~50 values are spilled to scratch and reloaded in the middle of the matrix phase
+  if (PERSIST) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const int n = bid.z;
   const int x0 = bid.x * TW, y0 = bid.y * TH;
   const size_t plane_in = (size_t)a.Hin * a.Win;
@@ -680,12 +694,20 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
   const float inv_s = a.wh[NSRC * HC_WTAB3] / mul;  // one scale for the whole (concatenated) weight tensor
   const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + bias_off + 4 * ch);
   const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
-  TileRegs<TW, TH, NT, 8> R;
-  float2 hreg = make_float2(0.f, 0.f);
-  if (wvec) {
-    stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
-    hreg = halo_load_h<UP>(a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+  if (!PERSIST) {
+    hreg = make_float2(0.f, 0.f);
+    if (wvec) {
+      stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+      hreg = halo_load_h<UP>(a.src[0] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    }
   }
+  auto prefetch_next = [&]() {   // PERSIST: the next tile's first source into the (now free) staging registers
+    if (PERSIST && have_next) {
+      const float* np = a.src[0] + (size_t)next.z * 8 * plane_in;
+      stage_load<TW, TH, NT, 8, UP, GN>(R, np, (unsigned)plane_in, a.Win, a.H, a.W, next.x * TW, next.y * TH, tid);
+      hreg = halo_load_h<UP>(np, (unsigned)plane_in, a.Win, a.H, a.W, next.x * TW, next.y * TH, tid);
+    }
+  };
   if (GN) {
     if (tid < NSRC * 8) {
       const int s = tid >> 3, c = tid & 7;
@@ -715,6 +737,7 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
   hc_lane_offsets(off, wave, lane);
   // identity residual: requested once the staging registers are free, so that it arrives during the matrix phase
   float resv[RES == 1 ? 2 : 1][4][4];
+  auto request_residual = [&]() {
   if (RES == 1 && wave_live) {
     const float* const lane_res = a.res[0] + ((size_t)n * 8 + 4 * ch) * plane + (size_t)gy0 * a.W + gx;
 #pragma unroll
@@ -732,11 +755,11 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
         }
       }
   }
-#ifdef HC_NSRC2_LATE   // diagnostic builds: the second source is requested AFTER the first matrix phase (full-register matrix phase, exposed load)
-  constexpr bool LATE2 = true;
-#else
-  constexpr bool LATE2 = false;
-#endif
+  };
+  if (!PERSIST) request_residual();   // PERSIST: behind the matrix phase (the prefetched next tile needs the registers)
+  // the second source is requested AFTER the first matrix phase in the persistent form (full-register matrix phase; measured equal to
+  // the early request in round 4: profiles/r4_conv8h_ab.txt) -- early, the loop-carried state on top of it spills
+  constexpr bool LATE2 = PERSIST;
   if (NSRC == 2 && wvec && !LATE2) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
     stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
@@ -746,7 +769,7 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
 #ifdef HC_PRIO_MFMA   // diagnostic builds (tools/diag/prio_ab.sh): static wave priority from the matrix phase on
   __builtin_amdgcn_s_setprio(HC_PRIO_MFMA);
 #endif
-  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2 && !LATE2, !DIAG>(tile, a.wh, acc, off, lane, a.term_mask, b0);
+  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2 && (!LATE2 || PERSIST), !DIAG>(tile, a.wh, acc, off, lane, a.term_mask, b0);
   if (NSRC == 2 && wvec && LATE2) {
     stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
@@ -760,9 +783,11 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
     if (wvec) stage_store_h<GN, true>(tile, R, hreg, a.H, a.W, x0, y0, &s_ab[8], tid);
     else stage_tile_scalar_h<GN, UP, true>(tile, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, &s_ab[8], tid);
     __syncthreads();
-    if (wave_live) conv_tile_mfma3(tile, a.wh + HC_WTAB3, acc, off, lane);
+    if (wave_live) conv_tile_mfma3<false, PERSIST>(tile, a.wh + HC_WTAB3, acc, off, lane);
   }
 
+  if (PERSIST) request_residual();
+  if (RES != 2) prefetch_next();   // behind the last matrix phase: live across the epilogue only (held across a matrix phase it spills)
   GC_STAMP(4);
 #ifdef HC_PRIO_EPI    // diagnostic builds: static wave priority for the epilogue (the workgroup's last phase)
   __builtin_amdgcn_s_setprio(HC_PRIO_EPI);
@@ -846,6 +871,7 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
       }
     }
 
+    if (RES == 2) prefetch_next();   // behind the shortcut's loads (in-order completion: in front of them they would wait for these)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int gy = gy0 + 2 * p;
@@ -870,10 +896,20 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
         part[4 + i] = p == 0 ? q : part[4 + i] + q;
       }
     }
+  } else if (RES == 2) {
+    prefetch_next();   // waves below the image (last tile row) stage the next tile like any other
   }
   GC_STAMP(5);
   if (a.dstat != nullptr) hc_stats_commit(part, s_red, a.dstat + (size_t)n * 16, tid);
   GC_STAMP(6);
+  if (PERSIST) __syncthreads();   // the next tile's coefficient / tile writes must not overtake this tile's LDS reads (s_red, last matrix phase)
+}
+// the one-tile form (per-layer launches, the dataflow kernel): registers of its own, nothing carried
+template <int NSRC, bool GN, bool UP, int RES, bool DIAG = false>
+__device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bid, unsigned char* tile, float (*s_ab)[2], float (*s_red)[16],
+                                            size_t bias_off = 0) {
+  HcCarry carry;
+  conv8h_tile<NSRC, GN, UP, RES, DIAG, false>(a, bid, tile, s_ab, s_red, bias_off, carry, false, bid);
 }
 
 template <int NSRC, bool GN, bool UP, int RES, bool DIAG = false>
@@ -886,6 +922,37 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8h_kernel(const Conv8Args a) {
   if (a.H < 0) s_pad[threadIdx.x] = 1.f;
 #endif
   conv8h_tile<NSRC, GN, UP, RES, DIAG>(a, xcd_block(a.xcd), tile, s_ab, s_red);
+}
+
+// Persistent form (round 5): a 1-D grid of at most the resident slots (3 per CU); workgroup b walks the tiles b, b + G, b + 2G, ... of the
+// (tx, ty, n) tile grid in xcd_block order (G % 8 == 0: a workgroup's tiles stay on its XCD's share).  Per tile the chain is the
+// one-tile kernel's, minus what a workgroup's slot otherwise sits through without issuing anything: the wait for the tile's first
+// loads (requested one tile ahead) and the drain of its stores (the workgroup moves on while they complete).  Vector widths only
+// (W % 4 == 0; Win % 2 == 0 for the nearest-x2 form): the host launches the one-tile kernel otherwise.
+template <int NSRC, bool GN, bool UP, int RES>
+__global__ __launch_bounds__(HC_NT, 3) void conv8hp_kernel(const Conv8Args a, int tx, int ty, int nz) {
+  __shared__ __align__(16) unsigned char tile[HC_TILE_BYTES];
+  __shared__ float s_ab[16][2];
+  __shared__ float s_red[HC_NT / 64][16];
+  const unsigned total = (unsigned)tx * ty * nz;
+  const size_t plane_in = (size_t)a.Hin * a.Win;
+  unsigned lin = blockIdx.x;
+  if (lin >= total) return;
+  BlockId bid = xcd_block_dims(a.xcd, lin, (unsigned)tx, (unsigned)ty, total);
+  HcCarry carry;
+  {
+    const float* sp = a.src[0] + (size_t)bid.z * 8 * plane_in;
+    stage_load<HC_TW, HC_TH, HC_NT, 8, UP, GN>(carry.R, sp, (unsigned)plane_in, a.Win, a.H, a.W, bid.x * HC_TW, bid.y * HC_TH, threadIdx.x);
+    carry.hreg = halo_load_h<UP>(sp, (unsigned)plane_in, a.Win, a.H, a.W, bid.x * HC_TW, bid.y * HC_TH, threadIdx.x);
+  }
+#pragma unroll 1
+  for (; lin < total; lin += gridDim.x) {
+    const unsigned nl = lin + gridDim.x;
+    const bool have_next = nl < total;
+    const BlockId nb = have_next ? xcd_block_dims(a.xcd, nl, (unsigned)tx, (unsigned)ty, total) : bid;
+    conv8h_tile<NSRC, GN, UP, RES, false, true>(a, bid, tile, s_ab, s_red, 0, carry, have_next, nb);
+    bid = nb;
+  }
 }
 
 // Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 three-term tables of HC_WTAB3 dwords + 64 floats (1 / scale, scale).

@@ -30,7 +30,7 @@ KernelTimer& kernel_timer() {
   static KernelTimer t;
   return t;
 }
-static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {2}, {-1}, {1}, {0}, {0}, {-1}, {1}};  // defaults, see ModeKey
+static std::atomic<long long> g_modes[MODE_COUNT] = {{0}, {0}, {0}, {2}, {-1}, {1}, {0}, {0}, {-1}, {1}, {16}};  // defaults, see ModeKey
 static std::atomic<bool> g_klog_armed{false};
 static std::mutex g_klog_mu;
 static std::map<std::string, int> g_klog;
@@ -65,6 +65,7 @@ int gencomm_set_mode(int key, long long value) {
   GC_CHECK_ARG(key != MODE_TILE_WANT || value >= 0, "GENCOMM_MODE_TILE_WANT: 0 (automatic) or a positive workgroup count");
   GC_CHECK_ARG(key != MODE_TILE8 || value >= -1, "GENCOMM_MODE_TILE8: -1 (automatic), 0 (off) or a positive workgroup count");
   GC_CHECK_ARG(key != MODE_BWD_STREAMS || (value >= 0 && value <= 2), "GENCOMM_MODE_BWD_STREAMS: 0 (off), 1 (automatic) or 2 (always)");
+  GC_CHECK_ARG(key != MODE_PERSIST || (value >= 0 && value <= 31), "GENCOMM_MODE_PERSIST: a mask of the five layer variants (0 .. 31)");
   g_modes[key].store(value, std::memory_order_relaxed);
   return GC_OK;
 }

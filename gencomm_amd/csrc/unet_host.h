@@ -42,6 +42,19 @@ inline void tile_dims(TileCfg t, int* tw, int* th) {
   *th = t == TILE_32x8 ? 8 : 16;
 }
 
+// CUs of the current device (cached per device index): the persistent kernels are launched with 3 workgroups per CU
+inline int device_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev] = v;
+  }
+  return cus[dev];
+}
+
 template <int NSRC, bool GN, bool UP, int RES>
 inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, hipStream_t st) {
   // algorithmic bytes: the source map(s), the residual source(s) and the destination, once each, fp32
@@ -61,6 +74,16 @@ inline void launch_conv8(const Modes& m, TileCfg t, const Conv8Args& a, int n, h
       if (t8 > 0 && (long long)grid.x * grid.y * grid.z < t8 && (a.W & 3) == 0 && a.W >= 4) {
         GC_KLOG(NSRC == 2 ? "conv8h8_kernel<2,GN,0> (64x8 tiles)" : RES == 2 ? "conv8h8_kernel<1,GN,2> (64x8 tiles)" : RES == 1 ? "conv8h8_kernel<1,GN,1> (64x8 tiles)" : "conv8h8_kernel<1,GN,0> (64x8 tiles)");
         conv8h8_kernel<NSRC, GN, RES><<<dim3(cdiv(a.W, 64), cdiv(a.H, 8), n), 256, 0, st>>>(a);
+        return;
+      }
+    }
+    if constexpr (GN || UP) {   // persistent form (MODE_PERSIST): more tiles than resident slots, vector widths
+      const long long tiles = (long long)grid.x * grid.y * grid.z;
+      const int slots = 3 * device_cu_count();
+      if ((m.v[MODE_PERSIST] & variant) && tiles > slots && (UP ? (a.Win & 1) == 0 : (a.W & 3) == 0)) {
+        GC_KLOG(UP ? "conv8hp_kernel<1,0,UP,0> (persistent)" : NSRC == 2 ? "conv8hp_kernel<2,GN,0,0> (persistent)" : RES == 2 ? "conv8hp_kernel<1,GN,0,2> (persistent)"
+                   : RES == 1 ? "conv8hp_kernel<1,GN,0,1> (persistent)" : "conv8hp_kernel<1,GN,0,0> (persistent)");
+        conv8hp_kernel<NSRC, GN, UP, RES><<<dim3((unsigned)slots), 256, 0, st>>>(a, (int)grid.x, (int)grid.y, (int)grid.z);
         return;
       }
     }

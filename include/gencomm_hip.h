@@ -96,13 +96,20 @@ const char* gencomm_build_info(void);
  *                             them back before its last launches, so they overlap the input-gradient chain (15.2 -> 13.7 ms per training step
  *                             at 4 x 64 x 200 x 704); every buffer is still ordered on the caller's stream when the call returns.  2: on every
  *                             call (costs host time on small maps).  0: every launch on the caller's stream
+ *   GENCOMM_MODE_PERSIST      bit mask of the 8-channel f16-pipe layer variants (1 conv1 8 -> 8, 2 conv1 16 -> 8, 4 conv2 + identity residual,
+ *                             8 conv2 + 1x1 shortcut, 16 Upsample) that run as a PERSISTENT kernel when a launch has more 64x16 tiles than the device
+ *                             has resident slots (3 per CU): every workgroup walks several tiles and requests the next tile's loads one tile
+ *                             ahead, so that a slot does not sit through the first-load wait and the store drain of every tile.  Same tile
+ *                             function, same arithmetic; results identical up to the summation order of the statistics.  Default 16: measured per
+ *                             variant on MI355X only the Upsample convolution gains (38.7 -> 35.0 us per launch); the GroupNorm'd variants
+ *                             lose 0 .. 13 % (registers carried across the tile: up to 96 B of scratch)
  *   GENCOMM_MODE_RESFUSE_EMU  0 (default).  1: TIMING EXPERIMENT ONLY -- the 8 -> 8 ResnetBlocks run the launch pattern a fused
  *                             conv1 + conv2 block would have (statistics-only conv1 pass; conv2 pass reading the block input with twice
  *                             the matrix work), an upper bound of that fusion's gain; the outputs are NOT the UNet's */
 enum {
   GENCOMM_MODE_ARITH = 0, GENCOMM_MODE_SAMPLER = 1, GENCOMM_MODE_TILE_WANT = 2, GENCOMM_MODE_ENH_FUSE = 3,
   GENCOMM_MODE_CONV8H_MASK = 4, GENCOMM_MODE_XCD_REMAP = 5, GENCOMM_MODE_DATAFLOW = 6, GENCOMM_MODE_RESFUSE_EMU = 7,
-  GENCOMM_MODE_TILE8 = 8, GENCOMM_MODE_BWD_STREAMS = 9
+  GENCOMM_MODE_TILE8 = 8, GENCOMM_MODE_BWD_STREAMS = 9, GENCOMM_MODE_PERSIST = 10
 };
 int gencomm_set_mode(int key, long long value);
 long long gencomm_get_mode(int key);

@@ -25,7 +25,7 @@ def modes():
     l = _lib.lib()
     keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
             "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP,
-            "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU, "tile8": _lib.MODE_TILE8, "bwd_streams": _lib.MODE_BWD_STREAMS}
+            "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU, "tile8": _lib.MODE_TILE8, "bwd_streams": _lib.MODE_BWD_STREAMS, "persist": _lib.MODE_PERSIST}
     names = {"split": 0, "f32": 1, "bf16": 2, "split2": 3, "latent": 2, "direct": 1, "auto": 0}
     prev = {k: l.gencomm_get_mode(k) for k in keys.values()}
 

@@ -350,3 +350,32 @@ def test_64x8_tiles_vs_oracle_with_partial_tiles(modes):
     with torch.no_grad():
         pred = gen(inp["feat"].to(DEV), inp["cond"].to(DEV), inp["record_len"], noise=(n0.to(DEV), sn.to(DEV)))["pred_feature"]
     assert_close(pred.cpu().numpy(), ref["pred_feature"].numpy(), 1e-4, 1e-5, "pred_feature (64x8 tiles)")
+
+
+# ---------------------------------------------------------------------- persistent form (GENCOMM_MODE_PERSIST; conv8hp_kernel)
+@pytest.mark.parametrize("shape,mask", [((16, 200, 704), 31), ((16, 200, 704), 2), ((13, 200, 704), 31), ((16, 104, 708), 31), ((6, 400, 704), 13)])
+def test_persistent_kernels_equal_one_tile_per_workgroup(modes, shape, mask):
+    """conv8hp_kernel walks several tiles per workgroup with the next tile's loads one tile ahead: the same tile function and products;
+    what may differ is the order in which a product block's six terms meet (the low-register matrix phase) and the order of the f64
+    statistics atomics.  Full-resolution launches of these shapes have more tiles than resident slots (the condition for the persistent
+    form); partial tiles in both directions, an agent count that does not divide the slots, every variant mask on its own."""
+    from gencomm_amd import GenComm, _lib, synth
+    n, H, W = shape
+    gen = GenComm(synth.default_gencomm_cfg(64, 20)).eval()
+    synth.fill_params_(gen, 5)
+    gen = gen.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(13)
+    x = torch.randn(n, 66, H, W, generator=g, device=DEV)
+    t = torch.full((n,), 4.0, device=DEV)
+    ys, logs = [], []
+    for persist in (0, mask, 0, mask):
+        modes(persist=persist)
+        with torch.no_grad(), _lib.kernel_log() as kl:
+            ys.append(gen.denoiser(x, t, T=20).clone())
+        logs.append(dict(kl.counts))
+    assert any("persistent" in k for k in logs[1]) and not any("persistent" in k for k in logs[0]), logs[1]
+    scale = float(ys[0].abs().max())
+    assert float((ys[0] - ys[2]).abs().max()) <= 1e-6 * scale
+    assert float((ys[1] - ys[3]).abs().max()) <= 1e-6 * scale
+    assert float((ys[0] - ys[1]).abs().max()) <= 2e-6 * scale, float((ys[0] - ys[1]).abs().max()) / scale
+    assert torch.isfinite(ys[1]).all()
