@@ -58,7 +58,7 @@ CONV8_FAMILIES = {1: "conv1 8->8 (GN+SiLU)", 16: "conv2 + identity residual", 17
 LATENT_FAMILY = 15
 ENH_FRONT_FAMILY = 9
 N_FAMILIES = 20
-CONV2D_FAMILY = 19      # the general convolution around the path (conv2d_igemm_kernel): its timer slot carries algorithmic FLOPs
+CONV2D_FAMILY = 19      # the general convolution around the path (conv2d_h3l / conv2d_h3 / conv2d_igemm kernels): its timer slot carries algorithmic FLOPs
 RESULT_OUT = sys.stdout   # main() replaces it by a private copy of the original stdout
 
 
@@ -374,9 +374,9 @@ def train_main(args, rank, world, device, backend):
     assert torch.isfinite(loss.detach()).all(), "non-finite training loss"
     value, elapsed, total_scenes = gdist.aggregate_throughput(args.steps * B, elapsed_here, dist, red_dev)
     grad_bytes = sum(p.numel() * p.element_size() for p in params) if sync is None else sync.bucket_bytes
-    # roofline of the step's dominant kernel family -- the general convolution on the exact-fp32 matrix cores (BEV backbone, shrink conv,
-    # heads, the Enhancer's Linear layers; forward and input gradients): HIP-event time and algorithmic FLOPs of every launch of ONE
-    # extra eager step (the library's kernel timer, family CONV2D_FAMILY), priced against the fp32 MFMA peak
+    # roofline of the step's dominant kernel family -- the general convolution (BEV backbone, shrink conv, heads, the Enhancer's Linear
+    # layers; forward and input gradients): HIP-event time and algorithmic FLOPs of every launch of ONE extra eager step (the library's
+    # kernel timer, family CONV2D_FAMILY), priced against the f16 pipe's peak over the six matrix instructions of a product block
     roofline = None
     if rank == 0:
         from gencomm_amd import _lib
@@ -391,12 +391,18 @@ def train_main(args, rank, world, device, backend):
         _lib.check(lib.gencomm_timer_stop_families(ms, cnt, wk, N_FAMILIES), "gencomm_timer_stop_families")
         if cnt[CONV2D_FAMILY] > 0:
             f_ms, f_fl, f_n = ms[CONV2D_FAMILY], wk[CONV2D_FAMILY], cnt[CONV2D_FAMILY]
-            roofline = {"kernel": "conv2d_igemm_kernel<KH, KW, ...> (general 3x3 / 1x1 / 2x2 convolutions of the step on v_mfma_f32_32x32x2_f32: exact fp32)",
-                        "bound": "mfma", "achieved": f_fl / (f_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": f_fl / (f_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None, "launches": f_n, "avg_launch_ms": f_ms / f_n,
+            ach = f_fl / (f_ms * 1e-3) / 1e12
+            roofline = {"kernel": "conv2d_h3l_kernel / conv2d_h3_kernel<KH, KW, ...> (general 3x3 / 1x1 / 2x2 convolutions of the step on the f16 matrix "
+                                  "pipe, six matrix instructions per product block from exact three-term operand splits: csrc/conv_h3_kernels.h; the few "
+                                  "shapes it does not take -- fewer than 32 GEMM rows or 16 input channels -- run conv2d_igemm_kernel on v_mfma_f32_32x32x2_f32)",
+                        "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS / MFMA_TERMS, "unit": "TFLOP/s (fp32-equivalent)",
+                        "frac": ach * MFMA_TERMS / F16_MFMA_PEAK_TFLOPS, "traffic": None, "launches": f_n, "avg_launch_ms": f_ms / f_n,
                         "flops_per_launch": f_fl / f_n, "share_of_step": f_ms / (1e3 * elapsed / args.steps),
+                        "frac_of_fp32_mfma_peak": ach / FP32_PEAK_TFLOPS,
                         "note": "algorithmic FLOPs = 2 N Ho Wo Cout Cin KH KW per launch (host-computed from the launch shape), HIP events around "
-                                "every launch of one untimed eager step; share_of_step = the family's summed device time over the step's wall time"}
+                                "every launch of one untimed eager step (launches of the side streams run beside them: durations are not "
+                                "isolated-kernel times); peak = the f16 pipe's 2 500 TFLOP/s over the six matrix instructions of a product block; "
+                                "share_of_step = the family's summed device time over the step's wall time"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_train_baseline(B, N, 128, 64, 128, T, model)

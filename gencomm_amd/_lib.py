@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW, MODE_RESFUSE_EMU, MODE_TILE8, MODE_BWD_STREAMS, MODE_PERSIST = range(11)
 
 _lock = threading.Lock()
@@ -73,6 +73,7 @@ _SIGNATURES = {
     "gencomm_pillar_encode_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "gencomm_conv2d_prepare": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "gencomm_conv2d_prepared_floats": (_ll, [_i, _i, _i, _i, _i]),
     "gencomm_conv2d_fold": (_i, [_p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _p]),
     "gencomm_conv2d_fwd": (_i, [_p, _p, _p, _p, _p] + [_i] * 13 + [_p]),
     "gencomm_conv2d_act_res_fwd": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),

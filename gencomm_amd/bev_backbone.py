@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .runtime import f32c, ptr, require_gpu, stream_ptr
+from .runtime import conv2d_prepare, f32c, ptr, require_gpu, stream_ptr
 
 
 def _versions(*tensors):
@@ -226,8 +226,7 @@ def conv2d_hip(x: torch.Tensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = 
     cache = getattr(conv, "_gc_cache", None)
     if cache is None or cache[0] != key:
         wd = f32c(w.detach())
-        prepared = torch.empty(wd.numel(), dtype=torch.float32, device=x.device)
-        _lib.check(l.gencomm_conv2d_prepare(ptr(wd), ptr(prepared), cin, cout, kh, kw, int(transposed), st), "gencomm_conv2d_prepare")
+        prepared = conv2d_prepare(wd, cin, cout, kh, kw, int(transposed), x.device)
         b = f32c(conv.bias.detach()) if conv.bias is not None else None
         if bn is None:   # scale 1, shift = bias: nothing to fold -- a cached unit row and the bias itself (training re-prepares every step)
             from .train_ops import _unit_scale_shift

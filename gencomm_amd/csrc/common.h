@@ -85,8 +85,8 @@ enum KernelFamily : int {
   KF_ENH_LN = 7, KF_ENH_PCONV = 8, KF_ENH_GEMM1 = 9, KF_ENH_DWGATE = 10, KF_ENH_GEMM2 = 11,
   KF_ENH_GATE = 12, KF_ENH_OUT = 13, KF_WARP_ATTFUSE = 14, KF_LATENT_STEP = 15, KF_CONV8_RES1 = 16, KF_CONV8_RES2 = 17,
   KF_DATAFLOW = 18,
-  KF_CONV2D = 19,   // the general convolution around the path (conv2d_igemm_kernel: BEV backbone, shrink conv, heads, Linear layers): its
-                    // `bytes` slot carries algorithmic FLOPs (2 N Ho Wo Cout Cin KH KW): the family is priced against the fp32 MFMA roof
+  KF_CONV2D = 19,   // the general convolution around the path (conv2d_h3l / conv2d_h3 / conv2d_igemm kernels: BEV backbone, shrink conv, heads,
+                    // Linear layers): its `bytes` slot carries algorithmic FLOPs (2 N Ho Wo Cout Cin KH KW)
   KF_COUNT = 20
 };
 inline const char* kernel_family_name(int id) {
@@ -99,7 +99,7 @@ inline const char* kernel_family_name(int id) {
       "latent_step_h_kernel | latent_step_kernel", "conv8h_kernel<1,GN,RES=1> | conv8_kernel (ResnetBlock conv2 + identity)",
       "conv8h_kernel<1,GN,RES=2> | conv8_kernel (ResnetBlock conv2 + nin_shortcut)",
       "unet_dataflow_kernel (UNet body of one call, persistent)",
-      "conv2d_igemm_kernel (general 3x3 / 1x1 / 2x2 convolution on the exact-fp32 matrix cores; slot = FLOPs)"};
+      "conv2d_h3l_kernel | conv2d_h3_kernel | conv2d_igemm_kernel (general 3x3 / 1x1 / 2x2 convolution; slot = FLOPs)"};
   return (id >= 0 && id < KF_COUNT) ? names[id] : "?";
 }
 struct KernelTimer {

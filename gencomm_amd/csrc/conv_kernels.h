@@ -1,8 +1,10 @@
 // General 2-D convolution for the layers AROUND the hot path (gfx950, wave64): BaseBEVBackbone blocks/deblocks, DownsampleConv,
-// the detection heads, the Linear layers of the fusion transformers.  Three kernels behind conv2d_enqueue:
-//   conv2d_igemm_kernel   exact fp32 on v_mfma_f32_32x32x2_f32 -- every shape; the only one in GENCOMM_MODE_ARITH = 1
-//   conv3x3_f16s_kernel   3x3 stride 1 / 2 with Cin % 16 == 0 on the f16 pipe, exact hi/lo split (default arithmetic mode)
-//   conv1x1_f16s_kernel   1x1 (and ConvTranspose2d, kernel == stride) with >= 128 GEMM rows, same arithmetic
+// the detection heads, the Linear layers of the fusion transformers.  Kernels behind conv2d_enqueue:
+//   conv2d_h3l_kernel     (conv_h3_kernels.h) DEFAULT for 3x3 stride 1 / 1x1 / 2x2 with Cin >= 16, Cin % 8 == 0, >= 32 GEMM rows: f16 pipe, six
+//   conv2d_h3_kernel       matrix instructions per product block from exact three-term operand splits (2^-26 products); _h3_: 3x3 stride 2
+//   conv2d_igemm_kernel   exact fp32 on v_mfma_f32_32x32x2_f32 -- every other shape; the only one in GENCOMM_MODE_ARITH = 1
+//   conv3x3_f16s_kernel   GENCOMM_MODE_ARITH = 3 (opt-in): 3x3 stride 1 / 2 with Cin % 8 == 0 on the f16 pipe from two-term splits (22-bit products)
+//   conv1x1_f16s_kernel   the same for 1x1 (and ConvTranspose2d, kernel == stride) with >= 128 GEMM rows
 //
 // Reference call sites: opencood/models/sub_modules/base_bev_backbone.py:40-92 (ZeroPad2d(1) + 3x3
 // stride-s conv, BatchNorm2d(eps 1e-3), ReLU; ConvTranspose2d(k = stride) deblocks),
@@ -34,6 +36,9 @@ struct Conv2dArgs {
   int Cin, H, W, CoutP, Ho, Wo;
   int stride, pad, relu /* 0 none, 1 ReLU, 2 erf-GELU, 3 ReLU after the residual */, ups, out_ctotal, out_coff;
   const float* res = nullptr;  // optional residual, same layout as y, added after the activation
+  // three-term operand form of the weights + per-row unscale (conv_h3_kernels.h), set by the ABI entries when the prepared buffer carries it
+  const unsigned char* w3 = nullptr;
+  const float* wsc = nullptr;
 };
 
 // TY = 8 (round 4): a wave owns TWO 32 x 32 accumulators (the same 32 output channels on two groups of four output rows), so the
@@ -531,7 +536,48 @@ __global__ __launch_bounds__(256) void conv3x3_f16s_kernel(const Conv2dArgs a) {
   }
 }
 
+}  // namespace gc
+#include "conv_h3_kernels.h"
+namespace gc {
+
+// default arithmetic mode: the three-term f16-pipe kernels for every shape whose prepared buffer carries the operand form
+template <int KH, int KW, int TY, int KS, int NSUB>
+inline int conv2d_h3l_launch(const Conv2dArgs& a, dim3 grid, hipStream_t st) {
+  using G = H3L<KH, KW, TY, KS, NSUB>;
+  static bool attr_set = false;   // (idempotent: a race sets it twice)
+  if (!attr_set) {
+    GC_HIP(hipFuncSetAttribute((const void*)conv2d_h3l_kernel<KH, KW, TY, KS, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
+    attr_set = true;
+  }
+  conv2d_h3l_kernel<KH, KW, TY, KS, NSUB><<<grid, 256, G::SMEM, st>>>(a);
+  return GC_OK;
+}
+inline int conv2d_h3_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_t st) {
+  const int cb = (a.CoutP + 63) / 64;
+  const long long tiles8 = (long long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+  const bool s2 = a.stride == 2;
+  const bool ty8 = !s2 && a.Ho >= 8 && tiles8 * cb * N >= 512;   // 8-row tiles while they still give every CU its two resident workgroups
+  const int tiles = ty8 ? (int)tiles8 : ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
+  const dim3 grid(tiles, cb, N);
+  if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv2d: too many channel tiles / samples");
+  GC_KLOG("conv2d_h3_kernel");
+  TimedLaunch tl(KF_CONV2D, st, 2.0 * N * a.Ho * a.Wo * (double)a.CoutP * a.Cin * KH * KW);   // algorithmic FLOPs (bench.py --workload train)
+  int rc = GC_OK;
+  if (KH == 3 && s2) conv2d_h3_kernel<3, 3, 2, 4, 1><<<grid, 256, 0, st>>>(a);
+  else if (KH == 3) rc = ty8 ? conv2d_h3l_launch<3, 3, 8, 1, 3>(a, grid, st) : conv2d_h3l_launch<3, 3, 4, 1, 3>(a, grid, st);
+  else if (KH == 1) rc = ty8 ? conv2d_h3l_launch<1, 1, 8, 2, 1>(a, grid, st) : conv2d_h3l_launch<1, 1, 4, 2, 1>(a, grid, st);
+  else rc = ty8 ? conv2d_h3l_launch<2, 2, 8, 1, 2>(a, grid, st) : conv2d_h3l_launch<2, 2, 4, 1, 2>(a, grid, st);
+  if (rc != GC_OK) return rc;
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
 inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_t st) {
+  {
+    const Modes md = modes_snapshot();
+    const bool shape = (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2)) || (KH == 1 && KW == 1 && a.stride == 1) || (KH == 2 && KW == 2 && a.stride == 1);
+    if (a.w3 != nullptr && shape && md.split() && !md.split2()) return conv2d_h3_enqueue(a, N, KH, KW, st);
+  }
   if (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2) && a.ups == 1 && a.Cin % 8 == 0 && a.CoutP >= 32 && modes_snapshot().split2()) {
     const int tiles3 = ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
     const dim3 g3(tiles3, (a.CoutP + 63) / 64, N);

@@ -673,11 +673,37 @@ int gencomm_pillar_encode_fwd(const float* voxel_features, const int* voxel_num_
 int gencomm_conv2d_prepare(const float* weight, float* prepared, int Cin, int Cout, int KH, int KW, int transposed, void* stream) {
   GC_CHECK_ARG(weight && prepared, "null pointer");
   GC_CHECK_ARG(Cin >= 1 && Cout >= 1 && KH >= 1 && KW >= 1, "bad Cin/Cout/KH/KW");
+  GC_CHECK_ARG(transposed >= 0 && transposed <= 2, "transposed: 0 (Conv2d), 1 (ConvTranspose2d, kernel == stride) or 2 (input-gradient convolution)");
   const long long total = (long long)Cin * Cout * KH * KW;
+  const int M = transposed == 1 ? Cout * KH * KW : Cout, T = transposed == 1 ? 1 : KH * KW;
+  if (h3_eligible(Cin, M, transposed == 1 ? 1 : KH, transposed == 1 ? 1 : KW)) {   // row scales, then both forms in one launch: fp32 k-major + three-term operand units
+    unsigned char* blob = reinterpret_cast<unsigned char*>(prepared + total);
+    PrepW3Args a{weight, prepared, blob, reinterpret_cast<float*>(blob + h3_blob_bytes(Cin, M, T)), Cin, Cout, KH, KW, transposed,
+                 M, T, h3_chunks(Cin), h3_blocks(M)};
+    GC_CHECK_ARG(a.nchunk <= 65535 && T <= 65535, "too many input-channel chunks");
+    conv_w3_rowscale_kernel<<<16 * a.nb, 256, 0, (hipStream_t)stream>>>(a);          // one wave per GEMM row
+    conv_prep_w3_kernel<<<dim3(a.nb, a.nchunk, T), 128, 0, (hipStream_t)stream>>>(a);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   PrepWArgs a{weight, prepared, Cin, Cout, KH, KW, transposed};
   conv_prep_w_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
   GC_HIP(hipGetLastError());
   return GC_OK;
+}
+long long gencomm_conv2d_prepared_floats(int Cin, int Cout, int KH, int KW, int transposed) {
+  if (Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || transposed < 0 || transposed > 2) {
+    fail(GC_ERR_ARG, "gencomm_conv2d_prepared_floats: bad dims");
+    return -1;
+  }
+  return conv2d_prepared_floats(Cin, Cout, KH, KW, transposed);
+}
+// the three-term operand form behind the fp32 form of a prepared buffer (present exactly for eligible GEMM shapes)
+static void conv2d_attach_w3(Conv2dArgs& a, const float* prepared, int KH, int KW) {
+  if (!h3_eligible(a.Cin, a.CoutP, KH, KW)) return;
+  const unsigned char* blob = reinterpret_cast<const unsigned char*>(prepared + (size_t)a.Cin * a.CoutP * KH * KW);
+  a.w3 = blob;
+  a.wsc = reinterpret_cast<const float*>(blob + h3_blob_bytes(a.Cin, a.CoutP, KH * KW));
 }
 
 int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const float* bn_running_mean, const float* bn_running_var,
@@ -706,6 +732,7 @@ int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale
   const int Ho = subpixel ? H : (H + 2 * pad - KH) / stride + 1, Wo = subpixel ? W : (W + 2 * pad - KW) / stride + 1;
   GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
   Conv2dArgs a{x, prepared, scale, shift, y, Cin, H, W, Cout * ups * ups, Ho, Wo, stride, pad, relu, ups, out_ctotal, out_coff};
+  conv2d_attach_w3(a, prepared, KH, KW);
   return conv2d_enqueue(a, N, KH, KW, (hipStream_t)stream);
 }
 // the same with act in {0 none, 1 ReLU, 2 erf-GELU, 3 ReLU applied AFTER the residual add} and an optional residual (layout of y)
@@ -717,6 +744,7 @@ int gencomm_conv2d_act_res_fwd(const float* x, const float* prepared, const floa
   GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
   Conv2dArgs a{x, prepared, scale, shift, y, Cin, H, W, Cout, Ho, Wo, stride, pad, act, 1, Cout, 0};
   a.res = residual;
+  conv2d_attach_w3(a, prepared, KH, KW);
   return conv2d_enqueue(a, N, KH, KW, (hipStream_t)stream);
 }
 

@@ -27,6 +27,22 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+_PREP_FLOATS: Dict[Tuple[int, int, int, int, int], int] = {}
+
+
+def conv2d_prepare(w: torch.Tensor, cin: int, cout: int, kh: int, kw: int, transposed: int, device: torch.device) -> torch.Tensor:
+    """gencomm_conv2d_prepare into a buffer of gencomm_conv2d_prepared_floats floats: the fp32 k-major matrix and, for the shapes the
+    f16-pipe kernel takes, the three-term operand form behind it (one launch).  `w`: contiguous fp32 in the layout `transposed` names."""
+    key = (cin, cout, kh, kw, int(transposed))
+    n = _PREP_FLOATS.get(key)
+    l = _lib.lib()
+    if n is None:
+        n = _PREP_FLOATS[key] = _lib.check_size(l.gencomm_conv2d_prepared_floats(*key), "gencomm_conv2d_prepared_floats")
+    prepared = torch.empty(n, dtype=torch.float32, device=device)
+    _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cin, cout, kh, kw, int(transposed), stream_ptr(device)), "gencomm_conv2d_prepare")
+    return prepared
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 

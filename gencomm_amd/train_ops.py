@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from .runtime import ptr, stream_ptr, zeros as pool_zeros
+from .runtime import conv2d_prepare, ptr, stream_ptr, zeros as pool_zeros
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -26,8 +26,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad: int
     n, cin, H, W = x.shape
     cout, _, kh, kw = w.shape
     l, st, dev = _lib.lib(), stream_ptr(x.device), x.device
-    prepared = torch.empty(w.numel(), dtype=torch.float32, device=dev)
-    _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cin, cout, kh, kw, 0, st), "gencomm_conv2d_prepare")
+    prepared = conv2d_prepare(w, cin, cout, kh, kw, 0, dev)
     unit = _unit_scale_shift(cout, dev)                     # scale 1; shift = the bias itself (or the cached zeros): no fold launch
     ss = (unit[0], _c(b) if b is not None else unit[1])
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
@@ -65,8 +64,7 @@ def conv2d_dgrad(dy: torch.Tensor, w: torch.Tensor, pad: int) -> torch.Tensor:
     cout, cin, kh, kw = w.shape            # forward weights: the gradient convolution maps cout -> cin channels
     n, _, H, W = dy.shape
     l, st, dev = _lib.lib(), stream_ptr(dy.device), dy.device
-    prepared = torch.empty(w.numel(), dtype=torch.float32, device=dev)
-    _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cout, cin, kh, kw, 2, st), "gencomm_conv2d_prepare")
+    prepared = conv2d_prepare(w, cout, cin, kh, kw, 2, dev)
     ss = _unit_scale_shift(cin, dev)
     p = kh - 1 - pad
     Ho, Wo = H + 2 * p - kh + 1, W + 2 * p - kw + 1
@@ -137,8 +135,7 @@ def _conv3x3_s2_dgrad_subpixel(dy: torch.Tensor, w: torch.Tensor) -> torch.Tenso
     dev = dy.device
     wp = s2_subpixel_weights(w)
     l, st = _lib.lib(), stream_ptr(dev)
-    prepared = torch.empty(wp.numel(), dtype=torch.float32, device=dev)
-    _lib.check(l.gencomm_conv2d_prepare(ptr(wp), ptr(prepared), cout, cin * 4, 2, 2, 0, st), "gencomm_conv2d_prepare")
+    prepared = conv2d_prepare(wp, cout, cin * 4, 2, 2, 0, dev)
     ss = _unit_scale_shift(cin, dev)
     dx = torch.empty(n, cin, 2 * Ho, 2 * Wo, dtype=torch.float32, device=dev)
     _lib.check(l.gencomm_conv2d_fwd(ptr(dy), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(dx), n, cout, Ho, Wo, cin, 2, 2, 1, 0, 0, 2, cin, 0, st),

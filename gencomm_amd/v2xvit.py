@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import _lib, train_ops as T
 from .fusion import MAX_AGENTS_PER_SCENE, gather_ego_thetas
-from .runtime import dev_ints, f32c, ptr, record_len_list, require_gpu, stream_ptr
+from .runtime import conv2d_prepare, dev_ints, f32c, ptr, record_len_list, require_gpu, stream_ptr
 
 
 # ----------------------------------------------------------------------------------------- parameter containers
@@ -173,8 +173,7 @@ class _LinearCache:
         w = f32c(w.detach())
         cout, cin = w.shape
         l, st = _lib.lib(), stream_ptr(device)
-        prepared = torch.empty(w.numel(), dtype=torch.float32, device=device)
-        _lib.check(l.gencomm_conv2d_prepare(ptr(w), ptr(prepared), cin, cout, 1, 1, 0, st), "gencomm_conv2d_prepare")
+        prepared = conv2d_prepare(w, cin, cout, 1, 1, 0, device)
         ss = torch.empty(2, cout, dtype=torch.float32, device=device)
         bb = f32c(b.detach()) if b is not None else None
         _lib.check(l.gencomm_conv2d_fold(None, None, None, None, ptr(bb), 0.0, cout, ptr(ss[0]), ptr(ss[1]), st), "gencomm_conv2d_fold")

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 9
+#define GENCOMM_ABI_VERSION 10
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -324,7 +324,10 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  * prepare: OIHW (transposed = 0), ConvTranspose2d IOHW with kernel == stride (transposed = 1), or (transposed = 2) the INPUT-GRADIENT
  *          convolution of a stride-1 layer straight from its forward OIHW weights (Cin = the forward's output channels, Cout = its input
  *          channels; taps flipped, channels transposed: what flip + transpose + contiguous + prepare did in four launches) -> k-major matrix
- *          [Cin*KH*KW][Cout] (resp. [Cin][Cout*KH*KW]) of the same number of floats.
+ *          [Cin*KH*KW][Cout] (resp. [Cin][Cout*KH*KW]) of the same number of floats, followed -- for GEMM shapes the f16-pipe kernel takes
+ *          (3x3 / 1x1 / 2x2, Cin >= 16, Cin % 8 == 0, >= 32 GEMM rows) -- by the three-term operand form of the weights and their per-row
+ *          power-of-two scales (csrc/conv_h3_kernels.h), written by the same launch.  `prepared` must hold
+ *          gencomm_conv2d_prepared_floats(Cin, Cout, KH, KW, transposed) floats (= Cin*Cout*KH*KW for the other shapes; -1: bad dims).
  * fold:    BatchNorm2d (eval) and/or conv bias -> per-channel scale/shift; pass NULL for the four BN tensors
  *          (and/or conv_bias) when absent.
  * fwd:     y[:, out_coff:out_coff+Cout] = act(conv(x) * scale + shift); supported: 3x3 stride 1|2 any pad, 1x1 stride 1;
@@ -333,10 +336,13 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  *          i.e. the input gradient of base_bev_backbone.py:57-63's stride-2 layers: GEMM row c*4 + a*2 + b = output channel c at
  *          pixel (2u + a, 2v + b), window = input rows u, u + 1 x columns v, v + 1 (zero beyond the map).
  *          y has out_ctotal channels (write into a slice of a concat buffer without a copy).
- *          Arithmetic follows GENCOMM_MODE_ARITH: 0 (default) and 1 = exact fp32 MFMA for every shape; 3 (opt-in) = 3x3 with
- *          Cin % 8 == 0 and 1x1 / ConvTranspose2d with >= 128 GEMM rows on the f16 matrix pipe from exact fp16 hi/lo operand splits
- *          (22-bit products, fp32 accumulation) with a running power-of-two activation scale: any finite fp32 input is safe. */
+ *          Arithmetic follows GENCOMM_MODE_ARITH: 0 (default) = shapes whose prepared buffer carries the three-term form run on the f16
+ *          matrix pipe with six matrix instructions per product block (operands split exactly into fp16 hi + fp16 lo + a third term:
+ *          products accurate to 2^-26, fp32 accumulation; activations under a running power-of-two scale, weights under a per-row one:
+ *          any finite fp32 input is safe), every other shape on the exact fp32 MFMA; 1 = exact fp32 MFMA for every shape; 3 (opt-in) =
+ *          3x3 with Cin % 8 == 0 and 1x1 / ConvTranspose2d with >= 128 GEMM rows from two-term splits (22-bit products). */
 int gencomm_conv2d_prepare(const float* weight, float* prepared, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
+long long gencomm_conv2d_prepared_floats(int Cin, int Cout, int KH, int KW, int transposed);
 int gencomm_conv2d_fold(const float* bn_weight, const float* bn_bias, const float* bn_running_mean, const float* bn_running_var,
                         const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream);
 int gencomm_conv2d_fwd(const float* x, const float* prepared, const float* scale, const float* shift, float* y,

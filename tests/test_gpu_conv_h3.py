@@ -1,0 +1,158 @@
+"""The general convolution on the f16 matrix pipe with three-term operands (csrc/conv_h3_kernels.h: the default kernel of
+gencomm_conv2d_fwd for 3x3 / 1x1 / 2x2 shapes with Cin >= 16, Cin % 8 == 0 and >= 32 GEMM rows) against float64 torch on the same
+inputs, beside the exact-fp32 kernel it replaces (GENCOMM_MODE_ARITH = 1): its error must stay at the level of fp32 accumulation --
+products are accurate to 2^-26 -- on ordinary activations, on gradient-sized inputs (the running power-of-two scale has to lift
+them), on inputs whose magnitude grows along the channel axis (the scale has to drop mid-sum and the accumulators follow), and on
+weights whose rows differ by many octaves (per-row weight scale).  Reference call sites: base_bev_backbone.py:40-92 (3x3 stride 1 / 2,
+ConvTranspose2d with kernel == stride), downsample_conv.py:17-24, the 1x1 heads of heter_model_baseline_w_gencomm_stage1.py:137-142."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _both(modes, fn):
+    """fn() under the default arithmetic (must run conv2d_h3_kernel) and under exact fp32 (must not)."""
+    from gencomm_amd import _lib
+    out = []
+    for arith in ("split", "f32"):
+        modes(arith=arith)
+        with _lib.kernel_log() as kl:
+            out.append(fn())
+        ran = any("conv2d_h3" in k for k in kl.counts)
+        assert ran == (arith == "split"), (arith, dict(kl.counts))
+    modes(arith="split")
+    return out
+
+
+def _check(y3, y32, ref, what):
+    scale = ref.abs().max().item()
+    e3 = (y3.double().cpu() - ref).abs().max().item() / scale
+    e32 = (y32.double().cpu() - ref).abs().max().item() / scale
+    assert torch.isfinite(y3).all(), what
+    assert e3 <= max(2.0 * e32, 4e-7) and e3 <= 3e-6, (what, e3, e32)
+    return e3, e32
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 64, 64, 40, 52, 1),      # backbone block, 8-row tiles off (few tiles)
+    (4, 64, 64, 128, 64, 1),     # 8-row tiles on: two accumulator groups per wave
+    (1, 24, 70, 19, 37, 1),      # Cin = 1.5 chunks (zero-padded tail), ragged output rows / columns, 70 rows = 3 partial blocks
+    (2, 128, 256, 16, 20, 1),    # many chunks
+    (2, 64, 128, 33, 47, 2),     # stride 2, odd sizes
+    (1, 384, 256, 32, 48, 1),    # shrink convolution: 24 chunks
+    (3, 16, 32, 9, 9, 1),        # the smallest eligible shape
+])
+def test_conv3x3_three_term_vs_float64(modes, shape):
+    from gencomm_amd import train_ops as T
+    N, Cin, Cout, H, W, stride = shape
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y3, y32 = _both(modes, lambda: T.conv2d(xd, wd, bd, 1, stride))
+    _check(y3, y32, ref, shape)
+
+
+@pytest.mark.parametrize("case", ["gradient_sized", "growing_along_channels", "row_scales", "zeros_then_data", "huge"])
+def test_three_term_ranges(modes, case):
+    from gencomm_amd import train_ops as T
+    g = torch.Generator().manual_seed(len(case))
+    N, Cin, Cout, H, W = 2, 96, 64, 24, 40
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 30.0
+    if case == "gradient_sized":
+        x = x * 3e-7
+    elif case == "growing_along_channels":          # every 16-channel chunk is 64 x larger than the one before: the scale drops five times mid-sum
+        x = x * (64.0 ** (torch.arange(Cin) // 16).float()).view(1, Cin, 1, 1) * 1e-6
+    elif case == "row_scales":                      # output rows 2^-20 .. 2^20 apart
+        w = w * (2.0 ** (torch.arange(Cout).float() - 32.0) ** 1).clamp(2.0 ** -20, 2.0 ** 20).view(Cout, 1, 1, 1)
+    elif case == "zeros_then_data":                 # the first chunks are exactly zero (no scale yet), one sample is all zero
+        x[:, :48] = 0.0
+        x[1] = 0.0
+    elif case == "huge":
+        x = x * 1e30
+        w = w * 1e-30
+    xd, wd = x.to(DEV), w.to(DEV)
+    y3, y32 = _both(modes, lambda: T.conv2d(xd, wd, None, 1))
+    if case == "row_scales":                        # judged per output channel: each row has its own magnitude
+        ref = F.conv2d(x.double(), w.double(), None, padding=1)
+        for co in (0, 17, 40, 63):
+            _check(y3[:, co], y32[:, co], ref[:, co], (case, co))
+    else:
+        _check(y3, y32, F.conv2d(x.double(), w.double(), None, padding=1), case)
+    if case == "zeros_then_data":
+        assert float(y3[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 256, (40, 52)), (128, 64, (130, 252)), (24, 70, (19, 37)), (384, 32, (16, 16)), (256, 14, (32, 32))])
+def test_conv1x1_three_term_vs_float64(modes, cin, cout, hw):
+    """1 x 1 (Linear layers, heads): two chunks per stage; residual, bias and a channel-slice destination; 14 rows is NOT eligible."""
+    from gencomm_amd import _lib, train_ops as T
+    g = torch.Generator().manual_seed(cin + cout)
+    n, (H, W) = 2, hw
+    x = torch.randn(n, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV)
+    if cout < 32:
+        with _lib.kernel_log() as kl:
+            y = T.conv2d(xd, wd, bd, 0)
+        assert not any("conv2d_h3" in k for k in kl.counts)
+        assert torch.allclose(y.double().cpu(), ref, rtol=1e-5, atol=2e-5)
+        return
+    y3, y32 = _both(modes, lambda: T.conv2d(xd, wd, bd, 0))
+    _check(y3, y32, ref, (cin, cout))
+    y3, y32 = _both(modes, lambda: T.conv2d(xd, wd, bd, 0, residual=rd))
+    _check(y3, y32, ref + res.double(), (cin, cout, "residual"))
+    buf = torch.full((n, cout + 5, H, W), -3.0, device=DEV)
+    T.conv2d(xd, wd, None, 0, out=buf, out_coff=2)
+    _check(buf[:, 2:2 + cout], buf[:, 2:2 + cout], F.conv2d(x.double(), w.double()), (cin, cout, "slice"))
+    assert bool((buf[:, :2] == -3.0).all()) and bool((buf[:, 2 + cout:] == -3.0).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 48), (1, 128, 64, 20, 36), (2, 256, 128, 16, 16)])
+def test_input_gradients_three_term_vs_float64(modes, shape):
+    """The input-gradient convolutions of the training step: stride 1 (flipped / transposed weights laid out by the prepare launch) and
+    stride 2 (2 x 2 sub-pixel form, GEMM rows = 4 x channels) against float64 autograd."""
+    from gencomm_amd import train_ops as T
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(H + W + Cin)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    for stride in (1, 2):
+        x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x, w.double(), None, stride=stride, padding=1)
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64) * 1e-4        # gradient-sized
+        y.backward(dy)
+        dyd, wd = dy.float().to(DEV), w.to(DEV)
+        d3, d32 = _both(modes, lambda: T.conv2d_dgrad_strided(dyd, wd, 1, stride, (H, W)))
+        assert d3.shape == x.grad.shape
+        _check(d3, d32, x.grad, (shape, stride))
+
+
+def test_deblock_transposed_convolution_three_term(modes):
+    """ConvTranspose2d with kernel == stride (base_bev_backbone.py:75-83) runs as a 1 x 1 GEMM with Cout s^2 rows + pixel shuffle."""
+    from gencomm_amd import _lib
+    from gencomm_amd.runtime import conv2d_prepare, ptr, stream_ptr
+    g = torch.Generator().manual_seed(3)
+    N, Cin, Cout, H, W, s = 2, 128, 64, 20, 28, 2
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, s, s, generator=g) / Cin ** 0.5
+    ref = F.conv_transpose2d(x.double(), w.double(), None, stride=s)
+    xd, wd = x.to(DEV), w.to(DEV)
+    ss = torch.stack([torch.ones(Cout), torch.zeros(Cout)]).to(DEV)
+
+    def run():
+        prepared = conv2d_prepare(wd, Cin, Cout, s, s, 1, xd.device)
+        y = torch.empty(N, Cout, H * s, W * s, device=DEV)
+        _lib.check(_lib.lib().gencomm_conv2d_fwd(ptr(xd), ptr(prepared), ptr(ss[0]), ptr(ss[1]), ptr(y), N, Cin, H, W, Cout, 1, 1, 1, 0, 0, s, Cout, 0,
+                                                 stream_ptr(xd.device)), "gencomm_conv2d_fwd")
+        return y
+    y3, y32 = _both(modes, run)
+    _check(y3, y32, ref, "deblock")
