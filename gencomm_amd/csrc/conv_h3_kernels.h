@@ -371,7 +371,7 @@ struct H3L {
 };
 
 template <int KH, int KW, int TY, int KS, int NSUB>
-__global__ __launch_bounds__(256, 2) void conv2d_h3l_kernel(const Conv2dArgs a) {
+__global__ __launch_bounds__(256, 2) void conv2d_h3l_kernel(const Conv2dArgs a, int tiles, int nsamp) {
   using G = H3L<KH, KW, TY, KS, NSUB>;
   constexpr int TX = G::TX, KHW = G::KHW, NA = G::NA, REC = G::REC, PW = G::PW, NPX = G::NPX, NIT = G::NIT, PIT = G::PIT;
   constexpr int NSTEP = G::NSTEP, SSTEP = G::SSTEP, WSLAB = G::WSLAB, BUF = G::BUF, NPIECE = SSTEP * 7;
@@ -381,9 +381,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3l_kernel(const Conv2dArgs a) 
   float (*s_max)[4] = reinterpret_cast<float (*)[4]>(h3l_smem + 2 * WSLAB + 2 * BUF);
   fp16_ovfl_clamp();
   const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  // 1-D launch, XCD-aware order (common.h): XCD k walks the k-th contiguous eighth of (tile fastest, then sample, then 64-channel block), so
+  // an XCD's workgroups share ONE or two channel blocks' weight slabs (L2-resident after the first touch: the 256-channel layers' 4 MB of
+  // operand units no longer compete in every L2) and neighbouring tiles' halos
+  const BlockId bid = xcd_block_dims(1, blockIdx.x, (unsigned)tiles, (unsigned)nsamp, gridDim.x);
+  const int cbi = bid.z, n = bid.y;
   const int tiles_x = (a.Wo + TX - 1) / TX;
-  const int ty0 = (blockIdx.x / tiles_x) * TY, tx0 = (blockIdx.x % tiles_x) * TX;
-  const int co0 = blockIdx.y * 64, n = blockIdx.z;
+  const int ty0 = (bid.x / tiles_x) * TY, tx0 = (bid.x % tiles_x) * TX;
+  const int co0 = cbi * 64;
   const int iy0 = ty0 - a.pad, ix0 = tx0 - a.pad;
   const size_t plane = (size_t)a.H * a.W;
   const float* __restrict__ xn = a.x + (size_t)n * a.Cin * plane;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3l_kernel(const Conv2dArgs a) 
   const int nb = h3_blocks(a.CoutP);
   const int nstage = (a.Cin + 16 * KS - 1) / (16 * KS), nsub = nstage * NSUB;
   const size_t ustride = (size_t)nb * H3_UNIT;
-  const unsigned char* __restrict__ wsrc = a.w3 + (size_t)blockIdx.y * H3_UNIT + l * 16;
+  const unsigned char* __restrict__ wsrc = a.w3 + (size_t)cbi * H3_UNIT + l * 16;
   // sub-stage u's slab -> weight buffer u & 1: piece p = 7 step + j, pieces dealt round-robin to the four waves (blob order: unit index =
   // matrix step index over the whole sum; past the last sub-stage the last one is re-read into a buffer nobody reads)
   auto dma_weights = [&](int u) {

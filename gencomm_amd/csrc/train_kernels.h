@@ -535,6 +535,10 @@ inline size_t wgrad3x3_wide_groups(int N, int Cin, int Cout, int Ho, int Wo, int
   // ~1 workgroup per CU over the whole launch (the kernel's residency), at least 4 tiles per workgroup
   long long chunk = std::max<long long>(4, (tiles * N * cblocks + 255) / 256);
   chunk = std::min(chunk, tiles);
+  // the per-sample rounding can push the launch just past 256 workgroups (24 x 2 x 6 = 288 on the stage-1 leg's 384-channel stride-2 layer:
+  // a second resident round of 32 workgroups doubled its 0.46 ms): between one and two rounds, lengthen the chunks until one round holds them
+  auto wgs = [&](long long c) { return (long long)N * ((tiles + c - 1) / c) * cblocks; };
+  while (wgs(chunk) > 256 && wgs(chunk) < 512 && chunk < tiles) ++chunk;
   if (chunk_out) *chunk_out = (int)chunk;
   return (size_t)N * (size_t)((tiles + chunk - 1) / chunk);
 }
