@@ -351,6 +351,22 @@ def train_main(args, rank, world, device, backend):
         barrier()
         for (name, where), c in sites.most_common(80):
             print(f"{c:5d}  {name:12s} {where}", file=sys.stderr)
+    if args.op_stacks:       # diagnostic: torch.profiler over one step -- the framework operators behind the fill / copy launches, with Python stacks
+        from torch.profiler import ProfilerActivity, profile
+        torch.autograd.set_multithreading_enabled(False)
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+            step()
+        torch.autograd.set_multithreading_enabled(True)
+        barrier()
+        import collections
+        agg = collections.Counter()
+        for e in prof.events():
+            if e.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::clone", "aten::zeros", "aten::zeros_like", "aten::contiguous", "aten::add_", "aten::add", "aten::mul"):
+                st = [f for f in (e.stack or []) if "site-packages" not in f and "dist-packages" not in f and "<built-in" not in f][:3]
+                shp = str(e.input_shapes[:1]) if e.input_shapes else ""
+                agg[(e.name, " <- ".join(x.split("/")[-1] for x in st) or "(autograd engine / C++)", shp)] += 1
+        for (name, where, shp), c in agg.most_common(70):
+            print(f"{c:5d}  {name:18s} {shp:28s} {where}"[:230], file=sys.stderr)
     if args.host_profile:    # diagnostic: cProfile of the host side of 10 steps (autograd on this thread), written to stderr
         import cProfile, io, pstats
         torch.autograd.set_multithreading_enabled(False)
@@ -448,6 +464,7 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
     ap.add_argument("--op-census", action="store_true", help="--workload train: call sites of the fill / zero / copy operators of one step (torch.profiler), to stderr")
+    ap.add_argument("--op-stacks", action="store_true", help="--workload train: torch.profiler over one step, fill / copy / add operators grouped by Python stack, to stderr")
     ap.add_argument("--host-profile", action="store_true", help="--workload train: cProfile of the host side of 10 untimed steps, to stderr")
     ap.add_argument("--sync-debug", action="store_true", help="run one untimed step under torch.cuda.set_sync_debug_mode('warn'): every host <-> device synchronisation warns with its stack")
     ap.add_argument("--grad-sync", choices=["flat", "ddp"], default="flat",

@@ -115,6 +115,10 @@ _SIGNATURES = {
     "gencomm_bn2d_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _i, _i, _i, _i, _p, _p]),
     "gencomm_bn2d_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_slot_max_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "gencomm_pfn_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_pfn_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gencomm_pfn_moment_doubles": (_ll, [_i]),
+    "gencomm_pfn_bwd_scratch_doubles": (_ll, [_i, _i]),
     "gencomm_slot_max_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "gencomm_dcn_sample_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_dcn_scatter_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -9,6 +9,7 @@
 #include "msgext_host.h"
 #include "noise_kernels.h"
 #include "pillar_kernels.h"
+#include "pfn_kernels.h"
 #include "train_kernels.h"
 #include "unet_bwd_host.h"
 #include "unet_host.h"
@@ -819,6 +820,43 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
 }
 
 // max over the P point slots of every pillar (training path of the PointPillars encoder): x [C][M][P] -> out [M][C], arg [M][C] (uint8)
+// PFNLayer in training mode without its [M P, C] intermediates (pfn_kernels.h).  F = 10 (the shipped encoder: 4 raw + 3 cluster + 3 centre
+// features) or 9 / 11 (no intensity / with distance); C in {32, 64, 128, 256}; P <= 255 (the arg slot is a byte)
+static int pfn_check(const char* who, int M, int P, int F, int C) {
+  if (!(M >= 1 && P >= 1 && P <= 255 && (F == 9 || F == 10 || F == 11) && (C == 32 || C == 64 || C == 128 || C == 256))) {
+    char b[160];
+    snprintf(b, sizeof b, "%s: supported: F in {9, 10, 11}, C in {32, 64, 128, 256}, P <= 255", who);
+    return fail(GC_ERR_ARG, b);
+  }
+  if ((size_t)(256 / C) * P * F * sizeof(float) > 64 * 1024) return fail(GC_ERR_ARG, "pfn: a block's pillars do not fit the LDS");
+  return GC_OK;
+}
+int gencomm_pfn_train_fwd(const float* feats, const float* weight, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, float momentum, float eps, float* out, unsigned char* arg, float* save, double* moments,
+                          int M, int P, int F, int C, void* stream) {
+  GC_CHECK_ARG(feats && weight && gamma && beta && out && arg && save && moments, "null pointer");
+  GC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or neither");
+  if (int rc = pfn_check("gencomm_pfn_train_fwd", M, P, F, C)) return rc;
+  PfnArgs a{feats, weight, gamma, beta, moments, save, M, P, F, C};
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 9) return pfn_train_fwd_t<9>(a, out, arg, running_mean, running_var, num_batches_tracked, momentum, eps, st);
+  if (F == 10) return pfn_train_fwd_t<10>(a, out, arg, running_mean, running_var, num_batches_tracked, momentum, eps, st);
+  return pfn_train_fwd_t<11>(a, out, arg, running_mean, running_var, num_batches_tracked, momentum, eps, st);
+}
+int gencomm_pfn_train_bwd(const float* feats, const float* weight, const float* gamma, const float* beta, const float* save, const double* moments,
+                          const float* gout, const unsigned char* arg, float* dweight, float* dgamma, float* dbeta, double* scratch,
+                          int M, int P, int F, int C, void* stream) {
+  GC_CHECK_ARG(feats && weight && gamma && beta && save && moments && gout && arg && scratch, "null pointer");
+  if (int rc = pfn_check("gencomm_pfn_train_bwd", M, P, F, C)) return rc;
+  PfnArgs a{feats, weight, gamma, beta, const_cast<double*>(moments), const_cast<float*>(save), M, P, F, C};
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 9) return pfn_train_bwd_t<9>(a, gout, arg, dweight, dgamma, dbeta, scratch, st);
+  if (F == 10) return pfn_train_bwd_t<10>(a, gout, arg, dweight, dgamma, dbeta, scratch, st);
+  return pfn_train_bwd_t<11>(a, gout, arg, dweight, dgamma, dbeta, scratch, st);
+}
+long long gencomm_pfn_moment_doubles(int F) { return F >= 1 && F <= PFN_MAXF ? (long long)pfn_moment_doubles(F) : -1; }
+long long gencomm_pfn_bwd_scratch_doubles(int F, int C) { return F >= 1 && F <= PFN_MAXF && C >= 1 ? (long long)PFN_BWD_BLOCKS * C * (F + 2) : -1; }
+
 int gencomm_slot_max_fwd(const float* x, float* out, unsigned char* arg, int C, int M, int P, void* stream) {
   GC_CHECK_ARG(x && out && arg && C >= 1 && M >= 0 && P >= 1 && P <= 255, "bad arguments");
   if (M == 0) return GC_OK;

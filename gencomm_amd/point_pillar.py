@@ -104,6 +104,48 @@ class _PillarNetFn(torch.autograd.Function):
                 dg if ctx.needs_input_grad[5] else None, db if ctx.needs_input_grad[6] else None)
 
 
+class _PillarNetFusedFn(torch.autograd.Function):
+    """The same layer in TRAINING mode (batch statistics) as two launches forward and two backward, without the [M P, 64] intermediates
+    (csrc/pfn_kernels.h: BatchNorm's statistics and the dense part of its backward follow exactly from the inputs' first and second
+    moments; ReLU(BN(.)) is monotone in the Linear output, so the slot max is taken on it).  feats [M, P, F] with masked slots zeroed."""
+
+    @staticmethod
+    def forward(ctx, feats, pfn, *params):
+        from .runtime import zeros as pool_zeros
+        l, dev = _lib.lib(), feats.device
+        M, P, F = feats.shape
+        w = f32c(pfn.linear.weight.detach())
+        bn = pfn.norm
+        C = w.shape[0]
+        gamma, beta = f32c(bn.weight.detach()), f32c(bn.bias.detach())
+        out = torch.empty(M, C, dtype=torch.float32, device=dev)
+        arg = torch.empty(M, C, dtype=torch.uint8, device=dev)
+        save = torch.empty(C, 2, dtype=torch.float32, device=dev)
+        moments = torch.empty(_lib.check_size(l.gencomm_pfn_moment_doubles(F), "gencomm_pfn_moment_doubles"), dtype=torch.float64, device=dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+        _lib.check(l.gencomm_pfn_train_fwd(ptr(feats), ptr(w), ptr(gamma), ptr(beta), ptr(bn.running_mean) if track else 0, ptr(bn.running_var) if track else 0,
+                                           ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None else 0, momentum, float(bn.eps),
+                                           ptr(out), ptr(arg), ptr(save), ptr(moments), M, P, F, C, stream_ptr(dev)), "gencomm_pfn_train_fwd")
+        ctx.pfn = pfn
+        ctx.save_for_backward(feats, w, gamma, beta, save, moments, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        feats, w, gamma, beta, save, moments, arg = ctx.saved_tensors
+        l, dev = _lib.lib(), feats.device
+        M, P, F = feats.shape
+        C = w.shape[0]
+        dw = torch.empty(C, F, dtype=torch.float32, device=dev)
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(_lib.check_size(l.gencomm_pfn_bwd_scratch_doubles(F, C), "gencomm_pfn_bwd_scratch_doubles"), dtype=torch.float64, device=dev)
+        _lib.check(l.gencomm_pfn_train_bwd(ptr(feats), ptr(w), ptr(gamma), ptr(beta), ptr(save), ptr(moments), ptr(f32c(gout)), ptr(arg),
+                                           ptr(dw), ptr(dg), ptr(db), ptr(scratch), M, P, F, C, stream_ptr(dev)), "gencomm_pfn_train_bwd")
+        return (None, None, dw if ctx.needs_input_grad[2] else None, dg if ctx.needs_input_grad[3] else None, db if ctx.needs_input_grad[4] else None)
+
+
 class PointPillar(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -112,6 +154,7 @@ class PointPillar(nn.Module):
         self.pillar_vfe = PillarVFE(args["pillar_vfe"], num_point_features=4, voxel_size=args["voxel_size"],
                                     point_cloud_range=args["lidar_range"])
         self.scatter = PointPillarScatter(args["point_pillar_scatter"])
+        self.fused_train_pfn = True     # False: the composed 1x1 convolution + BatchNorm + slot-max path (what the fused kernels are tested against)
 
     def _check_supported(self):
         v = self.pillar_vfe
@@ -146,8 +189,12 @@ class PointPillar(nn.Module):
             mask = (npts.view(-1, 1) > torch.arange(vf.shape[1], device=vf.device).view(1, -1)).unsqueeze(-1).to(vf.dtype)
             feats = torch.cat([vf, f_cluster, f_center], dim=-1) * mask                     # [M, P, 10]
             M, P, F = feats.shape
+        cout = pfn.linear.weight.shape[0]
+        if pfn.norm.training and F in (9, 10, 11) and cout in (32, 64, 128, 256) and P <= 255 and M > 0 and self.fused_train_pfn:
+            pillar = _PillarNetFusedFn.apply(feats.contiguous(), pfn, pfn.linear.weight, pfn.norm.weight, pfn.norm.bias)   # [M, 64]
+        else:
             x4 = feats.permute(2, 0, 1).reshape(1, F, 1, M * P).contiguous()               # channel-major point slots
-        pillar = _PillarNetFn.apply(x4, pfn, M, P, pfn.linear.weight, pfn.norm.weight, pfn.norm.bias)    # [M, 64]
+            pillar = _PillarNetFn.apply(x4, pfn, M, P, pfn.linear.weight, pfn.norm.weight, pfn.norm.bias)    # [M, 64]
         out = torch.zeros(batch_size, 64, self.scatter.ny * self.scatter.nx, dtype=vf.dtype, device=vf.device)
         idx = (coords[:, 1] + coords[:, 2] * self.scatter.nx + coords[:, 3]).long()
         out[coords[:, 0].long(), :, idx] = pillar

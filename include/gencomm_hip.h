@@ -538,6 +538,22 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
  * [1, C, 1, M P] point-slot layout (gencomm_conv2d_fwd / _wgrad), BatchNorm1d with batch statistics as gencomm_bn2d_train_*, and the
  * max over the P slots of a pillar here: x [C][M][P] -> out [M][C] with the arg-max slot (first maximum), backward = routing. */
 int gencomm_slot_max_fwd(const float* x, float* out, unsigned char* arg, int C, int M, int P, void* stream);
+/* The same layer in ONE piece for training mode (BatchNorm1d with batch statistics), without the [M P, C] intermediates (csrc/pfn_kernels.h):
+ * the statistics of the Linear output follow exactly from the inputs' first and second moments over all M P slots, ReLU(BN(.)) is
+ * monotone in the Linear output, and the dense part of BatchNorm's backward folds into the same moments -- two launches forward, two
+ * backward, instead of a 1x1 convolution, BatchNorm and slot-max over five 393-MB tensors at the stage-1 recipe's 48 000 pillars.
+ * feats [M][P][F] (slots beyond a pillar's point count zeroed, pillar_vfe.py:96-100), weight [C][F]; F in {9, 10, 11}, C in {32, 64, 128, 256},
+ * P <= 255.  fwd: out [M][C], arg [M][C] (the extreme slot), save [C][2] (mean, rstd), moments [gencomm_pfn_moment_doubles(F)] (kept for
+ * the backward); running statistics / num_batches_tracked updated as nn.BatchNorm1d does (may be null).  bwd: dweight [C][F], dgamma,
+ * dbeta WRITTEN (each may be null); scratch: gencomm_pfn_bwd_scratch_doubles(F, C) doubles (per-block partial sums, added up in a fixed order). */
+int gencomm_pfn_train_fwd(const float* feats, const float* weight, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, float momentum, float eps, float* out, unsigned char* arg, float* save, double* moments,
+                          int M, int P, int F, int C, void* stream);
+int gencomm_pfn_train_bwd(const float* feats, const float* weight, const float* gamma, const float* beta, const float* save, const double* moments,
+                          const float* gout, const unsigned char* arg, float* dweight, float* dgamma, float* dbeta, double* scratch,
+                          int M, int P, int F, int C, void* stream);
+long long gencomm_pfn_moment_doubles(int F);
+long long gencomm_pfn_bwd_scratch_doubles(int F, int C);
 int gencomm_slot_max_bwd(const float* dout, const unsigned char* arg, float* dx, int C, int M, int P, void* stream);
 
 /* Training path of MessageExtractorv2's deformable 3x3 convolution (message_extractor_v2.py:78,:108; DCNv1, padding 1, one offset

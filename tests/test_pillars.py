@@ -96,3 +96,39 @@ def test_hip_pillar_encoder_training_vs_torch_autograd(train_bn):
     for (k, b1), (_, b2) in zip(enc.named_buffers(), ref.named_buffers()):
         if b1.is_floating_point():
             assert_close(b1.cpu().numpy(), b2.cpu().numpy(), 1e-4, 1e-6, "running statistic " + k)
+
+
+@pytest.mark.gpu
+def test_fused_training_pfn_equals_the_composed_kernels_for_every_sign_of_gamma():
+    """csrc/pfn_kernels.h (statistics and BatchNorm's dense backward from the inputs' moments, slot max on the Linear output) against the
+    composed path it replaces (1x1 convolution, BatchNorm kernels, slot max: `fused_train_pfn = False`) on the same pillars: positive,
+    NEGATIVE (the extreme slot is the arg-MIN of the Linear output) and zero BatchNorm weights, output, all three gradients, the running
+    statistics and the batch counter."""
+    import copy
+    g, enc, pil = _setup()
+    enc = enc.to("cuda:0").train()
+    bn = enc.pillar_vfe.pfn_layers[0].norm
+    with torch.no_grad():
+        gen = torch.Generator().manual_seed(21)
+        bn.weight.copy_(torch.randn(64, generator=gen))          # both signs
+        bn.weight[5] = 0.0
+        bn.weight[17] = 0.0
+        bn.bias.copy_(torch.randn(64, generator=gen) * 0.5)
+    ref = copy.deepcopy(enc)
+    ref.fused_train_pfn = False
+    pil = {k: v.to("cuda:0") for k, v in pil.items()}
+    outs = []
+    for m in (enc, ref):
+        out = m({"inputs_m1": pil}, "m1")
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(8)).cuda()
+        (out * w).sum().backward()
+        outs.append(out.detach())
+    assert_close(outs[0].cpu().numpy(), outs[1].cpu().numpy(), 1e-5, 1e-6, "fused PFN output")
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        scale = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) <= 2e-4 * scale + 1e-7, (k, float((p.grad - q.grad).abs().max()), scale)
+    for (k, b1), (_, b2) in zip(enc.named_buffers(), ref.named_buffers()):
+        if b1.is_floating_point():
+            assert_close(b1.cpu().numpy(), b2.cpu().numpy(), 1e-5, 1e-7, "running statistic " + k)
+        else:
+            assert int(b1) == int(b2) == 1, k
