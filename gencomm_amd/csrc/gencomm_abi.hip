@@ -11,6 +11,7 @@
 #include "pillar_kernels.h"
 #include "pfn_kernels.h"
 #include "train_kernels.h"
+#include "wgrad_h3_kernels.h"
 #include "unet_bwd_host.h"
 #include "unet_host.h"
 

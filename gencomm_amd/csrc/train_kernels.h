@@ -683,6 +683,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_reduce_kernel(const Wgrad3x
     if (co < a.Cout) a.db[co] += v;
   }
 }
+int wgrad3x3_h3_launch(const Wgrad3x3Args& a, dim3 grid, hipStream_t st);   // wgrad_h3_kernels.h
 inline int wgrad3x3_wide_enqueue(const float* dy, const float* x, float* dw, float* db, int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo,
                                  int stride, int pad, float* scratch, hipStream_t st) {
   Wgrad3x3Args a{dy, x, dw, db, Cout, Cin, Ho, Wo, Hi, Wi, pad, 0, 0, 0, 0, scratch};
@@ -693,7 +694,11 @@ inline int wgrad3x3_wide_enqueue(const float* dy, const float* x, float* dw, flo
   a.chunks = (int)(groups / N);
   const dim3 grid((unsigned)groups, (Cout + 63) / 64, (Cin + 63) / 64);
   if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "wgrad 3x3: too many channel blocks");
-  if (stride == 1) wgrad3x3_wide_kernel<1, 2><<<grid, 256, 0, st>>>(a);
+  // stride 1 with scratch, default arithmetic: the three-term f16-pipe kernel (wgrad_h3_kernels.h: same tiles, same partial-sum layout)
+  const Modes md = modes_snapshot();
+  if (stride == 1 && scratch != nullptr && md.split() && !md.split2()) {
+    if (int rc = wgrad3x3_h3_launch(a, grid, st)) return rc;
+  } else if (stride == 1) wgrad3x3_wide_kernel<1, 2><<<grid, 256, 0, st>>>(a);
   else wgrad3x3_wide_kernel<2, 1><<<grid, 256, 0, st>>>(a);
   if (scratch != nullptr) {
     const int cop = (int)grid.y * 64, cip = (int)grid.z * 64;

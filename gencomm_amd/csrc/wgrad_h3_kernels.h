@@ -1,0 +1,278 @@
+// Weight gradient of a WIDE 3x3 stride-1 convolution on the f16 matrix pipe with three-term operands (round 5): the default behind
+// wgrad3x3_wide_enqueue when the caller gives scratch (train_kernels.h; the exact-fp32 kernel stays for stride 2, for
+// GENCOMM_MODE_ARITH = 1 and for the atomic form).  Same decomposition as wgrad3x3_wide_kernel<1, 2> -- a workgroup owns 64 output x 64
+// input channels and walks `chunk` pixel tiles of 2 rows x 32 columns of one sample, nine 32 x 32 accumulators per wave (one per tap),
+// partial sums stored per group and added up by wgrad3x3_wide_reduce_kernel -- with the matrix work of a tile cut from
+// 288 x 64 cycles (v_mfma_f32_32x32x2_f32) to 216 x 32 (v_mfma_f32_32x32x16_f16 / _bf8_bf8, six per product block).
+//
+//   dW[co][ci][ky][kx] = sum_{n, y, x} dY[n][co][y][x] X[n][ci][y + ky - pad][x + kx - pad]:  GEMM rows = co (A = dY), columns = ci (B = X),
+//   K = the tile's 64 pixels in four steps of 16 (a lane holds 8 CONSECUTIVE pixels of its row / column: both operands are pixel-contiguous).
+// Arithmetic as conv_h3_kernels.h: A takes the weight role (fp16 w1 + w2 + w3 exact, bf8 wb = bf8(v 2^-20)), B the activation role
+// (fp16 hi + lo, bf8 t = bf8(rest 2^20)); acc += w1 hi + w1 lo + w2 hi + w2 lo + w3 hi + wb t.  Both operands ride under RUNNING
+// power-of-two scales (largest |dY| resp. |X| seen so far by the workgroup in [2^13, 2^14): gradients are scaled up); when an
+// exponent grows the 144 accumulators are brought to the new scale with v_ldexp (exact).
+// The horizontal tap shift: a lane's 8 pixels for kx = 1 are one aligned 16-byte record of the X image (rows stored with an 8-pixel
+// left margin); for kx = 0 / 2 they straddle it by one pixel -- the record, the dword left and the dword right of it are read ONCE per
+// (ky, step) and the two shifted operands are formed with v_alignbit / v_alignbyte (14 vector instructions per 18 matrix instructions).
+#pragma once
+#include "conv8h_kernels.h"   // split3_pair, bf8x4, bf8x4s, half8_t
+#include "train_kernels.h"
+
+namespace gc {
+
+struct WgH3 {
+  static constexpr int SA = 144, SAB = 80;                 // bytes per dY row: fp16 planes (64 px + pad), bf8 plane
+  static constexpr int A_PLANE = 64 * SA, AB_PLANE = 64 * SAB;
+  static constexpr int SBR = 96, SB = 4 * SBR + 16;        // X: bytes per image row (48 px) and per channel (4 rows + pad) of an fp16 plane
+  static constexpr int STR = 48, ST = 4 * STR + 16;        // the same for the bf8 plane
+  static constexpr int B_PLANE = 64 * SB, BT_PLANE = 64 * ST;
+  static constexpr int OFF_A2 = A_PLANE, OFF_A3 = 2 * A_PLANE, OFF_AB = 3 * A_PLANE, OFF_BH = OFF_AB + AB_PLANE, OFF_BL = OFF_BH + B_PLANE,
+                       OFF_BT = OFF_BL + B_PLANE, OFF_MAX = OFF_BT + BT_PLANE, SMEM = OFF_MAX + 2 * 4 * 2 * 4;
+};
+
+__global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args a) {
+  using L = WgH3;
+  constexpr int TR = 2, TC = 32;
+  extern __shared__ __align__(16) unsigned char wg_smem[];
+  float (*s_max)[4][2] = reinterpret_cast<float (*)[4][2]>(wg_smem + L::OFF_MAX);   // [parity][wave][dY, X]
+  using f32x16t = __attribute__((ext_vector_type(16))) float;
+  fp16_ovfl_clamp();
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+  const int n = blockIdx.x / a.chunks, ck = blockIdx.x - n * a.chunks;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int mh = wv & 1, nh = wv >> 1;
+  const float* __restrict__ dyn = a.dy + (size_t)n * a.Cout * a.Ho * a.Wo;
+  const float* __restrict__ xn = a.x + (size_t)n * a.Cin * a.Hi * a.Wi;
+  f32x16t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  const int t_end = min((ck + 1) * a.chunk, a.tiles);
+
+  // staging: dY -- thread = (channel row tid / 4, 16 consecutive pixels of the tile's K order); X -- thread = (channel tid / 4, image row tid % 4):
+  // input columns ix0 .. ix0 + 33 (ix0 = ox0 - pad), i.e. one pixel of halo left and right of the 32 aligned ones
+  float va[16], vx[34];
+  const int srow = tid >> 2, seg = tid & 3;
+  auto load_tile = [&](int tile) {
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    {
+      const int co = co0 + srow, oy = oy0 + (seg >> 1), ox = ox0 + 16 * (seg & 1);
+      const bool row_ok = co < a.Cout && oy < a.Ho;
+      const float* __restrict__ pa = dyn + ((size_t)(row_ok ? co : 0) * a.Ho + (row_ok ? oy : 0)) * a.Wo + ox;
+      if (row_ok && ox + 16 <= a.Wo && (a.Wo & 3) == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+          const float4 u = *reinterpret_cast<const float4*>(pa + e);
+          va[e] = u.x; va[e + 1] = u.y; va[e + 2] = u.z; va[e + 3] = u.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) va[e] = (row_ok && ox + e < a.Wo) ? pa[e] : 0.f;
+      }
+    }
+    {
+      const int ci = ci0 + srow, iy = oy0 - a.pad + seg, ix0 = ox0 - a.pad;
+      const bool row_ok = ci < a.Cin && iy >= 0 && iy < a.Hi;
+      const float* __restrict__ px = xn + ((size_t)(row_ok ? ci : 0) * a.Hi + (row_ok ? iy : 0)) * a.Wi + ix0;
+      if (row_ok && ix0 + 1 >= 0 && ix0 + 33 <= a.Wi && ((ix0 + 1) & 3) == 0 && (a.Wi & 3) == 0) {
+#pragma unroll
+        for (int e = 0; e < 32; e += 4) {
+          const float4 u = *reinterpret_cast<const float4*>(px + 1 + e);
+          vx[1 + e] = u.x; vx[2 + e] = u.y; vx[3 + e] = u.z; vx[4 + e] = u.w;
+        }
+        vx[0] = ix0 >= 0 ? px[0] : 0.f;
+        vx[33] = ix0 + 33 < a.Wi ? px[33] : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 34; ++e) vx[e] = (row_ok && ix0 + e >= 0 && ix0 + e < a.Wi) ? px[e] : 0.f;
+      }
+    }
+  };
+
+  int eA = 0, eB = 0;            // exponents of the running scales 2^eA (dY), 2^eB (X); the accumulators hold sums of (dY 2^eA)(X 2^eB)
+  float runA = 0.f, runB = 0.f;
+  bool scaled = false;
+  auto exp_for = [](float run, int prev) {
+    if (!(run > 0.f) || !(run < 3.0e38f)) return prev;
+    int e;
+    (void)frexpf(run, &e);
+    return max(min(14 - e, 126), -126);
+  };
+
+  int tile = ck * a.chunk;
+  if (tile < t_end) load_tile(tile);
+  for (; tile < t_end; ++tile) {
+    // this tile's largest |dY| and |X| over the workgroup (published before the barrier that also retires the previous tile's matrix phase)
+    {
+      float ma = 0.f, mb = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ma = fmaxf(ma, fabsf(va[e]));
+#pragma unroll
+      for (int e = 0; e < 34; ++e) mb = fmaxf(mb, fabsf(vx[e]));
+      ma = wave_max_nonneg(ma);
+      mb = wave_max_nonneg(mb);
+      if (l == 0) { s_max[tile & 1][wv][0] = ma; s_max[tile & 1][wv][1] = mb; }
+    }
+    __syncthreads();
+    {
+      const float (*m)[2] = s_max[tile & 1];
+      runA = fmaxf(runA, fmaxf(fmaxf(m[0][0], m[1][0]), fmaxf(m[2][0], m[3][0])));
+      runB = fmaxf(runB, fmaxf(fmaxf(m[0][1], m[1][1]), fmaxf(m[2][1], m[3][1])));
+      const int nA = exp_for(runA, eA), nB = exp_for(runB, eB);
+      if (scaled && (nA != eA || nB != eB)) {     // an exponent grew: what is accumulated follows (exact)
+        const int d = (nA - eA) + (nB - eB);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][i] = ldexpf(acc[t][i], d);
+      }
+      eA = nA; eB = nB; scaled = true;
+    }
+    const float sA = ldexpf(1.0f, eA), sB = ldexpf(1.0f, eB);
+    {   // dY -> weight-role planes; the bias gradient's share of this tile
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += va[e];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      bsum += s;
+      uint32_t p1[8], p2[8], p3[8], pb[4];
+      constexpr float TS = 1.0f / HC_TSCALE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x0 = va[2 * i] * sA, x1 = va[2 * i + 1] * sA;
+        const half2_t h1 = __builtin_convertvector((float2_t){x0, x1}, half2_t);
+        const float r0 = x0 - (float)h1[0], r1 = x1 - (float)h1[1];
+        const half2_t h2 = __builtin_convertvector((float2_t){r0, r1}, half2_t);
+        const half2_t h3 = __builtin_convertvector((float2_t){r0 - (float)h2[0], r1 - (float)h2[1]}, half2_t);
+        p1[i] = __builtin_bit_cast(uint32_t, h1);
+        p2[i] = __builtin_bit_cast(uint32_t, h2);
+        p3[i] = __builtin_bit_cast(uint32_t, h3);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pb[i] = bf8x4(va[4 * i] * sA * TS, va[4 * i + 1] * sA * TS, va[4 * i + 2] * sA * TS, va[4 * i + 3] * sA * TS);
+      unsigned char* pa = wg_smem + srow * L::SA + 32 * seg;
+      *reinterpret_cast<uint4*>(pa) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+      *reinterpret_cast<uint4*>(pa + 16) = make_uint4(p1[4], p1[5], p1[6], p1[7]);
+      *reinterpret_cast<uint4*>(pa + L::OFF_A2) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+      *reinterpret_cast<uint4*>(pa + L::OFF_A2 + 16) = make_uint4(p2[4], p2[5], p2[6], p2[7]);
+      *reinterpret_cast<uint4*>(pa + L::OFF_A3) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+      *reinterpret_cast<uint4*>(pa + L::OFF_A3 + 16) = make_uint4(p3[4], p3[5], p3[6], p3[7]);
+      *reinterpret_cast<uint4*>(wg_smem + L::OFF_AB + srow * L::SAB + 16 * seg) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+    }
+    {   // X -> activation-role planes: stored pixel p = input column - ix0 + 7 (p = 7 .. 40; the 32 aligned ones at p = 8 .. 39)
+      uint32_t hi[17], lo[17];
+      float t[34];
+#pragma unroll
+      for (int i = 0; i < 17; ++i) split3_pair(vx[2 * i] * sB, vx[2 * i + 1] * sB, hi[i], lo[i], t[2 * i], t[2 * i + 1]);
+      // pairs are (vx[0], vx[1]), (vx[2], vx[3]) ...: stored pixel of vx[e] = 7 + e -- vx[1 .. 32] fill p = 8 .. 39, i.e. dword k of the aligned
+      // run holds (vx[1 + 2 k], vx[2 + 2 k]) = high half of pair k, low half of pair k + 1
+      unsigned char* ph = wg_smem + L::OFF_BH + srow * L::SB + seg * L::SBR;
+      unsigned char* pl = wg_smem + L::OFF_BL + srow * L::SB + seg * L::SBR;
+      unsigned char* pt = wg_smem + L::OFF_BT + srow * L::ST + seg * L::STR;
+      uint32_t dh[16], dl[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        dh[k] = __builtin_amdgcn_alignbit(hi[k + 1], hi[k], 16);
+        dl[k] = __builtin_amdgcn_alignbit(lo[k + 1], lo[k], 16);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<uint4*>(ph + 16 + 16 * q) = make_uint4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]);
+        *reinterpret_cast<uint4*>(pl + 16 + 16 * q) = make_uint4(dl[4 * q], dl[4 * q + 1], dl[4 * q + 2], dl[4 * q + 3]);
+      }
+      *reinterpret_cast<uint16_t*>(ph + 14) = (uint16_t)(hi[0] & 0xffffu);     // p = 7: vx[0], low half of pair 0
+      *reinterpret_cast<uint16_t*>(pl + 14) = (uint16_t)(lo[0] & 0xffffu);
+      *reinterpret_cast<uint16_t*>(ph + 80) = (uint16_t)(hi[16] >> 16);        // p = 40: vx[33], high half of pair 16
+      *reinterpret_cast<uint16_t*>(pl + 80) = (uint16_t)(lo[16] >> 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<uint2*>(pt + 8 + 8 * q) = make_uint2(bf8x4s(t[1 + 8 * q], t[2 + 8 * q], t[3 + 8 * q], t[4 + 8 * q]),
+                                                                bf8x4s(t[5 + 8 * q], t[6 + 8 * q], t[7 + 8 * q], t[8 + 8 * q]));
+      const uint32_t ends = bf8x4s(t[0], t[33], 0.f, 0.f);
+      pt[7] = (unsigned char)(ends & 0xffu);
+      pt[40] = (unsigned char)((ends >> 8) & 0xffu);
+    }
+    __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);
+
+    const unsigned char* __restrict__ pA = wg_smem + (32 * mh + r) * L::SA + 16 * h;            // + 32 s: 8 pixels of step s
+    const unsigned char* __restrict__ pAb = wg_smem + L::OFF_AB + (32 * mh + r) * L::SAB + 8 * h;
+    const unsigned char* __restrict__ pBh = wg_smem + L::OFF_BH + (32 * nh + r) * L::SB + 16 * h;
+    const unsigned char* __restrict__ pBl = wg_smem + L::OFF_BL + (32 * nh + r) * L::SB + 16 * h;
+    const unsigned char* __restrict__ pBt = wg_smem + L::OFF_BT + (32 * nh + r) * L::ST + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const half8_t w1 = *reinterpret_cast<const half8_t*>(pA + 32 * s);
+      const half8_t w2 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A2 + 32 * s);
+      const half8_t w3 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A3 + 32 * s);
+      const long wb = *reinterpret_cast<const long*>(pAb + 16 * s);
+      const int yr = s >> 1, xb = 32 * (s & 1);          // byte offset of the step's first column in an fp16 row (16 px = 32 B)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        // aligned record (kx = 1) at p = xc + 8, the dword left of it (p = xc + 6, xc + 7) and right of it (p = xc + 16, xc + 17)
+        const unsigned char* qh = pBh + (yr + ky) * L::SBR + xb + 16;
+        const unsigned char* ql = pBl + (yr + ky) * L::SBR + xb + 16;
+        const unsigned char* qt = pBt + (yr + ky) * L::STR + (xb >> 1) + 8;
+        const uint4 ch = *reinterpret_cast<const uint4*>(qh), cl = *reinterpret_cast<const uint4*>(ql);
+        const uint32_t hL = *reinterpret_cast<const uint32_t*>(qh - 4), hR = *reinterpret_cast<const uint32_t*>(qh + 16);
+        const uint32_t lL = *reinterpret_cast<const uint32_t*>(ql - 4), lR = *reinterpret_cast<const uint32_t*>(ql + 16);
+        const uint2 ct = *reinterpret_cast<const uint2*>(qt);
+        const uint32_t tL = *reinterpret_cast<const uint32_t*>(qt - 4), tR = *reinterpret_cast<const uint32_t*>(qt + 8);
+        const uint32_t h01 = __builtin_amdgcn_alignbit(ch.y, ch.x, 16), h12 = __builtin_amdgcn_alignbit(ch.z, ch.y, 16), h23 = __builtin_amdgcn_alignbit(ch.w, ch.z, 16);
+        const uint32_t l01 = __builtin_amdgcn_alignbit(cl.y, cl.x, 16), l12 = __builtin_amdgcn_alignbit(cl.z, cl.y, 16), l23 = __builtin_amdgcn_alignbit(cl.w, cl.z, 16);
+        half8_t bh[3], bl[3];
+        long bt[3];
+        bh[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(ch.x, hL, 16), h01, h12, h23));
+        bh[1] = __builtin_bit_cast(half8_t, ch);
+        bh[2] = __builtin_bit_cast(half8_t, make_uint4(h01, h12, h23, __builtin_amdgcn_alignbit(hR, ch.w, 16)));
+        bl[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(cl.x, lL, 16), l01, l12, l23));
+        bl[1] = __builtin_bit_cast(half8_t, cl);
+        bl[2] = __builtin_bit_cast(half8_t, make_uint4(l01, l12, l23, __builtin_amdgcn_alignbit(lR, cl.w, 16)));
+        bt[0] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(ct.x, tL, 3), __builtin_amdgcn_alignbyte(ct.y, ct.x, 3)));
+        bt[1] = __builtin_bit_cast(long, ct);
+        bt[2] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(ct.y, ct.x, 1), __builtin_amdgcn_alignbyte(tR, ct.y, 1)));
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(wb, bt[kx], acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, bl[kx], acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, bl[kx], acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+      }
+    }
+  }
+  // acc[t][reg]: row (co) = (reg & 3) + 8 (reg >> 2) + 4 h, column (ci) = r; stored per group as wgrad3x3_wide_kernel does
+  const int ci = ci0 + nh * 32 + r;
+  const size_t cop = (size_t)gridDim.y * 64, cip = (size_t)gridDim.z * 64;
+  float* __restrict__ pg = a.part + (size_t)blockIdx.x * cop * (9 * cip + 1);
+  const int un = -(eA + eB);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int co = co0 + mh * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pg[((size_t)co * 9 + t) * cip + ci] = ldexpf(acc[t][reg], un);   // 32 lanes = 128 contiguous bytes
+  }
+  if (blockIdx.z == 0 && seg == 0) pg[cop * 9 * cip + co0 + srow] = bsum;
+}
+
+inline int wgrad3x3_h3_launch(const Wgrad3x3Args& a, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;   // (idempotent: a race sets it twice)
+  if (!attr_set) {
+    GC_HIP(hipFuncSetAttribute((const void*)wgrad3x3_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WgH3::SMEM));
+    attr_set = true;
+  }
+  GC_KLOG("wgrad3x3_h3_kernel");
+  wgrad3x3_h3_kernel<<<grid, 256, WgH3::SMEM, st>>>(a);
+  return GC_OK;
+}
+
+}  // namespace gc

@@ -156,3 +156,46 @@ def test_deblock_transposed_convolution_three_term(modes):
         return y
     y3, y32 = _both(modes, run)
     _check(y3, y32, ref, "deblock")
+
+
+@pytest.mark.parametrize("shape,case", [
+    ((4, 64, 64, 128, 256), "plain"),            # the stage-1 leg's 64-channel level: aligned 128-bit loads, 8 tiles per workgroup
+    ((2, 128, 256, 32, 64), "gradient_sized"),   # dY ~ 1e-7: the running scale lifts it
+    ((2, 72, 40, 22, 40), "growing"),            # |dY| and |X| grow down the image: both scales drop mid-sum and the 144 accumulators follow
+    ((1, 64, 64, 17, 70), "ragged"),             # partial tiles in both directions, scalar loads
+    ((2, 64, 64, 24, 32), "zeros_first"),        # the first tiles of a workgroup are exactly zero (no scale yet)
+])
+def test_wide_weight_gradient_three_term_vs_float64(modes, shape, case):
+    """wgrad3x3_h3_kernel (csrc/wgrad_h3_kernels.h: the 3x3 stride-1 weight gradient on the f16 pipe, six matrix instructions per product
+    block, horizontal tap shifts formed from one aligned record with v_alignbit) against float64, beside the exact-fp32 kernel it replaces."""
+    from gencomm_amd import _lib, train_ops as T
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    if case == "gradient_sized":
+        dy = dy * 1e-7
+    elif case == "growing":
+        ramp = (10.0 ** torch.linspace(-5, 1, H)).view(1, 1, H, 1)
+        x, dy = x * ramp, dy * ramp * 1e-3
+    elif case == "zeros_first":
+        x[:, :, :8] = 0.0
+        dy[:, :, :6] = 0.0
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), stride=1, padding=1)
+    ref_b = dy.double().sum((0, 2, 3))
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    res = []
+    for arith in ("split", "f32"):
+        modes(arith=arith)
+        with _lib.kernel_log() as kl:
+            dw, db = T.conv2d_wgrad(dyd, xd, 3, 1, True, 1)
+        assert any("wgrad3x3_h3" in k for k in kl.counts) == (arith == "split"), dict(kl.counts)
+        res.append((dw.double().cpu(), db.double().cpu()))
+    modes(arith="split")
+    scale = ref_w.abs().max().item()
+    e3, e32 = (res[0][0] - ref_w).abs().max().item() / scale, (res[1][0] - ref_w).abs().max().item() / scale
+    assert torch.isfinite(res[0][0]).all() and e3 <= max(2.0 * e32, 4e-7) and e3 <= 3e-6, (shape, case, e3, e32)
+    for o in range(0, Cout, 7):                    # per output channel as well (each row has its own magnitude)
+        err = (res[0][0][o] - ref_w[o]).abs().max().item()
+        assert err <= 3e-6 * ref_w[o].abs().max().item() + 1e-12 * scale, (shape, case, o, err)
+    assert ((res[0][1] - ref_b).abs() <= 1e-6 * dy.double().abs().sum((0, 2, 3)) + 1e-30).all()
