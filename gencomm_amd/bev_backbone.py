@@ -331,11 +331,17 @@ class BaseBEVBackbone(nn.Module):
             chans = [seq[1].num_features for seq in list(self.deblocks)[:len(feats)]]
             s0 = self.deblocks[0][0].stride[0] if isinstance(self.deblocks[0][0], nn.ConvTranspose2d) else 1
             n, _, h0, w0 = feats[0].shape
-            x = torch.empty(n, sum(chans), h0 * s0, w0 * s0, dtype=torch.float32, device=feats[0].device)
-            off = 0
-            for i, f in enumerate(feats):
-                self._run_deblock(self.deblocks[i], f, out=x, coff=off)  # writes its slice of the concat
-                off += chans[i]
+            if torch.is_grad_enabled():
+                # gradient path: ONE concatenation whose backward hands out views.  Writing each deblock into its slice of a shared
+                # buffer is a differentiable slice assignment per deblock, and the backward of each of those clones the WHOLE 201-MB
+                # gradient of the concat and zero-fills a slice of it (three clones + three fills per step on the stage-1 leg)
+                x = torch.cat([self._run_deblock(self.deblocks[i], f) for i, f in enumerate(feats)], dim=1)
+            else:
+                x = torch.empty(n, sum(chans), h0 * s0, w0 * s0, dtype=torch.float32, device=feats[0].device)
+                off = 0
+                for i, f in enumerate(feats):
+                    self._run_deblock(self.deblocks[i], f, out=x, coff=off)  # writes its slice of the concat
+                    off += chans[i]
         if len(self.deblocks) > len(self.blocks):
             x = self._run_deblock(self.deblocks[-1], x)
         return x

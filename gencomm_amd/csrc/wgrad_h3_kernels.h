@@ -51,10 +51,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
   float bsum = 0.f;
   const int t_end = min((ck + 1) * a.chunk, a.tiles);
 
-  // staging: dY -- thread = (channel row tid / 4, 16 consecutive pixels of the tile's K order); X -- thread = (channel tid / 4, image row tid % 4):
-  // input columns ix0 .. ix0 + 33 (ix0 = ox0 - pad), i.e. one pixel of halo left and right of the 32 aligned ones
-  float va[16], vx[34];
+  // staging: dY -- thread = (channel row tid / 4, 16 consecutive pixels of the tile's K order); X -- the 256 (channel, image row) lines of the
+  // tile, 32 aligned input columns ix0 + 1 .. ix0 + 32 (ix0 = ox0 - pad) each: EIGHT lanes per line (a lane = 4 columns: one 128-byte
+  // line per 8 lanes, 8 lines per wave instruction -- one thread per line made every lane of a wave walk a cache line of its own and
+  // cost 12 k of the tile's 19 k cycles), line = 32 k + tid / 8 for k = 0 .. 7; the two halo columns (ix0, ix0 + 33) of line tid as scalars
+  float va[16], vx[8][4], vh[2];
+  unsigned xmask = 0u;   // bit k: line k of this thread is live (set by load_tile, applied where the values are used)
   const int srow = tid >> 2, seg = tid & 3;
+  const int xl = tid >> 3, xq = tid & 7;
   auto load_tile = [&](int tile) {
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = ty * TR, ox0 = tx * TC;
@@ -74,20 +78,33 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
       }
     }
     {
-      const int ci = ci0 + srow, iy = oy0 - a.pad + seg, ix0 = ox0 - a.pad;
-      const bool row_ok = ci < a.Cin && iy >= 0 && iy < a.Hi;
-      const float* __restrict__ px = xn + ((size_t)(row_ok ? ci : 0) * a.Hi + (row_ok ? iy : 0)) * a.Wi + ix0;
-      if (row_ok && ix0 + 1 >= 0 && ix0 + 33 <= a.Wi && ((ix0 + 1) & 3) == 0 && (a.Wi & 3) == 0) {
+      const int ix0 = ox0 - a.pad, iyb = oy0 - a.pad;
+      xmask = 0u;
+      const bool fast = ix0 + 1 >= 0 && ix0 + 33 <= a.Wi && ((ix0 + 1) & 3) == 0 && (a.Wi & 3) == 0;
 #pragma unroll
-        for (int e = 0; e < 32; e += 4) {
-          const float4 u = *reinterpret_cast<const float4*>(px + 1 + e);
-          vx[1 + e] = u.x; vx[2 + e] = u.y; vx[3 + e] = u.z; vx[4 + e] = u.w;
+      for (int k = 0; k < 8; ++k) {
+        const int line = 32 * k + xl, ci = ci0 + (line >> 2), iy = iyb + (line & 3);
+        const bool row_ok = ci < a.Cin && iy >= 0 && iy < a.Hi;
+        const float* __restrict__ px = xn + ((size_t)(row_ok ? ci : 0) * a.Hi + (row_ok ? iy : 0)) * a.Wi + (ix0 + 1 + 4 * xq);
+        if (fast) {          // branch-free: a line outside the image / beyond Cin reads (0, 0) of its sample and is zeroed when USED (xmask)
+          const float4 u = *reinterpret_cast<const float4*>(px);
+          vx[k][0] = u.x; vx[k][1] = u.y; vx[k][2] = u.z; vx[k][3] = u.w;
+          xmask |= (row_ok ? 1u : 0u) << k;
+        } else {
+          xmask |= 1u << k;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ix = ix0 + 1 + 4 * xq + e;
+            vx[k][e] = (row_ok && ix >= 0 && ix < a.Wi) ? px[e] : 0.f;
+          }
         }
-        vx[0] = ix0 >= 0 ? px[0] : 0.f;
-        vx[33] = ix0 + 33 < a.Wi ? px[33] : 0.f;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 34; ++e) vx[e] = (row_ok && ix0 + e >= 0 && ix0 + e < a.Wi) ? px[e] : 0.f;
+      }
+      {
+        const int ci = ci0 + (tid >> 2), iy = iyb + (tid & 3);
+        const bool row_ok = ci < a.Cin && iy >= 0 && iy < a.Hi;
+        const float* __restrict__ px = xn + ((size_t)(row_ok ? ci : 0) * a.Hi + (row_ok ? iy : 0)) * a.Wi + ix0;
+        vh[0] = (row_ok && ix0 >= 0 && ix0 < a.Wi) ? px[0] : 0.f;
+        vh[1] = (row_ok && ix0 + 33 >= 0 && ix0 + 33 < a.Wi) ? px[33] : 0.f;
       }
     }
   };
@@ -111,7 +128,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
 #pragma unroll
       for (int e = 0; e < 16; ++e) ma = fmaxf(ma, fabsf(va[e]));
 #pragma unroll
-      for (int e = 0; e < 34; ++e) mb = fmaxf(mb, fabsf(vx[e]));
+      for (int k = 0; k < 8; ++k) {
+        const float m4 = fmaxf(fmaxf(fabsf(vx[k][0]), fabsf(vx[k][1])), fmaxf(fabsf(vx[k][2]), fabsf(vx[k][3])));
+        mb = fmaxf(mb, ((xmask >> k) & 1u) ? m4 : 0.f);
+      }
+      mb = fmaxf(mb, fmaxf(fabsf(vh[0]), fabsf(vh[1])));
       ma = wave_max_nonneg(ma);
       mb = wave_max_nonneg(mb);
       if (l == 0) { s_max[tile & 1][wv][0] = ma; s_max[tile & 1][wv][1] = mb; }
@@ -164,37 +185,33 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
       *reinterpret_cast<uint4*>(wg_smem + L::OFF_AB + srow * L::SAB + 16 * seg) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
     }
     {   // X -> activation-role planes: stored pixel p = input column - ix0 + 7 (p = 7 .. 40; the 32 aligned ones at p = 8 .. 39)
-      uint32_t hi[17], lo[17];
-      float t[34];
 #pragma unroll
-      for (int i = 0; i < 17; ++i) split3_pair(vx[2 * i] * sB, vx[2 * i + 1] * sB, hi[i], lo[i], t[2 * i], t[2 * i + 1]);
-      // pairs are (vx[0], vx[1]), (vx[2], vx[3]) ...: stored pixel of vx[e] = 7 + e -- vx[1 .. 32] fill p = 8 .. 39, i.e. dword k of the aligned
-      // run holds (vx[1 + 2 k], vx[2 + 2 k]) = high half of pair k, low half of pair k + 1
-      unsigned char* ph = wg_smem + L::OFF_BH + srow * L::SB + seg * L::SBR;
-      unsigned char* pl = wg_smem + L::OFF_BL + srow * L::SB + seg * L::SBR;
-      unsigned char* pt = wg_smem + L::OFF_BT + srow * L::ST + seg * L::STR;
-      uint32_t dh[16], dl[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        dh[k] = __builtin_amdgcn_alignbit(hi[k + 1], hi[k], 16);
-        dl[k] = __builtin_amdgcn_alignbit(lo[k + 1], lo[k], 16);
+      for (int k = 0; k < 8; ++k) {
+        const int line = 32 * k + xl, ci = line >> 2, row = line & 3;
+        uint32_t h0, h1, l0, l1;
+        float t0, t1, t2, t3;
+        const bool lv = ((xmask >> k) & 1u) != 0u;
+        split3_pair(lv ? vx[k][0] * sB : 0.f, lv ? vx[k][1] * sB : 0.f, h0, l0, t0, t1);
+        split3_pair(lv ? vx[k][2] * sB : 0.f, lv ? vx[k][3] * sB : 0.f, h1, l1, t2, t3);
+        *reinterpret_cast<uint2*>(wg_smem + L::OFF_BH + ci * L::SB + row * L::SBR + 16 + 8 * xq) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(wg_smem + L::OFF_BL + ci * L::SB + row * L::SBR + 16 + 8 * xq) = make_uint2(l0, l1);
+        *reinterpret_cast<uint32_t*>(wg_smem + L::OFF_BT + ci * L::ST + row * L::STR + 8 + 4 * xq) = bf8x4s(t0, t1, t2, t3);
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<uint4*>(ph + 16 + 16 * q) = make_uint4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]);
-        *reinterpret_cast<uint4*>(pl + 16 + 16 * q) = make_uint4(dl[4 * q], dl[4 * q + 1], dl[4 * q + 2], dl[4 * q + 3]);
+      {   // the halo columns of line tid: p = 7 (the high half of its dword) and p = 40 (the low half)
+        uint32_t hh, ll;
+        float ta, tb;
+        split3_pair(vh[0] * sB, vh[1] * sB, hh, ll, ta, tb);
+        unsigned char* ph = wg_smem + L::OFF_BH + srow * L::SB + seg * L::SBR;
+        unsigned char* pl = wg_smem + L::OFF_BL + srow * L::SB + seg * L::SBR;
+        unsigned char* pt = wg_smem + L::OFF_BT + srow * L::ST + seg * L::STR;
+        *reinterpret_cast<uint16_t*>(ph + 14) = (uint16_t)(hh & 0xffffu);
+        *reinterpret_cast<uint16_t*>(pl + 14) = (uint16_t)(ll & 0xffffu);
+        *reinterpret_cast<uint16_t*>(ph + 80) = (uint16_t)(hh >> 16);
+        *reinterpret_cast<uint16_t*>(pl + 80) = (uint16_t)(ll >> 16);
+        const uint32_t ends = bf8x4s(ta, tb, 0.f, 0.f);
+        pt[7] = (unsigned char)(ends & 0xffu);
+        pt[40] = (unsigned char)((ends >> 8) & 0xffu);
       }
-      *reinterpret_cast<uint16_t*>(ph + 14) = (uint16_t)(hi[0] & 0xffffu);     // p = 7: vx[0], low half of pair 0
-      *reinterpret_cast<uint16_t*>(pl + 14) = (uint16_t)(lo[0] & 0xffffu);
-      *reinterpret_cast<uint16_t*>(ph + 80) = (uint16_t)(hi[16] >> 16);        // p = 40: vx[33], high half of pair 16
-      *reinterpret_cast<uint16_t*>(pl + 80) = (uint16_t)(lo[16] >> 16);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<uint2*>(pt + 8 + 8 * q) = make_uint2(bf8x4s(t[1 + 8 * q], t[2 + 8 * q], t[3 + 8 * q], t[4 + 8 * q]),
-                                                                bf8x4s(t[5 + 8 * q], t[6 + 8 * q], t[7 + 8 * q], t[8 + 8 * q]));
-      const uint32_t ends = bf8x4s(t[0], t[33], 0.f, 0.f);
-      pt[7] = (unsigned char)(ends & 0xffu);
-      pt[40] = (unsigned char)((ends >> 8) & 0xffu);
     }
     __syncthreads();
     if (tile + 1 < t_end) load_tile(tile + 1);
@@ -204,49 +221,95 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
     const unsigned char* __restrict__ pBh = wg_smem + L::OFF_BH + (32 * nh + r) * L::SB + 16 * h;
     const unsigned char* __restrict__ pBl = wg_smem + L::OFF_BL + (32 * nh + r) * L::SB + 16 * h;
     const unsigned char* __restrict__ pBt = wg_smem + L::OFF_BT + (32 * nh + r) * L::ST + 8 * h;
+    // 12 groups g = 3 s + ky of 18 matrix instructions; the LDS reads of group g + 1 (and the dY operands of the next step) are issued
+    // BETWEEN group g's matrix instructions (sched_group_barrier pins the interleave: one wave per SIMD, nobody else covers an LDS round
+    // trip -- left to the scheduler every group waited lgkmcnt for its own reads: ~11 k of a tile's 18 k cycles were not matrix work)
+    struct Raw { uint4 ch, cl; uint32_t hL, hR, lL, lR; uint2 ct; uint32_t tL, tR; };
+    struct AOp { half8_t w1, w2, w3; long wb; };
+    auto load_raw = [&](int g, Raw& q) {
+      const int s = g / 3, ky = g - 3 * s, yr = s >> 1, xb = 32 * (s & 1);     // xb: byte offset of the step's first column in an fp16 row
+      // aligned record (kx = 1) at p = xc + 8, the dword left of it (p = xc + 6, xc + 7) and right of it (p = xc + 16, xc + 17)
+      const unsigned char* qh = pBh + (yr + ky) * L::SBR + xb + 16;
+      const unsigned char* ql = pBl + (yr + ky) * L::SBR + xb + 16;
+      const unsigned char* qt = pBt + (yr + ky) * L::STR + (xb >> 1) + 8;
+      q.ch = *reinterpret_cast<const uint4*>(qh);
+      q.cl = *reinterpret_cast<const uint4*>(ql);
+      q.hL = *reinterpret_cast<const uint32_t*>(qh - 4);
+      q.hR = *reinterpret_cast<const uint32_t*>(qh + 16);
+      q.lL = *reinterpret_cast<const uint32_t*>(ql - 4);
+      q.lR = *reinterpret_cast<const uint32_t*>(ql + 16);
+      q.ct = *reinterpret_cast<const uint2*>(qt);
+      q.tL = *reinterpret_cast<const uint32_t*>(qt - 4);
+      q.tR = *reinterpret_cast<const uint32_t*>(qt + 8);
+    };
+    auto load_a = [&](int s, AOp& o) {
+      o.w1 = *reinterpret_cast<const half8_t*>(pA + 32 * s);
+      o.w2 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A2 + 32 * s);
+      o.w3 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A3 + 32 * s);
+      o.wb = *reinterpret_cast<const long*>(pAb + 16 * s);
+    };
+    Raw raw[2];
+    AOp aop[2];
+    load_a(0, aop[0]);
+    load_raw(0, raw[0]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const half8_t w1 = *reinterpret_cast<const half8_t*>(pA + 32 * s);
-      const half8_t w2 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A2 + 32 * s);
-      const half8_t w3 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A3 + 32 * s);
-      const long wb = *reinterpret_cast<const long*>(pAb + 16 * s);
-      const int yr = s >> 1, xb = 32 * (s & 1);          // byte offset of the step's first column in an fp16 row (16 px = 32 B)
+    for (int g = 0; g < 12; ++g) {
+      const int s = g / 3, ky = g - 3 * s;
+      if (g + 1 < 12) load_raw(g + 1, raw[(g + 1) & 1]);
+      if (ky == 2 && s + 1 < 4) load_a(s + 1, aop[(s + 1) & 1]);
+      const Raw& q = raw[g & 1];
+      const AOp& o = aop[s & 1];
+      const uint4 ch = q.ch, cl = q.cl;
+      const uint32_t h01 = __builtin_amdgcn_alignbit(ch.y, ch.x, 16), h12 = __builtin_amdgcn_alignbit(ch.z, ch.y, 16), h23 = __builtin_amdgcn_alignbit(ch.w, ch.z, 16);
+      const uint32_t l01 = __builtin_amdgcn_alignbit(cl.y, cl.x, 16), l12 = __builtin_amdgcn_alignbit(cl.z, cl.y, 16), l23 = __builtin_amdgcn_alignbit(cl.w, cl.z, 16);
+      half8_t bh[3], bl[3];
+      long bt[3];
+      bh[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(ch.x, q.hL, 16), h01, h12, h23));
+      bh[1] = __builtin_bit_cast(half8_t, ch);
+      bh[2] = __builtin_bit_cast(half8_t, make_uint4(h01, h12, h23, __builtin_amdgcn_alignbit(q.hR, ch.w, 16)));
+      bl[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(cl.x, q.lL, 16), l01, l12, l23));
+      bl[1] = __builtin_bit_cast(half8_t, cl);
+      bl[2] = __builtin_bit_cast(half8_t, make_uint4(l01, l12, l23, __builtin_amdgcn_alignbit(q.lR, cl.w, 16)));
+      bt[0] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(q.ct.x, q.tL, 3), __builtin_amdgcn_alignbyte(q.ct.y, q.ct.x, 3)));
+      bt[1] = __builtin_bit_cast(long, q.ct);
+      bt[2] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(q.ct.y, q.ct.x, 1), __builtin_amdgcn_alignbyte(q.tR, q.ct.y, 1)));
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        // aligned record (kx = 1) at p = xc + 8, the dword left of it (p = xc + 6, xc + 7) and right of it (p = xc + 16, xc + 17)
-        const unsigned char* qh = pBh + (yr + ky) * L::SBR + xb + 16;
-        const unsigned char* ql = pBl + (yr + ky) * L::SBR + xb + 16;
-        const unsigned char* qt = pBt + (yr + ky) * L::STR + (xb >> 1) + 8;
-        const uint4 ch = *reinterpret_cast<const uint4*>(qh), cl = *reinterpret_cast<const uint4*>(ql);
-        const uint32_t hL = *reinterpret_cast<const uint32_t*>(qh - 4), hR = *reinterpret_cast<const uint32_t*>(qh + 16);
-        const uint32_t lL = *reinterpret_cast<const uint32_t*>(ql - 4), lR = *reinterpret_cast<const uint32_t*>(ql + 16);
-        const uint2 ct = *reinterpret_cast<const uint2*>(qt);
-        const uint32_t tL = *reinterpret_cast<const uint32_t*>(qt - 4), tR = *reinterpret_cast<const uint32_t*>(qt + 8);
-        const uint32_t h01 = __builtin_amdgcn_alignbit(ch.y, ch.x, 16), h12 = __builtin_amdgcn_alignbit(ch.z, ch.y, 16), h23 = __builtin_amdgcn_alignbit(ch.w, ch.z, 16);
-        const uint32_t l01 = __builtin_amdgcn_alignbit(cl.y, cl.x, 16), l12 = __builtin_amdgcn_alignbit(cl.z, cl.y, 16), l23 = __builtin_amdgcn_alignbit(cl.w, cl.z, 16);
-        half8_t bh[3], bl[3];
-        long bt[3];
-        bh[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(ch.x, hL, 16), h01, h12, h23));
-        bh[1] = __builtin_bit_cast(half8_t, ch);
-        bh[2] = __builtin_bit_cast(half8_t, make_uint4(h01, h12, h23, __builtin_amdgcn_alignbit(hR, ch.w, 16)));
-        bl[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(cl.x, lL, 16), l01, l12, l23));
-        bl[1] = __builtin_bit_cast(half8_t, cl);
-        bl[2] = __builtin_bit_cast(half8_t, make_uint4(l01, l12, l23, __builtin_amdgcn_alignbit(lR, cl.w, 16)));
-        bt[0] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(ct.x, tL, 3), __builtin_amdgcn_alignbyte(ct.y, ct.x, 3)));
-        bt[1] = __builtin_bit_cast(long, ct);
-        bt[2] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(ct.y, ct.x, 1), __builtin_amdgcn_alignbyte(tR, ct.y, 1)));
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(o.wb, bt[kx], acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(wb, bt[kx], acc[ky * 3 + kx], 0, 0, 0);
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.w1, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.w1, bl[kx], acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, bl[kx], acc[ky * 3 + kx], 0, 0, 0);
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.w2, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.w2, bl[kx], acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, bl[kx], acc[ky * 3 + kx], 0, 0, 0);
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.w3, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+    }
+    // the interleave, in program order of the region: the first group's reads, then per group its 14 operand-forming instructions, (matrix, read)
+    // pairs for the next group's reads, the remaining matrix instructions
+    __builtin_amdgcn_sched_group_barrier(0x100, 13, 0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+      if (g == 11) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (g % 3 == 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+        }
       }
     }
   }
