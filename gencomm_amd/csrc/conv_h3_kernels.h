@@ -374,7 +374,7 @@ template <int KH, int KW, int TY, int KS, int NSUB>
 __global__ __launch_bounds__(256, 2) void conv2d_h3l_kernel(const Conv2dArgs a, int tiles, int nsamp) {
   using G = H3L<KH, KW, TY, KS, NSUB>;
   constexpr int TX = G::TX, KHW = G::KHW, NA = G::NA, REC = G::REC, PW = G::PW, NPX = G::NPX, NIT = G::NIT, PIT = G::PIT;
-  constexpr int NSTEP = G::NSTEP, SSTEP = G::SSTEP, WSLAB = G::WSLAB, BUF = G::BUF, NPIECE = SSTEP * 7;
+  constexpr int SSTEP = G::SSTEP, WSLAB = G::WSLAB, BUF = G::BUF, NPIECE = SSTEP * 7;
   extern __shared__ __align__(16) unsigned char h3l_smem[];
   unsigned char* const Wb = h3l_smem;
   unsigned char* const Ps = h3l_smem + 2 * WSLAB;
@@ -586,6 +586,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3l_kernel(const Conv2dArgs a, 
   const size_t oplane = (size_t)a.Ho * s * a.Wo * s;
   float* __restrict__ yn = a.y + ((size_t)n * a.out_ctotal + a.out_coff) * oplane;
   const float* __restrict__ rn = a.res != nullptr ? a.res + ((size_t)n * a.out_ctotal + a.out_coff) * oplane : nullptr;
+  if (KH == 2 && s == 2 && a.relu == 0 && rn == nullptr && (a.CoutP & 3) == 0) {
+    // sub-pixel form of a transposed 3x3 stride-2 convolution (the stride-2 layers' input gradient): GEMM row = 4 c + 2 a + b, so the four
+    // registers of a group (reg & 3) are the 2 x 2 output pixels of ONE channel -- two 8-byte stores per channel and lane (16 lanes = one
+    // 128-byte run) instead of four 4-byte stores at stride 8 with two integer divisions each
+#pragma unroll
+    for (int g = 0; g < NA; ++g) {
+      const int oy = ty0 + 4 * g + pyl, ox = tx0 + pxl;
+      if (oy >= a.Ho || ox >= a.Wo) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gco = co0 + 32 * (wv & 1) + 8 * q + 4 * h;       // row of reg = 4 q (its channel's sub-pixel (0, 0))
+        if (gco >= a.CoutP) continue;
+        const int co = gco >> 2;
+        const float sc = a.scale[co], sh = a.shift[co];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf((acc[g][4 * q + j] + accT[g][4 * q + j]) * (a.wsc[gco + j] * inv_xs), sc, sh);
+        float* __restrict__ d = yn + (size_t)co * oplane + (size_t)(2 * oy) * (a.Wo * 2) + 2 * ox;
+        *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+        *reinterpret_cast<float2*>(d + a.Wo * 2) = make_float2(v[2], v[3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < NA; ++g) {
     const int oy = ty0 + 4 * g + pyl, ox = tx0 + pxl;

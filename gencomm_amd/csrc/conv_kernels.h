@@ -566,7 +566,7 @@ inline int conv2d_h3_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStre
   if (KH == 3 && s2) conv2d_h3_kernel<3, 3, 2, 4, 1><<<grid, 256, 0, st>>>(a);
   else if (KH == 3) rc = ty8 ? conv2d_h3l_launch<3, 3, 8, 1, 3>(a, grid, st) : conv2d_h3l_launch<3, 3, 4, 1, 3>(a, grid, st);
   else if (KH == 1) rc = ty8 ? conv2d_h3l_launch<1, 1, 8, 2, 1>(a, grid, st) : conv2d_h3l_launch<1, 1, 4, 2, 1>(a, grid, st);
-  else rc = ty8 ? conv2d_h3l_launch<2, 2, 8, 1, 2>(a, grid, st) : conv2d_h3l_launch<2, 2, 4, 1, 2>(a, grid, st);
+  else rc = ty8 ? conv2d_h3l_launch<2, 2, 8, 1, 1>(a, grid, st) : conv2d_h3l_launch<2, 2, 4, 1, 1>(a, grid, st);   // one sub-stage of four steps: 80 KB, still two workgroups per CU
   if (rc != GC_OK) return rc;
   GC_HIP(hipGetLastError());
   return GC_OK;
