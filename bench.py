@@ -351,6 +351,30 @@ def train_main(args, rank, world, device, backend):
         barrier()
         for (name, where), c in sites.most_common(80):
             print(f"{c:5d}  {name:12s} {where}", file=sys.stderr)
+    if args.dispatch_census:   # diagnostic: every ATen operator of one step as the dispatcher sees it (autograd-engine nodes included), with the
+        import collections, traceback   # innermost frame of this repository on the Python stack at that moment, to stderr
+        from torch.utils._python_dispatch import TorchDispatchMode
+        seen, allops = collections.Counter(), collections.Counter()
+
+        class Census(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, a=(), kw=None):
+                name = str(func).replace("aten.", "")
+                allops[name] += 1
+                if any(k in name for k in ("fill", "zero", "copy", "clone", "zeros", "add", "mul", "cat", "contiguous", "sum", "index", "select_backward", "slice_backward")):
+                    fr = [f for f in traceback.extract_stack(limit=40) if "/gencomm_amd/" in f.filename or f.filename.endswith("bench.py")]
+                    fr = [f for f in fr if f.name not in ("__torch_dispatch__",)]
+                    where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno} {f.name}" for f in fr[-2:][::-1]) or "?"
+                    shp = next((tuple(t.shape) for t in a if isinstance(t, torch.Tensor)), ())
+                    seen[(name, str(shp), where)] += 1
+                return func(*a, **(kw or {}))
+        torch.autograd.set_multithreading_enabled(False)
+        with Census():
+            step()
+        torch.autograd.set_multithreading_enabled(True)
+        barrier()
+        print("all operators of the step: " + ", ".join(f"{n} x{c}" for n, c in allops.most_common(60)), file=sys.stderr)
+        for (name, shp, where), c in seen.most_common(90):
+            print(f"{c:5d}  {name:28s} {shp:26s} {where}"[:250], file=sys.stderr)
     if args.op_stacks:       # diagnostic: torch.profiler over one step -- the framework operators behind the fill / copy launches, with Python stacks
         from torch.profiler import ProfilerActivity, profile
         torch.autograd.set_multithreading_enabled(False)
@@ -464,6 +488,7 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="with --gpus N > 1 on a 1-GPU box: every rank on cuda:0, gloo process group (launcher / DDP rehearsal, not a scaling number)")
     ap.add_argument("--op-census", action="store_true", help="--workload train: call sites of the fill / zero / copy operators of one step (torch.profiler), to stderr")
+    ap.add_argument("--dispatch-census", action="store_true", help="--workload train: ATen operators of one step at the dispatcher (fill / copy / add / ...), by shape and repository frame, to stderr")
     ap.add_argument("--op-stacks", action="store_true", help="--workload train: torch.profiler over one step, fill / copy / add operators grouped by Python stack, to stderr")
     ap.add_argument("--host-profile", action="store_true", help="--workload train: cProfile of the host side of 10 untimed steps, to stderr")
     ap.add_argument("--sync-debug", action="store_true", help="run one untimed step under torch.cuda.set_sync_debug_mode('warn'): every host <-> device synchronisation warns with its stack")

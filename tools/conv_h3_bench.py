@@ -13,6 +13,7 @@ from gencomm_amd.runtime import conv2d_prepare, ptr, stream_ptr
 dev = torch.device("cuda:0")
 l = _lib.lib()
 SHAPES = [  # N, Cin, Cout, H, W, K, stride
+    (4, 64, 64, 128, 256, 3, 1), (4, 128, 128, 64, 128, 3, 1), (4, 256, 256, 32, 64, 3, 1),   # the stage-1 leg's backbone levels (9.7 GFLOP each)
     (4, 64, 64, 128, 64, 3, 1), (4, 128, 128, 64, 32, 3, 1), (4, 256, 256, 32, 16, 3, 1), (4, 384, 256, 128, 64, 3, 1),
     (4, 64, 64, 256, 128, 3, 2), (4, 128, 128, 128, 64, 1, 1), (4, 256, 128, 64, 128, 1, 1), (4, 128, 512, 64, 128, 1, 1), (4, 64, 64, 200, 704, 3, 1),
 ]
