@@ -3,31 +3,35 @@
 // GENCOMM_MODE_ARITH = 1 and for the atomic form).  Same decomposition as wgrad3x3_wide_kernel<1, 2> -- a workgroup owns 64 output x 64
 // input channels and walks `chunk` pixel tiles of 2 rows x 32 columns of one sample, nine 32 x 32 accumulators per wave (one per tap),
 // partial sums stored per group and added up by wgrad3x3_wide_reduce_kernel -- with the matrix work of a tile cut from
-// 288 x 64 cycles (v_mfma_f32_32x32x2_f32) to 216 x 32 (v_mfma_f32_32x32x16_f16 / _bf8_bf8, six per product block).
+// 288 x 64 cycles (v_mfma_f32_32x32x2_f32) to 216 x 32 (v_mfma_f32_32x32x16_f16, six per product block).
 //
 //   dW[co][ci][ky][kx] = sum_{n, y, x} dY[n][co][y][x] X[n][ci][y + ky - pad][x + kx - pad]:  GEMM rows = co (A = dY), columns = ci (B = X),
 //   K = the tile's 64 pixels in four steps of 16 (a lane holds 8 CONSECUTIVE pixels of its row / column: both operands are pixel-contiguous).
-// Arithmetic as conv_h3_kernels.h: A takes the weight role (fp16 w1 + w2 + w3 exact, bf8 wb = bf8(v 2^-20)), B the activation role
-// (fp16 hi + lo, bf8 t = bf8(rest 2^20)); acc += w1 hi + w1 lo + w2 hi + w2 lo + w3 hi + wb t.  Both operands ride under RUNNING
+// Arithmetic as conv_h3_kernels.h with the third activation term carried in fp16 instead of bf8: A takes the weight role (fp16 w1 + w2 + w3
+// exact, wq = fp16(v 2^-20)), B the activation role (fp16 hi + lo, tq = fp16(rest 2^20): the rest is a power of two, exact);
+// acc += w1 hi + w1 lo + w2 hi + w2 lo + w3 hi + wq tq -- six instructions of ONE type per product block, the third term exact, all
+// seven operand planes of one shape (one staging / read / shift path).  (The nine accumulators of a wave take every term; the stale-SrcC
+// hazard between matrix instructions of different input types that conv8h_kernels.h orders its 16x16x32 instructions around does not
+// exist for the 32x32x16 forms -- tools/probes/mfma_mixed_dep32_probe.hip -- so this is a simplification, not a workaround.)
+// Both operands ride under RUNNING
 // power-of-two scales (largest |dY| resp. |X| seen so far by the workgroup in [2^13, 2^14): gradients are scaled up); when an
 // exponent grows the 144 accumulators are brought to the new scale with v_ldexp (exact).
 // The horizontal tap shift: a lane's 8 pixels for kx = 1 are one aligned 16-byte record of the X image (rows stored with an 8-pixel
 // left margin); for kx = 0 / 2 they straddle it by one pixel -- the record, the dword left and the dword right of it are read ONCE per
-// (ky, step) and the two shifted operands are formed with v_alignbit / v_alignbyte (14 vector instructions per 18 matrix instructions).
+// (ky, step) and the two shifted operands are formed with v_alignbit (15 vector instructions per 18 matrix instructions).
 #pragma once
-#include "conv8h_kernels.h"   // split3_pair, bf8x4, bf8x4s, half8_t
+#include "conv8h_kernels.h"   // split3_pair, half8_t, HC_TSCALE
 #include "train_kernels.h"
 
 namespace gc {
 
 struct WgH3 {
-  static constexpr int SA = 144, SAB = 80;                 // bytes per dY row: fp16 planes (64 px + pad), bf8 plane
-  static constexpr int A_PLANE = 64 * SA, AB_PLANE = 64 * SAB;
+  static constexpr int SA = 144;                           // bytes per dY row of an fp16 plane (64 px + pad)
+  static constexpr int A_PLANE = 64 * SA;                  // planes w1, w2, w3, wq
   static constexpr int SBR = 96, SB = 4 * SBR + 16;        // X: bytes per image row (48 px) and per channel (4 rows + pad) of an fp16 plane
-  static constexpr int STR = 48, ST = 4 * STR + 16;        // the same for the bf8 plane
-  static constexpr int B_PLANE = 64 * SB, BT_PLANE = 64 * ST;
-  static constexpr int OFF_A2 = A_PLANE, OFF_A3 = 2 * A_PLANE, OFF_AB = 3 * A_PLANE, OFF_BH = OFF_AB + AB_PLANE, OFF_BL = OFF_BH + B_PLANE,
-                       OFF_BT = OFF_BL + B_PLANE, OFF_MAX = OFF_BT + BT_PLANE, SMEM = OFF_MAX + 2 * 4 * 2 * 4;
+  static constexpr int B_PLANE = 64 * SB;                  // planes hi, lo, tq
+  static constexpr int OFF_A2 = A_PLANE, OFF_A3 = 2 * A_PLANE, OFF_A4 = 3 * A_PLANE, OFF_BH = 4 * A_PLANE, OFF_BL = OFF_BH + B_PLANE,
+                       OFF_BQ = OFF_BL + B_PLANE, OFF_MAX = OFF_BQ + B_PLANE, SMEM = OFF_MAX + 2 * 4 * 2 * 4;
 };
 
 __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args a) {
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       bsum += s;
-      uint32_t p1[8], p2[8], p3[8], pb[4];
+      uint32_t p1[8], p2[8], p3[8], p4[8];
       constexpr float TS = 1.0f / HC_TSCALE;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -172,9 +176,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
         p1[i] = __builtin_bit_cast(uint32_t, h1);
         p2[i] = __builtin_bit_cast(uint32_t, h2);
         p3[i] = __builtin_bit_cast(uint32_t, h3);
+        p4[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((float2_t){x0 * TS, x1 * TS}, half2_t));
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pb[i] = bf8x4(va[4 * i] * sA * TS, va[4 * i + 1] * sA * TS, va[4 * i + 2] * sA * TS, va[4 * i + 3] * sA * TS);
       unsigned char* pa = wg_smem + srow * L::SA + 32 * seg;
       *reinterpret_cast<uint4*>(pa) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
       *reinterpret_cast<uint4*>(pa + 16) = make_uint4(p1[4], p1[5], p1[6], p1[7]);
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
       *reinterpret_cast<uint4*>(pa + L::OFF_A2 + 16) = make_uint4(p2[4], p2[5], p2[6], p2[7]);
       *reinterpret_cast<uint4*>(pa + L::OFF_A3) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
       *reinterpret_cast<uint4*>(pa + L::OFF_A3 + 16) = make_uint4(p3[4], p3[5], p3[6], p3[7]);
-      *reinterpret_cast<uint4*>(wg_smem + L::OFF_AB + srow * L::SAB + 16 * seg) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+      *reinterpret_cast<uint4*>(pa + L::OFF_A4) = make_uint4(p4[0], p4[1], p4[2], p4[3]);
+      *reinterpret_cast<uint4*>(pa + L::OFF_A4 + 16) = make_uint4(p4[4], p4[5], p4[6], p4[7]);
     }
     {   // X -> activation-role planes: stored pixel p = input column - ix0 + 7 (p = 7 .. 40; the 32 aligned ones at p = 8 .. 39)
 #pragma unroll
@@ -195,7 +199,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
         split3_pair(lv ? vx[k][2] * sB : 0.f, lv ? vx[k][3] * sB : 0.f, h1, l1, t2, t3);
         *reinterpret_cast<uint2*>(wg_smem + L::OFF_BH + ci * L::SB + row * L::SBR + 16 + 8 * xq) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(wg_smem + L::OFF_BL + ci * L::SB + row * L::SBR + 16 + 8 * xq) = make_uint2(l0, l1);
-        *reinterpret_cast<uint32_t*>(wg_smem + L::OFF_BT + ci * L::ST + row * L::STR + 8 + 4 * xq) = bf8x4s(t0, t1, t2, t3);
+        *reinterpret_cast<uint2*>(wg_smem + L::OFF_BQ + ci * L::SB + row * L::SBR + 16 + 8 * xq) =
+            make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector((float2_t){t0 * HC_TSCALE, t1 * HC_TSCALE}, half2_t)),
+                       __builtin_bit_cast(uint32_t, __builtin_convertvector((float2_t){t2 * HC_TSCALE, t3 * HC_TSCALE}, half2_t)));
       }
       {   // the halo columns of line tid: p = 7 (the high half of its dword) and p = 40 (the low half)
         uint32_t hh, ll;
@@ -203,50 +209,49 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
         split3_pair(vh[0] * sB, vh[1] * sB, hh, ll, ta, tb);
         unsigned char* ph = wg_smem + L::OFF_BH + srow * L::SB + seg * L::SBR;
         unsigned char* pl = wg_smem + L::OFF_BL + srow * L::SB + seg * L::SBR;
-        unsigned char* pt = wg_smem + L::OFF_BT + srow * L::ST + seg * L::STR;
+        unsigned char* pq = wg_smem + L::OFF_BQ + srow * L::SB + seg * L::SBR;
+        const uint32_t qq = __builtin_bit_cast(uint32_t, __builtin_convertvector((float2_t){ta * HC_TSCALE, tb * HC_TSCALE}, half2_t));
         *reinterpret_cast<uint16_t*>(ph + 14) = (uint16_t)(hh & 0xffffu);
         *reinterpret_cast<uint16_t*>(pl + 14) = (uint16_t)(ll & 0xffffu);
+        *reinterpret_cast<uint16_t*>(pq + 14) = (uint16_t)(qq & 0xffffu);
         *reinterpret_cast<uint16_t*>(ph + 80) = (uint16_t)(hh >> 16);
         *reinterpret_cast<uint16_t*>(pl + 80) = (uint16_t)(ll >> 16);
-        const uint32_t ends = bf8x4s(ta, tb, 0.f, 0.f);
-        pt[7] = (unsigned char)(ends & 0xffu);
-        pt[40] = (unsigned char)((ends >> 8) & 0xffu);
+        *reinterpret_cast<uint16_t*>(pq + 80) = (uint16_t)(qq >> 16);
       }
     }
     __syncthreads();
     if (tile + 1 < t_end) load_tile(tile + 1);
 
     const unsigned char* __restrict__ pA = wg_smem + (32 * mh + r) * L::SA + 16 * h;            // + 32 s: 8 pixels of step s
-    const unsigned char* __restrict__ pAb = wg_smem + L::OFF_AB + (32 * mh + r) * L::SAB + 8 * h;
     const unsigned char* __restrict__ pBh = wg_smem + L::OFF_BH + (32 * nh + r) * L::SB + 16 * h;
     const unsigned char* __restrict__ pBl = wg_smem + L::OFF_BL + (32 * nh + r) * L::SB + 16 * h;
-    const unsigned char* __restrict__ pBt = wg_smem + L::OFF_BT + (32 * nh + r) * L::ST + 8 * h;
+    const unsigned char* __restrict__ pBq = wg_smem + L::OFF_BQ + (32 * nh + r) * L::SB + 16 * h;
     // 12 groups g = 3 s + ky of 18 matrix instructions; the LDS reads of group g + 1 (and the dY operands of the next step) are issued
     // BETWEEN group g's matrix instructions (sched_group_barrier pins the interleave: one wave per SIMD, nobody else covers an LDS round
     // trip -- left to the scheduler every group waited lgkmcnt for its own reads: ~11 k of a tile's 18 k cycles were not matrix work)
-    struct Raw { uint4 ch, cl; uint32_t hL, hR, lL, lR; uint2 ct; uint32_t tL, tR; };
-    struct AOp { half8_t w1, w2, w3; long wb; };
+    struct Raw { uint4 ch, cl, cq; uint32_t hL, hR, lL, lR, qL, qR; };
+    struct AOp { half8_t w1, w2, w3, wq; };
     auto load_raw = [&](int g, Raw& q) {
       const int s = g / 3, ky = g - 3 * s, yr = s >> 1, xb = 32 * (s & 1);     // xb: byte offset of the step's first column in an fp16 row
       // aligned record (kx = 1) at p = xc + 8, the dword left of it (p = xc + 6, xc + 7) and right of it (p = xc + 16, xc + 17)
       const unsigned char* qh = pBh + (yr + ky) * L::SBR + xb + 16;
       const unsigned char* ql = pBl + (yr + ky) * L::SBR + xb + 16;
-      const unsigned char* qt = pBt + (yr + ky) * L::STR + (xb >> 1) + 8;
+      const unsigned char* qq = pBq + (yr + ky) * L::SBR + xb + 16;
       q.ch = *reinterpret_cast<const uint4*>(qh);
       q.cl = *reinterpret_cast<const uint4*>(ql);
+      q.cq = *reinterpret_cast<const uint4*>(qq);
       q.hL = *reinterpret_cast<const uint32_t*>(qh - 4);
       q.hR = *reinterpret_cast<const uint32_t*>(qh + 16);
       q.lL = *reinterpret_cast<const uint32_t*>(ql - 4);
       q.lR = *reinterpret_cast<const uint32_t*>(ql + 16);
-      q.ct = *reinterpret_cast<const uint2*>(qt);
-      q.tL = *reinterpret_cast<const uint32_t*>(qt - 4);
-      q.tR = *reinterpret_cast<const uint32_t*>(qt + 8);
+      q.qL = *reinterpret_cast<const uint32_t*>(qq - 4);
+      q.qR = *reinterpret_cast<const uint32_t*>(qq + 16);
     };
     auto load_a = [&](int s, AOp& o) {
       o.w1 = *reinterpret_cast<const half8_t*>(pA + 32 * s);
       o.w2 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A2 + 32 * s);
       o.w3 = *reinterpret_cast<const half8_t*>(pA + L::OFF_A3 + 32 * s);
-      o.wb = *reinterpret_cast<const long*>(pAb + 16 * s);
+      o.wq = *reinterpret_cast<const half8_t*>(pA + L::OFF_A4 + 32 * s);
     };
     Raw raw[2];
     AOp aop[2];
@@ -259,22 +264,22 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
       if (ky == 2 && s + 1 < 4) load_a(s + 1, aop[(s + 1) & 1]);
       const Raw& q = raw[g & 1];
       const AOp& o = aop[s & 1];
-      const uint4 ch = q.ch, cl = q.cl;
+      const uint4 ch = q.ch, cl = q.cl, cq = q.cq;
+      const uint32_t q01 = __builtin_amdgcn_alignbit(cq.y, cq.x, 16), q12 = __builtin_amdgcn_alignbit(cq.z, cq.y, 16), q23 = __builtin_amdgcn_alignbit(cq.w, cq.z, 16);
       const uint32_t h01 = __builtin_amdgcn_alignbit(ch.y, ch.x, 16), h12 = __builtin_amdgcn_alignbit(ch.z, ch.y, 16), h23 = __builtin_amdgcn_alignbit(ch.w, ch.z, 16);
       const uint32_t l01 = __builtin_amdgcn_alignbit(cl.y, cl.x, 16), l12 = __builtin_amdgcn_alignbit(cl.z, cl.y, 16), l23 = __builtin_amdgcn_alignbit(cl.w, cl.z, 16);
-      half8_t bh[3], bl[3];
-      long bt[3];
+      half8_t bh[3], bl[3], bq[3];
       bh[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(ch.x, q.hL, 16), h01, h12, h23));
       bh[1] = __builtin_bit_cast(half8_t, ch);
       bh[2] = __builtin_bit_cast(half8_t, make_uint4(h01, h12, h23, __builtin_amdgcn_alignbit(q.hR, ch.w, 16)));
       bl[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(cl.x, q.lL, 16), l01, l12, l23));
       bl[1] = __builtin_bit_cast(half8_t, cl);
       bl[2] = __builtin_bit_cast(half8_t, make_uint4(l01, l12, l23, __builtin_amdgcn_alignbit(q.lR, cl.w, 16)));
-      bt[0] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(q.ct.x, q.tL, 3), __builtin_amdgcn_alignbyte(q.ct.y, q.ct.x, 3)));
-      bt[1] = __builtin_bit_cast(long, q.ct);
-      bt[2] = __builtin_bit_cast(long, make_uint2(__builtin_amdgcn_alignbyte(q.ct.y, q.ct.x, 1), __builtin_amdgcn_alignbyte(q.tR, q.ct.y, 1)));
+      bq[0] = __builtin_bit_cast(half8_t, make_uint4(__builtin_amdgcn_alignbit(cq.x, q.qL, 16), q01, q12, q23));
+      bq[1] = __builtin_bit_cast(half8_t, cq);
+      bq[2] = __builtin_bit_cast(half8_t, make_uint4(q01, q12, q23, __builtin_amdgcn_alignbit(q.qR, cq.w, 16)));
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(o.wb, bt[kx], acc[ky * 3 + kx], 0, 0, 0);
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wq, bq[kx], acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.w1, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
@@ -286,12 +291,12 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.w3, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
     }
-    // the interleave, in program order of the region: the first group's reads, then per group its 14 operand-forming instructions, (matrix, read)
+    // the interleave, in program order of the region: the first group's reads, then per group its 15 operand-forming instructions, (matrix, read)
     // pairs for the next group's reads, the remaining matrix instructions
     __builtin_amdgcn_sched_group_barrier(0x100, 13, 0);
 #pragma unroll
     for (int g = 0; g < 12; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);
       if (g == 11) {
         __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
       } else {

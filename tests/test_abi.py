@@ -176,7 +176,10 @@ def _mfma_hazard_violations(asm):
     forwarding and places such pairs back to back (tools/probes/mfma_mixed_dep_probe.hip). Returns the offending pairs: a
     dependent pair of different types with fewer than two other matrix instructions (>= 8 issue cycles) in between."""
     import re
-    pat = re.compile(r"^\s*(v_mfma_f32_16x16x32_(bf8_bf8|f16|bf16|fp8_fp8|bf8_fp8|fp8_bf8))\s+(v\[\d+:\d+\]),\s*\S+,\s*\S+,\s*(v\[\d+:\d+\]|0)")
+    # Only the 16x16x32 forms (4 passes): the 32x32x16 forms (8 passes: enh_front_h_kernel, the general convolution) give exact results at
+    # 0 wait states in both directions, alone and with 12 waves per SIMD (tools/probes/mfma_mixed_dep32_probe.hip,
+    # profiles/r5_mfma_mixed_dep32_probe.txt)
+    pat = re.compile(r"^\s*(v_mfma_f32_16x16x32_(bf8_bf8|f16|bf16|fp8_fp8|bf8_fp8|fp8_bf8))\s+([av]\[\d+:\d+\]),\s*\S+,\s*\S+,\s*([av]\[\d+:\d+\]|0)")
     bad = []
     for name, body in zip(*(lambda p: (p[1::2], p[2::2]))(re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", asm))):
         recent = []   # (type, dst) of the matrix instructions issued so far, newest last; cleared by anything that waits long
@@ -203,6 +206,7 @@ def test_code_object_keeps_mixed_type_matrix_instructions_apart(tmp_path):
     objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
     asm = "\n".join(subprocess.run([objdump, "-d", str(tmp_path / o)], check=True, capture_output=True, text=True).stdout for o in sorted(objs))
     assert "v_mfma_f32_16x16x32_bf8_bf8" in asm          # the third-term instruction of the three-term products is there
+    assert "v_mfma_f32_32x32x16_bf8_bf8" in asm          # ... and of the general convolution / wide weight gradient
     bad = _mfma_hazard_violations(asm)
     assert not bad, bad[:5]
     # the detector itself: the pair hipcc produced before the order was pinned
