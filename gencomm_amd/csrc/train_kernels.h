@@ -670,11 +670,19 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_reduce_kernel(const Wgrad3x
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= per) return;
   const float* __restrict__ p = a.part + i;
-  float s0 = 0.f, s1 = 0.f;
+  // eight loads in flight per thread (two were: 256 groups x 2 dependent chains made the launch latency-bound at 2 TB/s); the order of the
+  // additions is fixed by (group mod 8), so the result does not depend on the launch
+  float sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int g = 0;
-  for (; g + 1 < groups; g += 2) { s0 += p[(size_t)g * per]; s1 += p[(size_t)(g + 1) * per]; }
-  if (g < groups) s0 += p[(size_t)g * per];
-  const float v = s0 + s1;
+  for (; g + 7 < groups; g += 8) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = p[(size_t)(g + k) * per];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sv[k] += t[k];
+  }
+  for (int k = 0; g < groups; ++g, ++k) sv[k] += p[(size_t)g * per];
+  const float v = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
   if (i < (size_t)cop * 9 * cip) {
     const int ci = (int)(i % cip), t = (int)((i / cip) % 9), co = (int)(i / ((size_t)9 * cip));
     if (co < a.Cout && ci < a.Cin) a.dw[((size_t)co * a.Cin + ci) * 9 + t] += v;
