@@ -447,6 +447,7 @@ def train_main(args, rank, world, device, backend):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_train_baseline(B, N, 128, 64, 128, T, model)
     if rank == 0:
+        from gencomm_amd import _lib as _lib_modes
         d = crit.logging(0, args.steps - 1, args.steps)
         print(json.dumps({
             "metric": "train scenes/sec", "value": value, "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
@@ -455,6 +456,7 @@ def train_main(args, rank, world, device, backend):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train: stage-1 recipe (opv2v/GenComm_yamls/gencomm/stage1/m1_att.yaml), {N} agents/scene, {B} scene(s)/step/GPU, "
                                    f"512x256 pillars -> 128x64x128 BEV, GenComm T={T}, forward + backward + Adam",
+                       "modes": {k: int(_lib_modes.lib().gencomm_get_mode(v)) for k, v in (("arith", _lib_modes.MODE_ARITH), ("bwd_streams", _lib_modes.MODE_BWD_STREAMS))},
                        "parallelism": (f"dp{world} (DistributedDataParallel, find_unused_parameters=True)" if sync is None else
                                        f"dp{world} (one flat gradient bucket per step: cat -> all_reduce -> scale -> multi-tensor copy)"),
                        "grad_sync": args.grad_sync, "process_group": backend, "hip_graph": graph_note,
@@ -521,20 +523,20 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     backend = launch.backend()
+    from gencomm_amd import _lib, normalize_pairwise_tfm
+    lib = _lib.lib()
+    mode_keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
+                 "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP,
+                 "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU, "tile8": _lib.MODE_TILE8, "bwd_streams": _lib.MODE_BWD_STREAMS, "persist": _lib.MODE_PERSIST}
+    for kv in args.mode:      # (before the training leg branches off: until the end of round 5 `--mode` was applied behind it and the leg ignored it)
+        k, v = kv.split("=")
+        _lib.check(lib.gencomm_set_mode(mode_keys[k], int(v)), "gencomm_set_mode")
     if args.workload == "train":
         return train_main(args, rank, world, device, backend)
     dist = gdist.init_process_group(backend, device)  # RCCL; only the timing barrier/reduction use it
     red_dev = device if backend == "nccl" else torch.device("cpu")   # gloo reduces host scalars
 
-    from gencomm_amd import _lib, normalize_pairwise_tfm
     from gencomm_amd.pipeline import ScenePipeline
-    lib = _lib.lib()
-    mode_keys = {"arith": _lib.MODE_ARITH, "sampler": _lib.MODE_SAMPLER, "tile_want": _lib.MODE_TILE_WANT,
-                 "enh_fuse": _lib.MODE_ENH_FUSE, "conv8h_mask": _lib.MODE_CONV8H_MASK, "xcd": _lib.MODE_XCD_REMAP,
-                 "dataflow": _lib.MODE_DATAFLOW, "resfuse_emu": _lib.MODE_RESFUSE_EMU, "tile8": _lib.MODE_TILE8, "bwd_streams": _lib.MODE_BWD_STREAMS, "persist": _lib.MODE_PERSIST}
-    for kv in args.mode:
-        k, v = kv.split("=")
-        _lib.check(lib.gencomm_set_mode(mode_keys[k], int(v)), "gencomm_set_mode")
 
     N, C, H, W, T = WORKLOADS[args.workload]
     HW = H * W
