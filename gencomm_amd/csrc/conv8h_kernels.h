@@ -466,9 +466,15 @@ __device__ __forceinline__ void load_wa3(WA3& o, const float* __restrict__ tab, 
 // and the lo records fetched behind the hi passes -- 30 fewer live registers.
 // INIT: the accumulators are not read -- the first matrix instruction on each of them (the bf8 one of tap group 0) takes `init` as its
 // C operand instead (bias x scale for all eight: 28 register copies less per wave).  Not with DIAG, whose term mask may skip it.
-template <bool DIAG = false, bool LOWREG = false, bool INIT = false>
+// `early` (round 5): work that REQUESTS memory for later -- the identity residual's loads, the second source's tile -- runs here, BEHIND the
+// first weight-operand loads.  Return counters are in order: requested in front of the matrix phase (as until now) those HBM loads stood
+// in front of this phase's L1 / L2 weight loads, and the first matrix instruction waited for them (s_waitcnt vmcnt(8) with eight
+// weight loads behind eight residual loads) -- the "early request" bought no overlap at all.
+struct HcNoEarly { __device__ __forceinline__ void operator()() const {} };
+template <bool DIAG = false, bool LOWREG = false, bool INIT = false, class Early = HcNoEarly>
 __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const float* __restrict__ tab, f32x4 (&acc)[2][4],
-                                                const int (&off)[4][3], int lane, int mask = 63, f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f}) {
+                                                const int (&off)[4][3], int lane, int mask = 63, f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f},
+                                                Early early = Early()) {
   static_assert(!(DIAG && INIT), "the diagnostic term mask needs initialised accumulators");
   // ORDER MATTERS.  On gfx950 a v_mfma_f32_16x16x32_f16 issued fewer than 6 wait states after a v_mfma_f32_16x16x32_bf8_bf8
   // whose result it accumulates onto (or the other way round) reads a STALE half of the accumulator: the hardware forwards
@@ -480,9 +486,11 @@ __device__ __forceinline__ void conv_tile_mfma3(const unsigned char* tile, const
   // different type on the same registers.  tests/test_abi.py checks the code object for violations.
   WA3 cur, nxt;
   load_wa3(cur, tab, 0, lane);
+  if (!LOWREG) load_wa3(nxt, tab, 1, lane);
+  early();
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    if (!LOWREG && c < 2) load_wa3(nxt, tab, c + 1, lane);
+    if (!LOWREG && c == 1) load_wa3(nxt, tab, 2, lane);
     long bt[2][4];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -756,20 +764,32 @@ __device__ __forceinline__ void conv8h_tile(const Conv8Args& a, const BlockId bi
       }
   }
   };
-  if (!PERSIST) request_residual();   // PERSIST: behind the matrix phase (the prefetched next tile needs the registers)
   // the second source is requested AFTER the first matrix phase in the persistent form (full-register matrix phase; measured equal to
   // the early request in round 4: profiles/r4_conv8h_ab.txt) -- early, the loop-carried state on top of it spills
   constexpr bool LATE2 = PERSIST;
-  if (NSRC == 2 && wvec && !LATE2) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
-    stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
-    hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
-  }
+  // requests for later (PERSIST: the residual goes behind the matrix phase -- the prefetched next tile needs the registers): issued
+  // behind the matrix phase's first weight loads (conv_tile_mfma3 `early`), not in front of the phase
+  auto early = [&]() {
+    if (!PERSIST) request_residual();
+    if (NSRC == 2 && wvec && !LATE2) {  // prefetch the skip tensor's tile while the first half is on the matrix cores
+      stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+      hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
+    }
+  };
+#ifdef HC_EARLY_IN_FRONT   // A/B builds (tools/diag/early_ab.sh): the requests in front of the phase, as until round 5
+  early();
+#endif
   __syncthreads();
   GC_STAMP(2);
 #ifdef HC_PRIO_MFMA   // diagnostic builds (tools/diag/prio_ab.sh): static wave priority from the matrix phase on
   __builtin_amdgcn_s_setprio(HC_PRIO_MFMA);
 #endif
+#ifdef HC_EARLY_IN_FRONT
   if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2 && (!LATE2 || PERSIST), !DIAG>(tile, a.wh, acc, off, lane, a.term_mask, b0);
+#else
+  if (wave_live) conv_tile_mfma3<DIAG, NSRC == 2 && (!LATE2 || PERSIST), !DIAG>(tile, a.wh, acc, off, lane, a.term_mask, b0, early);
+  else early();   // waves below the image issue no matrix instructions but take part in the second source's staging
+#endif
   if (NSRC == 2 && wvec && LATE2) {
     stage_load<TW, TH, NT, 8, UP, GN>(R, a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
     hreg = halo_load_h<UP>(a.src[1] + (size_t)n * 8 * plane_in, (unsigned)plane_in, a.Win, a.H, a.W, x0, y0, tid);
