@@ -177,8 +177,8 @@ def _mfma_hazard_violations(asm):
     dependent pair of different types with fewer than two other matrix instructions (>= 8 issue cycles) in between."""
     import re
     # Only the 16x16x32 forms (4 passes): the 32x32x16 forms (8 passes: enh_front_h_kernel, the general convolution) give exact results at
-    # 0 wait states in both directions, alone and with 12 waves per SIMD (tools/probes/mfma_mixed_dep32_probe.hip,
-    # profiles/r5_mfma_mixed_dep32_probe.txt)
+    # 0 wait states in both directions, alone and with 12 waves per SIMD (round 3: tools/probes/mfma32_mixed_dep_probe.hip,
+    # profiles/r3_mfma32_probe.txt; re-confirmed in round 5: tools/probes/mfma_mixed_dep32_probe.hip, profiles/r5_mfma_mixed_dep32_probe.txt)
     pat = re.compile(r"^\s*(v_mfma_f32_16x16x32_(bf8_bf8|f16|bf16|fp8_fp8|bf8_fp8|fp8_bf8))\s+([av]\[\d+:\d+\]),\s*\S+,\s*\S+,\s*([av]\[\d+:\d+\]|0)")
     bad = []
     for name, body in zip(*(lambda p: (p[1::2], p[2::2]))(re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", asm))):
