@@ -26,3 +26,27 @@ def test_stride2_subpixel_weights_follow_their_definition():
     sub = torch.nn.functional.conv2d(torch.nn.functional.pad(dy, (0, 1, 0, 1)), k)   # [n, ci * 4, Ho, Wo], taps (ty, tx) reach to the right / below
     dx = torch.nn.functional.pixel_shuffle(sub, 2)
     assert torch.allclose(dx, x.grad, atol=1e-12)
+
+
+def test_prepared_buffer_sizes_of_the_general_convolution():
+    """gencomm_conv2d_prepared_floats (no GPU needed: a size query): shapes the f16-pipe kernel does not take get exactly the fp32 matrix;
+    eligible shapes get it + the three-term operand units (7 KiB per (16-channel chunk padded to 4, tap, 64-row block)) + one scale per
+    row of the padded blocks; a transposed convolution is sized as the 1x1 GEMM it runs as; bad dims answer -1."""
+    from gencomm_amd import _lib
+    f = _lib.lib().gencomm_conv2d_prepared_floats
+
+    def want(cin, rows, taps):
+        chunks = ((cin + 15) // 16 + 3) // 4 * 4
+        blocks = (rows + 63) // 64
+        return chunks * taps * blocks * 7168 // 4 + 64 * blocks
+
+    assert f(8, 64, 3, 3, 0) == 8 * 64 * 9                        # fewer than 16 input channels
+    assert f(64, 14, 1, 1, 0) == 64 * 14                          # fewer than 32 GEMM rows (detection heads)
+    assert f(20, 64, 3, 3, 0) == 20 * 64 * 9                      # Cin not a multiple of 8
+    assert f(64, 64, 5, 5, 0) == 64 * 64 * 25                     # no 5x5 form
+    assert f(64, 64, 3, 3, 0) == 64 * 64 * 9 + want(64, 64, 9)
+    assert f(24, 70, 3, 3, 0) == 24 * 70 * 9 + want(24, 70, 9)
+    assert f(256, 128, 3, 3, 2) == 256 * 128 * 9 + want(256, 128, 9)              # input-gradient form: rows = the forward's input channels
+    assert f(128, 64, 2, 2, 1) == 128 * 64 * 4 + want(128, 64 * 4, 1)             # ConvTranspose2d(kernel = stride = 2): 1x1 GEMM, 256 rows
+    assert f(64, 256, 2, 2, 0) == 64 * 256 * 4 + want(64, 256, 4)                 # sub-pixel form of a stride-2 input gradient
+    assert f(0, 64, 3, 3, 0) == -1 and f(64, 64, 3, 3, 3) == -1
