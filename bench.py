@@ -432,9 +432,9 @@ def train_main(args, rank, world, device, backend):
         if cnt[CONV2D_FAMILY] > 0:
             f_ms, f_fl, f_n = ms[CONV2D_FAMILY], wk[CONV2D_FAMILY], cnt[CONV2D_FAMILY]
             ach = f_fl / (f_ms * 1e-3) / 1e12
-            roofline = {"kernel": "conv2d_h3l_kernel / conv2d_h3_kernel<KH, KW, ...> (general 3x3 / 1x1 / 2x2 convolutions of the step on the f16 matrix "
+            roofline = {"kernel": "conv2d_h3l_kernel / conv2d_h3_kernel<KH, KW, ...> (general 3x3 / 2x2 convolutions of the step on the f16 matrix "
                                   "pipe, six matrix instructions per product block from exact three-term operand splits: csrc/conv_h3_kernels.h; the few "
-                                  "shapes it does not take -- fewer than 32 GEMM rows or 16 input channels -- run conv2d_igemm_kernel on v_mfma_f32_32x32x2_f32)",
+                                  "shapes it does not take -- 1x1, fewer than 32 GEMM rows or 16 input channels -- run conv2d_igemm_kernel on v_mfma_f32_32x32x2_f32)",
                         "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS / MFMA_TERMS, "unit": "TFLOP/s (fp32-equivalent)",
                         "frac": ach * MFMA_TERMS / F16_MFMA_PEAK_TFLOPS, "traffic": None, "launches": f_n, "avg_launch_ms": f_ms / f_n,
                         "flops_per_launch": f_fl / f_n, "share_of_step": f_ms / (1e3 * elapsed / args.steps),

@@ -115,6 +115,8 @@ _SIGNATURES = {
     "gencomm_bn2d_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _i, _i, _i, _i, _p, _p]),
     "gencomm_bn2d_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_slot_max_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "gencomm_convbn_train_fwd": (_i, [_p] * 10 + [C.c_float, C.c_float, _i] + [_p] * 5 + [_i] * 8 + [_p]),
+    "gencomm_convbn_train_bwd": (_i, [_p] * 9 + [_i] + [_p] * 9 + [_ll] + [_i] * 7 + [_p]),
     "gencomm_pfn_train_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_pfn_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_pfn_moment_doubles": (_ll, [_i]),

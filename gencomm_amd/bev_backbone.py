@@ -28,6 +28,23 @@ def _versions(*tensors):
     return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
 
 
+_SIZES: dict = {}
+
+
+def _prepared_floats(cin, cout, k, transposed):
+    key = ("p", cin, cout, k, transposed)
+    if key not in _SIZES:
+        _SIZES[key] = _lib.check_size(_lib.lib().gencomm_conv2d_prepared_floats(cin, cout, k, k, transposed), "gencomm_conv2d_prepared_floats")
+    return _SIZES[key]
+
+
+def _wgrad_scratch_floats(n, cin, H, W, cout, k, pad):
+    key = ("w", n, cin, H, W, cout, k, pad)
+    if key not in _SIZES:
+        _SIZES[key] = _lib.check_size(_lib.lib().gencomm_conv2d_wgrad_scratch_floats(n, cin, H, W, cout, k, 1, pad), "gencomm_conv2d_wgrad_scratch_floats")
+    return _SIZES[key]
+
+
 def _conv_backward(x, g, conv, pad, need_x):
     """(dx, {parameter: gradient}) of the bare convolution given d(conv output) on the HIP primitives: nn.Conv2d 1x1 / 3x3 with stride
     1 or 2 (stride 2: dy spread onto the stride-1 grid, then the stride-1 input-gradient kernel), nn.ConvTranspose2d with kernel ==
@@ -99,9 +116,44 @@ class _ConvBnTrainFn(torch.autograd.Function):
     kernels, then the convolution's dgrad / wgrad)."""
 
     @staticmethod
+    def _fusable(conv, bn, x) -> bool:
+        """one foreign call per direction (gencomm_convbn_train_fwd / _bwd): plain square 1x1 / 3x3 Conv2d, stride 1 | 2, fp32 contiguous input,
+        momentum-style running statistics with the counter on the device"""
+        if not (isinstance(conv, nn.Conv2d) and conv.kernel_size in ((1, 1), (3, 3)) and conv.stride in ((1, 1), (2, 2)) and conv.groups == 1
+                and conv.dilation == (1, 1) and conv.padding[0] == conv.padding[1]):
+            return False
+        if x.dtype != torch.float32 or not x.is_contiguous() or conv.weight.dtype != torch.float32 or bn.weight is None or bn.momentum is None:
+            return False
+        nbt = bn.num_batches_tracked
+        return (not bn.track_running_stats) or (bn.running_mean is not None and nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64)
+
+    @staticmethod
     def forward(ctx, x, conv, bn, relu, pad, *params):
         from . import train_ops as T
         ctx.conv, ctx.bn, ctx.relu, ctx.pad = conv, bn, relu, pad
+        if _ConvBnTrainFn._fusable(conv, bn, x):
+            from .runtime import zeros as pool_zeros
+            w = conv.weight.detach().contiguous()
+            cout, cin, k, _ = w.shape
+            n, _, H, W = x.shape
+            st_, p = conv.stride[0], conv.padding[0] if pad is None else pad
+            Ho, Wo = (H + 2 * p - k) // st_ + 1, (W + 2 * p - k) // st_ + 1
+            l, dev = _lib.lib(), x.device
+            unit = T._unit_scale_shift(cout, dev)
+            prepared = torch.empty(_prepared_floats(cin, cout, k, 0), dtype=torch.float32, device=dev)
+            pre = torch.empty(n, cout, Ho, Wo, dtype=torch.float32, device=dev)
+            y = torch.empty_like(pre)
+            save = torch.empty(cout, 2, dtype=torch.float32, device=dev)
+            scratch = pool_zeros(2 * cout, torch.float64, dev)
+            track = bn.track_running_stats and bn.running_mean is not None
+            b = conv.bias.detach().contiguous() if conv.bias is not None else None
+            _lib.check(l.gencomm_convbn_train_fwd(ptr(x), ptr(w), ptr(b), ptr(unit[0]), ptr(unit[1]), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                                  ptr(bn.running_mean) if track else 0, ptr(bn.running_var) if track else 0,
+                                                  ptr(bn.num_batches_tracked) if track else 0, float(bn.momentum), float(bn.eps), int(relu),
+                                                  ptr(prepared), ptr(pre), ptr(y), ptr(save), ptr(scratch), n, cin, H, W, cout, k, st_, p,
+                                                  stream_ptr(dev)), "gencomm_convbn_train_fwd")
+            ctx.save_for_backward(x, pre, y, save)
+            return y
         pre = conv2d_hip_raw(x, conv, pad)
         with torch.no_grad():
             y, save = T.bn2d_train_fwd(pre, bn, relu)
@@ -114,6 +166,37 @@ class _ConvBnTrainFn(torch.autograd.Function):
         x, pre, y, save = ctx.saved_tensors
         conv, bn = ctx.conv, ctx.bn
         params = [p for p in (conv.weight, conv.bias, bn.weight, bn.bias) if p is not None]
+        from .runtime import SIDE_MIN_PIXELS, zeros as pool_zeros
+        mode = _lib.lib().gencomm_get_mode(_lib.MODE_BWD_STREAMS)
+        side = ctx.needs_input_grad[0] and (mode == 2 or (mode == 1 and x.shape[0] * x.shape[2] * x.shape[3] >= SIDE_MIN_PIXELS))
+        if (_ConvBnTrainFn._fusable(conv, bn, x) and conv.stride == (1, 1) and not side and gy.dtype == torch.float32
+                and conv.weight.requires_grad and bn.weight.requires_grad and bn.bias.requires_grad and (conv.bias is None or conv.bias.requires_grad)):
+            # stride 1, no side stream wanted for this map size: BatchNorm backward + weight gradient + input gradient as ONE foreign call
+            w = conv.weight.detach().contiguous()
+            cout, cin, k, _ = w.shape
+            n, _, H, W = x.shape
+            p = conv.padding[0] if ctx.pad is None else ctx.pad
+            l, dev = _lib.lib(), x.device
+            gyc = gy.contiguous()
+            unit = T._unit_scale_shift(cin, dev)
+            need_x = bool(ctx.needs_input_grad[0])
+            dpre = torch.empty_like(pre)
+            dx = torch.empty_like(x) if need_x else None
+            blob = pool_zeros(cout * cin * k * k + (cout if conv.bias is not None else 0), torch.float32, dev)
+            dw = blob[:cout * cin * k * k].view(cout, cin, k, k)
+            dbias = blob[cout * cin * k * k:] if conv.bias is not None else None
+            dg, db = torch.empty(2, cout, dtype=torch.float32, device=dev).unbind(0)
+            scratch = pool_zeros(2 * cout, torch.float64, dev)
+            prepared = torch.empty(_prepared_floats(cout, cin, k, 2), dtype=torch.float32, device=dev) if need_x else None
+            need = _wgrad_scratch_floats(n, cin, H, W, cout, k, p)
+            wscr = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+            _lib.check(l.gencomm_convbn_train_bwd(ptr(x), ptr(w), ptr(pre), ptr(y), ptr(gyc), ptr(save), ptr(bn.weight.detach()), ptr(unit[0]), ptr(unit[1]),
+                                                  int(ctx.relu), ptr(dpre), ptr(dx), ptr(dw), ptr(dbias), ptr(dg), ptr(db), ptr(scratch), ptr(prepared),
+                                                  ptr(wscr), need, n, cin, H, W, cout, k, p, stream_ptr(dev)), "gencomm_convbn_train_bwd")
+            grads = {conv.weight: dw, bn.weight: dg, bn.bias: db}
+            if conv.bias is not None:
+                grads[conv.bias] = dbias
+            return (dx, None, None, None, None, *[grads.get(q) if q.requires_grad else None for q in params])
         with torch.no_grad():
             dpre, dg, db = T.bn2d_train_bwd(pre, y, gy.float().contiguous(), save, bn.weight, ctx.relu)
             r = _conv_backward(x.detach().float().contiguous(), dpre, conv, ctx.pad, ctx.needs_input_grad[0])

@@ -37,7 +37,9 @@ constexpr int H3_UNIT = 7168;   // bytes of one (chunk, tap, 64-row block) weigh
 
 // eligibility of a GEMM shape for the three-term kernels (the prepared buffer carries the blob exactly when this holds)
 __host__ __device__ inline bool h3_eligible(int Cin, int CoutP, int KH, int KW) {
-  const bool k = (KH == 3 && KW == 3) || (KH == 1 && KW == 1) || (KH == 2 && KW == 2);
+  // (1x1 layers stay on the exact-fp32 kernel: per staged pixel a 1x1 layer has a ninth of a 3x3 layer's matrix work, the operand split does
+  // not pay -- V2X-ViT's Linear layers ran 11 % slower on this kernel, the Enhancer's training Linears 4 %: profiles/r5_h3_1x1_ab.txt)
+  const bool k = (KH == 3 && KW == 3) || (KH == 2 && KW == 2);
   return k && Cin >= 16 && Cin % 8 == 0 && CoutP >= 32;
 }
 __host__ __device__ inline int h3_chunks(int Cin) { return (((Cin + 15) / 16) + 3) & ~3; }   // 16-channel chunks, padded to a multiple of 4 (stages of up to 4 chunks)

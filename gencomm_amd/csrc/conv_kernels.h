@@ -1,8 +1,8 @@
 // General 2-D convolution for the layers AROUND the hot path (gfx950, wave64): BaseBEVBackbone blocks/deblocks, DownsampleConv,
 // the detection heads, the Linear layers of the fusion transformers.  Kernels behind conv2d_enqueue:
-//   conv2d_h3l_kernel     (conv_h3_kernels.h) DEFAULT for 3x3 stride 1 / 1x1 / 2x2 with Cin >= 16, Cin % 8 == 0, >= 32 GEMM rows: f16 pipe, six
+//   conv2d_h3l_kernel     (conv_h3_kernels.h) DEFAULT for 3x3 stride 1 / 2x2 with Cin >= 16, Cin % 8 == 0, >= 32 GEMM rows: f16 pipe, six
 //   conv2d_h3_kernel       matrix instructions per product block from exact three-term operand splits (2^-26 products); _h3_: 3x3 stride 2
-//   conv2d_igemm_kernel   exact fp32 on v_mfma_f32_32x32x2_f32 -- every other shape; the only one in GENCOMM_MODE_ARITH = 1
+//   conv2d_igemm_kernel   exact fp32 on v_mfma_f32_32x32x2_f32 -- every other shape (1x1 / Linear / transposed convolutions among them); the only one in GENCOMM_MODE_ARITH = 1
 //   conv3x3_f16s_kernel   GENCOMM_MODE_ARITH = 3 (opt-in): 3x3 stride 1 / 2 with Cin % 8 == 0 on the f16 pipe from two-term splits (22-bit products)
 //   conv1x1_f16s_kernel   the same for 1x1 (and ConvTranspose2d, kernel == stride) with >= 128 GEMM rows
 //
@@ -565,7 +565,6 @@ inline int conv2d_h3_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStre
   int rc = GC_OK;
   if (KH == 3 && s2) conv2d_h3_kernel<3, 3, 2, 4, 1><<<grid, 256, 0, st>>>(a);
   else if (KH == 3) rc = ty8 ? conv2d_h3l_launch<3, 3, 8, 1, 3>(a, grid, st) : conv2d_h3l_launch<3, 3, 4, 1, 3>(a, grid, st);
-  else if (KH == 1) rc = ty8 ? conv2d_h3l_launch<1, 1, 8, 2, 1>(a, grid, st) : conv2d_h3l_launch<1, 1, 4, 2, 1>(a, grid, st);
   else rc = ty8 ? conv2d_h3l_launch<2, 2, 8, 1, 1>(a, grid, st) : conv2d_h3l_launch<2, 2, 4, 1, 1>(a, grid, st);   // one sub-stage of four steps: 80 KB, still two workgroups per CU
   if (rc != GC_OK) return rc;
   GC_HIP(hipGetLastError());
@@ -575,7 +574,7 @@ inline int conv2d_h3_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStre
 inline int conv2d_enqueue(const Conv2dArgs& a, int N, int KH, int KW, hipStream_t st) {
   {
     const Modes md = modes_snapshot();
-    const bool shape = (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2)) || (KH == 1 && KW == 1 && a.stride == 1) || (KH == 2 && KW == 2 && a.stride == 1);
+    const bool shape = (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2)) || (KH == 2 && KW == 2 && a.stride == 1);
     if (a.w3 != nullptr && shape && md.split() && !md.split2()) return conv2d_h3_enqueue(a, N, KH, KW, st);
   }
   if (KH == 3 && KW == 3 && (a.stride == 1 || a.stride == 2) && a.ups == 1 && a.Cin % 8 == 0 && a.CoutP >= 32 && modes_snapshot().split2()) {

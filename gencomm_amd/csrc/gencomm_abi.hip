@@ -821,6 +821,42 @@ int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, cons
 }
 
 // max over the P point slots of every pillar (training path of the PointPillars encoder): x [C][M][P] -> out [M][C], arg [M][C] (uint8)
+// One conv -> BatchNorm2d(batch statistics) -> ReLU layer of the backbones in training mode per call (base_bev_backbone.py:40-83): the
+// forward is prepare + convolution + statistics + normalisation, the backward (stride 1) BatchNorm backward + weight gradient + input
+// gradient -- compositions of the entries above, so that a layer costs the host ONE foreign call per direction instead of three / four
+// (the stage-1 step is ~1 400 launches; on a slow host its Python side, not the device, sets the step time).
+int gencomm_convbn_train_fwd(const float* x, const float* weight, const float* bias, const float* unit_scale, const float* zero_shift,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                             float momentum, float eps, int relu, float* prepared, float* pre, float* y, float* save, double* stat_scratch,
+                             int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, void* stream) {
+  GC_CHECK_ARG(x && weight && unit_scale && zero_shift && gamma && beta && prepared && pre && y && save && stat_scratch, "null pointer");
+  GC_CHECK_ARG((K == 1 || K == 3) && (stride == 1 || stride == 2) && pad >= 0, "gencomm_convbn_train_fwd: 1x1 / 3x3, stride 1 / 2");
+  const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+  GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
+  if (int rc = gencomm_conv2d_prepare(weight, prepared, Cin, Cout, K, K, 0, stream)) return rc;
+  if (int rc = gencomm_conv2d_fwd(x, prepared, unit_scale, bias != nullptr ? bias : zero_shift, pre, N, Cin, H, W, Cout, K, K, stride, pad, 0, 1, Cout, 0, stream)) return rc;
+  return gencomm_bn2d_train_fwd(pre, gamma, beta, running_mean, running_var, y, save, stat_scratch, momentum, eps, (relu & 1) | 4, N, Cout, Ho * Wo,
+                                num_batches_tracked, stream);   // stat_scratch arrives ZEROED
+}
+// Backward of the same layer for stride 1.  dpre / prepared / wgrad_scratch: caller-owned scratch ([N][Cout][Ho][Wo] floats;
+// gencomm_conv2d_prepared_floats(Cout, Cin, K, K, 2); gencomm_conv2d_wgrad_scratch_floats(...)); dw and dbias (may be null) arrive ZEROED and are
+// accumulated into, dgamma / dbeta are written, stat_scratch (2 Cout doubles) arrives ZEROED; dx null = no input gradient wanted.
+int gencomm_convbn_train_bwd(const float* x, const float* weight, const float* pre, const float* y, const float* gy, const float* save, const float* gamma,
+                             const float* unit_scale, const float* zero_shift, int relu, float* dpre, float* dx, float* dw, float* dbias, float* dgamma,
+                             float* dbeta, double* stat_scratch, float* prepared, float* wgrad_scratch, long long wgrad_scratch_floats,
+                             int N, int Cin, int H, int W, int Cout, int K, int pad, void* stream) {
+  GC_CHECK_ARG(x && weight && pre && y && gy && save && gamma && unit_scale && zero_shift && dpre && dw && dgamma && dbeta && stat_scratch, "null pointer");
+  GC_CHECK_ARG((K == 1 || K == 3) && pad >= 0 && pad <= K - 1, "gencomm_convbn_train_bwd: 1x1 / 3x3, stride 1");
+  const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
+  GC_CHECK_ARG(Ho >= 1 && Wo >= 1, "empty output");
+  if (int rc = gencomm_bn2d_train_bwd(pre, y, gy, save, gamma, dpre, dgamma, dbeta, stat_scratch, (relu & 1) | 2 | 4, N, Cout, Ho * Wo, stream)) return rc;
+  if (int rc = gencomm_conv2d_wgrad_ws(dpre, x, dw, dbias, N, Cin, H, W, Cout, K, 1, pad, wgrad_scratch, wgrad_scratch_floats, stream)) return rc;
+  if (dx == nullptr) return GC_OK;
+  GC_CHECK_ARG(prepared != nullptr, "gencomm_convbn_train_bwd: the input gradient needs the prepared-weight scratch");
+  if (int rc = gencomm_conv2d_prepare(weight, prepared, Cout, Cin, K, K, 2, stream)) return rc;
+  return gencomm_conv2d_fwd(dpre, prepared, unit_scale, zero_shift, dx, N, Cout, Ho, Wo, Cin, K, K, 1, K - 1 - pad, 0, 1, Cin, 0, stream);
+}
+
 // PFNLayer in training mode without its [M P, C] intermediates (pfn_kernels.h).  F = 10 (the shipped encoder: 4 raw + 3 cluster + 3 centre
 // features) or 9 / 11 (no intensity / with distance); C in {32, 64, 128, 256}; P <= 255 (the arg slot is a byte)
 static int pfn_check(const char* who, int M, int P, int F, int C) {

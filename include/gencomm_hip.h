@@ -325,7 +325,7 @@ int gencomm_warp_attfuse_fwd(const float* x, const double* theta, const int* sce
  *          convolution of a stride-1 layer straight from its forward OIHW weights (Cin = the forward's output channels, Cout = its input
  *          channels; taps flipped, channels transposed: what flip + transpose + contiguous + prepare did in four launches) -> k-major matrix
  *          [Cin*KH*KW][Cout] (resp. [Cin][Cout*KH*KW]) of the same number of floats, followed -- for GEMM shapes the f16-pipe kernel takes
- *          (3x3 / 1x1 / 2x2, Cin >= 16, Cin % 8 == 0, >= 32 GEMM rows) -- by the three-term operand form of the weights and their per-row
+ *          (3x3 / 2x2, Cin >= 16, Cin % 8 == 0, >= 32 GEMM rows; 1x1 and transposed convolutions stay on the exact-fp32 kernel: measured faster) -- by the three-term operand form of the weights and their per-row
  *          power-of-two scales (csrc/conv_h3_kernels.h), written by the same launch.  `prepared` must hold
  *          gencomm_conv2d_prepared_floats(Cin, Cout, KH, KW, transposed) floats (= Cin*Cout*KH*KW for the other shapes; -1: bad dims).
  * fold:    BatchNorm2d (eval) and/or conv bias -> per-channel scale/shift; pass NULL for the four BN tensors
@@ -533,6 +533,21 @@ int gencomm_bn2d_train_fwd(const float* x, const float* gamma, const float* beta
                            void* stream);
 int gencomm_bn2d_train_bwd(const float* x, const float* y, const float* dy, const float* save, const float* gamma, float* dx, float* dgamma,
                            float* dbeta, double* scratch, int relu, int n, int C, int HW, void* stream);
+/* ABI v10: one conv -> BatchNorm2d(batch statistics) -> ReLU layer (base_bev_backbone.py:40-83) per call and direction -- compositions of
+ * gencomm_conv2d_prepare / _fwd / _wgrad_ws and gencomm_bn2d_train_*, so that a layer costs the host ONE foreign call instead of three or four.
+ * fwd: weight OIHW [Cout][Cin][K][K] (K 1 | 3, stride 1 | 2), bias may be null; unit_scale / zero_shift: [Cout] ones / zeros; prepared:
+ * scratch of gencomm_conv2d_prepared_floats(Cin, Cout, K, K, 0) floats; pre = the convolution's output (kept for the backward), y, save
+ * [Cout][2]; stat_scratch: 2 Cout doubles, ZEROED by the caller.  bwd (stride 1): dpre scratch [N][Cout][Ho][Wo]; dw / dbias (may be null)
+ * arrive ZEROED and are accumulated into, dgamma / dbeta written, dx may be null; unit_scale / zero_shift: [Cin]; prepared:
+ * gencomm_conv2d_prepared_floats(Cout, Cin, K, K, 2) floats; wgrad_scratch as gencomm_conv2d_wgrad_ws. */
+int gencomm_convbn_train_fwd(const float* x, const float* weight, const float* bias, const float* unit_scale, const float* zero_shift,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                             float momentum, float eps, int relu, float* prepared, float* pre, float* y, float* save, double* stat_scratch,
+                             int N, int Cin, int H, int W, int Cout, int K, int stride, int pad, void* stream);
+int gencomm_convbn_train_bwd(const float* x, const float* weight, const float* pre, const float* y, const float* gy, const float* save, const float* gamma,
+                             const float* unit_scale, const float* zero_shift, int relu, float* dpre, float* dx, float* dw, float* dbias, float* dgamma,
+                             float* dbeta, double* stat_scratch, float* prepared, float* wgrad_scratch, long long wgrad_scratch_floats,
+                             int N, int Cin, int H, int W, int Cout, int K, int pad, void* stream);
 
 /* Training path of the PointPillars per-pillar network (pillar_vfe.py:31-54): the Linear layer runs as a 1x1 convolution over the
  * [1, C, 1, M P] point-slot layout (gencomm_conv2d_fwd / _wgrad), BatchNorm1d with batch statistics as gencomm_bn2d_train_*, and the

@@ -31,7 +31,7 @@ def test_stride2_subpixel_weights_follow_their_definition():
 def test_prepared_buffer_sizes_of_the_general_convolution():
     """gencomm_conv2d_prepared_floats (no GPU needed: a size query): shapes the f16-pipe kernel does not take get exactly the fp32 matrix;
     eligible shapes get it + the three-term operand units (7 KiB per (16-channel chunk padded to 4, tap, 64-row block)) + one scale per
-    row of the padded blocks; a transposed convolution is sized as the 1x1 GEMM it runs as; bad dims answer -1."""
+    row of the padded blocks; 1x1 layers and transposed convolutions (1x1 GEMMs) stay on the fp32 kernel; bad dims answer -1."""
     from gencomm_amd import _lib
     f = _lib.lib().gencomm_conv2d_prepared_floats
 
@@ -47,6 +47,7 @@ def test_prepared_buffer_sizes_of_the_general_convolution():
     assert f(64, 64, 3, 3, 0) == 64 * 64 * 9 + want(64, 64, 9)
     assert f(24, 70, 3, 3, 0) == 24 * 70 * 9 + want(24, 70, 9)
     assert f(256, 128, 3, 3, 2) == 256 * 128 * 9 + want(256, 128, 9)              # input-gradient form: rows = the forward's input channels
-    assert f(128, 64, 2, 2, 1) == 128 * 64 * 4 + want(128, 64 * 4, 1)             # ConvTranspose2d(kernel = stride = 2): 1x1 GEMM, 256 rows
+    assert f(128, 64, 2, 2, 1) == 128 * 64 * 4                                    # ConvTranspose2d(kernel = stride = 2) runs as a 1x1 GEMM: fp32 kernel
+    assert f(128, 256, 1, 1, 0) == 128 * 256                                      # 1x1 / Linear layers: fp32 kernel
     assert f(64, 256, 2, 2, 0) == 64 * 256 * 4 + want(64, 256, 4)                 # sub-pixel form of a stride-2 input gradient
     assert f(0, 64, 3, 3, 0) == -1 and f(64, 64, 3, 3, 3) == -1
