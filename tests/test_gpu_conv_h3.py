@@ -188,3 +188,38 @@ def test_wide_weight_gradient_three_term_vs_float64(modes, shape, case):
         err = (res[0][0][o] - ref_w[o]).abs().max().item()
         assert err <= 3e-6 * ref_w[o].abs().max().item() + 1e-12 * scale, (shape, case, o, err)
     assert ((res[0][1] - ref_b).abs() <= 1e-6 * dy.double().abs().sum((0, 2, 3)) + 1e-30).all()
+
+
+def test_random_shapes_three_term_convolution_and_weight_gradient_vs_float64(modes):
+    """Thirty seeded random shapes (channel counts off the 16 / 32 / 64 grids, maps off the tile grids, both strides) through the three-term
+    convolution, its input gradient and the three-term weight gradient against float64: the same error bound as the exact-fp32 kernels."""
+    import random
+    from gencomm_amd import train_ops as T
+    rnd = random.Random(20261005)
+    g = torch.Generator().manual_seed(77)
+    for it in range(30):
+        N = rnd.randint(1, 3)
+        Cin = rnd.choice([16, 24, 32, 40, 64, 72, 136])
+        Cout = rnd.choice([32, 40, 64, 96, 200])
+        H, W = rnd.randint(5, 70), rnd.randint(5, 70)
+        stride = rnd.choice([1, 1, 2])
+        mag = 10.0 ** rnd.uniform(-6, 3)
+        x = torch.randn(N, Cin, H, W, generator=g) * mag
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * (10.0 ** rnd.uniform(-3, 1))
+        ref = F.conv2d(x.double(), w.double(), None, stride=stride, padding=1)
+        y = T.conv2d(x.to(DEV), w.to(DEV), None, 1, stride)
+        scale = ref.abs().max().item()
+        err = (y.double().cpu() - ref).abs().max().item()
+        assert torch.isfinite(y).all() and err <= 3e-6 * scale, ("fwd", it, (N, Cin, Cout, H, W, stride), err / scale)
+        if stride == 1:
+            dy = torch.randn(ref.shape, generator=g) * (10.0 ** rnd.uniform(-7, 0))
+            xr = x.double().requires_grad_(True)
+            wr = w.double().requires_grad_(True)
+            F.conv2d(xr, wr, None, stride=1, padding=1).backward(dy.double())
+            dx = T.conv2d_dgrad(dy.to(DEV), w.to(DEV), 1)
+            sx = xr.grad.abs().max().item()
+            assert (dx.double().cpu() - xr.grad).abs().max().item() <= 3e-6 * sx, ("dgrad", it, (N, Cin, Cout, H, W))
+            if Cin >= 32:
+                dw, _ = T.conv2d_wgrad(dy.to(DEV), x.to(DEV), 3, 1, False, 1)
+                sw = wr.grad.abs().max().item()
+                assert (dw.double().cpu() - wr.grad).abs().max().item() <= 3e-6 * sw, ("wgrad", it, (N, Cin, Cout, H, W))
