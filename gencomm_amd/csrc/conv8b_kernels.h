@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void prep_conv8b_kernel(const float* __restric
     const int s = i / BC_WTAB, rem = i - s * BC_WTAB;
     const int d = rem & 3, l = (rem >> 2) & 63, c = rem >> 8;
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
-    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
+    const int dyp = hc_tap_row(kg), dx = c, dy = dyp - r;
     float x[2];
     for (int e = 0; e < 2; ++e) {
       const int ic = s * 8 + 2 * d + e;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void h8_lane_offsets(int (&off)[4][3], int wave, int 
   constexpr int WRAP = 4 * HC_PHASE - 16;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const int t = 4 * c + kg, dyp = t / 3, sx = t - 3 * dyp - 1;
+    const int dyp = hc_tap_row(kg), sx = c - 1;
     const int base = (2 * wave + dyp) * HC_ROW + (n + 1) * 16 + sx * HC_PHASE;
     off[0][c] = base + (sx < 0 ? WRAP : 0);
     off[1][c] = base + HC_PHASE;

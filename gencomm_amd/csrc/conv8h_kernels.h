@@ -384,8 +384,18 @@ __device__ __noinline__ void stage_tile_scalar_h(unsigned char* __restrict__ til
   }
 }
 
-// Per-lane byte offsets of the B operand: off[j][c] for pixel group j (pixel 4n + j) and MFMA c (taps 4c .. 4c+3,
-// this lane's tap t = 4c + lane/16: window row t / 3, column shift t % 3 - 1), row pair 0 of wave `wave`.
+// Which of the 12 taps of a row pair's 4-row x 3-column window a K group of a matrix instruction holds: instruction c = column
+// dx = c, K group kg (= lane / 16) = window row 0, 2, 1, 3.  The order is chosen for the LDS banks.  ds_read_b128 serves a wave in
+// four groups of 16 lanes that are NOT the K groups: {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- half of K group
+// 2h and half of K group 2h + 1 at complementary pixel indices -- so a read is conflict-free exactly when the two K groups' 256-byte
+// spans start at the same offset modulo 256.  Window rows two apart do (2 HC_ROW = 9 x 256 bytes); neighbouring rows are 128 bytes
+// off and neighbouring columns 32 (the order t = 4c + kg -> row t / 3, column t % 3 of rounds 2-5 paired exactly those: every
+// operand read took 8 LDS cycles instead of 4, SQ_LDS_BANK_CONFLICT = 0.39-0.44 of SQ_LDS_IDX_ACTIVE).  The bf8 plane's ds_read_b64
+// (two groups of 32 lanes, 128-byte spans per K group) wants the spans 128 bytes apart modulo 256: half of 2 HC_ROW is.
+__host__ __device__ constexpr int hc_tap_row(int kg) { return ((kg & 1) << 1) | (kg >> 1); }
+
+// Per-lane byte offsets of the B operand: off[j][c] for pixel group j (pixel 4n + j) and MFMA c (column shift c - 1, this lane's
+// window row hc_tap_row(lane / 16)), row pair 0 of wave `wave`.
 __device__ __forceinline__ void hc_lane_offsets(int (&off)[4][3], int wave, int lane) {
   const int n = lane & 15, kg = lane >> 4;
   // hc_addr(row, 4n + j + s), s = dx - 1, is linear in j (one phase = HC_PHASE bytes per pixel step) except where the pixel
@@ -394,7 +404,7 @@ __device__ __forceinline__ void hc_lane_offsets(int (&off)[4][3], int wave, int 
   constexpr int WRAP = 4 * HC_PHASE - 16;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const int t = 4 * c + kg, dyp = t / 3, sx = t - 3 * dyp - 1;
+    const int dyp = hc_tap_row(kg), sx = c - 1;
     const int base = (4 * wave + dyp) * HC_ROW + (n + 1) * 16 + sx * HC_PHASE;
     off[0][c] = base + (sx < 0 ? WRAP : 0);
     off[1][c] = base + HC_PHASE;
@@ -976,8 +986,8 @@ __global__ __launch_bounds__(HC_NT, 3) void conv8hp_kernel(const Conv8Args a, in
 }
 
 // Weight preparation: OIHW [8][IC][3][3] (IC = 8 or 16) -> IC/8 three-term tables of HC_WTAB3 dwords + 64 floats (1 / scale, scale).
-// A operand of MFMA c, lane l: row m = l % 16 = (r = m / 8, oc = m % 8), K group l / 16 -> tap t = 4c + l/16 of the 4x3
-// window (window row dyp = t / 3, column dx = t % 3), 8 input channels; tap row of the kernel = dyp - r (zero outside 0..2).
+// A operand of MFMA c, lane l: row m = l % 16 = (r = m / 8, oc = m % 8), K group l / 16 -> the tap of the 4x3 window in
+// column dx = c, window row dyp = hc_tap_row(l / 16), 8 input channels; tap row of the kernel = dyp - r (zero outside 0..2).
 // Per tap group: fp16 terms w1, w2, w3 of w * scale ([term][lane][4 dwords], channels 2d, 2d+1 in dword d), then the
 // bf8 rounding of w * scale * 2^-20 ([lane][2 dwords], channel k in byte k).
 __global__ __launch_bounds__(256) void prep_conv8h_kernel(const float* __restrict__ w, float* __restrict__ dst, int IC) {
@@ -1002,7 +1012,7 @@ __global__ __launch_bounds__(256) void prep_conv8h_kernel(const float* __restric
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(dst);
   auto weight = [&](int s, int c, int l, int ch) -> float {  // scaled weight of (source s, tap group c, lane l, channel ch)
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
-    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
+    const int dyp = hc_tap_row(kg), dx = c, dy = dyp - r;
     return (dy >= 0 && dy <= 2) ? w[((oc * IC + s * 8 + ch) * 3 + dy) * 3 + dx] * scale : 0.f;
   };
   for (int i = tid; i < nsrc * HC_WTAB3; i += 256) {

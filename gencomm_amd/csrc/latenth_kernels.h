@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void prep_latent_h_kernel(const float* __restr
     const int s = i / HC_WTAB3, rem = i - s * HC_WTAB3;
     const int c = rem / HC_WC3, q = rem - c * HC_WC3, l = lane_of(q);
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
-    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
+    const int dyp = hc_tap_row(kg), dx = c, dy = dyp - r;
     const bool live = dy >= 0 && dy <= 2;
     float wv[8];
     for (int ch = 0; ch < 8; ++ch) wv[ch] = live ? w_in[(((size_t)oc * CI + 2 + s * 8 + ch) * 3 + dy) * 3 + dx] * scale : 0.f;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void prep_latent_h_kernel(const float* __restr
   for (int i = tid; i < HC_WTAB3; i += 256) {
     const int c = i / HC_WC3, q = i - c * HC_WC3, l = lane_of(q);
     const int mrow = l & 15, kg = l >> 4, r = mrow >> 3, oc = mrow & 7;
-    const int t = 4 * c + kg, dyp = t / 3, dx = t - 3 * dyp, dy = dyp - r;
+    const int dyp = hc_tap_row(kg), dx = c, dy = dyp - r;
     const bool live = dy >= 0 && dy <= 2;
     float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int ch = 0; ch < 2; ++ch) wv[ch] = live ? w_in[(((size_t)oc * CI + ch) * 3 + dy) * 3 + dx] * scale : 0.f;
