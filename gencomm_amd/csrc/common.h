@@ -38,6 +38,23 @@ inline int fail(int code, const char* msg) {
     }                                                                            \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set it once per device ordinal this process launches
+// the kernel on, not once per process (a single static flag covers only the device of the first launch).
+// One static instance per launch helper; a race sets the attribute twice, which is harmless.
+struct LdsAttrOnce {
+  unsigned long long done = 0;   // bit d: set for device ordinal d (ordinals >= 64 set it on every launch)
+  template <class K>
+  int set(K kernel, int bytes) {
+    int d = 0;
+    GC_HIP(hipGetDevice(&d));
+    const unsigned long long bit = d < 64 ? 1ull << d : 0ull;
+    if (done & bit) return 0;
+    GC_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
+    return 0;
+  }
+};
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------

@@ -544,11 +544,8 @@ namespace gc {
 template <int KH, int KW, int TY, int KS, int NSUB>
 inline int conv2d_h3l_launch(const Conv2dArgs& a, dim3 grid, hipStream_t st) {   // grid = (tiles, channel blocks, samples): launched 1-D, decoded XCD-aware
   using G = H3L<KH, KW, TY, KS, NSUB>;
-  static bool attr_set = false;   // (idempotent: a race sets it twice)
-  if (!attr_set) {
-    GC_HIP(hipFuncSetAttribute((const void*)conv2d_h3l_kernel<KH, KW, TY, KS, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (const int rc = attr.set(conv2d_h3l_kernel<KH, KW, TY, KS, NSUB>, G::SMEM)) return rc;
   conv2d_h3l_kernel<KH, KW, TY, KS, NSUB><<<dim3(grid.x * grid.y * grid.z), 256, G::SMEM, st>>>(a, (int)grid.x, (int)grid.z);
   return GC_OK;
 }

@@ -395,12 +395,9 @@ inline int nms_rotated_enqueue(const float* corners, const float* scores, const 
   int* order = (int*)ws;
   int* k_dev = (int*)(ws + align_up(kNmsMaxTop * 4, 256));
   unsigned long long* mask = (unsigned long long*)(ws + align_up(kNmsMaxTop * 4, 256) + 256);
-  static bool attr_done = false;
-  if (!attr_done) {
-    GC_HIP(hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kNmsMaxN * 8));
-    GC_HIP(hipFuncSetAttribute((const void*)nms_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kNmsMaxTop * (kNmsMaxTop / 64) * 8));
-    attr_done = true;
-  }
+  static LdsAttrOnce attr_sort, attr_greedy;
+  if (const int rc = attr_sort.set(nms_sort_kernel, kNmsMaxN * 8)) return rc;
+  if (const int rc = attr_greedy.set(nms_greedy_kernel, kNmsMaxTop * (kNmsMaxTop / 64) * 8)) return rc;
   nms_sort_kernel<<<1, 1024, kNmsMaxN * 8, st>>>(scores, n_dev, top, order, k_dev);
   nms_mask_kernel<<<dim3(kNmsMaxTop / 64, kNmsMaxTop / 64), 64, 0, st>>>(corners, order, k_dev, thr, mask);
   NmsOutArgs o{corners, scores, order, k_dev, mask, range6, out_boxes, out_scores, out_index, out_count};

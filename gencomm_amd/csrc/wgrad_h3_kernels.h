@@ -333,11 +333,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_h3_kernel(const Wgrad3x3Args 
 }
 
 inline int wgrad3x3_h3_launch(const Wgrad3x3Args& a, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;   // (idempotent: a race sets it twice)
-  if (!attr_set) {
-    GC_HIP(hipFuncSetAttribute((const void*)wgrad3x3_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WgH3::SMEM));
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (const int rc = attr.set(wgrad3x3_h3_kernel, WgH3::SMEM)) return rc;
   GC_KLOG("wgrad3x3_h3_kernel");
   wgrad3x3_h3_kernel<<<grid, 256, WgH3::SMEM, st>>>(a);
   return GC_OK;
