@@ -389,7 +389,11 @@ def train_main(args, rank, world, device, backend):
                 st = [f for f in (e.stack or []) if "site-packages" not in f and "dist-packages" not in f and "<built-in" not in f][:3]
                 shp = str(e.input_shapes[:1]) if e.input_shapes else ""
                 agg[(e.name, " <- ".join(x.split("/")[-1] for x in st) or "(autograd engine / C++)", shp)] += 1
-        for (name, where, shp), c in agg.most_common(70):
+        totals = collections.Counter()
+        for (name, _, _), c in agg.items():
+            totals[name] += c
+        print("operators of the step by name: " + ", ".join(f"{n} x{c}" for n, c in totals.most_common()), file=sys.stderr)
+        for (name, where, shp), c in agg.most_common(160):
             print(f"{c:5d}  {name:18s} {shp:28s} {where}"[:230], file=sys.stderr)
     if args.host_profile:    # diagnostic: cProfile of the host side of 10 steps (autograd on this thread), written to stderr
         import cProfile, io, pstats

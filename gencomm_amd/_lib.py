@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GENCOMM_HIP_LIB", os.path.join(PKG_DIR, "libgencomm_hip.so"))  # override: diagnostic builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 MODE_ARITH, MODE_SAMPLER, MODE_TILE_WANT, MODE_ENH_FUSE, MODE_CONV8H_MASK, MODE_XCD_REMAP, MODE_DATAFLOW, MODE_RESFUSE_EMU, MODE_TILE8, MODE_BWD_STREAMS, MODE_PERSIST = range(11)
 
 _lock = threading.Lock()
@@ -122,6 +122,7 @@ _SIGNATURES = {
     "gencomm_pfn_moment_doubles": (_ll, [_i]),
     "gencomm_pfn_bwd_scratch_doubles": (_ll, [_i, _i]),
     "gencomm_slot_max_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "gencomm_head_loss": (_i, [_p] * 10 + [_i] * 5 + [_p, C.c_double] + [C.c_float] * 7 + [_i, _p]),
     "gencomm_dcn_sample_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_dcn_scatter_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gencomm_dcn_scatter_scratch_floats": (_ll, [_i, _i, _i, _i]),

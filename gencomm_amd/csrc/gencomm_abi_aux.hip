@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "iou3d_kernels.h"
+#include "loss_kernels.h"
 #include "sparse_kernels.h"
 #include "v2xvit_kernels.h"
 #include "voxel_kernels.h"
@@ -398,6 +399,24 @@ int gencomm_mean_vfe_fwd(const float* voxels, const int* num_points, const int* 
   mean_vfe_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(voxels, num_points, perm, out, n, max_points, nfeat);
   GC_HIP(hipGetLastError());
   return GC_OK;
+}
+
+int gencomm_head_loss(const float* cls, const float* reg, const float* dir, const float* pos, const float* neg, const float* tgt, float* gcls,
+                      float* greg, float* gdir, double* sums, int B, int A, int H, int W, int num_bins, const double* anchor_yaw, double dir_offset,
+                      float pos_cls_weight, float gamma, float alpha, float cls_weight, float sigma, float reg_weight, float dir_weight,
+                      int batch_size, void* stream) {
+  GC_CHECK_ARG(cls && reg && pos && neg && tgt && gcls && greg && sums, "null pointer");
+  GC_CHECK_ARG(B >= 1 && A >= 1 && A <= kLossMaxAnchors && H >= 1 && W >= 1 && batch_size >= 1 && sigma > 0.f, "bad dims");
+  GC_CHECK_ARG((long long)H * W * A < (1LL << 30) && B <= 65535, "map too large");
+  GC_CHECK_ARG(dir == nullptr || (gdir && anchor_yaw && num_bins >= 1 && num_bins <= A), "direction term: gdir, anchor_yaw [A] and 1 <= num_bins <= A");
+  HeadLossArgs a{};
+  a.cls = cls; a.reg = reg; a.dir = dir; a.pos = pos; a.neg = neg; a.tgt = tgt;
+  a.gcls = gcls; a.greg = greg; a.gdir = gdir; a.sums = sums;
+  a.B = B; a.A = A; a.HW = H * W; a.has_dir = dir != nullptr; a.num_bins = num_bins;
+  a.pos_cls_weight = pos_cls_weight; a.gamma = gamma; a.alpha = alpha; a.cls_weight = cls_weight; a.sigma = sigma; a.reg_weight = reg_weight;
+  a.dir_weight = dir_weight; a.inv_bs = 1.0f / (float)batch_size; a.dir_offset = dir_offset;
+  for (int i = 0; i < kLossMaxAnchors; ++i) a.anchor_yaw[i] = (dir != nullptr && i < A) ? anchor_yaw[i] : 0.0;
+  return head_loss_enqueue(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

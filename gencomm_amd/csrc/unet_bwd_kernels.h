@@ -535,6 +535,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradArgs 
   }
 }
 
+constexpr int kWgradDirectMaxWg = 64;   // conv_wgrad_enqueue: at most this many workgroups per channel pair add into dw directly
+
 // floats of WgradArgs::part for a layer (stride-1 "same" layers only; 0 otherwise)
 inline size_t conv_wgrad_scratch_floats(int Cout, int Cin, int K, int H, int W, int n) {
   const size_t NT = (size_t)(8 * K * K + 1 + 15) / 16;
@@ -551,10 +553,15 @@ inline int conv_wgrad_enqueue(const WgradArgs& a, int n, hipStream_t st) {
     b.tpc = (int)std::min<long long>(8, std::max<long long>(1, ((long long)tiles * pairs * n + 767) / 768));
     const dim3 grid((tiles + b.tpc - 1) / b.tpc, (unsigned)pairs, n);
     if (grid.y > 65535 || grid.z > 65535) return fail(GC_ERR_ARG, "conv_wgrad: too many channel chunks / samples");
+    // Few workgroups per channel pair (the UNet of a training step at the shipped map sizes: 64 / 16 / 4): each adds its columns straight
+    // into dw -- kWgradDirectMaxWg-way contention per address at most, what the second stage's 16 slices already have -- and the second
+    // launch (a third of this layer's backward launches) is not issued.  Larger maps keep the partial sums + reduce.
+    const int nwg = (int)(grid.x * grid.z);
+    if (nwg <= kWgradDirectMaxWg) b.part = nullptr;
     if (a.K == 3) conv_wgrad_mfma_kernel<3><<<grid, 256, 0, st>>>(b);
     else conv_wgrad_mfma_kernel<1><<<grid, 256, 0, st>>>(b);
-    if (a.part != nullptr) {
-      const int nwg = (int)(grid.x * grid.z), slices = std::min(nwg, 16), per = (nwg + slices - 1) / slices;
+    if (b.part != nullptr) {
+      const int slices = std::min(nwg, 16), per = (nwg + slices - 1) / slices;
       const int NW = ((8 * a.K * a.K + 1 + 15) / 16) * 128;
       const dim3 rg((NW + 255) / 256, grid.y, (nwg + per - 1) / per);
       if (a.K == 3) conv_wgrad_reduce_kernel<3><<<rg, 256, 0, st>>>(a, nwg, per);

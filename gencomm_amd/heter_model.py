@@ -40,6 +40,24 @@ def fix_bn(m):  # opencood/tools/train_utils.py (freeze BatchNorm statistics of 
         m.eval()
 
 
+def assemble_agents(per_modality, agent_modality_list):
+    """The batch in agent order from the per-modality batches (stage1.py:213-224: the k-th agent of modality m is row k of that
+    modality's batch).  The reference selects agent by agent and stacks -- one select per agent forward, one full-size zero fill +
+    copy + add per agent backward.  Here runs of consecutive agents of one modality are slices, and a batch of a single modality is
+    the modality's tensor itself: same values, no copy, a slice's backward."""
+    counting, runs = {}, []   # runs: [modality, first row, one past the last]
+    for m in agent_modality_list:
+        i = counting.get(m, 0)
+        if runs and runs[-1][0] == m and runs[-1][2] == i:
+            runs[-1][2] = i + 1
+        else:
+            runs.append([m, i, i + 1])
+        counting[m] = i + 1
+    if len(runs) == 1 and runs[0][2] == per_modality[runs[0][0]].shape[0]:
+        return per_modality[runs[0][0]]
+    return torch.cat([per_modality[m][a:b] for m, a, b in runs])
+
+
 class HeterModelBaselineWGenComm(nn.Module):
     STAGE2 = False
 
@@ -173,17 +191,11 @@ class HeterModelBaselineWGenComm(nn.Module):
             feats[m] = feature
             msgs[m] = getattr(self, f"message_extractor_{m}")(feature)
 
-        counting = {m: 0 for m in self.modality_name_list}
-        f_list, m_list = [], []
-        for m in agent_modality_list:
-            i = counting[m]
-            f_list.append(feats[m][i])
-            m_list.append(msgs[m][i])
-            counting[m] += 1
-        heter_feature_2d = torch.stack(f_list)
-        heter_message = torch.stack(m_list)
+        heter_feature_2d = assemble_agents(feats, agent_modality_list)
+        heter_message = assemble_agents(msgs, agent_modality_list)
 
         if not self.training and self.missing_message:
+            heter_message = heter_message.clone()   # written in place below; may be the extractor's own output
             keep = 0.1 if self.STAGE2 else 0.4  # stage2.py:267 / stage1.py:233
             for i in range(1, heter_message.shape[0]):
                 mask = torch.rand(heter_message.shape[1:], device=heter_message.device) > keep

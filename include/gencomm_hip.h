@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GENCOMM_ABI_VERSION 10
+#define GENCOMM_ABI_VERSION 11
 
 int gencomm_abi_version(void);
 const char* gencomm_last_error(void);
@@ -570,6 +570,17 @@ int gencomm_pfn_train_bwd(const float* feats, const float* weight, const float* 
 long long gencomm_pfn_moment_doubles(int F);
 long long gencomm_pfn_bwd_scratch_doubles(int F, int C);
 int gencomm_slot_max_bwd(const float* dout, const unsigned char* arg, float* dx, int C, int M, int P, void* stream);
+
+/* Detection-head terms of the training criterion in one launch, forward and gradients (opencood/loss/point_pillar_loss.py:36-126 with
+ * :129-170 and :216-245; called through point_pillar_gencomm_loss.py:16-58): sigmoid focal classification loss, smooth-L1 regression loss
+ * on the sin-difference encoding, softmax cross entropy of the heading bin, each weighted and divided by batch_size.
+ * cls [B][A][H][W], reg [B][7A][H][W], dir [B][A*A][H][W] (the reference's view(-1, anchor_num): logits of anchor a = channels a*A..a*A+A-1;
+ * null: no direction term), pos / neg [B][H][W][A], tgt [B][H][W][7A]; A <= 8.  sums [4] (double, ZEROED BY THE CALLER) += cls, reg, dir loss, their sum;
+ * gcls / greg / gdir = d (cls + reg + dir loss) / d map, overwritten.  anchor_yaw: HOST array of A radians (float64 like the reference). */
+int gencomm_head_loss(const float* cls, const float* reg, const float* dir, const float* pos, const float* neg, const float* tgt, float* gcls,
+                      float* greg, float* gdir, double* sums, int B, int A, int H, int W, int num_bins, const double* anchor_yaw, double dir_offset,
+                      float pos_cls_weight, float gamma, float alpha, float cls_weight, float sigma, float reg_weight, float dir_weight,
+                      int batch_size, void* stream);
 
 /* Training path of MessageExtractorv2's deformable 3x3 convolution (message_extractor_v2.py:78,:108; DCNv1, padding 1, one offset
  * group), split into its sampling half and its GEMM half so that the backward is GEMMs on the general kernels + one scatter:

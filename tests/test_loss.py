@@ -65,3 +65,41 @@ def test_resolver_name_and_unsupported_keys():
     args = json.loads(str(np.load(GOLD)["args"]))
     with pytest.raises(NotImplementedError):
         PointPillarGencommLoss(dict(args, iou={"sigma": 3.0, "weight": 1.0}))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["golden_shape", "wide", "no_positives", "gamma_1p5_no_dir"])
+def test_one_launch_head_loss_equals_the_operator_composition(case):
+    """gencomm_head_loss (csrc/loss_kernels.h) against the framework-operator composition of the same criterion on the GPU: totals,
+    components and the gradients of every head map; a sample without positives (pos_norm clamps to 1), a non-quadratic focal exponent
+    and a criterion without the direction term included."""
+    g = np.load(GOLD)
+    args = json.loads(str(g["args"]))
+    B, H, W, A, C = (int(v) for v in g["dims"])
+    if case == "wide":
+        B, H, W = 3, 50, 88
+    t = {k: torch.from_numpy(v).to("cuda:0") for k, v in synth.make_loss_inputs(7 + len(case), B, H, W, A, C).items()}
+    if case == "no_positives":
+        t["pos_equal_one"][0] = 0
+    if case == "gamma_1p5_no_dir":
+        args = dict(args, cls=dict(args["cls"], gamma=1.5))
+        args.pop("dir")
+    res = {}
+    for fused in (True, False):
+        crit = PointPillarGencommLoss(args)
+        crit.fuse_heads = fused
+        leaves = {k: t[k].clone().requires_grad_(True) for k in ("cls_preds", "reg_preds", "dir_preds", "pred_feature")}
+        out = dict(leaves, gt_feature=t["gt_feature"])
+        total = crit(out, {k: t[k] for k in ("pos_equal_one", "neg_equal_one", "targets")})
+        total.backward()
+        res[fused] = (float(total.detach()), {k: float(v) for k, v in crit.loss_dict.items()}, {k: v.grad for k, v in leaves.items()})
+    assert res[True][0] == pytest.approx(res[False][0], rel=3e-6)
+    assert set(res[True][1]) == set(res[False][1])
+    for k, v in res[False][1].items():
+        assert res[True][1][k] == pytest.approx(v, rel=3e-6, abs=1e-7), k
+    for k, gr in res[False][2].items():
+        if gr is None:                       # dir_preds without a direction term
+            assert res[True][2][k] is None
+            continue
+        scale = float(gr.abs().max()) + 1e-30
+        assert float((res[True][2][k] - gr).abs().max()) <= 2e-5 * scale, k

@@ -281,3 +281,26 @@ def test_stage2_shell_forward_vs_reference_golden():
     assert_close(sub(out["pred_feature"], 5), g["pred_feature"], what="pred_feature", **tol)
     for k in ("cls_preds", "reg_preds", "dir_preds"):
         assert_close(out[k].cpu().numpy(), g[k], what=k, **tol)
+
+
+@pytest.mark.parametrize("order", [["m1"] * 4, ["m1", "m2", "m1", "m1"], ["m2", "m1"], ["m1", "m1", "m2", "m2", "m1"], ["m1", "m1", "m1"]])
+def test_agent_assembly_equals_select_and_stack(order):
+    """heter_model.assemble_agents (slices / the tensor itself) against the reference's per-agent select + stack (stage1.py:213-224):
+    same values and the same gradients; a modality batch longer than its agents in the list is not aliased."""
+    from gencomm_amd.heter_model import assemble_agents
+    g = torch.Generator().manual_seed(len(order))
+    extra = 1 if order == ["m1", "m1", "m1"] else 0
+    per = {m: torch.randn(order.count(m) + extra, 3, 2, 5, generator=g).requires_grad_() for m in sorted(set(order))}
+    counting, rows = {m: 0 for m in per}, []
+    for m in order:
+        rows.append(per[m][counting[m]])
+        counting[m] += 1
+    want = torch.stack(rows)
+    got = assemble_agents(per, order)
+    assert torch.equal(got, want)
+    w = torch.randn(want.shape, generator=g)
+    g_want = torch.autograd.grad((want * w).sum(), list(per.values()))
+    g_got = torch.autograd.grad((got * w).sum(), list(per.values()))
+    assert all(torch.equal(a, b) for a, b in zip(g_got, g_want))
+    if len(set(order)) == 1 and not extra:
+        assert got is per[order[0]]     # one modality: no copy
