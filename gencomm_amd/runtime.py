@@ -92,7 +92,7 @@ class _ZeroPool:
     twice, so nothing aliases: a block is freed (back to torch's caching allocator) when its last view dies.  One pool per (device,
     stream): the fill is ordered on the stream the views are used on.  While a HIP graph is being captured the pool steps aside
     (plain ``torch.zeros``): a view of a block filled before the capture began would not be re-zeroed by a replay."""
-    BLOCK = 4 << 20
+    BLOCK = 64 << 20   # one training-leg step asks for ~60 MB of zeros (weight-gradient blobs up to 2.4 MB, statistics scratch): one fill per step
     ALIGN = 256
 
     def __init__(self):

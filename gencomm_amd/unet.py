@@ -281,7 +281,7 @@ class DiffusionUNet(nn.Module):
             ws = workspaces.get(dev, _lib.check_size(l.gencomm_unet_bwd_workspace_bytes(n, C, H, W, L, R, A), "gencomm_unet_bwd_workspace_bytes"), "unet_bwd")
         gx = torch.empty_like(x_t)
         gc = torch.empty_like(cond)
-        graw = zeros(raw.shape, raw.dtype, raw.device)   # runtime._ZeroPool: carved from a zero-filled block (one fill per 4 MB, not per call)
+        graw = zeros(raw.shape, raw.dtype, raw.device)   # runtime._ZeroPool: carved from a zero-filled block (one fill per block, not per call)
         alpha, beta, d_prev = chain if chain is not None else (1.0, 0.0, None)
         _lib.check(l.gencomm_unet_bwd_chain(ptr(prepared), ptr(raw), ptr(x_t), ptr(cond), int(t_int), ptr(grad_x0), float(alpha), float(beta),
                                             ptr(d_prev), ptr(gx), ptr(gc), ptr(graw), n, C, H, W, L, R, A, T, int(done), ptr(ws), ws.numel(),
