@@ -69,6 +69,9 @@ def test_argument_errors_are_status_codes_not_exits(lib):
     # null pointers are rejected before anything is launched
     assert lib.gencomm_unet_fwd(None, None, None, None, 0, 1, 64, 16, 16, 2, 2, 0, 3, None, 0, None) == 1
     assert lib.gencomm_warp_attfuse_fwd(None, None, None, None, 1, 1, 8, 4, 4, None) == 1
+    assert lib.gencomm_head_loss(None, None, None, None, None, None, None, None, None, None, 2, 2, 64, 128, 2, None, 0.7853,
+                                 2.0, 2.0, 0.25, 2.0, 3.0, 2.0, 0.2, 2, None) == 1
+    assert b"null pointer" in lib.gencomm_last_error()
 
 
 def test_cpu_tensors_fail_loudly():
